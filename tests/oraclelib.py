@@ -1,0 +1,295 @@
+"""ctypes binding of oracle/libppo_oracle.so — the CPU parity oracle (test infrastructure only).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module
+(see oracle/ppo_oracle.h). The product package never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(_ROOT, "oracle", "libppo_oracle.so")
+
+
+class OrcConfig(C.Structure):
+    _fields_ = [
+        ("num_steps", C.c_int32), ("num_envs", C.c_int32), ("num_minibatches", C.c_int32),
+        ("update_epochs", C.c_int32), ("lr", C.c_float), ("gamma", C.c_float), ("gae_lambda", C.c_float),
+        ("clip_coef", C.c_float), ("ent_coeff", C.c_float), ("v_coef", C.c_float),
+        ("normalize_advantages", C.c_int32), ("clip_value_loss", C.c_int32), ("anneal_lr", C.c_int32),
+        ("obs_dim", C.c_int32), ("n_act", C.c_int32), ("hidden", C.c_int32), ("gae_mode", C.c_int32),
+        ("env_kind", C.c_int32), ("stale_obs", C.c_int32), ("env_id_offset", C.c_int32), ("seed", C.c_uint64),
+    ]
+
+
+class OrcStats(C.Structure):
+    _fields_ = [(n, C.c_double) for n in
+                ("loss", "pg_loss", "v_loss", "entropy_loss", "adv_mean", "adv_std", "u", "n_unclipped_wins")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class OrcState(C.Structure):
+    _fields_ = [
+        ("obs", C.POINTER(C.c_float)), ("action", C.POINTER(C.c_int32)), ("logprob", C.POINTER(C.c_float)),
+        ("reward", C.POINTER(C.c_float)), ("terminal", C.POINTER(C.c_uint8)), ("value", C.POINTER(C.c_float)),
+        ("adv", C.POINTER(C.c_float)), ("ret", C.POINTER(C.c_float)),
+        ("env_state", C.POINTER(C.c_float)), ("env_t", C.POINTER(C.c_int32)), ("cur_obs", C.POINTER(C.c_float)),
+        ("next_done", C.POINTER(C.c_uint8)), ("ep_return", C.POINTER(C.c_float)), ("ep_length", C.POINTER(C.c_int32)),
+        ("ep_count", C.c_double), ("ep_return_sum", C.c_double), ("ep_length_sum", C.c_double),
+        ("params", C.POINTER(C.c_float)), ("grads", C.POINTER(C.c_float)), ("adam_m", C.POINTER(C.c_float)),
+        ("adam_v", C.POINTER(C.c_float)), ("betap", C.c_double * 24), ("perm", C.POINTER(C.c_int32)),
+        ("iteration", C.c_uint64),
+    ]
+
+
+def build(force=False):
+    src = os.path.join(_ROOT, "oracle", "ppo_oracle.c")
+    hdr = os.path.join(_ROOT, "oracle", "ppo_oracle.h")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle"), "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        fp, ip, dp, u8p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_uint8)
+        cp = C.POINTER(OrcConfig)
+        L.orc_param_count.restype = C.c_int32
+        L.orc_param_count.argtypes = [cp]
+        L.orc_param_offsets.argtypes = [cp, ip]
+        L.orc_tanh_fast.restype = C.c_float
+        L.orc_tanh_fast.argtypes = [C.c_float]
+        L.orc_sin_poly.restype = C.c_float
+        L.orc_sin_poly.argtypes = [C.c_float]
+        L.orc_cos_poly.restype = C.c_float
+        L.orc_cos_poly.argtypes = [C.c_float]
+        L.orc_u53.restype = C.c_double
+        L.orc_u53.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32]
+        L.orc_philox.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
+        L.orc_mlp_forward.argtypes = [cp, fp, C.c_int, fp, fp, fp, fp]
+        L.orc_get_action.argtypes = [cp, fp, fp, dp, C.c_int32, ip, fp, fp, dp]
+        L.orc_logprob_actions.argtypes = [cp, fp, fp, ip, C.c_int32, fp, fp]
+        L.orc_gae.argtypes = [fp, C.c_ssize_t, fp, C.c_ssize_t, u8p, C.c_ssize_t, C.c_int32, C.c_float, C.c_float,
+                              C.c_int32, fp, C.c_ssize_t]
+        L.orc_gae_batch.argtypes = [fp, fp, u8p, fp, u8p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, fp, fp]
+        L.orc_loss_grad.argtypes = [cp, fp, fp, ip, fp, fp, fp, fp, ip, C.c_int32, dp, fp, C.POINTER(OrcStats)]
+        L.orc_clipnorm_adam.argtypes = [cp, fp, fp, fp, fp, dp, C.c_double, C.c_double]
+        L.orc_cartpole_step.argtypes = [fp, ip, C.c_int32, C.c_int32, ip]
+        L.orc_env_reset.argtypes = [cp, fp, C.c_uint32, C.c_uint64, C.c_uint32]
+        L.orc_state_create.restype = C.POINTER(OrcState)
+        L.orc_state_create.argtypes = [cp]
+        L.orc_state_destroy.argtypes = [C.POINTER(OrcState)]
+        L.orc_env_init.argtypes = [cp, C.POINTER(OrcState)]
+        L.orc_rollout.argtypes = [cp, C.POINTER(OrcState)]
+        L.orc_compute_gae.argtypes = [cp, C.POINTER(OrcState)]
+        L.orc_shuffle_fy.argtypes = [ip, C.c_int32, C.c_uint64, C.c_uint64]
+        L.orc_update_minibatch.argtypes = [cp, C.POINTER(OrcState), C.c_int32, C.c_double, C.POINTER(OrcStats)]
+        L.orc_iterate.argtypes = [cp, C.POINTER(OrcState), C.c_int32, C.c_int32, C.POINTER(OrcStats)]
+        _lib = L
+    return _lib
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+def fptr(a):
+    assert a.dtype == np.float32 and a.flags.c_contiguous or a.flags.f_contiguous
+    return _p(a, C.c_float)
+
+
+def make_config(num_envs=8, num_steps=128, num_minibatches=4, update_epochs=4, lr=2.5e-4, gamma=0.99,
+                gae_lambda=0.95, clip_coef=0.2, ent_coeff=0.01, v_coef=0.5, normalize_advantages=True,
+                clip_value_loss=True, anneal_lr=True, obs_dim=4, n_act=2, hidden=64, gae_mode=0, env_kind=0,
+                stale_obs=1, env_id_offset=0, seed=0x5EED):
+    return OrcConfig(num_steps, num_envs, num_minibatches, update_epochs, lr, gamma, gae_lambda, clip_coef, ent_coeff,
+                     v_coef, int(normalize_advantages), int(clip_value_loss), int(anneal_lr), obs_dim, n_act, hidden,
+                     gae_mode, env_kind, stale_obs, env_id_offset, seed)
+
+
+def param_offsets(cfg):
+    o = np.zeros(13, np.int32)
+    lib().orc_param_offsets(C.byref(cfg), _p(o, C.c_int32))
+    return o
+
+
+def get_action(cfg, params, obs, u, with_value=True):
+    n = obs.shape[-1] if obs.ndim == 2 else 1
+    obs = np.asfortranarray(obs, np.float32)
+    action = np.zeros(n, np.int32); logprob = np.zeros(n, np.float32); value = np.zeros(n, np.float32)
+    margin = np.zeros(n, np.float64)
+    u = np.ascontiguousarray(u, np.float64)
+    lib().orc_get_action(C.byref(cfg), fptr(params), fptr(obs), _p(u, C.c_double), n, _p(action, C.c_int32),
+                         fptr(logprob), fptr(value) if with_value else None, _p(margin, C.c_double))
+    return action, logprob, value, margin
+
+
+def logprob_actions(cfg, params, obs, actions):
+    n = obs.shape[-1]
+    obs = np.asfortranarray(obs, np.float32)
+    actions = np.ascontiguousarray(actions, np.int32)
+    logprob = np.zeros(n, np.float32); ent = np.zeros((cfg.n_act, n), np.float32, order="F")
+    lib().orc_logprob_actions(C.byref(cfg), fptr(params), fptr(obs), _p(actions, C.c_int32), n, fptr(logprob), fptr(ent))
+    return logprob, ent
+
+
+def gae(values, rewards, terminals, gamma, lam, mode=0):
+    values = np.ascontiguousarray(values, np.float32); rewards = np.ascontiguousarray(rewards, np.float32)
+    terminals = np.ascontiguousarray(terminals, np.uint8)
+    k = rewards.shape[0]
+    adv = np.zeros(k, np.float32)
+    lib().orc_gae(fptr(values), 1, fptr(rewards), 1, _p(terminals, C.c_uint8), 1, k, gamma, lam, mode, fptr(adv), 1)
+    return adv
+
+
+def gae_batch(value, reward, terminal, next_value, next_done, gamma, lam, mode=0):
+    """value/reward/terminal are (nt,k) Fortran-ordered."""
+    nt, k = value.shape
+    value = np.asfortranarray(value, np.float32); reward = np.asfortranarray(reward, np.float32)
+    terminal = np.asfortranarray(terminal, np.uint8)
+    next_value = np.ascontiguousarray(next_value, np.float32); next_done = np.ascontiguousarray(next_done, np.uint8)
+    adv = np.zeros((nt, k), np.float32, order="F"); ret = np.zeros((nt, k), np.float32, order="F")
+    lib().orc_gae_batch(fptr(value), fptr(reward), _p(terminal, C.c_uint8), fptr(next_value), _p(next_done, C.c_uint8),
+                        nt, k, gamma, lam, mode, fptr(adv), fptr(ret))
+    return adv, ret
+
+
+def loss_grad(cfg, params, states, actions, logprobs, values, advantages, returns, mb_inds, adv_stats=None):
+    P = lib().orc_param_count(C.byref(cfg))
+    grads = np.zeros(P, np.float32)
+    st = OrcStats()
+    states = np.asfortranarray(states, np.float32)
+    arrs = [np.ascontiguousarray(a, np.float32).ravel(order="F") for a in (logprobs, values, advantages, returns)]
+    actions = np.ascontiguousarray(actions, np.int32).ravel(order="F")
+    mb = np.ascontiguousarray(mb_inds, np.int32)
+    stats = None
+    if adv_stats is not None:
+        stats = np.ascontiguousarray(adv_stats, np.float64)
+    lib().orc_loss_grad(C.byref(cfg), fptr(params), fptr(states), _p(actions, C.c_int32), fptr(arrs[0]), fptr(arrs[1]),
+                        fptr(arrs[2]), fptr(arrs[3]), _p(mb, C.c_int32), len(mb),
+                        _p(stats, C.c_double) if stats is not None else None, fptr(grads), C.byref(st))
+    return grads, st.as_dict()
+
+
+def clipnorm_adam(cfg, params, grads, m, v, betap, eta, thresh=0.5):
+    lib().orc_clipnorm_adam(C.byref(cfg), fptr(params), fptr(grads), fptr(m), fptr(v), _p(betap, C.c_double), eta, thresh)
+
+
+class State:
+    """Owns an orc_state and exposes its arrays as numpy views."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.ptr = lib().orc_state_create(C.byref(cfg))
+        s = self.ptr.contents
+        nt, k, d = cfg.num_envs, cfg.num_steps, cfg.obs_dim
+        B = nt * k
+        self.P = lib().orc_param_count(C.byref(cfg))
+        v = lambda p, n, dt: np.ctypeslib.as_array(p, shape=(n,)).view(dt) if n else None
+        self.obs = np.ctypeslib.as_array(s.obs, shape=(B * d,)).reshape((d, nt, k), order="F")
+        self.action = np.ctypeslib.as_array(s.action, shape=(B,)).reshape((nt, k), order="F")
+        self.logprob = np.ctypeslib.as_array(s.logprob, shape=(B,)).reshape((nt, k), order="F")
+        self.reward = np.ctypeslib.as_array(s.reward, shape=(B,)).reshape((nt, k), order="F")
+        self.terminal = np.ctypeslib.as_array(s.terminal, shape=(B,)).reshape((nt, k), order="F")
+        self.value = np.ctypeslib.as_array(s.value, shape=(B,)).reshape((nt, k), order="F")
+        self.adv = np.ctypeslib.as_array(s.adv, shape=(B,)).reshape((nt, k), order="F")
+        self.ret = np.ctypeslib.as_array(s.ret, shape=(B,)).reshape((nt, k), order="F")
+        self.env_state = np.ctypeslib.as_array(s.env_state, shape=(nt * d,)).reshape((d, nt), order="F")
+        self.env_t = np.ctypeslib.as_array(s.env_t, shape=(nt,))
+        self.cur_obs = np.ctypeslib.as_array(s.cur_obs, shape=(nt * d,)).reshape((d, nt), order="F")
+        self.next_done = np.ctypeslib.as_array(s.next_done, shape=(nt,))
+        self.ep_return = np.ctypeslib.as_array(s.ep_return, shape=(nt,))
+        self.ep_length = np.ctypeslib.as_array(s.ep_length, shape=(nt,))
+        self.params = np.ctypeslib.as_array(s.params, shape=(self.P,))
+        self.grads = np.ctypeslib.as_array(s.grads, shape=(self.P,))
+        self.adam_m = np.ctypeslib.as_array(s.adam_m, shape=(self.P,))
+        self.adam_v = np.ctypeslib.as_array(s.adam_v, shape=(self.P,))
+        self.perm = np.ctypeslib.as_array(s.perm, shape=(B,))
+        del v
+
+    @property
+    def iteration(self):
+        return self.ptr.contents.iteration
+
+    @property
+    def episode_stats(self):
+        s = self.ptr.contents
+        return s.ep_count, s.ep_return_sum, s.ep_length_sum
+
+    @property
+    def betap(self):
+        return np.array(list(self.ptr.contents.betap))
+
+    def env_init(self):
+        lib().orc_env_init(C.byref(self.cfg), self.ptr)
+
+    def rollout(self):
+        lib().orc_rollout(C.byref(self.cfg), self.ptr)
+
+    def compute_gae(self):
+        lib().orc_compute_gae(C.byref(self.cfg), self.ptr)
+
+    def update_minibatch(self, mb, eta):
+        st = OrcStats()
+        lib().orc_update_minibatch(C.byref(self.cfg), self.ptr, mb, eta, C.byref(st))
+        return st.as_dict()
+
+    def iterate(self, num_updates_total, gen_perm=True):
+        n = self.cfg.update_epochs * self.cfg.num_minibatches
+        arr = (OrcStats * n)()
+        lib().orc_iterate(C.byref(self.cfg), self.ptr, num_updates_total, int(gen_perm), arr)
+        return [a.as_dict() for a in arr]
+
+    def close(self):
+        if self.ptr:
+            lib().orc_state_destroy(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shuffle_fy(perm, seed, epoch_id):
+    perm = np.ascontiguousarray(perm, np.int32)
+    lib().orc_shuffle_fy(_p(perm, C.c_int32), len(perm), seed, epoch_id)
+    return perm
+
+
+def orthogonal_params(cfg, seed=0):
+    """Flux.orthogonal-shaped init (networks.jl:9,40-41): gains sqrt(2) hidden, 0.01 actor head, 1.0 critic head,
+    zero biases. QR of a Gaussian with sign fix — Flux's stream is not reproducible here; weights are an INPUT."""
+    rng = np.random.default_rng(seed)
+    o = param_offsets(cfg)
+    P = int(o[12])
+    out = np.zeros(P, np.float32)
+    h, d, A = cfg.hidden, cfg.obs_dim, cfg.n_act
+
+    def orth(rows, cols, gain):
+        a = rng.standard_normal((max(rows, cols), min(rows, cols)))
+        q, r = np.linalg.qr(a)
+        q = q * np.sign(np.diag(r))
+        if rows < cols:
+            q = q.T
+        return (gain * q[:rows, :cols]).astype(np.float32)
+
+    shapes = [(h, d, np.sqrt(2)), None, (h, h, np.sqrt(2)), None, (A, h, 0.01), None,
+              (h, d, np.sqrt(2)), None, (h, h, np.sqrt(2)), None, (1, h, 1.0), None]
+    for i, sh in enumerate(shapes):
+        if sh is None:
+            continue
+        W = orth(sh[0], sh[1], sh[2])
+        out[o[i]:o[i + 1]] = W.ravel(order="F")
+    return out

@@ -1,0 +1,314 @@
+"""Pins the CPU oracle (oracle/ppo_oracle.c): SURVEY §8-KA known-answer vectors, an independent
+torch-float64 autograd restatement of the loss closure (ppo.jl:202-244), numpy restatements of gae /
+ClipNorm+Adam, and the Philox known-answer test. The reference itself holds no tests or fixtures (parity unpinned)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import oraclelib as O
+
+
+def test_philox_known_answer():
+    # Random123 kat_vectors: philox4x32-10, ctr = key = 0 and the all-ones vector
+    out = (C.c_uint32 * 4)()
+    O.lib().orc_philox(0, 0, 0, 0, 0, 0, out)
+    assert [hex(x) for x in out] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    O.lib().orc_philox(0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, out)
+    assert [hex(x) for x in out] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+
+
+def test_tanh_fast_close_to_tanh():
+    xs = np.linspace(-9, 9, 20001).astype(np.float32)
+    got = np.array([O.lib().orc_tanh_fast(float(x)) for x in xs[::10]])
+    ref = np.tanh(xs[::10].astype(np.float64))
+    assert np.max(np.abs(got - ref)) < 5e-7  # NNlib documents ~few-ulp error for the Float32 rational
+    assert O.lib().orc_tanh_fast(9.0) == 1.0 and O.lib().orc_tanh_fast(-9.0) == -1.0
+
+
+def test_small_angle_trig():
+    xs = np.linspace(-0.35, 0.35, 4001).astype(np.float32)
+    s = np.array([O.lib().orc_sin_poly(float(x)) for x in xs])
+    c = np.array([O.lib().orc_cos_poly(float(x)) for x in xs])
+    assert np.max(np.abs(s - np.sin(xs.astype(np.float64)))) < 4e-8
+    assert np.max(np.abs(c - np.cos(xs.astype(np.float64)))) < 7e-8
+
+
+# ---- SURVEY §8-KA GAE vectors (hand-derived from ppo.jl:48-73) -------------------------------------------
+def test_gae_known_answers():
+    v = [1, 2, 3, 4, 5]; r = [1, 1, 1, 1]; t = [0, 0, 1, 0, 0]
+    a = O.gae(v, r, t, 0.5, 0.5, mode=0)
+    assert a[:3].tolist() == [0.75, -1.0, 0.0] and a[3] == 0.0  # slot k is undefined upstream (Q1); we define 0
+    a = O.gae(v, r, t, 0.5, 0.5, mode=1)
+    assert a.tolist() == [0.75, -1.0, -0.125, -0.5]
+    a = O.gae(v, r, t, 0.99, 0.95, mode=0).astype(np.float64)
+    assert a[:3].tolist() == [1.0394999980926514, -1.0, 1.9600000381469727]
+    a = O.gae(v, r, t, 0.99, 0.95, mode=1).astype(np.float64)
+    assert a.tolist() == [1.0394999980926514, -1.0, 3.7939751148223877, 1.9500000476837158]
+
+
+def _gae_numpy(values, rewards, terminals, gamma, lam):
+    """Line-by-line numpy restatement of ppo.jl:62-72 (compat), independent of the C code."""
+    k = len(rewards)
+    adv = np.zeros(k, np.float32)
+    nonterm = 1.0 - terminals.astype(np.float64)
+    g = np.float32(gamma); l = np.float32(lam)
+    gae = 0.0
+    for t in range(k - 2, -1, -1):
+        delta = float(rewards[t]) + float(g) * nonterm[t + 1] * float(values[t + 1]) - float(values[t])
+        gae = delta + float(np.float32(g * l)) * nonterm[t + 1] * gae
+        adv[t] = np.float32(gae)
+    return adv
+
+
+def test_gae_matches_numpy_restatement():
+    rng = np.random.default_rng(0)
+    for k in (2, 3, 17, 128):
+        v = (rng.standard_normal(k + 1) * 10).astype(np.float32)
+        r = (rng.random(k) > 0.02).astype(np.float32)
+        t = (rng.random(k + 1) < 0.1).astype(np.uint8)
+        assert np.array_equal(O.gae(v, r, t, 0.99, 0.95, 0), _gae_numpy(v, r, t, 0.99, 0.95))
+
+
+def test_gae_batch_layout_and_returns():
+    rng = np.random.default_rng(1)
+    nt, k = 5, 9
+    value = np.asfortranarray((rng.standard_normal((nt, k)) * 3).astype(np.float32))
+    reward = np.asfortranarray(rng.random((nt, k)).astype(np.float32))
+    term = np.asfortranarray((rng.random((nt, k)) < 0.2).astype(np.uint8))
+    nv = rng.standard_normal(nt).astype(np.float32); nd = (rng.random(nt) < 0.5).astype(np.uint8)
+    for mode in (0, 1):
+        adv, ret = O.gae_batch(value, reward, term, nv, nd, 0.99, 0.95, mode)
+        for e in range(nt):
+            row = O.gae(np.append(value[e], nv[e]), reward[e], np.append(term[e], nd[e]), 0.99, 0.95, mode)
+            assert np.array_equal(adv[e], row)
+        assert np.array_equal(ret, adv + value)
+
+
+# ---- SURVEY §8-KA loss vector -----------------------------------------------------------------------------
+def _torch_loss(params64, cfg, off, states, actions, old_lp, old_v, adv, ret, adv_stats=None):
+    """Independent float64 autograd restatement of ppo.jl:203-243 (formulas of SURVEY §8-LOSS)."""
+    h, d, A = cfg.hidden, cfg.obs_dim, cfg.n_act
+
+    def tanh_fast(x):
+        x2 = x * x
+        n = 1.0 + x2 * (0.1346604 + x2 * (0.0035974074 + x2 * (2.2332108e-5 + x2 * 1.587199e-8)))
+        dd = 1.0 + x2 * (0.4679937 + x2 * (0.026262015 + x2 * (0.0003453992 + x2 * 8.7767893e-7)))
+        return torch.where(x2 < 66.0, x * (n / dd), torch.sign(x))
+
+    def net(base, n_out, x):
+        W1 = params64[off[base]:off[base + 1]].reshape(d, h).T
+        b1 = params64[off[base + 1]:off[base + 2]]
+        W2 = params64[off[base + 2]:off[base + 3]].reshape(h, h).T
+        b2 = params64[off[base + 3]:off[base + 4]]
+        W3 = params64[off[base + 4]:off[base + 5]].reshape(h, n_out).T
+        b3 = params64[off[base + 5]:off[base + 6]]
+        h1 = tanh_fast(W1 @ x + b1[:, None])
+        h2 = tanh_fast(W2 @ h1 + b2[:, None])
+        return W3 @ h2 + b3[:, None]
+
+    x = torch.tensor(states, dtype=torch.float64)
+    z = net(0, A, x)
+    v = net(6, 1, x)[0]
+    lp = torch.log_softmax(z, dim=0)
+    p = torch.softmax(z, dim=0)
+    M = x.shape[1]
+    nlp = lp[torch.tensor(actions, dtype=torch.long), torch.arange(M)]
+    E = -(p * lp)
+    a = torch.tensor(adv, dtype=torch.float64)
+    if adv_stats is None:
+        Ahat = (a - a.mean()) / (a.std(unbiased=True) + 1e-8)
+    else:
+        Ahat = (a - adv_stats[0]) / (adv_stats[1] + 1e-8)
+    ratio = torch.exp(nlp - torch.tensor(old_lp, dtype=torch.float64))
+    eps = float(np.float32(cfg.clip_coef))
+    lo, hi = float(np.float32(1) - np.float32(cfg.clip_coef)), float(np.float32(1) + np.float32(cfg.clip_coef))
+    pg = torch.maximum(-Ahat * ratio, -Ahat * torch.clamp(ratio, lo, hi)).mean()
+    R = torch.tensor(ret, dtype=torch.float64); ov = torch.tensor(old_v, dtype=torch.float64)
+    if cfg.clip_value_loss:
+        u = (v - R ** 2).mean()
+        vc = ov + torch.clamp(v - ov, -eps, eps)
+        vl = 0.5 * torch.maximum(u.expand_as(vc), (vc - R) ** 2).mean()
+    else:
+        vl = 0.5 * ((v - R) ** 2).mean()
+    ent = E.mean()
+    loss = pg - float(np.float32(cfg.ent_coeff)) * ent + float(np.float32(cfg.v_coef)) * vl
+    return loss, pg, vl, ent
+
+
+def test_loss_formulas_known_answer():
+    """§8-KA loss vector evaluated directly on the formulas (logits given, no network)."""
+    z = torch.tensor([[0, 1, -1, .5], [0, 0, 1, -.5]], dtype=torch.float64)
+    a = torch.tensor([0, 1, 0, 1]); old_lp = math.log(.5)
+    adv = torch.tensor([1, -1, 2, 0], dtype=torch.float64)
+    v = torch.tensor([.5, 1, -.5, 2], dtype=torch.float64); ov = torch.tensor([0, 1.5, 0, 1], dtype=torch.float64)
+    R = torch.tensor([1, 1, .5, 1.5], dtype=torch.float64)
+    lp = torch.log_softmax(z, 0); p = torch.softmax(z, 0)
+    nlp = lp[a, torch.arange(4)]
+    assert np.allclose(nlp.numpy(), [-0.6931472, -1.3132616, -2.126928, -1.3132616], atol=1e-6)
+    Ahat = (adv - adv.mean()) / (adv.std() + 1e-8)
+    assert np.allclose(Ahat.numpy(), [0.38729834, -1.16189503, 1.16189503, -0.38729834], atol=1e-7)
+    ratio = torch.exp(nlp - old_lp)
+    pg = torch.maximum(-Ahat * ratio, -Ahat * torch.clamp(ratio, 0.8, 1.2)).mean()
+    assert abs(pg.item() - 0.143763454) < 1e-7
+    u = (v - R ** 2).mean(); assert abs(u.item() + 0.375) < 1e-12
+    vc = ov + torch.clamp(v - ov, -.2, .2)
+    vl = 0.5 * torch.maximum(u.expand(4), (vc - R) ** 2).mean()
+    assert abs(vl.item() - 0.16375) < 1e-12
+    ent = (-(p * lp)).mean(); assert abs(ent.item() - 0.27786088) < 1e-7
+    assert abs((pg - .01 * ent + .5 * vl).item() - 0.222859842) < 1e-7
+
+
+def _random_batch(cfg, B, rng, ret_scale=10.0):
+    d = cfg.obs_dim
+    states = np.asfortranarray(rng.standard_normal((d, B)).astype(np.float32))
+    actions = rng.integers(0, cfg.n_act, B).astype(np.int32)
+    old_lp = (np.log(1.0 / cfg.n_act) + 0.3 * rng.standard_normal(B)).astype(np.float32)
+    old_v = rng.standard_normal(B).astype(np.float32)
+    adv = (rng.standard_normal(B) * 2).astype(np.float32)
+    ret = (rng.standard_normal(B) * ret_scale).astype(np.float32)
+    return states, actions, old_lp, old_v, adv, ret
+
+
+@pytest.mark.parametrize("ret_scale,clipv", [(10.0, True), (0.05, True), (3.0, False)])
+def test_loss_grad_matches_torch_autograd(ret_scale, clipv):
+    """ret_scale=0.05 forces u = mean(v - R^2) > 0 for many samples: the rare unclipped-wins branch (Q4)."""
+    rng = np.random.default_rng(3)
+    cfg = O.make_config(num_envs=8, num_steps=16, hidden=64, clip_value_loss=clipv)
+    params = O.orthogonal_params(cfg, 1)
+    params += (0.05 * rng.standard_normal(params.shape)).astype(np.float32)  # non-zero biases, bigger actor head
+    off = O.param_offsets(cfg)
+    B = 128
+    states, actions, old_lp, old_v, adv, ret = _random_batch(cfg, B, rng, ret_scale)
+    if ret_scale < 1:
+        old_v = (0.05 * rng.standard_normal(B)).astype(np.float32)
+        params[off[11]] = 0.3  # critic head bias: u = mean(v) - mean(R^2) ≈ 0.3 beats q for part of the batch
+    mb = rng.permutation(B)[:64].astype(np.int32)
+    g, st = O.loss_grad(cfg, params, states, actions, old_lp, old_v, adv, ret, mb)
+    if ret_scale < 1 and clipv:
+        assert st["n_unclipped_wins"] > 0, "test must exercise the u > q branch"
+    p64 = torch.tensor(params.astype(np.float64), requires_grad=True)
+    loss, pg, vl, ent = _torch_loss(p64, cfg, off, states[:, mb], actions[mb], old_lp[mb], old_v[mb], adv[mb], ret[mb])
+    loss.backward()
+    gt = p64.grad.numpy()
+    assert abs(st["loss"] - loss.item()) < 2e-6 * max(1, abs(loss.item()))
+    assert abs(st["pg_loss"] - pg.item()) < 2e-6
+    assert abs(st["v_loss"] - vl.item()) < 2e-6 * max(1, abs(vl.item()))
+    assert abs(st["entropy_loss"] - ent.item()) < 2e-6
+    for i in range(12):
+        a, b = g[off[i]:off[i + 1]], gt[off[i]:off[i + 1]]
+        assert np.linalg.norm(a - b) <= 2e-5 * max(np.linalg.norm(b), 1e-6), f"array {i}"
+
+
+def test_clipnorm_adam_matches_numpy_restatement():
+    rng = np.random.default_rng(5)
+    cfg = O.make_config()
+    off = O.param_offsets(cfg); P = int(off[12])
+    params = rng.standard_normal(P).astype(np.float32)
+    m = np.zeros(P, np.float32); v = np.zeros(P, np.float32)
+    betap = np.array([0.9, 0.999] * 12)
+    pr, mr, vr, bpr = params.copy(), m.copy(), v.copy(), betap.copy()
+    for step in range(3):
+        grads = (rng.standard_normal(P) * (0.001 if step == 1 else 0.1)).astype(np.float32)
+        g2 = grads.copy()
+        O.clipnorm_adam(cfg, params, grads, m, v, betap, 2.5e-4)
+        for a in range(12):
+            sl = slice(off[a], off[a + 1])
+            gg = g2[sl].astype(np.float64)
+            n = np.float32(np.sqrt(np.sum(gg * gg)))
+            if n > 0.5:
+                gg = (gg * (0.5 / float(n))).astype(np.float32).astype(np.float64)
+            mr[sl] = (0.9 * mr[sl].astype(np.float64) + (1 - 0.9) * gg).astype(np.float32)
+            vr[sl] = (0.999 * vr[sl].astype(np.float64) + (1 - 0.999) * gg * gg).astype(np.float32)
+            d = mr[sl].astype(np.float64) / (1 - bpr[2 * a]) / (np.sqrt(vr[sl].astype(np.float64) / (1 - bpr[2 * a + 1])) + 1e-8) * 2.5e-4
+            pr[sl] = pr[sl] - d.astype(np.float32)
+            bpr[2 * a] *= 0.9; bpr[2 * a + 1] *= 0.999
+        assert np.array_equal(params, pr) and np.array_equal(m, mr) and np.array_equal(v, vr)
+        assert np.allclose(betap, bpr, rtol=0, atol=0)
+
+
+def test_sampling_inverse_cdf():
+    cfg = O.make_config()
+    params = O.orthogonal_params(cfg, 2)
+    params[O.param_offsets(cfg)[4]:O.param_offsets(cfg)[5]] *= 100  # spread the logits
+    rng = np.random.default_rng(7)
+    obs = np.asfortranarray(rng.standard_normal((4, 512)).astype(np.float32))
+    u = rng.random(512)
+    a, lp, val, margin = O.get_action(cfg, params, obs, u)
+    lpa, ent = O.logprob_actions(cfg, params, obs, a)
+    assert np.array_equal(lp, lpa)
+    p0 = np.exp(O.logprob_actions(cfg, params, obs, np.zeros(512, np.int32))[0].astype(np.float64))
+    expect = (u > p0).astype(np.int32)
+    safe = margin > 1e-6
+    assert np.array_equal(a[safe], expect[safe]) and safe.mean() > 0.99
+    # u = 0 always picks the first action, u → 1 the last (while cw < t && i < n)
+    a0, *_ = O.get_action(cfg, params, obs, np.zeros(512))
+    assert not a0.any()
+
+
+def test_cartpole_dynamics_and_termination():
+    s = np.array([0.01, -0.02, 0.03, 0.04], np.float32); t = np.zeros(1, np.int32); done = np.zeros(1, np.int32)
+    s64 = s.astype(np.float64).copy()
+    L = O.lib()
+    for i in range(10):
+        a = i % 2
+        # float64 restatement of the textbook dynamics
+        force = 10.0 if a == 1 else -10.0
+        x, xd, th, thd = s64
+        tmp = (force + 0.05 * thd * thd * math.sin(th)) / 1.1
+        tha = (9.8 * math.sin(th) - math.cos(th) * tmp) / (0.5 * (4 / 3 - 0.1 * math.cos(th) ** 2 / 1.1))
+        xa = tmp - 0.05 * tha * math.cos(th) / 1.1
+        s64 = np.array([x + 0.02 * xd, xd + 0.02 * xa, th + 0.02 * thd, thd + 0.02 * tha])
+        L.orc_cartpole_step(O.fptr(s), t.ctypes.data_as(C.POINTER(C.c_int32)), a, 500, done.ctypes.data_as(C.POINTER(C.c_int32)))
+        assert np.allclose(s, s64, atol=2e-6)
+    assert t[0] == 10 and done[0] == 0
+    s[:] = [2.39, 10.0, 0, 0]
+    L.orc_cartpole_step(O.fptr(s), t.ctypes.data_as(C.POINTER(C.c_int32)), 1, 500, done.ctypes.data_as(C.POINTER(C.c_int32)))
+    assert done[0] == 1
+    s[:] = 0; t[0] = 500
+    L.orc_cartpole_step(O.fptr(s), t.ctypes.data_as(C.POINTER(C.c_int32)), 1, 500, done.ctypes.data_as(C.POINTER(C.c_int32)))
+    assert done[0] == 1 and t[0] == 501  # t > max_steps (Q12)
+
+
+def test_rollout_buffer_semantics():
+    cfg = O.make_config(num_envs=8, num_steps=128)
+    st = O.State(cfg)
+    st.params[:] = O.orthogonal_params(cfg, 0)
+    st.env_init()
+    first_obs = st.cur_obs.copy()
+    st.rollout()
+    assert np.array_equal(st.obs[:, :, 0], first_obs)
+    assert not st.terminal[:, 0].any()
+    # terminal[e,t] is the done flag produced by step t-1 (ppo.jl:138,144); reward is 0 exactly on terminal steps
+    done_after = (st.reward == 0)
+    assert np.array_equal(st.terminal[:, 1:], done_after[:, :-1].astype(np.uint8))
+    assert np.array_equal(st.next_done, done_after[:, -1].astype(np.uint8))
+    # Q7: the observation stored right after a terminal step is the terminal one (outside the thresholds)
+    e, t = np.argwhere(st.terminal[:, 1:] == 1)[0]
+    ob = st.obs[:, e, t + 1]
+    assert abs(ob[0]) > 2.4 or abs(ob[2]) > 0.20943951
+    n_ep, ret_sum, len_sum = st.episode_stats
+    assert n_ep == done_after.sum() and n_ep > 0
+    st.compute_gae()
+    assert np.array_equal(st.ret, st.adv + st.value) and not st.adv[:, -1].any()
+    st.close()
+
+
+def test_iterate_runs_and_learns_direction():
+    cfg = O.make_config(num_envs=8, num_steps=128)
+    st = O.State(cfg)
+    st.params[:] = O.orthogonal_params(cfg, 0)
+    st.env_init()
+    p0 = st.params.copy()
+    stats = st.iterate(10)
+    assert len(stats) == 16 and all(np.isfinite(s["loss"]) for s in stats)
+    assert st.iteration == 1 and not np.array_equal(p0, st.params)
+    assert sorted(st.perm.tolist()) == list(range(1024))
+    st.close()
+
+
+def test_shuffle_fy_is_permutation_and_deterministic():
+    a = O.shuffle_fy(np.arange(1000), 1, 0); b = O.shuffle_fy(np.arange(1000), 1, 0); c = O.shuffle_fy(np.arange(1000), 1, 1)
+    assert sorted(a.tolist()) == list(range(1000)) and np.array_equal(a, b) and not np.array_equal(a, c)
