@@ -1,0 +1,274 @@
+"""ctypes binding of libcleanrl_hip.so (include/cleanrl_hip.h).
+
+There is NO CPU fallback anywhere in this package: if the HIP library is missing the import of this module raises,
+and every compute entry point returns an error when no GPU is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcleanrl_hip.so")
+
+
+class CrlError(RuntimeError):
+    pass
+
+
+class CrlConfig(C.Structure):
+    """crl_ppo_config — mirror of PPOConfig (ppo.jl:1-19) + shapes."""
+    _fields_ = [
+        ("total_timesteps", C.c_int64), ("num_steps", C.c_int32), ("num_envs", C.c_int32),
+        ("num_minibatches", C.c_int32), ("update_epochs", C.c_int32), ("lr", C.c_float), ("gamma", C.c_float),
+        ("gae_lambda", C.c_float), ("clip_coef", C.c_float), ("ent_coeff", C.c_float), ("v_coef", C.c_float),
+        ("normalize_advantages", C.c_int32), ("clip_value_loss", C.c_int32), ("anneal_lr", C.c_int32),
+        ("obs_dim", C.c_int32), ("n_act", C.c_int32), ("hidden", C.c_int32), ("gae_mode", C.c_int32),
+        ("env_kind", C.c_int32), ("stale_obs", C.c_int32), ("env_id_offset", C.c_int32), ("shuffle_mode", C.c_int32),
+        ("seed", C.c_uint64),
+    ]
+
+
+class CrlStats(C.Structure):
+    _fields_ = [(n, C.c_double) for n in
+                ("loss", "pg_loss", "v_loss", "entropy_loss", "adv_mean", "adv_std", "u_value", "n_unclipped_wins")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class CrlEpisodeStats(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("episodes", "return_sum", "length_sum", "return_max")]
+
+
+# every symbol include/cleanrl_hip.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "crl_version", "crl_last_error", "crl_device_count", "crl_ppo_create", "crl_ppo_destroy", "crl_ppo_param_count",
+    "crl_sync", "crl_ppo_write", "crl_ppo_read", "crl_policy_act", "crl_logprob_actions", "crl_gae",
+    "crl_rollout_store", "crl_env_reset", "crl_rollout_run", "crl_episode_stats_read", "crl_compute_gae",
+    "crl_shuffle", "crl_adv_stats", "crl_ppo_update_minibatch", "crl_ppo_iterate", "crl_ppo_iteration",
+    "crl_comm_unique_id", "crl_comm_init", "crl_prof_enable", "crl_prof_read", "crl_prof_reset",
+]
+
+# crl_field
+F_OBS, F_ACTION, F_LOGPROB, F_REWARD, F_TERMINAL, F_VALUE, F_ADVANTAGE, F_RETURN, F_PERM, F_PARAMS, F_GRADS, F_ADAM_M, \
+    F_ADAM_V, F_ENV_STATE, F_CUR_OBS, F_NEXT_DONE, F_ENV_T, F_BETAP = range(18)
+GAE_COMPAT, GAE_FIXED = 0, 1
+ENV_CARTPOLE, ENV_EXTERNAL = 0, 2
+SHUFFLE_FISHER_YATES, SHUFFLE_BIJECTION = 0, 1
+K_ROLLOUT, K_GAE, K_SHUFFLE, K_ADV_STATS, K_UPDATE, K_REDUCE, K_OPTIM, K_ALLREDUCE = range(8)
+KERNEL_NAMES = ["rollout", "gae", "shuffle", "adv_stats", "update", "reduce", "optim", "allreduce"]
+
+_lib = None
+
+
+def load():
+    """Loads the in-tree HIP library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CrlError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, fp, ip, dp, u8p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_uint8)
+    L.crl_version.restype = C.c_int32
+    L.crl_last_error.restype = C.c_char_p
+    L.crl_device_count.argtypes = [ip]
+    L.crl_ppo_create.argtypes = [C.POINTER(CrlConfig), C.c_int32, C.POINTER(vp)]
+    L.crl_ppo_destroy.argtypes = [vp]
+    L.crl_ppo_param_count.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.crl_sync.argtypes = [vp]
+    L.crl_ppo_write.argtypes = [vp, C.c_int32, vp, C.c_size_t]
+    L.crl_ppo_read.argtypes = [vp, C.c_int32, vp, C.c_size_t]
+    L.crl_policy_act.argtypes = [vp, fp, dp, C.c_int32, ip, fp, fp]
+    L.crl_logprob_actions.argtypes = [vp, fp, ip, C.c_int32, fp, fp]
+    L.crl_gae.argtypes = [C.c_int32, fp, fp, u8p, fp, u8p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, fp, fp]
+    L.crl_rollout_store.argtypes = [vp, C.c_int32, fp, ip, fp, fp, u8p, fp]
+    L.crl_env_reset.argtypes = [vp]
+    L.crl_rollout_run.argtypes = [vp]
+    L.crl_episode_stats_read.argtypes = [vp, C.POINTER(CrlEpisodeStats)]
+    L.crl_compute_gae.argtypes = [vp]
+    L.crl_shuffle.argtypes = [vp, C.c_uint64]
+    L.crl_adv_stats.argtypes = [vp]
+    L.crl_ppo_update_minibatch.argtypes = [vp, C.c_int32, C.c_double, C.c_int32, C.POINTER(CrlStats)]
+    L.crl_ppo_iterate.argtypes = [vp, C.c_int32, C.POINTER(CrlStats)]
+    L.crl_ppo_iteration.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.crl_comm_unique_id.argtypes = [u8p]
+    L.crl_comm_init.argtypes = [vp, u8p, C.c_int32, C.c_int32]
+    L.crl_prof_enable.argtypes = [vp, C.c_int32]
+    L.crl_prof_read.argtypes = [vp, C.c_int32, dp, C.POINTER(C.c_int64)]
+    L.crl_prof_reset.argtypes = [vp]
+    for name in EXPORTS:
+        if name not in ("crl_version", "crl_last_error"):
+            getattr(L, name).restype = C.c_int32
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise CrlError(load().crl_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    n = C.c_int32(0)
+    rc = load().crl_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def _ptr(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+_FIELD_DTYPES = {
+    F_OBS: np.float32, F_ACTION: np.int32, F_LOGPROB: np.float32, F_REWARD: np.float32, F_TERMINAL: np.uint8,
+    F_VALUE: np.float32, F_ADVANTAGE: np.float32, F_RETURN: np.float32, F_PERM: np.int32, F_PARAMS: np.float32,
+    F_GRADS: np.float32, F_ADAM_M: np.float32, F_ADAM_V: np.float32, F_ENV_STATE: np.float32, F_CUR_OBS: np.float32,
+    F_NEXT_DONE: np.uint8, F_ENV_T: np.int32, F_BETAP: np.float64,
+}
+
+
+class Handle:
+    """Owns one crl_ppo (one GPU / one data-parallel shard)."""
+
+    def __init__(self, cfg: CrlConfig, device: int = 0):
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        check(load().crl_ppo_create(C.byref(cfg), device, C.byref(self._h)))
+        n = C.c_int64()
+        check(load().crl_ppo_param_count(self._h, C.byref(n)))
+        self.P = n.value
+        self.nt, self.k, self.d, self.A = cfg.num_envs, cfg.num_steps, cfg.obs_dim, cfg.n_act
+        self.B = self.nt * self.k
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            load().crl_ppo_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _shape(self, f):
+        nt, k, d, B, P = self.nt, self.k, self.d, self.B, self.P
+        return {F_OBS: (d, nt, k), F_PERM: (B,), F_PARAMS: (P,), F_GRADS: (P,), F_ADAM_M: (P,), F_ADAM_V: (P,),
+                F_ENV_STATE: (d, nt), F_CUR_OBS: (d, nt), F_NEXT_DONE: (nt,), F_ENV_T: (nt,), F_BETAP: (24,)}.get(f, (nt, k))
+
+    def read(self, f):
+        out = np.zeros(self._shape(f), _FIELD_DTYPES[f], order="F")
+        check(load().crl_ppo_read(self._h, f, out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+    def write(self, f, arr):
+        a = np.asfortranarray(arr, _FIELD_DTYPES[f])
+        if a.shape != self._shape(f):
+            a = a.reshape(self._shape(f), order="F")
+        a = np.asfortranarray(a)
+        check(load().crl_ppo_write(self._h, f, a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def sync(self):
+        check(load().crl_sync(self._h))
+
+    def policy_act(self, obs, u, with_value=True):
+        obs = np.asfortranarray(obs, np.float32)
+        n = obs.shape[1] if obs.ndim == 2 else 1
+        u = np.ascontiguousarray(u, np.float64)
+        action = np.zeros(n, np.int32); logprob = np.zeros(n, np.float32); value = np.zeros(n, np.float32)
+        check(load().crl_policy_act(self._h, _ptr(obs, C.c_float), _ptr(u, C.c_double), n, _ptr(action, C.c_int32),
+                                    _ptr(logprob, C.c_float), _ptr(value, C.c_float) if with_value else None))
+        return action, logprob, value
+
+    def logprob_actions(self, obs, actions):
+        obs = np.asfortranarray(obs, np.float32)
+        n = obs.shape[1]
+        actions = np.ascontiguousarray(actions, np.int32)
+        logprob = np.zeros(n, np.float32); ent = np.zeros((self.A, n), np.float32, order="F")
+        check(load().crl_logprob_actions(self._h, _ptr(obs, C.c_float), _ptr(actions, C.c_int32), n, _ptr(logprob, C.c_float),
+                                         _ptr(ent, C.c_float)))
+        return logprob, ent
+
+    def rollout_store(self, step, obs, action, logprob, reward, terminal, value):
+        obs = np.asfortranarray(obs, np.float32); action = np.ascontiguousarray(action, np.int32)
+        logprob = np.ascontiguousarray(logprob, np.float32); reward = np.ascontiguousarray(reward, np.float32)
+        terminal = np.ascontiguousarray(terminal, np.uint8); value = np.ascontiguousarray(value, np.float32)
+        check(load().crl_rollout_store(self._h, step, _ptr(obs, C.c_float), _ptr(action, C.c_int32), _ptr(logprob, C.c_float),
+                                       _ptr(reward, C.c_float), _ptr(terminal, C.c_uint8), _ptr(value, C.c_float)))
+
+    def env_reset(self):
+        check(load().crl_env_reset(self._h))
+
+    def rollout_run(self):
+        check(load().crl_rollout_run(self._h))
+
+    def episode_stats(self):
+        st = CrlEpisodeStats()
+        check(load().crl_episode_stats_read(self._h, C.byref(st)))
+        return {"episodes": st.episodes, "return_sum": st.return_sum, "length_sum": st.length_sum, "return_max": st.return_max}
+
+    def compute_gae(self):
+        check(load().crl_compute_gae(self._h))
+
+    def shuffle(self, epoch_id):
+        check(load().crl_shuffle(self._h, epoch_id))
+
+    def adv_stats(self):
+        check(load().crl_adv_stats(self._h))
+
+    def update_minibatch(self, mb, eta, apply_update=True, want_stats=True):
+        st = CrlStats()
+        check(load().crl_ppo_update_minibatch(self._h, mb, eta, int(apply_update), C.byref(st) if want_stats else None))
+        return st.as_dict() if want_stats else None
+
+    def iterate(self, n_iters=1, want_stats=True):
+        n = self.cfg.update_epochs * self.cfg.num_minibatches
+        arr = (CrlStats * n)()
+        check(load().crl_ppo_iterate(self._h, n_iters, arr if want_stats else None))
+        return [a.as_dict() for a in arr] if want_stats else None
+
+    @property
+    def iteration(self):
+        it = C.c_int64()
+        check(load().crl_ppo_iteration(self._h, C.byref(it)))
+        return it.value
+
+    def comm_init(self, unique_id: bytes, world_size: int, rank: int):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        check(load().crl_comm_init(self._h, buf, world_size, rank))
+
+    def prof_enable(self, on=True):
+        check(load().crl_prof_enable(self._h, int(on)))
+
+    def prof_reset(self):
+        check(load().crl_prof_reset(self._h))
+
+    def prof_read(self):
+        out = {}
+        for kid, name in enumerate(KERNEL_NAMES):
+            ms = C.c_double(); n = C.c_int64()
+            check(load().crl_prof_read(self._h, kid, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
+
+
+def comm_unique_id() -> bytes:
+    buf = (C.c_uint8 * 128)()
+    check(load().crl_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def gae_host(value, reward, terminal, next_value, next_done, gamma, lam, mode=GAE_COMPAT, device=0):
+    """crl_gae on host arrays: value/reward/terminal are (nt,k) Fortran-ordered."""
+    value = np.asfortranarray(value, np.float32); reward = np.asfortranarray(reward, np.float32)
+    terminal = np.asfortranarray(terminal, np.uint8)
+    nt, k = value.shape
+    nv = None if next_value is None else np.ascontiguousarray(next_value, np.float32)
+    nd = None if next_done is None else np.ascontiguousarray(next_done, np.uint8)
+    adv = np.zeros((nt, k), np.float32, order="F"); ret = np.zeros((nt, k), np.float32, order="F")
+    check(load().crl_gae(device, _ptr(value, C.c_float), _ptr(reward, C.c_float), _ptr(terminal, C.c_uint8),
+                         _ptr(nv, C.c_float) if nv is not None else None, _ptr(nd, C.c_uint8) if nd is not None else None,
+                         nt, k, gamma, lam, mode, _ptr(adv, C.c_float), _ptr(ret, C.c_float)))
+    return adv, ret

@@ -1,0 +1,440 @@
+// api.cpp — the extern "C" boundary of libcleanrl_hip.so (include/cleanrl_hip.h). Host orchestration only; every
+// numeric step is a HIP kernel in gae.hip / policy.hip / update.hip / optim.hip / shuffle.hip. There is no CPU fallback:
+// without a GPU every entry point that computes returns an error.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "ppo_ctx.hpp"
+
+namespace crl {
+thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int comm_unique_id(uint8_t id[128]);
+int comm_init(crl_ppo* h, const uint8_t id[128], int world, int rank);
+int launch_iota(crl_ppo* h);
+
+int ensure_stage(crl_ppo* h, size_t bytes) {
+  if (h->stage_bytes >= bytes) return 0;
+  if (h->stage) CRL_HIP_CHECK(hipFree(h->stage));
+  h->stage = nullptr; h->stage_bytes = 0;
+  size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+  CRL_HIP_CHECK(hipMalloc(&h->stage, want));
+  h->stage_bytes = want;
+  return 0;
+}
+
+template <typename T>
+static int dalloc(T** p, size_t n, bool zero = true) {
+  CRL_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)));
+  if (zero) CRL_HIP_CHECK(hipMemset(*p, 0, n * sizeof(T)));
+  return 0;
+}
+
+struct FieldRef { void* ptr; size_t bytes; };
+static bool field_ref(crl_ppo* h, int f, FieldRef* out) {
+  const size_t B = (size_t)h->dc.B, nt = (size_t)h->dc.nt, d = (size_t)h->dc.D, P = (size_t)h->P;
+  switch (f) {
+    case CRL_F_OBS: *out = {h->obs, B * d * 4}; return true;
+    case CRL_F_ACTION: *out = {h->action, B * 4}; return true;
+    case CRL_F_LOGPROB: *out = {h->logprob, B * 4}; return true;
+    case CRL_F_REWARD: *out = {h->reward, B * 4}; return true;
+    case CRL_F_TERMINAL: *out = {h->terminal, B}; return true;
+    case CRL_F_VALUE: *out = {h->value, B * 4}; return true;
+    case CRL_F_ADVANTAGE: *out = {h->adv, B * 4}; return true;
+    case CRL_F_RETURN: *out = {h->ret, B * 4}; return true;
+    case CRL_F_PERM: *out = {h->perm, B * 4}; return true;
+    case CRL_F_PARAMS: *out = {h->params, P * 4}; return true;
+    case CRL_F_GRADS: *out = {h->grads, P * 4}; return true;
+    case CRL_F_ADAM_M: *out = {h->adam_m, P * 4}; return true;
+    case CRL_F_ADAM_V: *out = {h->adam_v, P * 4}; return true;
+    case CRL_F_ENV_STATE: *out = {h->env_state, nt * d * 4}; return true;
+    case CRL_F_CUR_OBS: *out = {h->cur_obs, nt * d * 4}; return true;
+    case CRL_F_NEXT_DONE: *out = {h->next_done, nt}; return true;
+    case CRL_F_ENV_T: *out = {h->env_t, nt * 4}; return true;
+    case CRL_F_BETAP: *out = {h->betap, 24 * 8}; return true;
+    default: return false;
+  }
+}
+
+static int prof_collect(crl_ppo* h) {
+  for (int k = 0; k < CRL_K_COUNT; ++k) {
+    auto& s = h->prof_slots[k];
+    for (auto& pr : s.pending) {
+      CRL_HIP_CHECK(hipEventSynchronize(pr.second));
+      float ms = 0.f;
+      CRL_HIP_CHECK(hipEventElapsedTime(&ms, pr.first, pr.second));
+      s.total_ms += ms; s.launches += 1;
+      hipEventDestroy(pr.first); hipEventDestroy(pr.second);
+    }
+    s.pending.clear();
+  }
+  return 0;
+}
+}  // namespace crl
+
+using namespace crl;
+
+#define CRL_GUARD(h)                                         \
+  if (!(h)) { set_error("null crl_ppo handle"); return 1; } \
+  CRL_HIP_CHECK(hipSetDevice((h)->device));
+
+extern "C" {
+
+int32_t crl_version(void) { return CRL_VERSION; }
+const char* crl_last_error(void) { return g_err.c_str(); }
+
+int32_t crl_device_count(int32_t* n) {
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) { *n = 0; set_error(std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); return 1; }
+  *n = c;
+  return 0;
+}
+
+int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out) {
+  if (!cfg || !out) { set_error("crl_ppo_create: null argument"); return 1; }
+  *out = nullptr;
+  if (cfg->num_envs <= 0 || cfg->num_steps <= 0 || cfg->num_minibatches <= 0 || cfg->update_epochs <= 0) {
+    set_error("crl_ppo_create: num_envs, num_steps, num_minibatches, update_epochs must be positive"); return 1;
+  }
+  if (!cfg->normalize_advantages) {
+    set_error("normalize_advantages=false is not a valid configuration (the reference errors too: ppo.jl:219-222)"); return 1;
+  }
+  if (cfg->obs_dim != 4 || cfg->n_act != 2 || cfg->hidden != 64) {
+    set_error("this build of libcleanrl_hip supports obs_dim=4, n_act=2, hidden=64 (2x64 MLP) only"); return 1;
+  }
+  const int64_t B64 = (int64_t)cfg->num_envs * cfg->num_steps;
+  if (B64 > (1ll << 30)) { set_error("batch too large"); return 1; }
+  if (B64 % cfg->num_minibatches != 0) {
+    set_error("num_envs*num_steps must be divisible by num_minibatches"); return 1;
+  }
+  if (cfg->num_steps > 1024) { set_error("num_steps > 1024 is not supported"); return 1; }
+  int ndev = 0;
+  CRL_HIP_CHECK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) { set_error("crl_ppo_create: no such HIP device (no GPU → no CPU fallback)"); return 1; }
+  CRL_HIP_CHECK(hipSetDevice(device));
+  crl_ppo* h = new (std::nothrow) crl_ppo();
+  if (!h) { set_error("out of host memory"); return 1; }
+  h->cfg = *cfg; h->device = device;
+  DevCfg& c = h->dc;
+  c.nt = cfg->num_envs; c.k = cfg->num_steps; c.B = (int)B64; c.nmb = cfg->num_minibatches; c.M = c.B / c.nmb;
+  c.D = cfg->obs_dim; c.A = cfg->n_act; c.gamma = cfg->gamma; c.lambda = cfg->gae_lambda; c.clip = cfg->clip_coef;
+  c.ent_coeff = cfg->ent_coeff; c.v_coef = cfg->v_coef; c.clip_vloss = cfg->clip_value_loss; c.gae_mode = cfg->gae_mode;
+  c.env_kind = cfg->env_kind; c.stale_obs = cfg->stale_obs; c.env_id_offset = (uint32_t)cfg->env_id_offset; c.seed = cfg->seed;
+  const int hN = cfg->hidden, d = cfg->obs_dim, A = cfg->n_act;
+  h->Pa = (int64_t)hN * d + hN + hN * hN + hN + A * hN + A;
+  h->Pc = (int64_t)hN * d + hN + hN * hN + hN + hN + 1;
+  h->P = h->Pa + h->Pc;
+  h->num_updates = cfg->total_timesteps / B64;
+  if (h->num_updates < 1) h->num_updates = 1;
+  int rc = 0;
+  hipError_t se = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (se != hipSuccess) { set_error(std::string("hipStreamCreate: ") + hipGetErrorString(se)); delete h; return 1; }
+  const size_t B = (size_t)c.B, nt = (size_t)c.nt;
+  rc |= dalloc(&h->obs, B * d); rc |= dalloc(&h->action, B); rc |= dalloc(&h->logprob, B); rc |= dalloc(&h->reward, B);
+  rc |= dalloc(&h->terminal, B); rc |= dalloc(&h->value, B); rc |= dalloc(&h->adv, B); rc |= dalloc(&h->ret, B);
+  rc |= dalloc(&h->env_state, nt * d); rc |= dalloc(&h->env_t, nt); rc |= dalloc(&h->cur_obs, nt * d);
+  rc |= dalloc(&h->next_done, nt); rc |= dalloc(&h->ep_return, nt); rc |= dalloc(&h->ep_length, nt);
+  rc |= dalloc(&h->next_value, nt); rc |= dalloc(&h->ep_stats, 4);
+  rc |= dalloc(&h->params, h->P); rc |= dalloc(&h->grads, h->P); rc |= dalloc(&h->adam_m, h->P); rc |= dalloc(&h->adam_v, h->P);
+  rc |= dalloc(&h->betap, 24); rc |= dalloc(&h->perm, B);
+  // update grid: two 256-thread blocks per CU, alternating roles; never more waves than tiles
+  hipDeviceProp_t prop;
+  CRL_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  int ntiles = (c.M + 31) / 32;
+  int ub = cus;  // blocks per role
+  if (ub * 4 > ntiles) ub = (ntiles + 3) / 4;
+  if (ub < 1) ub = 1;
+  h->update_blocks = ub;
+  rc |= dalloc(&h->gpart, (size_t)2 * ub * h->Pa + 4096); rc |= dalloc(&h->lpart, (size_t)2 * ub * 2);
+  rc |= dalloc(&h->adv_sums, (size_t)c.nmb * 2); rc |= dalloc(&h->adv_ms, (size_t)c.nmb * 2);
+  rc |= dalloc(&h->newv, (size_t)c.M); rc |= dalloc(&h->vfix, 8);
+  rc |= dalloc(&h->stats_dev, (size_t)cfg->update_epochs * c.nmb);
+  rc |= dalloc(&h->comm_buf, (size_t)h->P + 8);
+  if (rc) { crl_ppo_destroy(h); return 1; }
+  double bp[24];
+  for (int i = 0; i < 12; ++i) { bp[2 * i] = 0.9; bp[2 * i + 1] = 0.999; }
+  CRL_HIP_CHECK(hipMemcpy(h->betap, bp, sizeof(bp), hipMemcpyHostToDevice));
+  if (launch_iota(h)) { crl_ppo_destroy(h); return 1; }
+  CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  *out = h;
+  return 0;
+}
+
+int32_t crl_ppo_destroy(crl_ppo* h) {
+  if (!h) return 0;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  comm_destroy(h);
+  void* ptrs[] = {h->obs, h->action, h->logprob, h->reward, h->terminal, h->value, h->adv, h->ret, h->env_state, h->env_t,
+                  h->cur_obs, h->next_done, h->ep_return, h->ep_length, h->next_value, h->ep_stats, h->params, h->grads,
+                  h->adam_m, h->adam_v, h->betap, h->perm, h->gpart, h->lpart, h->adv_sums, h->adv_ms, h->newv, h->vfix,
+                  h->stats_dev, h->comm_buf, h->stage};
+  for (void* p : ptrs) if (p) hipFree(p);
+  for (int k = 0; k < CRL_K_COUNT; ++k)
+    for (auto& pr : h->prof_slots[k].pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return 0;
+}
+
+int32_t crl_ppo_param_count(const crl_ppo* h, int64_t* n) {
+  if (!h || !n) { set_error("null argument"); return 1; }
+  *n = h->P;
+  return 0;
+}
+
+int32_t crl_sync(crl_ppo* h) {
+  CRL_GUARD(h);
+  CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int32_t crl_ppo_write(crl_ppo* h, int32_t field, const void* host, size_t nbytes) {
+  CRL_GUARD(h);
+  FieldRef fr;
+  if (!field_ref(h, field, &fr)) { set_error("crl_ppo_write: unknown field"); return 1; }
+  if (nbytes != fr.bytes) { set_error("crl_ppo_write: size mismatch for field " + std::to_string(field) + ": got " +
+                                      std::to_string(nbytes) + ", want " + std::to_string(fr.bytes)); return 1; }
+  CRL_HIP_CHECK(hipMemcpyAsync(fr.ptr, host, nbytes, hipMemcpyHostToDevice, h->stream));
+  CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int32_t crl_ppo_read(crl_ppo* h, int32_t field, void* host, size_t nbytes) {
+  CRL_GUARD(h);
+  FieldRef fr;
+  if (!field_ref(h, field, &fr)) { set_error("crl_ppo_read: unknown field"); return 1; }
+  if (nbytes != fr.bytes) { set_error("crl_ppo_read: size mismatch for field " + std::to_string(field) + ": got " +
+                                      std::to_string(nbytes) + ", want " + std::to_string(fr.bytes)); return 1; }
+  CRL_HIP_CHECK(hipMemcpyAsync(host, fr.ptr, nbytes, hipMemcpyDeviceToHost, h->stream));
+  CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int32_t crl_policy_act(crl_ppo* h, const float* obs, const double* u, int32_t n, int32_t* action, float* logprob,
+                       float* value) {
+  CRL_GUARD(h);
+  if (n < 0 || (n > 0 && (!obs || !u || !action || !logprob))) { set_error("crl_policy_act: bad arguments"); return 1; }
+  if (n == 0) return 0;
+  const size_t d = (size_t)h->dc.D, N = (size_t)n;
+  const size_t o_obs = 0, o_u = o_obs + ((N * d * 4 + 15) & ~(size_t)15), o_act = o_u + N * 8, o_lp = o_act + N * 4,
+               o_val = o_lp + N * 4, total = o_val + N * 4;
+  if (ensure_stage(h, total)) return 1;
+  char* s = static_cast<char*>(h->stage);
+  CRL_HIP_CHECK(hipMemcpyAsync(s + o_obs, obs, N * d * 4, hipMemcpyHostToDevice, h->stream));
+  CRL_HIP_CHECK(hipMemcpyAsync(s + o_u, u, N * 8, hipMemcpyHostToDevice, h->stream));
+  if (launch_policy_act(h, (const float*)(s + o_obs), (const double*)(s + o_u), n, (int32_t*)(s + o_act), (float*)(s + o_lp),
+                        (float*)(s + o_val))) return 1;
+  CRL_HIP_CHECK(hipMemcpyAsync(action, s + o_act, N * 4, hipMemcpyDeviceToHost, h->stream));
+  CRL_HIP_CHECK(hipMemcpyAsync(logprob, s + o_lp, N * 4, hipMemcpyDeviceToHost, h->stream));
+  if (value) CRL_HIP_CHECK(hipMemcpyAsync(value, s + o_val, N * 4, hipMemcpyDeviceToHost, h->stream));
+  CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int32_t crl_logprob_actions(crl_ppo* h, const float* obs, const int32_t* actions, int32_t n, float* logprob,
+                            float* entropy) {
+  CRL_GUARD(h);
+  if (n < 0 || (n > 0 && (!obs || !actions || !logprob || !entropy))) { set_error("crl_logprob_actions: bad arguments"); return 1; }
+  if (n == 0) return 0;
+  const size_t d = (size_t)h->dc.D, A = (size_t)h->dc.A, N = (size_t)n;
+  const size_t o_obs = 0, o_act = o_obs + ((N * d * 4 + 15) & ~(size_t)15), o_lp = o_act + N * 4, o_ent = o_lp + N * 4,
+               total = o_ent + N * A * 4;
+  if (ensure_stage(h, total)) return 1;
+  char* s = static_cast<char*>(h->stage);
+  CRL_HIP_CHECK(hipMemcpyAsync(s + o_obs, obs, N * d * 4, hipMemcpyHostToDevice, h->stream));
+  CRL_HIP_CHECK(hipMemcpyAsync(s + o_act, actions, N * 4, hipMemcpyHostToDevice, h->stream));
+  if (launch_logprob_actions(h, (const float*)(s + o_obs), (const int32_t*)(s + o_act), n, (float*)(s + o_lp), (float*)(s + o_ent))) return 1;
+  CRL_HIP_CHECK(hipMemcpyAsync(logprob, s + o_lp, N * 4, hipMemcpyDeviceToHost, h->stream));
+  CRL_HIP_CHECK(hipMemcpyAsync(entropy, s + o_ent, N * A * 4, hipMemcpyDeviceToHost, h->stream));
+  CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int32_t crl_gae(int32_t device, const float* value, const float* reward, const uint8_t* terminal, const float* next_value,
+                const uint8_t* next_done, int32_t nt, int32_t k, float gamma, float lambda, int32_t mode, float* adv,
+                float* ret) {
+  if (nt < 0 || k < 0) { set_error("crl_gae: negative size"); return 1; }
+  if (nt == 0 || k == 0) return 0;  // gae of an empty rollout is empty
+  if (!value || !reward || !terminal || !adv) { set_error("crl_gae: null argument"); return 1; }
+  if (mode == CRL_GAE_FIXED && (!next_value || !next_done)) { set_error("crl_gae: fixed mode needs next_value/next_done"); return 1; }
+  CRL_HIP_CHECK(hipSetDevice(device));
+  const size_t B = (size_t)nt * k;
+  char* buf = nullptr;
+  const size_t o_v = 0, o_r = o_v + B * 4, o_a = o_r + B * 4, o_ret = o_a + B * 4, o_nv = o_ret + B * 4,
+               o_t = o_nv + (size_t)nt * 4, o_nd = o_t + ((B + 15) & ~(size_t)15), total = o_nd + (size_t)nt;
+  CRL_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&buf), total));
+  int rc = 0;
+  auto fail = [&](hipError_t e, const char* what) { set_error(std::string(what) + ": " + hipGetErrorString(e)); rc = 1; };
+  hipError_t e;
+  if ((e = hipMemcpy(buf + o_v, value, B * 4, hipMemcpyHostToDevice)) != hipSuccess) fail(e, "copy value");
+  if (!rc && (e = hipMemcpy(buf + o_r, reward, B * 4, hipMemcpyHostToDevice)) != hipSuccess) fail(e, "copy reward");
+  if (!rc && (e = hipMemcpy(buf + o_t, terminal, B, hipMemcpyHostToDevice)) != hipSuccess) fail(e, "copy terminal");
+  if (!rc && next_value && (e = hipMemcpy(buf + o_nv, next_value, (size_t)nt * 4, hipMemcpyHostToDevice)) != hipSuccess) fail(e, "copy next_value");
+  if (!rc && next_done && (e = hipMemcpy(buf + o_nd, next_done, (size_t)nt, hipMemcpyHostToDevice)) != hipSuccess) fail(e, "copy next_done");
+  if (!rc)
+    rc = launch_gae(nullptr, (const float*)(buf + o_v), (const float*)(buf + o_r), (const uint8_t*)(buf + o_t),
+                    next_value ? (const float*)(buf + o_nv) : nullptr, next_done ? (const uint8_t*)(buf + o_nd) : nullptr, nt, k,
+                    gamma, lambda, mode, (float*)(buf + o_a), (float*)(buf + o_ret));
+  if (!rc && (e = hipDeviceSynchronize()) != hipSuccess) fail(e, "gae kernel");
+  if (!rc && (e = hipMemcpy(adv, buf + o_a, B * 4, hipMemcpyDeviceToHost)) != hipSuccess) fail(e, "copy adv");
+  if (!rc && ret && (e = hipMemcpy(ret, buf + o_ret, B * 4, hipMemcpyDeviceToHost)) != hipSuccess) fail(e, "copy ret");
+  hipFree(buf);
+  return rc;
+}
+
+int32_t crl_rollout_store(crl_ppo* h, int32_t step, const float* obs, const int32_t* action, const float* logprob,
+                          const float* reward, const uint8_t* terminal, const float* value) {
+  CRL_GUARD(h);
+  if (step < 0 || step >= h->dc.k) { set_error("crl_rollout_store: step out of range"); return 1; }
+  if (!obs || !action || !logprob || !reward || !terminal || !value) { set_error("crl_rollout_store: null argument"); return 1; }
+  const size_t nt = (size_t)h->dc.nt, d = (size_t)h->dc.D, off = nt * (size_t)step;
+  CRL_HIP_CHECK(hipMemcpyAsync(h->obs + off * d, obs, nt * d * 4, hipMemcpyHostToDevice, h->stream));
+  CRL_HIP_CHECK(hipMemcpyAsync(h->action + off, action, nt * 4, hipMemcpyHostToDevice, h->stream));
+  CRL_HIP_CHECK(hipMemcpyAsync(h->logprob + off, logprob, nt * 4, hipMemcpyHostToDevice, h->stream));
+  CRL_HIP_CHECK(hipMemcpyAsync(h->reward + off, reward, nt * 4, hipMemcpyHostToDevice, h->stream));
+  CRL_HIP_CHECK(hipMemcpyAsync(h->terminal + off, terminal, nt, hipMemcpyHostToDevice, h->stream));
+  CRL_HIP_CHECK(hipMemcpyAsync(h->value + off, value, nt * 4, hipMemcpyHostToDevice, h->stream));
+  CRL_HIP_CHECK(hipStreamSynchronize(h->stream));  // host buffers are only borrowed for the call
+  return 0;
+}
+
+int32_t crl_env_reset(crl_ppo* h) {
+  CRL_GUARD(h);
+  return launch_env_reset(h);
+}
+
+int32_t crl_rollout_run(crl_ppo* h) {
+  CRL_GUARD(h);
+  return launch_rollout(h);
+}
+
+int32_t crl_episode_stats_read(crl_ppo* h, crl_episode_stats* out) {
+  CRL_GUARD(h);
+  if (!out) { set_error("null argument"); return 1; }
+  double v[4];
+  CRL_HIP_CHECK(hipMemcpyAsync(v, h->ep_stats, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+  CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  out->episodes = v[0]; out->return_sum = v[1]; out->length_sum = v[2]; out->return_max = v[3];
+  return 0;
+}
+
+int32_t crl_compute_gae(crl_ppo* h) {
+  CRL_GUARD(h);
+  const bool fixed = h->cfg.gae_mode == CRL_GAE_FIXED;
+  if (fixed && launch_next_value(h)) return 1;
+  ProfScope ps(h, CRL_K_GAE);
+  return launch_gae(h->stream, h->value, h->reward, h->terminal, fixed ? h->next_value : nullptr, h->next_done, h->dc.nt,
+                    h->dc.k, h->cfg.gamma, h->cfg.gae_lambda, h->cfg.gae_mode, h->adv, h->ret);
+}
+
+int32_t crl_shuffle(crl_ppo* h, uint64_t epoch_id) {
+  CRL_GUARD(h);
+  return launch_shuffle(h, epoch_id);
+}
+
+int32_t crl_adv_stats(crl_ppo* h) {
+  CRL_GUARD(h);
+  if (launch_adv_stats_sums(h)) return 1;
+  if (comm_allreduce(h, h->adv_sums, (size_t)h->dc.nmb * 2, true)) return 1;
+  return launch_adv_stats_finish(h);
+}
+
+static int update_step(crl_ppo* h, int mb, double eta, int apply, int slot) {
+  if (launch_update(h, mb)) return 1;
+  if (launch_update_finish(h, mb, h->stats_dev + slot)) return 1;
+  if (apply && launch_optim(h, eta)) return 1;
+  return 0;
+}
+
+int32_t crl_ppo_update_minibatch(crl_ppo* h, int32_t mb, double eta, int32_t apply_update, crl_ppo_stats* stats) {
+  CRL_GUARD(h);
+  if (mb < 0 || mb >= h->dc.nmb) { set_error("crl_ppo_update_minibatch: minibatch index out of range"); return 1; }
+  if (update_step(h, mb, eta, apply_update, mb)) return 1;
+  if (stats) {
+    CRL_HIP_CHECK(hipMemcpyAsync(stats, h->stats_dev + mb, sizeof(crl_ppo_stats), hipMemcpyDeviceToHost, h->stream));
+    CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  }
+  return 0;
+}
+
+int32_t crl_ppo_iterate(crl_ppo* h, int32_t n_iters, crl_ppo_stats* stats) {
+  CRL_GUARD(h);
+  if (h->cfg.env_kind != CRL_ENV_CARTPOLE) { set_error("crl_ppo_iterate needs the on-device env (env_kind = CRL_ENV_CARTPOLE)"); return 1; }
+  const int E = h->cfg.update_epochs, nmb = h->dc.nmb;
+  for (int it = 0; it < n_iters; ++it) {
+    double eta = (double)h->cfg.lr;
+    if (h->cfg.anneal_lr) {  // ppo.jl:118-121 (update is 1-based)
+      const double frac = 1.0 - ((double)(h->iteration + 1) - 1.0) / (double)h->num_updates;
+      eta = frac * (double)h->cfg.lr;
+    }
+    if (launch_rollout(h)) return 1;
+    if (crl_compute_gae(h)) return 1;
+    if (h->cfg.shuffle_mode == CRL_SHUFFLE_FISHER_YATES && launch_iota(h)) return 1;  // ppo.jl:191
+    for (int ep = 0; ep < E; ++ep) {
+      if (launch_shuffle(h, (uint64_t)h->iteration * (uint64_t)E + (uint64_t)ep)) return 1;
+      if (crl_adv_stats(h)) return 1;
+      for (int mb = 0; mb < nmb; ++mb)
+        if (update_step(h, mb, eta, 1, ep * nmb + mb)) return 1;
+    }
+    h->iteration += 1;
+  }
+  if (stats) {
+    CRL_HIP_CHECK(hipMemcpyAsync(stats, h->stats_dev, sizeof(crl_ppo_stats) * (size_t)E * nmb, hipMemcpyDeviceToHost, h->stream));
+    CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  }
+  if (h->world > 1) {
+    double vf[8];
+    CRL_HIP_CHECK(hipMemcpyAsync(vf, h->vfix, sizeof(vf), hipMemcpyDeviceToHost, h->stream));
+    CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (vf[4] != 0.0) {
+      set_error("value-loss branch u = mean(v - R^2) > 0 was taken in a data-parallel run; its exact pass is single-GPU only in this build");
+      return 1;
+    }
+  }
+  return 0;
+}
+
+int32_t crl_ppo_iteration(const crl_ppo* h, int64_t* it) {
+  if (!h || !it) { set_error("null argument"); return 1; }
+  *it = h->iteration;
+  return 0;
+}
+
+int32_t crl_comm_unique_id(uint8_t id[128]) { return comm_unique_id(id); }
+
+int32_t crl_comm_init(crl_ppo* h, const uint8_t id[128], int32_t world_size, int32_t rank) {
+  CRL_GUARD(h);
+  if (comm_init(h, id, world_size, rank)) return 1;
+  // num_updates = total_timesteps ÷ (global batch) (ppo.jl:89-91)
+  const int64_t gb = (int64_t)h->dc.B * h->world;
+  h->num_updates = h->cfg.total_timesteps / gb;
+  if (h->num_updates < 1) h->num_updates = 1;
+  return 0;
+}
+
+int32_t crl_prof_enable(crl_ppo* h, int32_t on) {
+  CRL_GUARD(h);
+  h->prof = on != 0;
+  return 0;
+}
+int32_t crl_prof_read(crl_ppo* h, int32_t kernel_id, double* total_ms, int64_t* launches) {
+  CRL_GUARD(h);
+  if (kernel_id < 0 || kernel_id >= CRL_K_COUNT) { set_error("bad kernel id"); return 1; }
+  if (prof_collect(h)) return 1;
+  if (total_ms) *total_ms = h->prof_slots[kernel_id].total_ms;
+  if (launches) *launches = h->prof_slots[kernel_id].launches;
+  return 0;
+}
+int32_t crl_prof_reset(crl_ppo* h) {
+  CRL_GUARD(h);
+  if (prof_collect(h)) return 1;
+  for (int k = 0; k < CRL_K_COUNT; ++k) { h->prof_slots[k].total_ms = 0; h->prof_slots[k].launches = 0; }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+// gae.hip — GAE advantages + returns (ppo.jl:48-73,169-181) as a segmented reverse scan.
+//
+// The recurrence A_t = δ_t + c_t·A_{t+1} (δ_t = r_t + γ·nt_{t+1}·v_{t+1} − v_t, c_t = (γλ)·nt_{t+1}) is affine, so the
+// time axis is cut into segments of L=16 steps that run in parallel: each thread owns (env, segment), keeps its 16
+// (v, r, done) triples in registers, composes the segment's map A_lo = D + C·A_in, the per-segment maps are folded
+// through LDS, and the thread replays its segment from the resolved carry. One HBM read of value/reward/terminal
+// (9 B) and one write of advantage/return (8 B) per (env, step): 17 B — the algorithmic minimum.
+// Arithmetic is Float64 like the reference's accumulator (ppo.jl:63,65; Q2), stored Float32 (ppo.jl:62).
+// Layout: (nt, k) column-major, env fastest ⇒ lanes of a wave read consecutive envs: coalesced 128/256-B rows.
+#include "ppo_ctx.hpp"
+
+namespace crl {
+
+constexpr int GAE_L = 16;
+
+template <int EB>
+__global__ void __launch_bounds__(1024) gae_kernel(const float* __restrict__ value, const float* __restrict__ reward,
+                                                   const uint8_t* __restrict__ terminal,
+                                                   const float* __restrict__ next_value,
+                                                   const uint8_t* __restrict__ next_done, int nt, int k, float gamma,
+                                                   float gl, int mode, float* __restrict__ adv,
+                                                   float* __restrict__ ret) {
+#pragma clang fp contract(off)
+  extern __shared__ double sm[];
+  const int S = blockDim.x / EB;
+  const int el = threadIdx.x % EB, seg = threadIdx.x / EB;
+  const int e = blockIdx.x * EB + el;
+  const bool ev = e < nt;
+  const int lo = seg * GAE_L;
+  double* smD = sm;
+  double* smC = sm + S * EB;
+
+  float v[GAE_L + 1], r[GAE_L];
+  uint8_t tm[GAE_L];
+#pragma unroll
+  for (int i = 0; i < GAE_L; ++i) {
+    const int t = lo + i;
+    const bool ok = ev && t < k;
+    const size_t idx = (size_t)e + (size_t)nt * t;
+    v[i] = ok ? value[idx] : 0.0f;
+    r[i] = ok ? reward[idx] : 0.0f;
+    // done flag that gates step t is terminal[t+1]; beyond the buffer it is next_done (ppo.jl:176)
+    tm[i] = ok ? ((t + 1 < k) ? terminal[idx + nt] : (next_done ? next_done[e] : (uint8_t)0)) : (uint8_t)0;
+  }
+  {
+    const int t = lo + GAE_L;
+    v[GAE_L] = (ev && t < k) ? value[(size_t)e + (size_t)nt * t] : 0.0f;
+  }
+  // the bootstrap value follows the LAST buffered step (ppo.jl:174 hcat(value, next_values'))
+  const float nv = (ev && next_value) ? next_value[e] : 0.0f;
+
+  // phase 1: compose the segment's affine map
+  double D = 0.0, Cc = 1.0;
+  double dl[GAE_L], cl[GAE_L];
+#pragma unroll
+  for (int i = GAE_L - 1; i >= 0; --i) {
+    const int t = lo + i;
+    const float vnext = (t + 1 < k) ? v[i + 1] : nv;
+    const double nonterm = 1.0 - (double)(tm[i] ? 1 : 0);
+    double delta = (double)r[i] + ((double)gamma * nonterm) * (double)vnext - (double)v[i];
+    double c = (double)gl * nonterm;
+    // compat (ppo.jl:66): the loop starts at k-1 (1-based) so the last slot keeps carry 0 and is defined as 0
+    const bool dead = (t >= k) || (mode == CRL_GAE_COMPAT && t == k - 1);
+    if (t >= k) { delta = 0.0; c = 1.0; }        // padding steps are the identity map
+    else if (dead) { delta = 0.0; c = 0.0; }
+    dl[i] = delta; cl[i] = c;
+    D = delta + c * D;
+    Cc = c * Cc;
+  }
+  smD[seg * EB + el] = D;
+  smC[seg * EB + el] = Cc;
+  __syncthreads();
+  // fold the segments above this one (later in time) into the incoming carry
+  double A = 0.0;
+  for (int s = S - 1; s > seg; --s) A = smD[s * EB + el] + smC[s * EB + el] * A;
+  // phase 2: replay from the carry, fused returns = advantages + value (ppo.jl:181)
+#pragma unroll
+  for (int i = GAE_L - 1; i >= 0; --i) {
+    const int t = lo + i;
+    A = dl[i] + (cl[i] * A);
+    if (ev && t < k) {
+      const size_t idx = (size_t)e + (size_t)nt * t;
+      const float a32 = (float)A;
+      adv[idx] = a32;
+      if (ret) ret[idx] = a32 + v[i];
+    }
+  }
+}
+
+int launch_gae(hipStream_t st, const float* value, const float* reward, const uint8_t* terminal,
+               const float* next_value, const uint8_t* next_done, int nt, int k, float gamma, float lambda, int mode,
+               float* adv, float* ret) {
+  if (nt <= 0 || k <= 0) { set_error("gae: empty input"); return 1; }
+  const int S = (k + GAE_L - 1) / GAE_L;
+  const float gl = gamma * lambda;  // Float32 product, as `γ * λ` with both T=Float32 (ppo.jl:68)
+  // enough blocks to cover 256 CUs: narrower env tiles when the shard is small
+  int EB = 64;
+  if (S * 64 > 1024 || (nt + 63) / 64 < 512) EB = 32;
+  if (S * EB > 1024) EB = 16;
+  if (S * EB > 1024) { set_error("gae: num_steps > 1024 is not supported"); return 1; }
+  const dim3 block(S * EB), grid((nt + EB - 1) / EB);
+  const size_t smem = sizeof(double) * 2 * S * EB;
+  if (EB == 64) hipLaunchKernelGGL(gae_kernel<64>, grid, block, smem, st, value, reward, terminal, next_value, next_done, nt, k, gamma, gl, mode, adv, ret);
+  else if (EB == 32) hipLaunchKernelGGL(gae_kernel<32>, grid, block, smem, st, value, reward, terminal, next_value, next_done, nt, k, gamma, gl, mode, adv, ret);
+  else hipLaunchKernelGGL(gae_kernel<16>, grid, block, smem, st, value, reward, terminal, next_value, next_done, nt, k, gamma, gl, mode, adv, ret);
+  CRL_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace crl

@@ -1,0 +1,116 @@
+// optim.hip — advantage statistics (ppo.jl:221) and Optimiser(ClipNorm(0.5), Adam(η)) (ppo.jl:93,250).
+#include "common.hpp"
+#include "ppo_ctx.hpp"
+
+namespace crl {
+
+// Σadv, Σadv² per minibatch of the current permutation, Float64, fixed-order two-level sum (reproducible).
+// One launch covers all num_minibatches slices; grid = (blocks_per_mb, nmb).
+__global__ void adv_sums_kernel(const float* __restrict__ adv, const int32_t* __restrict__ perm, int M,
+                                double* __restrict__ part /* [nmb][gridDim.x][2] */) {
+  const int mb = blockIdx.y;
+  double s = 0.0, s2 = 0.0;
+  for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < M; pos += gridDim.x * blockDim.x) {
+    const double a = (double)adv[perm[(size_t)mb * M + pos]];
+    s += a; s2 += a * a;
+  }
+  __shared__ double sm[2][16];
+  s = wave_sum(s); s2 = wave_sum(s2);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sm[0][w] = s; sm[1][w] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0, t2 = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { t += sm[0][i]; t2 += sm[1][i]; }
+    part[((size_t)mb * gridDim.x + blockIdx.x) * 2 + 0] = t;
+    part[((size_t)mb * gridDim.x + blockIdx.x) * 2 + 1] = t2;
+  }
+}
+__global__ void adv_sums_fold_kernel(const double* __restrict__ part, int nblk, int nmb, double* __restrict__ sums) {
+  const int mb = threadIdx.x;
+  if (mb >= nmb) return;
+  double t = 0.0, t2 = 0.0;
+  for (int b = 0; b < nblk; ++b) { t += part[((size_t)mb * nblk + b) * 2]; t2 += part[((size_t)mb * nblk + b) * 2 + 1]; }
+  sums[2 * mb] = t; sums[2 * mb + 1] = t2;
+}
+// mean / corrected std (StatsBase mean/std, ppo.jl:221) from the (all-reduced) sums; n = global minibatch size
+__global__ void adv_finish_kernel(const double* __restrict__ sums, int nmb, double n, double* __restrict__ ms) {
+  const int mb = threadIdx.x;
+  if (mb >= nmb) return;
+  const double mean = sums[2 * mb] / n;
+  double var = (sums[2 * mb + 1] - n * mean * mean) / (n - 1.0);
+  var = var > 0.0 ? var : 0.0;
+  ms[2 * mb] = (double)(float)mean;
+  ms[2 * mb + 1] = (double)(float)sqrt(var);
+}
+
+int launch_adv_stats_sums(crl_ppo* h) {
+  const int nblk = 64;
+  double* part = reinterpret_cast<double*>(h->gpart);  // gpart is idle between optimiser steps
+  ProfScope ps(h, CRL_K_ADV_STATS);
+  hipLaunchKernelGGL(adv_sums_kernel, dim3(nblk, h->dc.nmb), dim3(512), 0, h->stream, h->adv, h->perm, h->dc.M, part);
+  hipLaunchKernelGGL(adv_sums_fold_kernel, dim3(1), dim3(64), 0, h->stream, part, nblk, h->dc.nmb, h->adv_sums);
+  CRL_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+int launch_adv_stats_finish(crl_ppo* h) {
+  hipLaunchKernelGGL(adv_finish_kernel, dim3(1), dim3(64), 0, h->stream, h->adv_sums, h->dc.nmb,
+                     (double)h->dc.M * h->world, h->adv_ms);
+  CRL_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Flux 0.13.4 Optimiser(ClipNorm(thresh), Adam(η, (0.9, 0.999), 1e-8)) applied to each of the 12 parameter arrays
+// independently (Q9): one block per array, Float64 scalar math, Float32 state — oracle: orc_clipnorm_adam.
+// ------------------------------------------------------------------------------------------------------
+struct OptimArgs {
+  int off[13];
+  float* params; const float* grads; float* m; float* v; double* betap;
+  double eta, thresh;
+};
+
+__global__ void __launch_bounds__(256) clipnorm_adam_kernel(OptimArgs a) {
+#pragma clang fp contract(off)
+  const int arr = blockIdx.x;
+  const int lo = a.off[arr], hi = a.off[arr + 1];
+  __shared__ double sm[4];
+  double ss = 0.0;
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) { const double g = a.grads[i]; ss += g * g; }
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  ss = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+  const float nrm = (float)sqrt(ss);
+  const bool clip = (double)nrm > a.thresh;
+  const double sc = clip ? a.thresh / (double)nrm : 1.0;
+  const double b1 = 0.9, b2 = 0.999, epsn = 1e-8;
+  const double bp0 = a.betap[2 * arr], bp1 = a.betap[2 * arr + 1];
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    double g = (double)a.grads[i];
+    if (clip) g = (double)(float)(g * sc);
+    const float mi = (float)(b1 * (double)a.m[i] + (1 - b1) * g);
+    const float vi = (float)(b2 * (double)a.v[i] + (1 - b2) * g * g);
+    a.m[i] = mi; a.v[i] = vi;
+    const double delta = (double)mi / (1 - bp0) / (sqrt((double)vi / (1 - bp1)) + epsn) * a.eta;
+    a.params[i] = a.params[i] - (float)delta;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { a.betap[2 * arr] = bp0 * b1; a.betap[2 * arr + 1] = bp1 * b2; }
+}
+
+int launch_optim(crl_ppo* h, double eta) {
+  OptimArgs a;
+  const int hN = h->cfg.hidden, d = h->cfg.obs_dim, A = h->cfg.n_act;
+  const int sizes[12] = {hN * d, hN, hN * hN, hN, A * hN, A, hN * d, hN, hN * hN, hN, hN, 1};
+  a.off[0] = 0;
+  for (int i = 0; i < 12; ++i) a.off[i + 1] = a.off[i] + sizes[i];
+  a.params = h->params; a.grads = h->grads; a.m = h->adam_m; a.v = h->adam_v; a.betap = h->betap;
+  a.eta = eta; a.thresh = 0.5;
+  ProfScope ps(h, CRL_K_OPTIM);
+  hipLaunchKernelGGL(clipnorm_adam_kernel, dim3(12), dim3(256), 0, h->stream, a);
+  CRL_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace crl

@@ -1,0 +1,335 @@
+// policy.hip — policy/critic forward, categorical sampling, the on-device vectorised CartPole and the persistent
+// rollout loop (ppo.jl:21-45,123-166; multi_thread_env.jl:86-133).
+//
+// One wave owns a tile of 32 envs (the N dimension of v_mfma_f32_32x32x2_f32). Both 64x64 hidden layers run on
+// MFMA with the weight A-fragments staged once per launch in LDS and the activations chained register→register
+// (the C fragment of one layer is the B operand of the next, no LDS round trip). Envs never interact, so the whole
+// `for step in 1:num_steps` loop is ONE launch: 128 dependent steps per wave, no grid synchronisation.
+// Stores go to the (·, nt, k) buffer with env fastest: lanes 0-31 write 128/512 contiguous bytes per field per step.
+#include "common.hpp"
+#include "ppo_ctx.hpp"
+
+namespace crl {
+
+// ------------------------------------------------------------------------------------------------------
+// CartPoleEnv{Float32} step (RLEnvs 0.6.12 semantics; oracle/ppo_oracle.c:orc_cartpole_step is the restatement).
+// Contraction is off and the promotions to Float64 follow the reference expression (`4 / 3` is a Float64 literal),
+// so this is bit-identical to the CPU oracle.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sin_poly(float x) {
+  float x2 = x * x;
+  float p = __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, 2.7557319e-6f, -1.9841270e-4f), 8.3333333e-3f), -1.6666667e-1f);
+  return __builtin_fmaf(x * x2, p, x);
+}
+__device__ __forceinline__ float cos_poly(float x) {
+  float x2 = x * x;
+  float p = __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, 2.4801587e-5f, -1.3888889e-3f), 4.1666667e-2f), -0.5f);
+  return __builtin_fmaf(x2, p, 1.0f);
+}
+
+__device__ __forceinline__ bool cartpole_step(float (&s)[4], int& t, int action) {
+#pragma clang fp contract(off)
+  const float gravity = 9.8f, masspole = 0.1f, totalmass = 1.1f, halflength = 0.5f, pml = 0.05f;
+  const float forcemag = 10.0f, dt = 0.02f, ththr = 0.20943951f, xthr = 2.4f;
+  t += 1;
+  const float force = action == 1 ? forcemag : -forcemag;
+  const float xdot = s[1], theta = s[2], thetadot = s[3];
+  const float costheta = cos_poly(theta), sintheta = sin_poly(theta);
+  const float tmp = (force + (pml * (thetadot * thetadot)) * sintheta) / totalmass;
+  const float num = gravity * sintheta - costheta * tmp;
+  const double den = (double)halflength * (4.0 / 3.0 - (double)((masspole * (costheta * costheta)) / totalmass));
+  const double thetaacc = (double)num / den;
+  const double xacc = (double)tmp - (((double)pml * thetaacc) * (double)costheta) / (double)totalmass;
+  s[0] = s[0] + dt * xdot;
+  s[1] = (float)((double)s[1] + (double)dt * xacc);
+  s[2] = s[2] + dt * thetadot;
+  s[3] = (float)((double)s[3] + (double)dt * thetaacc);
+  return (fabsf(s[0]) > xthr) || (fabsf(s[2]) > ththr) || (t > 500);
+}
+
+__device__ __forceinline__ void cartpole_reset(float (&s)[4], uint64_t seed, uint32_t gid, uint64_t gstep, uint32_t stream) {
+#pragma clang fp contract(off)
+  u32x4 o = philox_env(seed, gid, gstep, stream);
+  s[0] = 0.1f * ((float)(o.x >> 8) * 0x1.0p-24f) - 0.05f;
+  s[1] = 0.1f * ((float)(o.y >> 8) * 0x1.0p-24f) - 0.05f;
+  s[2] = 0.1f * ((float)(o.z >> 8) * 0x1.0p-24f) - 0.05f;
+  s[3] = 0.1f * ((float)(o.w >> 8) * 0x1.0p-24f) - 0.05f;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// get_action / critic on caller-supplied observations (crl_policy_act) — ppo.jl:21-32,128
+// ------------------------------------------------------------------------------------------------------
+template <int D, int A>
+__global__ void __launch_bounds__(256) policy_act_kernel(const float* __restrict__ params, const float* __restrict__ obs,
+                                                         const double* __restrict__ u, int n, int32_t* __restrict__ action,
+                                                         float* __restrict__ logprob, float* __restrict__ value) {
+  using IA = NetImage<D, A, false>;
+  using IC = NetImage<D, 1, false>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* imgA = smem;
+  float* imgC = smem + IA::SIZE;
+  stage_net<D, A, false>(imgA, params, threadIdx.x, blockDim.x);
+  stage_net<D, 1, false>(imgC, params + NetParams<D, A>::SIZE, threadIdx.x, blockDim.x);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, hf = lane >> 5;
+  const int wpb = blockDim.x >> 6;
+  for (int tile = blockIdx.x * wpb + wave; tile * TILE < n; tile += gridDim.x * wpb) {
+    const int b = tile * TILE + j;
+    const bool ok = b < n;
+    float x[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) x[i] = ok ? obs[(size_t)D * b + i] : 0.0f;
+    f32x16 h1[2], h2[2];
+    float z[A], v[1], p[A], lp[A];
+    mlp_forward<D, A, false>(imgA, x, h1, h2, z, lane);
+    softmax_logsoftmax<A>(z, p, lp);
+    const int a = sample_weights<A>(p, ok ? u[b] : 0.0);
+    float lpa = lp[0];
+#pragma unroll
+    for (int i = 1; i < A; ++i) lpa = (a == i) ? lp[i] : lpa;
+    mlp_forward<D, 1, false>(imgC, x, h1, h2, v, lane);
+    if (ok && hf == 0) {
+      action[b] = a;
+      logprob[b] = lpa;
+      if (value) value[b] = v[0];
+    }
+  }
+}
+
+// logprob_actions — ppo.jl:34-45 (entropy is the element-wise matrix, Q3)
+template <int D, int A>
+__global__ void __launch_bounds__(256) logprob_actions_kernel(const float* __restrict__ params, const float* __restrict__ obs,
+                                                              const int32_t* __restrict__ actions, int n,
+                                                              float* __restrict__ logprob, float* __restrict__ entropy) {
+  using IA = NetImage<D, A, false>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  stage_net<D, A, false>(smem, params, threadIdx.x, blockDim.x);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, hf = lane >> 5;
+  const int wpb = blockDim.x >> 6;
+  for (int tile = blockIdx.x * wpb + wave; tile * TILE < n; tile += gridDim.x * wpb) {
+    const int b = tile * TILE + j;
+    const bool ok = b < n;
+    float x[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) x[i] = ok ? obs[(size_t)D * b + i] : 0.0f;
+    f32x16 h1[2], h2[2];
+    float z[A], p[A], lp[A];
+    mlp_forward<D, A, false>(smem, x, h1, h2, z, lane);
+    softmax_logsoftmax<A>(z, p, lp);
+    if (ok && hf == 0) {
+      const int a = actions[b];
+      float lpa = lp[0];
+#pragma unroll
+      for (int i = 1; i < A; ++i) lpa = (a == i) ? lp[i] : lpa;
+      logprob[b] = lpa;
+#pragma unroll
+      for (int i = 0; i < A; ++i) entropy[(size_t)A * b + i] = -(p[i] * lp[i]);
+    }
+  }
+  (void)IA::SIZE;
+}
+
+// critic(state(env)) for the bootstrap (ppo.jl:169-171; live only in fixed GAE mode, Q10)
+template <int D>
+__global__ void __launch_bounds__(256) value_kernel(const float* __restrict__ params_critic, const float* __restrict__ obs,
+                                                    int n, float* __restrict__ value) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  stage_net<D, 1, false>(smem, params_critic, threadIdx.x, blockDim.x);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, hf = lane >> 5;
+  const int wpb = blockDim.x >> 6;
+  for (int tile = blockIdx.x * wpb + wave; tile * TILE < n; tile += gridDim.x * wpb) {
+    const int b = tile * TILE + j;
+    const bool ok = b < n;
+    float x[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) x[i] = ok ? obs[(size_t)D * b + i] : 0.0f;
+    f32x16 h1[2], h2[2];
+    float v[1];
+    mlp_forward<D, 1, false>(smem, x, h1, h2, v, lane);
+    if (ok && hf == 0) value[b] = v[0];
+  }
+}
+
+// reset!(env) at construction + next_obs/next_done initialisation — ppo.jl:80-83,112-115
+__global__ void env_reset_kernel(DevCfg c, float* __restrict__ env_state, int32_t* __restrict__ env_t,
+                                 float* __restrict__ cur_obs, uint8_t* __restrict__ next_done,
+                                 float* __restrict__ ep_return, int32_t* __restrict__ ep_length, double* ep_stats) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e == 0) { ep_stats[0] = ep_stats[1] = ep_stats[2] = ep_stats[3] = 0.0; }
+  if (e >= c.nt) return;
+  float s[4];
+  cartpole_reset(s, c.seed, c.env_id_offset + (uint32_t)e, 0, 2);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { env_state[4 * e + i] = s[i]; cur_obs[4 * e + i] = s[i]; }
+  env_t[e] = 0; next_done[e] = 0; ep_return[e] = 0.0f; ep_length[e] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// The rollout loop — ppo.jl:123-166 — one launch for all num_steps.
+// ------------------------------------------------------------------------------------------------------
+struct RolloutArgs {
+  DevCfg c;
+  const float* params;
+  float* obs; int32_t* action; float* logprob; float* reward; uint8_t* terminal; float* value;
+  float* env_state; int32_t* env_t; float* cur_obs; uint8_t* next_done; float* ep_return; int32_t* ep_length;
+  double* ep_stats;
+  uint64_t iteration;
+};
+
+template <int A>
+__global__ void __launch_bounds__(256) rollout_cartpole_kernel(RolloutArgs a) {
+  constexpr int D = 4;
+  using IA = NetImage<D, A, false>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* imgA = smem;
+  float* imgC = smem + IA::SIZE;
+  stage_net<D, A, false>(imgA, a.params, threadIdx.x, blockDim.x);
+  stage_net<D, 1, false>(imgC, a.params + NetParams<D, A>::SIZE, threadIdx.x, blockDim.x);
+  __syncthreads();
+  const DevCfg& c = a.c;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, hf = lane >> 5;
+  const int wpb = blockDim.x >> 6;
+  const int e = (blockIdx.x * wpb + wave) * TILE + j;
+  const bool ok = e < c.nt;
+  const bool writer = ok && hf == 0;
+  const int ee = ok ? e : 0;
+  const uint32_t gid = c.env_id_offset + (uint32_t)ee;
+
+  float s[4], co[4];
+  {
+    const float4 sv = reinterpret_cast<const float4*>(a.env_state)[ee];
+    const float4 cv = reinterpret_cast<const float4*>(a.cur_obs)[ee];
+    s[0] = sv.x; s[1] = sv.y; s[2] = sv.z; s[3] = sv.w;
+    co[0] = cv.x; co[1] = cv.y; co[2] = cv.z; co[3] = cv.w;
+  }
+  int t_env = a.env_t[ee];
+  uint8_t nd = a.next_done[ee];
+  float ep_ret = a.ep_return[ee];
+  int ep_len = a.ep_length[ee];
+  double st_n = 0.0, st_ret = 0.0, st_len = 0.0, st_max = 0.0;
+
+  for (int step = 0; step < c.k; ++step) {
+    const uint64_t gstep = a.iteration * (uint64_t)c.k + (uint64_t)step;
+    const size_t b = (size_t)ee + (size_t)c.nt * step;
+    ep_len += 1;                                                     // ppo.jl:125
+    f32x16 h1[2], h2[2];
+    float z[A], v[1], p[A], lp[A];
+    mlp_forward<D, A, false>(imgA, co, h1, h2, z, lane);             // ppo.jl:127 get_action
+    softmax_logsoftmax<A>(z, p, lp);
+    const double u = u53(philox_env(c.seed, gid, gstep, 0));
+    const int act = sample_weights<A>(p, u);
+    float lpa = lp[0];
+#pragma unroll
+    for (int i = 1; i < A; ++i) lpa = (act == i) ? lp[i] : lpa;
+    mlp_forward<D, 1, false>(imgC, co, h1, h2, v, lane);             // ppo.jl:128
+    const bool done = cartpole_step(s, t_env, act);                  // ppo.jl:130
+    const float rew = done ? 0.0f : 1.0f;                            // ppo.jl:132 (RLEnvs: reward 0 on the terminal step)
+    if (writer) {                                                    // ppo.jl:133-140 Buffer.add!
+      reinterpret_cast<float4*>(a.obs)[b] = make_float4(co[0], co[1], co[2], co[3]);
+      a.action[b] = act; a.logprob[b] = lpa; a.reward[b] = rew; a.terminal[b] = nd; a.value[b] = v[0];
+    }
+    co[0] = s[0]; co[1] = s[1]; co[2] = s[2]; co[3] = s[3];         // ppo.jl:143 next_obs (before reset!, Q7)
+    nd = done ? 1 : 0;                                               // ppo.jl:144
+    ep_ret += rew;                                                   // ppo.jl:145
+    if (done) {                                                      // ppo.jl:147-165
+      if (writer) { st_n += 1.0; st_ret += (double)ep_ret; st_len += (double)ep_len; st_max = fmax(st_max, (double)ep_ret); }
+      ep_ret = 0.0f; ep_len = 0;
+      cartpole_reset(s, c.seed, gid, gstep, 1);                      // ppo.jl:164 reset!(env)
+      t_env = 0;
+      if (!c.stale_obs) { co[0] = s[0]; co[1] = s[1]; co[2] = s[2]; co[3] = s[3]; }
+    }
+  }
+  if (writer) {
+    reinterpret_cast<float4*>(a.env_state)[e] = make_float4(s[0], s[1], s[2], s[3]);
+    reinterpret_cast<float4*>(a.cur_obs)[e] = make_float4(co[0], co[1], co[2], co[3]);
+    a.env_t[e] = t_env; a.next_done[e] = nd; a.ep_return[e] = ep_ret; a.ep_length[e] = ep_len;
+  }
+  // episode statistics of this rollout ("Episode Statistics" record, aggregated): one atomic set per wave
+  st_n = wave_sum(st_n); st_ret = wave_sum(st_ret); st_len = wave_sum(st_len);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) st_max = fmax(st_max, __shfl_xor(st_max, o, 64));
+  if (lane == 0 && st_n > 0.0) {
+    atomicAdd(&a.ep_stats[0], st_n); atomicAdd(&a.ep_stats[1], st_ret); atomicAdd(&a.ep_stats[2], st_len);
+    // return_max: episode returns are non-negative integers ≤ 501 here, so the f64 bit pattern orders like u64
+    atomicMax(reinterpret_cast<unsigned long long*>(&a.ep_stats[3]), (unsigned long long)__double_as_longlong(st_max));
+  }
+}
+
+template <int D, int A>
+static size_t act_smem() { return sizeof(float) * (NetImage<D, A, false>::SIZE + NetImage<D, 1, false>::SIZE); }
+
+static int check_shape(crl_ppo* h) {
+  if (h->cfg.obs_dim != 4 || h->cfg.n_act != 2 || h->cfg.hidden != 64) {
+    set_error("this build of libcleanrl_hip supports obs_dim=4, n_act=2, hidden=64 (2x64 MLP) only");
+    return 1;
+  }
+  return 0;
+}
+
+static int grid_for_tiles(int n, int wpb) {
+  int tiles = (n + TILE - 1) / TILE;
+  int blocks = (tiles + wpb - 1) / wpb;
+  return blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+}
+
+int launch_policy_act(crl_ppo* h, const float* obs_d, const double* u_d, int n, int32_t* action_d, float* logprob_d,
+                      float* value_d) {
+  if (check_shape(h)) return 1;
+  const int wpb = 4;
+  const size_t smem = act_smem<4, 2>();
+  hipLaunchKernelGGL((policy_act_kernel<4, 2>), dim3(grid_for_tiles(n, wpb)), dim3(64 * wpb), smem, h->stream,
+                     h->params, obs_d, u_d, n, action_d, logprob_d, value_d);
+  CRL_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_logprob_actions(crl_ppo* h, const float* obs_d, const int32_t* act_d, int n, float* logprob_d, float* ent_d) {
+  if (check_shape(h)) return 1;
+  const int wpb = 4;
+  const size_t smem = sizeof(float) * NetImage<4, 2, false>::SIZE;
+  hipLaunchKernelGGL((logprob_actions_kernel<4, 2>), dim3(grid_for_tiles(n, wpb)), dim3(64 * wpb), smem, h->stream, h->params, obs_d, act_d, n, logprob_d, ent_d);
+  CRL_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_next_value(crl_ppo* h) {
+  if (check_shape(h)) return 1;
+  const int wpb = 4;
+  const size_t smem = sizeof(float) * NetImage<4, 1, false>::SIZE;
+  hipLaunchKernelGGL((value_kernel<4>), dim3(grid_for_tiles(h->dc.nt, wpb)), dim3(64 * wpb), smem, h->stream, h->params + h->Pa, h->cur_obs, h->dc.nt,
+                     h->next_value);
+  CRL_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_env_reset(crl_ppo* h) {
+  if (h->cfg.env_kind != CRL_ENV_CARTPOLE) { set_error("crl_env_reset: on-device env is CartPole only"); return 1; }
+  hipLaunchKernelGGL(env_reset_kernel, dim3((h->dc.nt + 255) / 256), dim3(256), 0, h->stream, h->dc, h->env_state, h->env_t,
+                     h->cur_obs, h->next_done, h->ep_return, h->ep_length, h->ep_stats);
+  CRL_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_rollout(crl_ppo* h) {
+  if (check_shape(h)) return 1;
+  if (h->cfg.env_kind != CRL_ENV_CARTPOLE) { set_error("crl_rollout_run: on-device env is CartPole only"); return 1; }
+  CRL_HIP_CHECK(hipMemsetAsync(h->ep_stats, 0, 4 * sizeof(double), h->stream));
+  RolloutArgs a;
+  a.c = h->dc; a.params = h->params;
+  a.obs = h->obs; a.action = h->action; a.logprob = h->logprob; a.reward = h->reward; a.terminal = h->terminal; a.value = h->value;
+  a.env_state = h->env_state; a.env_t = h->env_t; a.cur_obs = h->cur_obs; a.next_done = h->next_done;
+  a.ep_return = h->ep_return; a.ep_length = h->ep_length; a.ep_stats = h->ep_stats; a.iteration = (uint64_t)h->iteration;
+  // one wave per 32 envs; spread waves over all 256 CUs before stacking them inside a block
+  const int tiles = (h->dc.nt + TILE - 1) / TILE;
+  int wpb = tiles >= 2048 ? 4 : (tiles >= 1024 ? 2 : 1);
+  const int blocks = (tiles + wpb - 1) / wpb;
+  ProfScope ps(h, CRL_K_ROLLOUT);
+  const size_t smem = act_smem<4, 2>();
+  hipLaunchKernelGGL((rollout_cartpole_kernel<2>), dim3(blocks), dim3(64 * wpb), smem, h->stream, a);
+  CRL_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace crl

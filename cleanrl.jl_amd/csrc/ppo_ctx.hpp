@@ -1,0 +1,113 @@
+// ppo_ctx.hpp — the opaque crl_ppo handle: every buffer of the path resident in HBM, one HIP stream.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/cleanrl_hip.h"
+
+namespace crl {
+
+void set_error(const std::string& msg);
+
+#define CRL_HIP_CHECK(expr)                                                                                   \
+  do {                                                                                                        \
+    hipError_t _e = (expr);                                                                                   \
+    if (_e != hipSuccess) {                                                                                   \
+      crl::set_error(std::string(#expr) + " failed: " + hipGetErrorString(_e) + " (" + __FILE__ + ":" +      \
+                     std::to_string(__LINE__) + ")");                                                         \
+      return 1;                                                                                               \
+    }                                                                                                         \
+  } while (0)
+
+// Device-side mirror of the hyper-parameters kernels need
+struct DevCfg {
+  int nt, k, B, M, nmb, D, A;
+  float gamma, lambda, clip, ent_coeff, v_coef;
+  int clip_vloss, gae_mode, env_kind, stale_obs;
+  uint32_t env_id_offset;
+  uint64_t seed;
+};
+
+struct ProfSlot {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  double total_ms = 0;
+  int64_t launches = 0;
+};
+
+}  // namespace crl
+
+struct crl_ppo {
+  crl_ppo_config cfg;
+  crl::DevCfg dc;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int64_t P = 0, Pa = 0, Pc = 0;  // total / actor / critic parameter counts
+  int64_t iteration = 0;
+  int64_t num_updates = 1;
+
+  // rollout buffer, Julia (·, nt, k) column-major (replay_buffer.jl:15-18)
+  float* obs = nullptr; int32_t* action = nullptr; float* logprob = nullptr; float* reward = nullptr;
+  uint8_t* terminal = nullptr; float* value = nullptr; float* adv = nullptr; float* ret = nullptr;
+  // loop state (ppo.jl:106-115)
+  float* env_state = nullptr; int32_t* env_t = nullptr; float* cur_obs = nullptr; uint8_t* next_done = nullptr;
+  float* ep_return = nullptr; int32_t* ep_length = nullptr; float* next_value = nullptr;
+  double* ep_stats = nullptr;  // [4] episodes, return_sum, length_sum, return_max
+  // optimiser
+  float* params = nullptr; float* grads = nullptr; float* adam_m = nullptr; float* adam_v = nullptr;
+  double* betap = nullptr;     // [24]
+  int32_t* perm = nullptr;
+  // update workspace
+  int update_blocks = 0;       // blocks per role
+  float* gpart = nullptr;      // [2 roles][update_blocks][Pmax] per-block gradient partials
+  double* lpart = nullptr;     // [2 roles][update_blocks][4] per-block loss partial sums
+  double* adv_sums = nullptr;  // [nmb][2] Σadv, Σadv² (+ [nmb] count) — all-reduced under DP
+  double* adv_ms = nullptr;    // [nmb][2] mean, std
+  float* newv = nullptr;       // [M] critic outputs of the current minibatch (value-loss fix-up path)
+  double* vfix = nullptr;      // [8] u, count(u>q), -, flag, sticky flag
+  crl_ppo_stats* stats_dev = nullptr;  // [epochs*nmb]
+  float* comm_buf = nullptr;   // [P + 8] gradient (+ loss scalars) message for the all-reduce
+  // staging for host-pointer calls
+  void* stage = nullptr; size_t stage_bytes = 0;
+  void* pinned = nullptr; size_t pinned_bytes = 0;
+
+  // RCCL (loaded lazily; world_size 1 = no communicator)
+  void* comm = nullptr; int world = 1, rank = 0;
+
+  bool prof = false;
+  crl::ProfSlot prof_slots[CRL_K_COUNT];
+};
+
+namespace crl {
+int ensure_stage(crl_ppo* h, size_t bytes);
+
+struct ProfScope {
+  crl_ppo* h; int id; hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(crl_ppo* h_, int id_) : h(h_), id(id_) {
+    if (h->prof) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, h->stream); }
+  }
+  ~ProfScope() {
+    if (h->prof) { (void)hipEventRecord(b, h->stream); h->prof_slots[id].pending.emplace_back(a, b); }
+  }
+};
+
+// kernel launchers (each in its own translation unit)
+int launch_gae(hipStream_t st, const float* value, const float* reward, const uint8_t* terminal,
+               const float* next_value, const uint8_t* next_done, int nt, int k, float gamma, float lambda, int mode,
+               float* adv, float* ret);
+int launch_policy_act(crl_ppo* h, const float* obs_d, const double* u_d, int n, int32_t* action_d, float* logprob_d,
+                      float* value_d);
+int launch_logprob_actions(crl_ppo* h, const float* obs_d, const int32_t* act_d, int n, float* logprob_d, float* ent_d);
+int launch_env_reset(crl_ppo* h);
+int launch_rollout(crl_ppo* h);
+int launch_next_value(crl_ppo* h);
+int launch_shuffle(crl_ppo* h, uint64_t epoch_id);
+int launch_adv_stats_sums(crl_ppo* h);
+int launch_adv_stats_finish(crl_ppo* h);
+int launch_update(crl_ppo* h, int mb);
+int launch_update_finish(crl_ppo* h, int mb, crl_ppo_stats* stats_slot);
+int launch_optim(crl_ppo* h, double eta);
+int comm_allreduce(crl_ppo* h, void* buf, size_t count, bool is_double);
+void comm_destroy(crl_ppo* h);
+}  // namespace crl

@@ -1,0 +1,494 @@
+// update.hip — one PPO optimiser step's loss + gradient (ppo.jl:202-244 and the Zygote pullbacks behind it).
+//
+// Work split: actor and critic are independent networks that meet only in the scalar loss, so blocks alternate roles
+// (even = actor, odd = critic); each wave walks 32-sample tiles of the minibatch:
+//   gather by permutation → forward (MFMA, weights in LDS as A-fragments, activations chained in registers)
+//   → per-sample loss terms and output cotangent → backward:
+//       dh = Wᵀ·δ        MFMA, B operand = δ straight from its C-fragment registers
+//       dW2ᵀ += h1·δ2ᵀ   MFMA with K = samples: both operands transposed through a wave-private LDS tile [64][36]
+//       dW1, dW3, biases  "lane = row" VALU sums over the same transposed tiles
+// dW accumulates in registers across all tiles of the wave; waves → block through LDS; blocks → a per-block partial in
+// HBM; a second kernel sums the partials in fixed order (bitwise reproducible; no float atomics).
+// 196 MFMAs of 32x32x2 per (tile, network): 192 of them are the three 64x64 GEMMs (fwd, dW, dX).
+//
+// Value loss (ppo.jl:231-237, Q4): max.(u, q_b) with the SCALAR u = mean(v - R²) needs u before any critic
+// cotangent exists. q_b ≥ 0, so whenever u ≤ 0 every max picks q_b: the kernel speculates on that, and
+// reduce_kernel raises a flag if u > 0; only then do vfix_count_kernel and a critic-only exact pass rerun.
+#include "common.hpp"
+#include "ppo_ctx.hpp"
+
+namespace crl {
+
+constexpr int TSTRIDE = 36;  // floats per row of the transposed tile: 144 B keeps b128 reads aligned and conflict-free
+
+struct UpdateArgs {
+  DevCfg c;
+  const float* params;
+  const float* states; const int32_t* actions; const float* logprobs; const float* values;
+  const float* advantages; const float* returns;
+  const int32_t* perm;
+  const double* adv_ms;   // [nmb][2] mean, std of the (global) minibatch advantages
+  const double* vfix;     // [8] u, #{u > q}, -, flag, sticky flag
+  float* gpart; double* lpart; float* newv;
+  int mb, mode, blocks_per_role, gstride;
+  double Mglobal;         // minibatch size over all ranks (the 1/M of every mean)
+};
+
+template <int D, int A, int ROLE>
+__device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, float* smem) {
+  constexpr int NOUT = ROLE == 0 ? A : 1;
+  using I = NetImage<D, NOUT, true>;
+  using P = NetParams<D, NOUT>;
+  constexpr int SCR = 64 * TSTRIDE + TILE * D + A * TILE;
+  const DevCfg& c = a.c;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hf = lane >> 5;
+  float* img = smem;
+  float* T = smem + I::SIZE + wave * SCR;
+  float* xs = T + 64 * TSTRIDE;
+  float* d3s = xs + TILE * D;
+  const float* p = a.params + (ROLE ? NetParams<D, A>::SIZE : 0);
+  stage_net<D, NOUT, true>(img, p, tid, blockDim.x);
+  __syncthreads();
+
+  f32x16 dW2t[2][2];  // dW2ᵀ accumulators: [mj = h1-row block][ni = δ2-row block]
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dW2t[x][y][r] = 0.0f;
+  float dW1acc[D], dW3acc[NOUT], db3acc[NOUT], db1acc = 0.0f, db2acc = 0.0f;
+#pragma unroll
+  for (int i = 0; i < D; ++i) dW1acc[i] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NOUT; ++i) { dW3acc[i] = 0.0f; db3acc[i] = 0.0f; }
+  double ls0 = 0.0, ls1 = 0.0;
+
+  const int M = c.M;
+  const double invM = 1.0 / a.Mglobal;
+  const int ntiles = (M + TILE - 1) / TILE;
+  const int nwaves = a.blocks_per_role * (blockDim.x >> 6);
+  // role constants
+  float mean_f = 0.0f; double denom = 1.0;
+  if (ROLE == 0) { mean_f = (float)a.adv_ms[2 * a.mb]; denom = (double)(float)a.adv_ms[2 * a.mb + 1] + 1e-8; }
+  const float eps = c.clip, lo = 1.0f - c.clip, hi = 1.0f + c.clip;
+  const bool exact = a.mode == 1;
+  const float u_exact = exact ? (float)a.vfix[0] : 0.0f;
+  const double nwin = exact ? a.vfix[1] : 0.0;
+  const double entk = (double)c.ent_coeff / ((double)A * a.Mglobal);
+  const double vk = (double)c.v_coef * 0.5 * invM;
+
+  for (int tile = rb * (blockDim.x >> 6) + wave; tile < ntiles; tile += nwaves) {
+    const int pos = tile * TILE + j;
+    const bool ok = pos < M;
+    const int smp = ok ? a.perm[(size_t)a.mb * M + pos] : 0;
+    float x[D];
+    if (D == 4) {
+      const float4 xv = reinterpret_cast<const float4*>(a.states)[smp];
+      x[0] = xv.x; x[1] = xv.y; x[2] = xv.z; x[3] = xv.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < D; ++i) x[i] = a.states[(size_t)D * smp + i];
+    }
+    f32x16 h1[2], h2[2];
+    float out[NOUT], dout[NOUT];
+    mlp_forward<D, NOUT, true>(img, x, h1, h2, out, lane);
+
+    if constexpr (ROLE == 0) {
+      // policy loss + entropy (ppo.jl:213,219-228,242)
+      float pr[A], lp[A];
+      softmax_logsoftmax<A>(out, pr, lp);
+      const int act = a.actions[smp];
+      float nlp = lp[0];
+#pragma unroll
+      for (int i = 1; i < A; ++i) nlp = (act == i) ? lp[i] : nlp;
+      double Hs = 0.0;
+#pragma unroll
+      for (int i = 0; i < A; ++i) Hs += (double)(-(pr[i] * lp[i]));
+      const double Ahat = (double)(a.advantages[smp] - mean_f) / denom;
+      const float ratio = expf(nlp - a.logprobs[smp]);
+      const float rc = fminf(fmaxf(ratio, lo), hi);
+      const double pg1 = -Ahat * (double)ratio, pg2 = -Ahat * (double)rc;
+      double dnlp, pg;
+      if (pg1 > pg2) { pg = pg1; dnlp = pg1; }
+      else { pg = pg2; dnlp = (ratio >= lo && ratio <= hi) ? pg1 : 0.0; }
+      dnlp *= invM;
+#pragma unroll
+      for (int i = 0; i < A; ++i)
+        dout[i] = (float)(dnlp * ((i == act ? 1.0 : 0.0) - (double)pr[i]) + entk * (double)pr[i] * ((double)lp[i] + Hs));
+      if (ok && hf == 0) { ls0 += pg; ls1 += Hs; }
+    } else {
+      // value loss (ppo.jl:214,231-240)
+      const float v = out[0], R = a.returns[smp], ov = a.values[smp];
+      double dv, term;
+      if (c.clip_vloss) {
+        const float dvv = v - ov;
+        const float cl = fminf(fmaxf(dvv, -eps), eps);
+        const float vc = ov + cl;
+        const float q = (vc - R) * (vc - R);
+        const bool q_wins = exact ? !(u_exact > q) : true;  // max.(u, q): ties → q
+        term = q_wins ? (double)q : (double)u_exact;
+        const double inner = (q_wins && dvv >= -eps && dvv <= eps) ? 2.0 * (double)(vc - R) : 0.0;
+        dv = vk * (nwin * invM + inner);
+      } else {
+        const float e = v - R;
+        term = (double)(e * e);
+        dv = vk * 2.0 * (double)e;
+      }
+      dout[0] = (float)dv;
+      if (ok && hf == 0) {
+        ls0 += (double)(v - R * R);
+        ls1 += term;
+        if (!exact) a.newv[pos] = v;
+      }
+    }
+    if (!ok) {
+#pragma unroll
+      for (int i = 0; i < NOUT; ++i) dout[i] = 0.0f;
+    }
+
+    // ---- backward ------------------------------------------------------------------------------------
+    // (1) h2ᵀ, the output cotangents and x into the wave-private scratch
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) T[(32 * mt + rowmap(r, hf)) * TSTRIDE + j] = h2[mt][r];
+    if (hf == 0) {
+#pragma unroll
+      for (int i = 0; i < NOUT; ++i) d3s[i * TILE + j] = dout[i];
+#pragma unroll
+      for (int i = 0; i < D; ++i) xs[j * D + i] = x[i];
+    }
+    wave_lds_fence();
+    // (2) lane = row: dW3[a][lane] += Σ_s h2[lane][s]·δ3[a][s];  db3[a] += Σ_s δ3[a][s]
+    {
+      f32x4 row[8];
+      const f32x4* tr = reinterpret_cast<const f32x4*>(T + lane * TSTRIDE);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) row[q] = tr[q];
+#pragma unroll
+      for (int i = 0; i < NOUT; ++i) {
+        const f32x4* dr = reinterpret_cast<const f32x4*>(d3s + i * TILE);
+        float accw = 0.0f, accb = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const f32x4 dv4 = dr[q];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { accw = __builtin_fmaf(row[q][e], dv4[e], accw); accb += dv4[e]; }
+        }
+        dW3acc[i] += accw; db3acc[i] += accb;
+      }
+    }
+    // (3) δ2 = (W3ᵀ·δ3) ⊙ (1 − h2²) in C-fragment registers
+    f32x16 d2[2];
+    {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d2[mt][r] = 0.0f;
+#pragma unroll
+      for (int i = 0; i < NOUT; ++i) {
+        const f32x4* w = reinterpret_cast<const f32x4*>(img + I::W3 + i * 64 + hf * 32);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const f32x4 wv = w[q];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int idx = q * 4 + e;
+            d2[idx >> 4][idx & 15] = __builtin_fmaf(wv[e], dout[i], d2[idx >> 4][idx & 15]);
+          }
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d2[mt][r] *= (1.0f - h2[mt][r] * h2[mt][r]);
+    }
+    wave_lds_fence();
+    // (4) δ2ᵀ → scratch; db2; B-fragments (δ2 rows on lanes, samples along k: smp(s,hf) = s + 16hf)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) T[(32 * mt + rowmap(r, hf)) * TSTRIDE + j] = d2[mt][r];
+    wave_lds_fence();
+    f32x4 bfr[2][4];
+    {
+      const f32x4* tr = reinterpret_cast<const f32x4*>(T + lane * TSTRIDE);
+      float s = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { const f32x4 t4 = tr[q]; s += (t4[0] + t4[1]) + (t4[2] + t4[3]); }
+      db2acc += s;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const f32x4* fr = reinterpret_cast<const f32x4*>(T + (32 * ni + j) * TSTRIDE + 16 * hf);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bfr[ni][q] = fr[q];
+      }
+    }
+    wave_lds_fence();
+    // h1ᵀ → scratch; A-fragments streamed; dW2ᵀ[mj][ni] += h1[mj-block]·δ2[ni-block]ᵀ over the tile's 32 samples
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) T[(32 * mt + rowmap(r, hf)) * TSTRIDE + j] = h1[mt][r];
+    wave_lds_fence();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(T + (j) * TSTRIDE + 16 * hf + 4 * q);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(T + (32 + j) * TSTRIDE + 16 * hf + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dW2t[0][0] = mfma32(a0[e], bfr[0][q][e], dW2t[0][0]);
+        dW2t[0][1] = mfma32(a0[e], bfr[1][q][e], dW2t[0][1]);
+        dW2t[1][0] = mfma32(a1[e], bfr[0][q][e], dW2t[1][0]);
+        dW2t[1][1] = mfma32(a1[e], bfr[1][q][e], dW2t[1][1]);
+      }
+    }
+    // (5) dh1 = W2ᵀ·δ2 (A-fragments of W2ᵀ from LDS, B = δ2 registers); δ1 = dh1 ⊙ (1 − h1²)
+    f32x16 d1[2];
+    {
+      f32x16 c0, c1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { c0[r] = 0.0f; c1[r] = 0.0f; }
+      const f32x4* w0 = reinterpret_cast<const f32x4*>(img + I::WB2) + lane;
+      const f32x4* w1 = reinterpret_cast<const f32x4*>(img + I::WB2 + 2048) + lane;
+#pragma unroll
+      for (int s4 = 0; s4 < 8; ++s4) {
+        const f32x4 fa = w0[s4 * 64], fb = w1[s4 * 64];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int s = s4 * 4 + e;
+          const float b = d2[s >> 4][s & 15];
+          c0 = mfma32(fa[e], b, c0);
+          c1 = mfma32(fb[e], b, c1);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        d1[0][r] = c0[r] * (1.0f - h1[0][r] * h1[0][r]);
+        d1[1][r] = c1[r] * (1.0f - h1[1][r] * h1[1][r]);
+      }
+    }
+    wave_lds_fence();
+    // (6) δ1ᵀ → scratch; lane = row: db1, dW1[lane][c] += Σ_s δ1[lane][s]·x[s][c]
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) T[(32 * mt + rowmap(r, hf)) * TSTRIDE + j] = d1[mt][r];
+    wave_lds_fence();
+    {
+      const f32x4* tr = reinterpret_cast<const f32x4*>(T + lane * TSTRIDE);
+      float sb = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const f32x4 t4 = tr[q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int s = q * 4 + e;
+          sb += t4[e];
+          if (D == 4) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + s * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dW1acc[i] = __builtin_fmaf(t4[e], xv[i], dW1acc[i]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < D; ++i) dW1acc[i] = __builtin_fmaf(t4[e], xs[s * D + i], dW1acc[i]);
+          }
+        }
+      }
+      db1acc += sb;
+    }
+    wave_lds_fence();
+  }
+
+  // ---- block reduction: waves add their accumulators into one LDS image in flat Flux order ------------------
+  __syncthreads();
+  float* R = smem;  // the weight image is dead now
+  for (int i = tid; i < P::SIZE; i += blockDim.x) R[i] = 0.0f;
+  double* lsum = reinterpret_cast<double*>(smem + 6144);  // inside the dead weight image, past R (all LDS stays dynamic)
+  ls0 = wave_sum(ls0); ls1 = wave_sum(ls1);
+  if (lane == 0) { lsum[wave] = ls0; lsum[8 + wave] = ls1; }
+  __syncthreads();
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int mj = 0; mj < 2; ++mj)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            R[P::W2 + (32 * ni + j) + H * (32 * mj + rowmap(r, hf))] += dW2t[mj][ni][r];
+#pragma unroll
+      for (int i = 0; i < D; ++i) R[P::W1 + lane + H * i] += dW1acc[i];
+      R[P::B1 + lane] += db1acc;
+      R[P::B2 + lane] += db2acc;
+#pragma unroll
+      for (int i = 0; i < NOUT; ++i) R[P::W3 + i + NOUT * lane] += dW3acc[i];
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) R[P::B3 + i] += db3acc[i];
+      }
+    }
+    __syncthreads();
+  }
+  float* gp = a.gpart + ((size_t)ROLE * a.blocks_per_role + rb) * a.gstride;
+  for (int i = tid; i < P::SIZE; i += blockDim.x) gp[i] = R[i];
+  if (tid == 0) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { s0 += lsum[w]; s1 += lsum[8 + w]; }
+    double* lp = a.lpart + ((size_t)ROLE * a.blocks_per_role + rb) * 2;
+    lp[0] = s0; lp[1] = s1;
+  }
+}
+
+template <int D, int A>
+__global__ void __launch_bounds__(256, 2) update_kernel(UpdateArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (a.mode == 1) {
+    if (a.vfix[3] == 0.0) return;  // speculation held: nothing to redo
+    update_role<D, A, 1>(a, blockIdx.x, smem);
+  } else if ((blockIdx.x & 1) == 0) {
+    update_role<D, A, 0>(a, blockIdx.x >> 1, smem);
+  } else {
+    update_role<D, A, 1>(a, blockIdx.x >> 1, smem);
+  }
+}
+
+// Σ over per-block partials in fixed order → flat gradient (+ the loss sums appended for the all-reduce message)
+// msg layout: [P gradient floats][pg_sum, ent_sum, u_sum, q_sum as floats]
+__global__ void reduce_kernel(const float* __restrict__ gpart, const double* __restrict__ lpart, int blocks_per_role,
+                              int gstride, int Pa, int Pc, float* __restrict__ msg, const double* __restrict__ vfix,
+                              int mode) {
+  if (mode == 1 && vfix[3] == 0.0) return;
+  const int P = Pa + Pc;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < P) {
+    const int role = i >= Pa;
+    if (mode == 1 && role == 0) return;
+    const float* g = gpart + (size_t)role * blocks_per_role * gstride + (role ? i - Pa : i);
+    float s = 0.0f;
+    for (int b = 0; b < blocks_per_role; ++b) s += g[(size_t)b * gstride];
+    msg[i] = s;
+  } else if (i < P + 4) {
+    const int which = i - P;  // 0 pg, 1 ent (actor) ; 2 u, 3 q (critic)
+    const int role = which >> 1;
+    if (mode == 1 && role == 0) return;
+    const double* l = lpart + (size_t)role * blocks_per_role * 2 + (which & 1);
+    double s = 0.0;
+    for (int b = 0; b < blocks_per_role; ++b) s += l[b * 2];
+    msg[i] = (float)s;
+  }
+}
+
+// "Training Statistics" (ppo.jl:247) from the (all-reduced) sums; raises the value-loss speculation flag
+__global__ void stats_kernel(const float* __restrict__ msg, int P, DevCfg c, double Mglobal, const double* __restrict__ adv_ms,
+                             int mb, double* __restrict__ vfix, crl_ppo_stats* __restrict__ out, int mode) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (mode == 1 && vfix[3] == 0.0) return;
+  const double pg = (double)msg[P] / Mglobal;
+  const double ent = (double)(float)((double)msg[P + 1] / ((double)c.A * Mglobal));
+  const double u = (double)(float)((double)msg[P + 2] / Mglobal);
+  double vl;
+  if (mode == 0) {
+    vl = 0.5 * (double)(float)((double)msg[P + 3] / Mglobal);
+    vfix[0] = u;
+    vfix[3] = (c.clip_vloss && u > 0.0) ? 1.0 : 0.0;
+    if (vfix[3] != 0.0) vfix[4] = 1.0;  // sticky: lets a data-parallel run fail loudly (no exact pass there yet)
+    out->n_unclipped_wins = 0.0;
+  } else {
+    vl = 0.5 * (double)(float)((double)msg[P + 3] / Mglobal);
+    out->n_unclipped_wins = vfix[1];
+  }
+  out->pg_loss = pg; out->entropy_loss = ent; out->v_loss = vl; out->u_value = u;
+  out->loss = pg - (double)(c.ent_coeff * (float)ent) + (double)c.v_coef * vl;
+  out->adv_mean = (double)(float)adv_ms[2 * mb]; out->adv_std = (double)(float)adv_ms[2 * mb + 1];
+}
+
+// #{b : u > q_b} over the minibatch (only when the speculation flag is up)
+__global__ void vfix_count_kernel(DevCfg c, const int32_t* __restrict__ perm, int mb, const float* __restrict__ newv,
+                                  const float* __restrict__ values, const float* __restrict__ returns, double* vfix) {
+  if (vfix[3] == 0.0) return;
+  __shared__ double sm[4];
+  const float u = (float)vfix[0];
+  double cnt = 0.0;
+  for (int pos = threadIdx.x; pos < c.M; pos += blockDim.x) {
+    const int smp = perm[(size_t)mb * c.M + pos];
+    const float v = newv[pos], ov = values[smp], R = returns[smp];
+    const float cl = fminf(fmaxf(v - ov, -c.clip), c.clip);
+    const float vc = ov + cl;
+    const float q = (vc - R) * (vc - R);
+    cnt += (u > q) ? 1.0 : 0.0;
+  }
+  cnt = wave_sum(cnt);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sm[w];
+    vfix[1] = s;
+  }
+}
+
+static int run_update(crl_ppo* h, int mb, int mode) {
+  UpdateArgs a;
+  a.c = h->dc; a.params = h->params;
+  a.states = h->obs; a.actions = h->action; a.logprobs = h->logprob; a.values = h->value;
+  a.advantages = h->adv; a.returns = h->ret; a.perm = h->perm; a.adv_ms = h->adv_ms; a.vfix = h->vfix;
+  a.gpart = h->gpart; a.lpart = h->lpart; a.newv = h->newv;
+  a.mb = mb; a.mode = mode; a.blocks_per_role = h->update_blocks; a.gstride = (int)h->Pa;
+  a.Mglobal = (double)h->dc.M * h->world;
+  constexpr int SCR = 64 * TSTRIDE + TILE * 4 + 2 * TILE;
+  const size_t smem = sizeof(float) * (NetImage<4, 2, true>::SIZE + 4 * SCR);
+  const int grid = mode == 1 ? h->update_blocks : 2 * h->update_blocks;
+  hipLaunchKernelGGL((update_kernel<4, 2>), dim3(grid), dim3(256), smem, h->stream, a);
+  CRL_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_update(crl_ppo* h, int mb) {
+  if (h->cfg.obs_dim != 4 || h->cfg.n_act != 2 || h->cfg.hidden != 64) {
+    set_error("this build of libcleanrl_hip supports obs_dim=4, n_act=2, hidden=64 (2x64 MLP) only");
+    return 1;
+  }
+  const int P = (int)h->P;
+  const int slot = mb;  // caller indexes stats_dev
+  (void)slot;
+  {
+    ProfScope ps(h, CRL_K_UPDATE);
+    if (run_update(h, mb, 0)) return 1;
+  }
+  {
+    ProfScope ps(h, CRL_K_REDUCE);
+    hipLaunchKernelGGL(reduce_kernel, dim3((P + 4 + 255) / 256), dim3(256), 0, h->stream, h->gpart, h->lpart, h->update_blocks,
+                       (int)h->Pa, (int)h->Pa, (int)h->Pc, h->comm_buf, h->vfix, 0);
+    CRL_HIP_CHECK(hipGetLastError());
+  }
+  if (h->world > 1) {
+    ProfScope ps(h, CRL_K_ALLREDUCE);
+    if (comm_allreduce(h, h->comm_buf, (size_t)P + 4, false)) return 1;
+  }
+  return 0;
+}
+
+// second half of a step: statistics, the (rare) exact value-loss pass, gradient hand-off
+int launch_update_finish(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
+  const int P = (int)h->P;
+  const double Mg = (double)h->dc.M * h->world;
+  hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(64), 0, h->stream, h->comm_buf, P, h->dc, Mg, h->adv_ms, mb, h->vfix, stats_slot, 0);
+  CRL_HIP_CHECK(hipGetLastError());
+  if (h->cfg.clip_value_loss && h->world == 1) {
+    // early-exit launches unless stats_kernel raised the flag (u > 0)
+    hipLaunchKernelGGL(vfix_count_kernel, dim3(1), dim3(1024), 0, h->stream, h->dc, h->perm, mb, h->newv, h->value, h->ret, h->vfix);
+    CRL_HIP_CHECK(hipGetLastError());
+    if (run_update(h, mb, 1)) return 1;
+    hipLaunchKernelGGL(reduce_kernel, dim3((P + 4 + 255) / 256), dim3(256), 0, h->stream, h->gpart, h->lpart, h->update_blocks,
+                       (int)h->Pa, (int)h->Pa, (int)h->Pc, h->comm_buf, h->vfix, 1);
+    CRL_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(64), 0, h->stream, h->comm_buf, P, h->dc, Mg, h->adv_ms, mb, h->vfix, stats_slot, 1);
+    CRL_HIP_CHECK(hipGetLastError());
+  }
+  CRL_HIP_CHECK(hipMemcpyAsync(h->grads, h->comm_buf, sizeof(float) * P, hipMemcpyDeviceToDevice, h->stream));
+  return 0;
+}
+
+}  // namespace crl

@@ -1,0 +1,170 @@
+/*
+ * cleanrl_hip.h — C ABI of libcleanrl_hip.so: the MI355X-native PPO rollout + GAE + update hot path.
+ *
+ * Drop-in boundary for sash-a/CleanRL.jl `src/algorithms/ppo.jl`. The reference has no FFI today (it is pure
+ * Julia); each entry point below names the reference function / lines it replaces, and INTEGRATION.md shows the
+ * `ccall` a maintainer adds on the Julia side. Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Conventions
+ *  - every call returns 0 on success, non-zero on error; crl_last_error() gives the message (thread-local).
+ *    No exception crosses the boundary. Julia wrapper: `rc == 0 || error(unsafe_string(crl_last_error()))`.
+ *  - host pointers are borrowed for the duration of the call only (Julia: GC.@preserve); device memory is owned by
+ *    the library behind the opaque crl_ppo handle.
+ *  - layouts are Julia column-major, passed without copies: obs (obs_dim, n); buffers (nt, k); flat sample index
+ *    b = e + nt*t (ppo.jl:184-189). Actions are 0-based int32 here (Julia side adds 1); terminals are uint8
+ *    (widen the env's BitArray to Vector{Bool} first, multi_thread_env.jl:18).
+ *  - parameters travel as ONE flat float vector in Flux.params(actor, critic) order (ppo.jl:196):
+ *    actor W1(h,obs) b1(h) W2(h,h) b2(h) W3(A,h) b3(A), critic W1 b1 W2 b2 W3(1,h) b3(1); W is (out,in) col-major.
+ *  - calls on one handle must be serialised by the caller; work is asynchronous on the handle's HIP stream until
+ *    crl_sync() or a call that copies results to the host.
+ */
+#ifndef CLEANRL_HIP_H
+#define CLEANRL_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRL_VERSION 100 /* 0.1.0 */
+
+/* gae_mode */
+#define CRL_GAE_COMPAT 0 /* ppo.jl:66 loop k-1:-1:1, carry 0, slot k defined as 0 (upstream leaves it uninitialised) */
+#define CRL_GAE_FIXED 1  /* loop from k with the bootstrap value (CleanRL-python semantics) */
+/* env_kind */
+#define CRL_ENV_CARTPOLE 0 /* CartPoleEnv(T=Float32, max_steps=500) ppo.jl:82 */
+#define CRL_ENV_EXTERNAL 2 /* envs stepped by the caller: crl_policy_act + crl_rollout_store */
+/* shuffle mode */
+#define CRL_SHUFFLE_FISHER_YATES 0 /* exact serial Fisher–Yates on device (ppo.jl:194 semantics) */
+#define CRL_SHUFFLE_BLOCKED 1      /* parallel keyed bijection + per-block Fisher–Yates in LDS (throughput path) */
+/* rollout / state fields for crl_ppo_read / crl_ppo_write */
+enum crl_field {
+  CRL_F_OBS = 0,      /* float  (obs_dim, nt, k)  replay_buffer.jl:15-18 / ppo.jl:96 */
+  CRL_F_ACTION = 1,   /* int32  (nt, k) 0-based   ppo.jl:97  */
+  CRL_F_LOGPROB = 2,  /* float  (nt, k)           ppo.jl:98  */
+  CRL_F_REWARD = 3,   /* float  (nt, k)           ppo.jl:99  */
+  CRL_F_TERMINAL = 4, /* uint8  (nt, k)           ppo.jl:100 */
+  CRL_F_VALUE = 5,    /* float  (nt, k)           ppo.jl:101 */
+  CRL_F_ADVANTAGE = 6,/* float  (nt, k)           ppo.jl:180 */
+  CRL_F_RETURN = 7,   /* float  (nt, k)           ppo.jl:181 */
+  CRL_F_PERM = 8,     /* int32  (nt*k) 0-based    ppo.jl:194 b_inds */
+  CRL_F_PARAMS = 9,   /* float  (P)               ppo.jl:196 */
+  CRL_F_GRADS = 10,   /* float  (P) gradient of the last minibatch (after all-reduce, before ClipNorm) ppo.jl:202 */
+  CRL_F_ADAM_M = 11,  /* float  (P) */
+  CRL_F_ADAM_V = 12,  /* float  (P) */
+  CRL_F_ENV_STATE = 13, /* float (obs_dim, nt) env-internal state */
+  CRL_F_CUR_OBS = 14,   /* float (obs_dim, nt) next_obs of ppo.jl:114,143 */
+  CRL_F_NEXT_DONE = 15, /* uint8 (nt)          next_done of ppo.jl:115,144 */
+  CRL_F_ENV_T = 16,     /* int32 (nt) steps since reset */
+  CRL_F_BETAP = 17      /* double (24) Adam running beta powers per array */
+};
+
+/* Mirror of PPOConfig (ppo.jl:1-19) + the shapes the reference hard-codes (networks.jl:36, CartPole) */
+typedef struct crl_ppo_config {
+  int64_t total_timesteps;      /* ppo.jl:2 */
+  int32_t num_steps;            /* ppo.jl:3 */
+  int32_t num_envs;             /* ppo.jl:4  — envs owned by THIS handle (one data-parallel shard) */
+  int32_t num_minibatches;      /* ppo.jl:5 */
+  int32_t update_epochs;        /* ppo.jl:6 */
+  float lr;                     /* ppo.jl:8 */
+  float gamma;                  /* ppo.jl:9 */
+  float gae_lambda;             /* ppo.jl:10 */
+  float clip_coef;              /* ppo.jl:12 */
+  float ent_coeff;              /* ppo.jl:13 */
+  float v_coef;                 /* ppo.jl:14 */
+  int32_t normalize_advantages; /* ppo.jl:16 — must be 1 (0 is an error upstream too, ppo.jl:219-222) */
+  int32_t clip_value_loss;      /* ppo.jl:17 */
+  int32_t anneal_lr;            /* ppo.jl:18 */
+  int32_t obs_dim;              /* 4 */
+  int32_t n_act;                /* 2 */
+  int32_t hidden;               /* 64 (networks.jl:36) */
+  int32_t gae_mode;             /* CRL_GAE_* */
+  int32_t env_kind;             /* CRL_ENV_* */
+  int32_t stale_obs;            /* 1 = ppo.jl:143-164 behaviour: policy sees the terminal obs after a reset */
+  int32_t env_id_offset;        /* global id of local env 0 (rank * num_envs under data parallelism) */
+  int32_t shuffle_mode;         /* CRL_SHUFFLE_* */
+  uint64_t seed;
+} crl_ppo_config;
+
+/* "Training Statistics" record of ppo.jl:247, one per optimiser step */
+typedef struct crl_ppo_stats {
+  double loss, pg_loss, v_loss, entropy_loss;
+  double adv_mean, adv_std, u_value, n_unclipped_wins;
+} crl_ppo_stats;
+
+/* "Episode Statistics" of ppo.jl:147-162 aggregated over one rollout */
+typedef struct crl_episode_stats {
+  double episodes, return_sum, length_sum, return_max;
+} crl_episode_stats;
+
+typedef struct crl_ppo crl_ppo;
+
+int32_t crl_version(void);
+const char* crl_last_error(void);
+int32_t crl_device_count(int32_t* n);
+
+/* ppo.jl:75-115 setup: buffers, optimiser state, env state — all resident in HBM on `device`. */
+int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out);
+int32_t crl_ppo_destroy(crl_ppo* h);
+int32_t crl_ppo_param_count(const crl_ppo* h, int64_t* n);
+int32_t crl_sync(crl_ppo* h);
+
+/* Raw field access (parity tests, checkpointing, Julia-side inspection). nbytes must match the field size. */
+int32_t crl_ppo_write(crl_ppo* h, int32_t field, const void* host, size_t nbytes);
+int32_t crl_ppo_read(crl_ppo* h, int32_t field, void* host, size_t nbytes);
+
+/* get_action(obs, actor) + critic(obs) — ppo.jl:21-32,127-128. obs (obs_dim,n) f32, u[n] uniform f64 in [0,1)
+ * (the rand() of StatsBase.sample); outputs action[n] (0-based), logprob[n], value[n] (may be NULL). */
+int32_t crl_policy_act(crl_ppo* h, const float* obs, const double* u, int32_t n, int32_t* action, float* logprob,
+                       float* value);
+/* logprob_actions(obs, actor, actions) — ppo.jl:34-45. entropy is the (n_act,n) matrix -p.*logp. */
+int32_t crl_logprob_actions(crl_ppo* h, const float* obs, const int32_t* actions, int32_t n, float* logprob,
+                            float* entropy);
+/* gae.(eachrow(...)) — ppo.jl:48-73,173-181 on host arrays: value/reward (nt,k) f32, terminal (nt,k) u8,
+ * next_value[nt], next_done[nt]; writes adv (nt,k) and ret (nt,k) (ret may be NULL). Stateless. */
+int32_t crl_gae(int32_t device, const float* value, const float* reward, const uint8_t* terminal,
+                const float* next_value, const uint8_t* next_done, int32_t nt, int32_t k, float gamma, float lambda,
+                int32_t mode, float* adv, float* ret);
+
+/* Buffer.add!(rb, transition) — replay_buffer.jl:23-37 / ppo.jl:133-140, external-env path: slot = step (0-based). */
+int32_t crl_rollout_store(crl_ppo* h, int32_t step, const float* obs, const int32_t* action, const float* logprob,
+                          const float* reward, const uint8_t* terminal, const float* value);
+
+/* reset!(env); next_obs = state(env) — ppo.jl:112-115 for the on-device vectorised env. */
+int32_t crl_env_reset(crl_ppo* h);
+/* The whole `for step in 1:num_steps` loop — ppo.jl:123-166 — in one launch (on-device env + policy + sampling). */
+int32_t crl_rollout_run(crl_ppo* h);
+int32_t crl_episode_stats_read(crl_ppo* h, crl_episode_stats* out);
+/* bootstrap + advantages + returns — ppo.jl:169-181 — on the resident buffer. */
+int32_t crl_compute_gae(crl_ppo* h);
+/* b_inds = shuffle(b_inds) — ppo.jl:194. epoch_id keys the counter-based stream. */
+int32_t crl_shuffle(crl_ppo* h, uint64_t epoch_id);
+/* per-minibatch advantage mean/std of the current permutation (ppo.jl:221), all num_minibatches at once;
+ * all-reduced across ranks when a communicator is attached. Must follow crl_shuffle / a CRL_F_PERM write. */
+int32_t crl_adv_stats(crl_ppo* h);
+/* One `for start in 1:minibatch_size:batch_size` body — ppo.jl:197-251: loss, gradient, (all-reduce), per-array
+ * ClipNorm(0.5) + Adam(eta). apply_update=0 stops after the gradient (parity tests). stats may be NULL (no sync). */
+int32_t crl_ppo_update_minibatch(crl_ppo* h, int32_t mb, double eta, int32_t apply_update, crl_ppo_stats* stats);
+/* n_iters passes of the ppo.jl:117-253 loop body, fully on device. stats (may be NULL) receives
+ * update_epochs*num_minibatches records of the LAST iteration. */
+int32_t crl_ppo_iterate(crl_ppo* h, int32_t n_iters, crl_ppo_stats* stats);
+int32_t crl_ppo_iteration(const crl_ppo* h, int64_t* it);
+
+/* Data parallelism over num_envs: one RCCL communicator per handle (one process per GPU). The 128-byte id comes
+ * from crl_comm_unique_id on rank 0 and is broadcast by the host launcher. Gradients (+ advantage statistics) are
+ * all-reduced once per optimiser step (ppo.jl:250 cadence) and averaged; ClipNorm/Adam then run replicated. */
+int32_t crl_comm_unique_id(uint8_t id[128]);
+int32_t crl_comm_init(crl_ppo* h, const uint8_t id[128], int32_t world_size, int32_t rank);
+
+/* Profiling: HIP-event timing of each kernel class on the handle's stream (bench.py roofline). */
+enum crl_kernel_id { CRL_K_ROLLOUT = 0, CRL_K_GAE = 1, CRL_K_SHUFFLE = 2, CRL_K_ADV_STATS = 3, CRL_K_UPDATE = 4,
+                     CRL_K_REDUCE = 5, CRL_K_OPTIM = 6, CRL_K_ALLREDUCE = 7, CRL_K_COUNT = 8 };
+int32_t crl_prof_enable(crl_ppo* h, int32_t on);
+int32_t crl_prof_read(crl_ppo* h, int32_t kernel_id, double* total_ms, int64_t* launches);
+int32_t crl_prof_reset(crl_ppo* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

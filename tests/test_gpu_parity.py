@@ -1,0 +1,291 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+Bars (BASELINE.json north_star): bit-exact action indices / permutations / integer fields; float32 results within
+1e-5 relative. GAE is additionally expected bit-exact (Float64 accumulation on both sides)."""
+import numpy as np
+import pytest
+
+import oraclelib as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def crl():
+    import cleanrl_jl_amd as crl
+    assert crl.device_count() >= 1, "HIP library loaded but no GPU visible"
+    return crl
+
+
+def make_agent(crl, nt=8, k=128, params=None, **kw):
+    cfg = crl.PPOConfig(num_envs=nt, num_steps=k, total_timesteps=nt * k * 10, **{a: b for a, b in kw.items() if a in
+                        ("num_minibatches", "update_epochs", "clip_value_loss", "anneal_lr", "lr", "clip_coef", "ent_coeff", "v_coef")})
+    shape = {a: b for a, b in kw.items() if a in ("gae_mode", "shuffle_mode", "stale_obs", "env_id_offset", "seed")}
+    return crl.Agent(cfg, params=params, **shape)
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3)) if a.size else 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nt,k", [(1, 1), (1, 2), (3, 5), (8, 128), (33, 17), (64, 16), (100, 129), (4096, 128)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_gae_matches_oracle(crl, nt, k, mode):
+    rng = np.random.default_rng(nt * 1000 + k)
+    value = np.asfortranarray((rng.standard_normal((nt, k)) * 10).astype(np.float32))
+    reward = np.asfortranarray((rng.random((nt, k)) > 0.02).astype(np.float32))
+    term = np.asfortranarray((rng.random((nt, k)) < 0.02).astype(np.uint8))
+    nv = (rng.standard_normal(nt) * 10).astype(np.float32); nd = (rng.random(nt) < 0.1).astype(np.uint8)
+    adv_o, ret_o = O.gae_batch(value, reward, term, nv, nd, 0.99, 0.95, mode)
+    adv_g, ret_g = crl._lib.gae_host(value, reward, term, nv, nd, 0.99, 0.95, mode)
+    mism = np.sum(adv_o != adv_g)
+    assert mism <= adv_o.size * 1e-6, f"{mism} of {adv_o.size} advantages differ bitwise"
+    assert rel_err(adv_g, adv_o) < 1e-6 and rel_err(ret_g, ret_o) < 1e-6
+
+
+def test_gae_single_env_api_and_edges(crl):
+    v = [1, 2, 3, 4, 5]; r = [1, 1, 1, 1]; t = [0, 0, 1, 0, 0]
+    a = crl.gae(v, r, t, 0.5, 0.5)
+    assert a.tolist() == [0.75, -1.0, 0.0, 0.0]
+    a = crl.gae(v, r, t, 0.5, 0.5, mode=crl._lib.GAE_FIXED)
+    assert a.tolist() == [0.75, -1.0, -0.125, -0.5]
+    assert crl.gae([1.0], [], [0], 0.99, 0.95).shape == (0,)       # empty rollout
+    with pytest.raises(ValueError):
+        crl.gae([1, 2], [1, 1], [0, 0], 0.99, 0.95)                  # ragged input
+
+
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 100, 4096])
+def test_policy_act_matches_oracle(crl, n):
+    rng = np.random.default_rng(n)
+    agent = make_agent(crl)
+    cfg = O.make_config()
+    params = O.orthogonal_params(cfg, 3)
+    params += (0.05 * rng.standard_normal(params.shape)).astype(np.float32)
+    off = O.param_offsets(cfg)
+    params[off[4]:off[5]] *= 30  # spread the logits so both actions occur with non-trivial probabilities
+    agent.set_params(params)
+    obs = np.asfortranarray((rng.standard_normal((4, n)) * np.array([[1.0], [1.0], [0.1], [1.0]])).astype(np.float32))
+    u = rng.random(n)
+    a_o, lp_o, v_o, margin = O.get_action(cfg, params, obs, u)
+    a_g, lp_g, v_g = agent.handle.policy_act(obs, u)
+    safe = margin > 1e-6
+    assert np.array_equal(a_g[safe], a_o[safe]), "action indices must be bit-exact away from CDF knots"
+    assert safe.mean() > 0.99
+    same = a_g == a_o
+    assert rel_err(lp_g[same], lp_o[same]) < RTOL
+    assert rel_err(v_g, v_o) < RTOL
+    # 1-based wrapper like the reference
+    a1, lp1 = crl.get_action(obs, agent.actor, u=u)
+    assert np.array_equal(a1, a_g + 1) and np.array_equal(lp1, lp_g)
+    agent.close()
+
+
+def test_logprob_actions_matches_oracle(crl):
+    rng = np.random.default_rng(11)
+    agent = make_agent(crl)
+    cfg = O.make_config()
+    params = O.orthogonal_params(cfg, 4) + (0.1 * rng.standard_normal(O.lib().orc_param_count(cfg))).astype(np.float32)
+    agent.set_params(params)
+    n = 257
+    obs = np.asfortranarray(rng.standard_normal((4, n)).astype(np.float32))
+    acts = rng.integers(0, 2, n).astype(np.int32)
+    lp_o, ent_o = O.logprob_actions(cfg, params, obs, acts)
+    lp_g, ent_g = crl.logprob_actions(obs, agent.actor, acts + 1)
+    assert rel_err(lp_g, lp_o) < RTOL and rel_err(ent_g, ent_o) < RTOL and ent_g.shape == (2, n)
+    with pytest.raises(TypeError):
+        crl.logprob_actions(obs, agent.actor, acts.astype(np.int64))
+    agent.close()
+
+
+# ---------------------------------------------------------------------------------------------------------
+def _oracle_state(nt, k, params, **kw):
+    cfg = O.make_config(num_envs=nt, num_steps=k, **kw)
+    st = O.State(cfg)
+    st.params[:] = params
+    st.env_init()
+    return cfg, st
+
+
+@pytest.mark.parametrize("nt,stale", [(8, 1), (8, 0), (70, 1)])
+def test_rollout_matches_oracle(crl, nt, stale):
+    k = 128
+    agent = make_agent(crl, nt=nt, k=k, stale_obs=stale)
+    params = agent.get_params()
+    cfg, st = _oracle_state(nt, k, params, stale_obs=stale)
+    h = agent.handle
+    h.env_reset()
+    assert np.array_equal(h.read(crl._lib.F_CUR_OBS), st.cur_obs), "reset stream must match bit for bit"
+    h.rollout_run(); st.rollout()
+    act_g, act_o = h.read(crl._lib.F_ACTION), st.action
+    assert np.array_equal(act_g, act_o), f"{np.sum(act_g != act_o)} actions differ"
+    assert np.array_equal(h.read(crl._lib.F_TERMINAL), st.terminal)
+    assert np.array_equal(h.read(crl._lib.F_REWARD), st.reward)
+    assert np.array_equal(h.read(crl._lib.F_OBS), st.obs), "env dynamics are bit-exact by construction"
+    assert rel_err(h.read(crl._lib.F_LOGPROB), st.logprob) < RTOL
+    assert rel_err(h.read(crl._lib.F_VALUE), st.value) < RTOL
+    assert np.array_equal(h.read(crl._lib.F_NEXT_DONE), st.next_done)
+    assert np.array_equal(h.read(crl._lib.F_ENV_STATE), st.env_state)
+    es = h.episode_stats(); n_ep, ret_sum, len_sum = st.episode_stats
+    assert (es["episodes"], es["return_sum"], es["length_sum"]) == (n_ep, ret_sum, len_sum)
+    h.compute_gae(); st.compute_gae()
+    assert rel_err(h.read(crl._lib.F_ADVANTAGE), st.adv) < RTOL and rel_err(h.read(crl._lib.F_RETURN), st.ret) < RTOL
+    agent.close(); st.close()
+
+
+def _inject_batch(crl, agent, st, rng, ret_scale=10.0):
+    """Same synthetic rollout buffer into the GPU handle and the oracle state."""
+    nt, k = st.cfg.num_envs, st.cfg.num_steps
+    st.obs[:] = rng.standard_normal((4, nt, k)).astype(np.float32)
+    st.action[:] = rng.integers(0, 2, (nt, k))
+    st.logprob[:] = (np.log(0.5) + 0.3 * rng.standard_normal((nt, k))).astype(np.float32)
+    st.value[:] = rng.standard_normal((nt, k)).astype(np.float32) * (1.0 if ret_scale > 1 else 0.05)
+    st.adv[:] = (2 * rng.standard_normal((nt, k))).astype(np.float32)
+    st.ret[:] = (ret_scale * rng.standard_normal((nt, k))).astype(np.float32)
+    st.perm[:] = rng.permutation(nt * k).astype(np.int32)
+    h = agent.handle; F = crl._lib
+    for f, a in ((F.F_OBS, st.obs), (F.F_ACTION, st.action), (F.F_LOGPROB, st.logprob), (F.F_VALUE, st.value),
+                 (F.F_ADVANTAGE, st.adv), (F.F_RETURN, st.ret), (F.F_PERM, st.perm)):
+        h.write(f, a)
+
+
+def _grad_close(g_gpu, g_orc, off, tol=RTOL):
+    for i in range(12):
+        a, b = g_gpu[off[i]:off[i + 1]].astype(np.float64), g_orc[off[i]:off[i + 1]].astype(np.float64)
+        err = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12)
+        assert err < tol, f"gradient array {i}: rel L2 error {err:.3e}"
+
+
+@pytest.mark.parametrize("nt,k,ret_scale,clipv", [(8, 128, 10.0, True), (8, 128, 0.05, True), (8, 128, 3.0, False),
+                                                   (64, 128, 10.0, True), (37, 64, 10.0, True)])
+def test_update_gradient_matches_oracle(crl, nt, k, ret_scale, clipv):
+    """ret_scale=0.05 drives u = mean(v - R²) > 0: the speculative value-loss pass must be redone exactly (Q4)."""
+    if (nt * k) % 4:
+        pytest.skip("batch not divisible")
+    rng = np.random.default_rng(nt + k)
+    cfgo = O.make_config(num_envs=nt, num_steps=k, clip_value_loss=clipv)
+    params = O.orthogonal_params(cfgo, 5) + (0.05 * rng.standard_normal(O.lib().orc_param_count(cfgo))).astype(np.float32)
+    off = O.param_offsets(cfgo)
+    if ret_scale < 1:
+        params[off[11]] = 0.3
+    agent = make_agent(crl, nt=nt, k=k, params=params, clip_value_loss=clipv)
+    st = O.State(cfgo); st.params[:] = params
+    _inject_batch(crl, agent, st, rng, ret_scale)
+    h = agent.handle
+    h.adv_stats()
+    M = nt * k // 4
+    for mb in (0, 3):
+        gs = h.update_minibatch(mb, 2.5e-4, apply_update=False)
+        g_gpu = h.read(crl._lib.F_GRADS)
+        g_orc, so = O.loss_grad(cfgo, params, st.obs.reshape(4, -1, order="F"), st.action, st.logprob, st.value, st.adv, st.ret,
+                                st.perm[mb * M:(mb + 1) * M])
+        if ret_scale < 1 and clipv:
+            assert so["n_unclipped_wins"] > 0 and gs["n_unclipped_wins"] == so["n_unclipped_wins"]
+        for key in ("loss", "pg_loss", "v_loss", "entropy_loss"):
+            assert abs(gs[key] - so[key]) <= RTOL * max(1.0, abs(so[key])), (key, gs[key], so[key])
+        assert abs(gs["adv_mean"] - so["adv_mean"]) < 1e-6 and abs(gs["adv_std"] - so["adv_std"]) < 1e-5 * so["adv_std"]
+        _grad_close(g_gpu, g_orc, off)
+    agent.close(); st.close()
+
+
+def test_optimizer_step_matches_oracle(crl):
+    rng = np.random.default_rng(21)
+    nt, k = 8, 128
+    cfgo = O.make_config(num_envs=nt, num_steps=k)
+    params = O.orthogonal_params(cfgo, 6)
+    agent = make_agent(crl, nt=nt, k=k, params=params)
+    st = O.State(cfgo); st.params[:] = params
+    _inject_batch(crl, agent, st, rng)
+    h = agent.handle
+    h.adv_stats()
+    m = np.zeros_like(params); v = np.zeros_like(params); betap = np.array([0.9, 0.999] * 12)
+    p_ref = params.copy()
+    for step, mb in enumerate((0, 1, 2)):
+        h.update_minibatch(mb, 2.5e-4 * (1 - 0.1 * step), apply_update=True)
+        g = h.read(crl._lib.F_GRADS).copy()
+        O.clipnorm_adam(cfgo, p_ref, g, m, v, betap, 2.5e-4 * (1 - 0.1 * step))
+        assert np.array_equal(h.read(crl._lib.F_PARAMS), p_ref), "ClipNorm+Adam is Float64 scalar math: expect bit parity"
+        assert np.array_equal(h.read(crl._lib.F_ADAM_M), m) and np.array_equal(h.read(crl._lib.F_ADAM_V), v)
+        assert np.allclose(h.read(crl._lib.F_BETAP), betap, rtol=1e-15)
+    agent.close(); st.close()
+
+
+def test_shuffle_fisher_yates_matches_oracle(crl):
+    agent = make_agent(crl, nt=8, k=128, shuffle_mode=0, seed=77)
+    h = agent.handle
+    ref = np.arange(1024, dtype=np.int32)
+    for ep in range(3):  # cumulative like b_inds = shuffle(b_inds) (ppo.jl:194)
+        h.shuffle(ep); ref = O.shuffle_fy(ref, 77, ep)
+        assert np.array_equal(h.read(crl._lib.F_PERM), ref)
+    agent.close()
+
+
+@pytest.mark.parametrize("nt,k", [(8, 128), (37, 64), (4096, 128)])
+def test_shuffle_bijection_is_a_permutation(crl, nt, k):
+    agent = make_agent(crl, nt=nt, k=k, shuffle_mode=1)
+    h = agent.handle
+    h.shuffle(5); p1 = h.read(crl._lib.F_PERM)
+    h.shuffle(5); p2 = h.read(crl._lib.F_PERM)
+    h.shuffle(6); p3 = h.read(crl._lib.F_PERM)
+    B = nt * k
+    assert np.array_equal(np.sort(p1), np.arange(B)) and np.array_equal(p1, p2) and not np.array_equal(p1, p3)
+    # crude mixing check: each minibatch slice draws from the whole index range
+    q = p1[:B // 4].astype(np.float64)
+    assert abs(q.mean() / B - 0.5) < 0.05 and np.mean(p1 == np.arange(B)) < 0.01
+    agent.close()
+
+
+@pytest.mark.parametrize("n_iters", [1, 3])
+def test_full_iteration_matches_oracle(crl, n_iters):
+    """C1 (BASELINE configs[0]): num_envs=8, num_steps=128 — whole ppo.jl:117-253 loop body, exact Fisher–Yates."""
+    nt, k = 8, 128
+    agent = make_agent(crl, nt=nt, k=k, shuffle_mode=0)
+    params = agent.get_params()
+    cfgo, st = _oracle_state(nt, k, params)
+    h = agent.handle
+    h.env_reset()
+    for it in range(n_iters):
+        gs = h.iterate(1)
+        os_ = st.iterate(10, gen_perm=True)
+        assert np.array_equal(h.read(crl._lib.F_PERM), st.perm)
+        acts = h.read(crl._lib.F_ACTION)
+        assert np.array_equal(acts, st.action), f"iteration {it}: {np.sum(acts != st.action)} actions differ"
+        assert rel_err(h.read(crl._lib.F_ADVANTAGE), st.adv) < RTOL
+        for a, b in zip(gs, os_):
+            for key in ("loss", "pg_loss", "v_loss", "entropy_loss"):
+                assert abs(a[key] - b[key]) <= 2e-5 * max(1.0, abs(b[key])), (it, key, a[key], b[key])
+        pg, po = h.read(crl._lib.F_PARAMS), st.params
+        assert np.max(np.abs(pg - po)) < 2e-5, np.max(np.abs(pg - po))
+    assert h.iteration == n_iters
+    agent.close(); st.close()
+
+
+def test_errors_are_reported_not_thrown(crl):
+    with pytest.raises(crl.CrlError, match="normalize_advantages"):
+        crl.Agent(crl.PPOConfig(normalize_advantages=False))
+    with pytest.raises(crl.CrlError, match="divisible"):
+        crl.Agent(crl.PPOConfig(num_envs=3, num_steps=5, num_minibatches=4))
+    with pytest.raises(crl.CrlError, match="2x64"):
+        crl.Agent(crl.PPOConfig(), hidden=256)
+    agent = make_agent(crl)
+    with pytest.raises(crl.CrlError, match="out of range"):
+        agent.handle.update_minibatch(9, 1e-3)
+    agent.close()
+
+
+# ---- BASELINE full size: properties that do not need the oracle to be fast --------------------------------
+def test_full_size_gae_and_scan_linearity(crl):
+    nt, k = 65536, 128
+    rng = np.random.default_rng(0)
+    value = np.asfortranarray((rng.standard_normal((nt, k)) * 10).astype(np.float32))
+    reward = np.asfortranarray((rng.random((nt, k)) > 0.02).astype(np.float32))
+    term = np.asfortranarray((rng.random((nt, k)) < 0.02).astype(np.uint8))
+    adv, ret = crl._lib.gae_host(value, reward, term, None, None, 0.99, 0.95, 0)
+    adv_o, ret_o = O.gae_batch(value, reward, term, np.zeros(nt, np.float32), np.zeros(nt, np.uint8), 0.99, 0.95, 0)
+    assert np.sum(adv != adv_o) <= 10 and rel_err(adv, adv_o) < 1e-6
+    assert np.array_equal(ret, adv + value) and not adv[:, -1].any()
+    # a terminal at t+1 cuts the scan: advantage at t is exactly δ_t = r_t - v_t
+    e, t = np.argwhere(term[:, 1:] == 1)[0]
+    assert adv[e, t] == np.float32(np.float64(reward[e, t]) - np.float64(value[e, t]))
