@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec of the whole PPO loop (rollout + GAE + update; ppo.jl:117-253) on MI355X.
+
+A "step" is one PPO iteration over one batch of synthetic CartPole rollouts: num_steps=128 env steps of every env,
+GAE, then update_epochs=4 x num_minibatches=4 optimiser steps. Workload (BASELINE.json metric): CartPole PPO,
+num_envs=65536 in total, 2x64 actor/critic, reference default hyper-parameters. With N GPUs the envs are sharded
+65536/N per rank (strong scaling) and the flat gradient is all-reduced over RCCL once per optimiser step.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+TOTAL_ENVS = 65536
+NUM_STEPS = 128
+FWD_FLOPS_PER_SAMPLE = 17792          # actor + critic forward, 2x64, obs 4, act 2
+UPDATE_FLOPS_PER_SAMPLE = 3 * FWD_FLOPS_PER_SAMPLE   # forward + backward (≈2x forward) per sample per optimiser pass
+GAE_BYTES_PER_STEP, GAE_BYTES_PER_ENV = 17, 5
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBPS = 8000.0
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(target_seconds=12.0):
+    """The CPU restatement of ppo.jl (oracle, kind="port") timed on this box's host cores, same workload shape on a
+    bounded sample: num_envs=2048 (not 65536), num_steps=128, whole iterations until ~target_seconds have elapsed."""
+    import numpy as np
+    import oraclelib as O
+    nt = 2048
+    cfg = O.make_config(num_envs=nt, num_steps=NUM_STEPS)
+    st = O.State(cfg)
+    st.params[:] = O.orthogonal_params(cfg, 0)
+    st.env_init()
+    st.iterate(1000)  # warm-up (page-in, OpenMP pool)
+    t0 = time.perf_counter(); iters = 0
+    while time.perf_counter() - t0 < target_seconds:
+        st.iterate(1000); iters += 1
+    dt = time.perf_counter() - t0
+    st.close()
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": nt * NUM_STEPS * iters / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"num_envs={nt}, num_steps={NUM_STEPS}, {iters} full PPO iterations (rollout+GAE+16 optimiser steps), "
+                      f"OpenMP over envs/samples, {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--total-envs", type=int, default=TOTAL_ENVS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shuffle", choices=["bijection", "fisher-yates"], default="bijection")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    import cleanrl_jl_amd as crl
+    L = crl._lib
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)  # control plane; gradients go over RCCL
+    torch.cuda.set_device(local_rank)
+
+    nt_local = args.total_envs // world
+    assert nt_local * world == args.total_envs, "total envs must divide by the number of GPUs"
+    cfg = crl.PPOConfig(num_envs=nt_local, num_steps=NUM_STEPS, total_timesteps=args.total_envs * NUM_STEPS * (args.steps + args.warmup))
+    agent = crl.Agent(cfg, device=local_rank, env_id_offset=rank * nt_local,
+                      shuffle_mode=L.SHUFFLE_BIJECTION if args.shuffle == "bijection" else L.SHUFFLE_FISHER_YATES)
+    h = agent.handle
+    if world > 1:
+        ids = [crl.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        h.comm_init(ids[0], world, rank)
+    h.env_reset()
+
+    def barrier():
+        h.sync(); torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        h.iterate(1, want_stats=False)
+    barrier()
+    h.prof_enable(True); h.prof_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        h.iterate(1, want_stats=False)
+    barrier()
+    dt = time.perf_counter() - t0
+    h.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    prof = h.prof_read()
+    ep = h.episode_stats()
+    stats = h.iterate(1)  # one extra, untimed, to read the loss records back
+    agent.close()
+
+    if rank == 0:
+        env_steps = args.total_envs * NUM_STEPS * args.steps
+        M = nt_local * NUM_STEPS // cfg.num_minibatches
+        upd_ms, upd_n = prof["update"]
+        gae_ms, gae_n = prof["gae"]
+        upd_avg_s = upd_ms / max(upd_n, 1) * 1e-3
+        gae_avg_s = gae_ms / max(gae_n, 1) * 1e-3
+        upd_tflops = UPDATE_FLOPS_PER_SAMPLE * M / upd_avg_s / 1e12 if upd_n else 0.0
+        gae_bytes = GAE_BYTES_PER_STEP * nt_local * NUM_STEPS + GAE_BYTES_PER_ENV * nt_local
+        gae_gbps = gae_bytes / gae_avg_s / 1e9 if gae_n else 0.0
+        out = {
+            "metric": "env-steps/sec (whole node), CartPole PPO num_envs=65536 at 1/2/4/8 GPUs",
+            "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"PPO CartPole-v1-shaped on-device env, num_envs={args.total_envs} total "
+                                   f"({nt_local}/GPU), num_steps={NUM_STEPS}, 2x64 actor+critic MLP, update_epochs=4, "
+                                   f"num_minibatches=4, anneal_lr", "global_batch": args.total_envs * NUM_STEPS,
+                       "parallelism": f"dp{world}", "shuffle": args.shuffle},
+            "roofline": {"bound": "mfma", "kernel": "update_kernel (fwd+bwd of one minibatch, actor+critic)",
+                         "achieved": upd_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": upd_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "avg_launch_ms": upd_avg_s * 1e3, "launches": upd_n, "flops_per_launch": UPDATE_FLOPS_PER_SAMPLE * M},
+            "roofline_gae": {"bound": "hbm", "kernel": "gae_kernel (advantages + returns)", "achieved": gae_gbps,
+                             "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gae_gbps / PEAK_HBM_GBPS, "traffic": None,
+                             "avg_launch_ms": gae_avg_s * 1e3, "launches": gae_n, "bytes_per_launch": gae_bytes},
+            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+            "last_iteration": {"loss": stats[-1]["loss"], "episodes": ep["episodes"],
+                               "mean_episode_return": ep["return_sum"] / max(ep["episodes"], 1.0)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

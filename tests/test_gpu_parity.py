@@ -25,9 +25,14 @@ def make_agent(crl, nt=8, k=128, params=None, **kw):
     return crl.Agent(cfg, params=params, **shape)
 
 
+ATOL = 1e-6
+
+
 def rel_err(a, b):
+    """max |a-b| / (|b| + ATOL/RTOL): `< RTOL` ⇔ |a-b| <= RTOL*|b| + ATOL. The absolute floor covers float32 results
+    that cancel to ~0 (a value head summing 64 O(0.1) terms carries ~1e-7 absolute rounding on BOTH sides)."""
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
-    return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3)) if a.size else 0.0
+    return np.max(np.abs(a - b) / (np.abs(b) + ATOL / RTOL)) if a.size else 0.0
 
 
 # ---------------------------------------------------------------------------------------------------------
