@@ -83,16 +83,15 @@ def main():
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)  # control plane; gradients go over RCCL
     torch.cuda.set_device(local_rank)
 
-    nt_local = args.total_envs // world
-    assert nt_local * world == args.total_envs, "total envs must divide by the number of GPUs"
+    import importlib
+    crl_dist = importlib.import_module("cleanrl_jl_amd.dist")
+    nt_local, env_off = crl_dist.shard_envs(args.total_envs, world, rank)
     cfg = crl.PPOConfig(num_envs=nt_local, num_steps=NUM_STEPS, total_timesteps=args.total_envs * NUM_STEPS * (args.steps + args.warmup))
-    agent = crl.Agent(cfg, device=local_rank, env_id_offset=rank * nt_local,
+    agent = crl.Agent(cfg, device=local_rank, env_id_offset=env_off,
                       shuffle_mode=L.SHUFFLE_BIJECTION if args.shuffle == "bijection" else L.SHUFFLE_FISHER_YATES)
     h = agent.handle
     if world > 1:
-        ids = [crl.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        h.comm_init(ids[0], world, rank)
+        h.comm_init(crl_dist.exchange_unique_id(dist, rank, crl.comm_unique_id), world, rank)
     h.env_reset()
 
     def barrier():

@@ -66,7 +66,7 @@ static int prof_collect(crl_ppo* h) {
       float ms = 0.f;
       CRL_HIP_CHECK(hipEventElapsedTime(&ms, pr.first, pr.second));
       s.total_ms += ms; s.launches += 1;
-      hipEventDestroy(pr.first); hipEventDestroy(pr.second);
+      (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
     }
     s.pending.clear();
   }
@@ -166,17 +166,17 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
 
 int32_t crl_ppo_destroy(crl_ppo* h) {
   if (!h) return 0;
-  hipSetDevice(h->device);
-  if (h->stream) hipStreamSynchronize(h->stream);
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
   comm_destroy(h);
   void* ptrs[] = {h->obs, h->action, h->logprob, h->reward, h->terminal, h->value, h->adv, h->ret, h->env_state, h->env_t,
                   h->cur_obs, h->next_done, h->ep_return, h->ep_length, h->next_value, h->ep_stats, h->params, h->grads,
                   h->adam_m, h->adam_v, h->betap, h->perm, h->gpart, h->lpart, h->adv_sums, h->adv_ms, h->newv, h->vfix,
                   h->stats_dev, h->comm_buf, h->stage};
-  for (void* p : ptrs) if (p) hipFree(p);
+  for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int k = 0; k < CRL_K_COUNT; ++k)
-    for (auto& pr : h->prof_slots[k].pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
-  if (h->stream) hipStreamDestroy(h->stream);
+    for (auto& pr : h->prof_slots[k].pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return 0;
 }
@@ -283,7 +283,7 @@ int32_t crl_gae(int32_t device, const float* value, const float* reward, const u
   if (!rc && (e = hipDeviceSynchronize()) != hipSuccess) fail(e, "gae kernel");
   if (!rc && (e = hipMemcpy(adv, buf + o_a, B * 4, hipMemcpyDeviceToHost)) != hipSuccess) fail(e, "copy adv");
   if (!rc && ret && (e = hipMemcpy(ret, buf + o_ret, B * 4, hipMemcpyDeviceToHost)) != hipSuccess) fail(e, "copy ret");
-  hipFree(buf);
+  (void)hipFree(buf);
   return rc;
 }
 

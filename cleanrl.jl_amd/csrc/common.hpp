@@ -19,16 +19,15 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// NNlib tanh_fast (networks.jl:6): rational approximation; n/d via rcp + one Newton step (<= 1 ulp of IEEE divide)
+// NNlib tanh_fast (networks.jl:6): rational approximation; n/d via v_rcp_f32 (1 ulp), ±1 beyond x² >= 66
 __device__ __forceinline__ float tanh_fast(float x) {
+  // the reference switches to sign(x) at x² >= 66; clamping |x| to sqrt(66) instead (one v_med3_f32) returns
+  // 0.9999999 there — 1 ulp below the reference's 1.0 — and saves the compare/copysign/select per activation
+  x = __builtin_amdgcn_fmed3f(x, -8.1240384f, 8.1240384f);
   float x2 = x * x;
   float n = __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, 1.587199e-8f, 2.2332108e-5f), 0.0035974074f), 0.1346604f), 1.0f);
   float d = __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, 8.7767893e-7f, 0.0003453992f), 0.026262015f), 0.4679937f), 1.0f);
-  float r = __builtin_amdgcn_rcpf(d);
-  r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
-  float y = x * (n * r);
-  float s = x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : x);
-  return x2 < 66.0f ? y : s;
+  return x * (n * __builtin_amdgcn_rcpf(d));   // v_rcp_f32: 1 ulp
 }
 
 // Philox4x32-10 (counter-based; identical stream in oracle/ppo_oracle.c for end-to-end parity runs)

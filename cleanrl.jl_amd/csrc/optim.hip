@@ -70,17 +70,18 @@ struct OptimArgs {
   double eta, thresh;
 };
 
-__global__ void __launch_bounds__(256) clipnorm_adam_kernel(OptimArgs a) {
+__global__ void __launch_bounds__(1024) clipnorm_adam_kernel(OptimArgs a) {
 #pragma clang fp contract(off)
   const int arr = blockIdx.x;
   const int lo = a.off[arr], hi = a.off[arr + 1];
-  __shared__ double sm[4];
+  __shared__ double sm[16];
   double ss = 0.0;
   for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) { const double g = a.grads[i]; ss += g * g; }
   ss = wave_sum(ss);
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = ss;
   __syncthreads();
-  ss = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+  ss = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) ss += sm[w];
   const float nrm = (float)sqrt(ss);
   const bool clip = (double)nrm > a.thresh;
   const double sc = clip ? a.thresh / (double)nrm : 1.0;
@@ -108,7 +109,7 @@ int launch_optim(crl_ppo* h, double eta) {
   a.params = h->params; a.grads = h->grads; a.m = h->adam_m; a.v = h->adam_v; a.betap = h->betap;
   a.eta = eta; a.thresh = 0.5;
   ProfScope ps(h, CRL_K_OPTIM);
-  hipLaunchKernelGGL(clipnorm_adam_kernel, dim3(12), dim3(256), 0, h->stream, a);
+  hipLaunchKernelGGL(clipnorm_adam_kernel, dim3(12), dim3(1024), 0, h->stream, a);
   CRL_HIP_CHECK(hipGetLastError());
   return 0;
 }

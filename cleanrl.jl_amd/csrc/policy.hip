@@ -6,6 +6,8 @@
 // (the C fragment of one layer is the B operand of the next, no LDS round trip). Envs never interact, so the whole
 // `for step in 1:num_steps` loop is ONE launch: 128 dependent steps per wave, no grid synchronisation.
 // Stores go to the (·, nt, k) buffer with env fastest: lanes 0-31 write 128/512 contiguous bytes per field per step.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "ppo_ctx.hpp"
 
@@ -176,17 +178,18 @@ struct RolloutArgs {
   float* env_state; int32_t* env_t; float* cur_obs; uint8_t* next_done; float* ep_return; int32_t* ep_length;
   double* ep_stats;
   uint64_t iteration;
+  int stagger;  // s_sleep units (64 clocks) by which waves 4-7 of an 8-wave block start late
 };
 
 template <int A>
-__global__ void __launch_bounds__(256) rollout_cartpole_kernel(RolloutArgs a) {
+__global__ void __launch_bounds__(512, 2) rollout_cartpole_kernel(RolloutArgs a) {
   constexpr int D = 4;
   using IA = NetImage<D, A, false>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* imgA = smem;
-  float* imgC = smem + IA::SIZE;
-  stage_net<D, A, false>(imgA, a.params, threadIdx.x, blockDim.x);
-  stage_net<D, 1, false>(imgC, a.params + NetParams<D, A>::SIZE, threadIdx.x, blockDim.x);
+  float* imgA0 = smem;
+  float* imgC0 = smem + IA::SIZE;
+  stage_net<D, A, false>(imgA0, a.params, threadIdx.x, blockDim.x);
+  stage_net<D, 1, false>(imgC0, a.params + NetParams<D, A>::SIZE, threadIdx.x, blockDim.x);
   __syncthreads();
   const DevCfg& c = a.c;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, hf = lane >> 5;
@@ -210,12 +213,25 @@ __global__ void __launch_bounds__(256) rollout_cartpole_kernel(RolloutArgs a) {
   int ep_len = a.ep_length[ee];
   double st_n = 0.0, st_ret = 0.0, st_len = 0.0, st_max = 0.0;
 
+  // Waves w and w+4 of an 8-wave block share a SIMD and run the same program: started together they march through
+  // the MFMA-heavy and VALU-only phases of a step in lockstep and leave the matrix pipe idle; a one-time delay of
+  // the second half keeps one wave's VALU phase under the other's MFMAs for all 128 steps.
+  if (__builtin_amdgcn_readfirstlane(wave) >= 4) {
+    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+  }
+
   for (int step = 0; step < c.k; ++step) {
     const uint64_t gstep = a.iteration * (uint64_t)c.k + (uint64_t)step;
     const size_t b = (size_t)ee + (size_t)c.nt * step;
     ep_len += 1;                                                     // ppo.jl:125
     f32x16 h1[2], h2[2];
     float z[A], v[1], p[A], lp[A];
+    // opaque per-step offset: the weight fragments are re-read from LDS every step instead of being hoisted out of
+    // the 128-step loop into ~250 registers (which would halve the waves per SIMD)
+    int lds_off = 0;
+    asm volatile("" : "+v"(lds_off));
+    const float* imgA = imgA0 + lds_off;
+    const float* imgC = imgC0 + lds_off;
     mlp_forward<D, A, false>(imgA, co, h1, h2, z, lane);             // ppo.jl:127 get_action
     softmax_logsoftmax<A>(z, p, lp);
     const double u = u53(philox_env(c.seed, gid, gstep, 0));
@@ -323,7 +339,10 @@ int launch_rollout(crl_ppo* h) {
   a.ep_return = h->ep_return; a.ep_length = h->ep_length; a.ep_stats = h->ep_stats; a.iteration = (uint64_t)h->iteration;
   // one wave per 32 envs; spread waves over all 256 CUs before stacking them inside a block
   const int tiles = (h->dc.nt + TILE - 1) / TILE;
-  int wpb = tiles >= 2048 ? 4 : (tiles >= 1024 ? 2 : 1);
+  int wpb = tiles >= 2048 ? 8 : (tiles >= 1024 ? 4 : (tiles >= 512 ? 2 : 1));
+  static int stagger_env = -1;
+  if (stagger_env < 0) { const char* e = getenv("CRL_ROLLOUT_STAGGER"); stagger_env = e ? atoi(e) : 6; }
+  a.stagger = wpb == 8 ? stagger_env : 0;
   const int blocks = (tiles + wpb - 1) / wpb;
   ProfScope ps(h, CRL_K_ROLLOUT);
   const size_t smem = act_smem<4, 2>();

@@ -34,20 +34,48 @@ struct UpdateArgs {
   double Mglobal;         // minibatch size over all ranks (the 1/M of every mean)
 };
 
-template <int D, int A, int ROLE>
-__device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, float* smem) {
+// Per-sample inputs of one tile, gathered through the permutation (36 B per sample)
+template <int D>
+struct Gathered {
+  float x[D];
+  float f0, f1;  // actor: old logprob, advantage ; critic: old value, return
+  int act;
+};
+
+template <int D, int ROLE>
+__device__ __forceinline__ void gather(const UpdateArgs& a, int smp, Gathered<D>& g) {
+  if (D == 4) {
+    const float4 xv = reinterpret_cast<const float4*>(a.states)[smp];
+    g.x[0] = xv.x; g.x[1] = xv.y; g.x[2] = xv.z; g.x[3] = xv.w;
+  } else {
+#pragma unroll
+    for (int i = 0; i < D; ++i) g.x[i] = a.states[(size_t)D * smp + i];
+  }
+  if (ROLE == 0) { g.act = a.actions[smp]; g.f0 = a.logprobs[smp]; g.f1 = a.advantages[smp]; }
+  else { g.act = 0; g.f0 = a.values[smp]; g.f1 = a.returns[smp]; }
+}
+
+// One role (actor or critic) = RW waves of the block: `smem` is the role's weight image, `scratch` the first of its
+// RW wave-private tiles. All barriers are block-wide and both roles execute the same number of them.
+constexpr int RW = 4;          // waves per role per block
+constexpr int SCR_FLOATS = 64 * TSTRIDE + TILE * 4 + 2 * TILE;
+
+template <int D, int A, int ROLE, bool EXACT>
+__device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, float* smem, float* scratch) {
   constexpr int NOUT = ROLE == 0 ? A : 1;
   using I = NetImage<D, NOUT, true>;
   using P = NetParams<D, NOUT>;
-  constexpr int SCR = 64 * TSTRIDE + TILE * D + A * TILE;
+  constexpr int SCR = SCR_FLOATS;
+  static_assert(64 * TSTRIDE + TILE * D + A * TILE <= SCR_FLOATS, "scratch too small");
   const DevCfg& c = a.c;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hf = lane >> 5;
-  float* img = smem;
-  float* T = smem + I::SIZE + wave * SCR;
+  const int tid = threadIdx.x & (64 * RW - 1), lane = tid & 63, wave = tid >> 6, j = lane & 31, hf = lane >> 5;
+  constexpr int NT = 64 * RW;  // threads of this role
+  float* img0 = smem;
+  float* T = scratch + wave * SCR;
   float* xs = T + 64 * TSTRIDE;
   float* d3s = xs + TILE * D;
   const float* p = a.params + (ROLE ? NetParams<D, A>::SIZE : 0);
-  stage_net<D, NOUT, true>(img, p, tid, blockDim.x);
+  stage_net<D, NOUT, true>(img0, p, tid, NT);
   __syncthreads();
 
   f32x16 dW2t[2][2];  // dW2ᵀ accumulators: [mj = h1-row block][ni = δ2-row block]
@@ -67,46 +95,59 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
   const int M = c.M;
   const double invM = 1.0 / a.Mglobal;
   const int ntiles = (M + TILE - 1) / TILE;
-  const int nwaves = a.blocks_per_role * (blockDim.x >> 6);
+  const int nwaves = a.blocks_per_role * RW;
   // role constants
-  float mean_f = 0.0f; double denom = 1.0;
-  if (ROLE == 0) { mean_f = (float)a.adv_ms[2 * a.mb]; denom = (double)(float)a.adv_ms[2 * a.mb + 1] + 1e-8; }
+  float mean_f = 0.0f; double inv_denom = 1.0;
+  if (ROLE == 0) { mean_f = (float)a.adv_ms[2 * a.mb]; inv_denom = 1.0 / ((double)(float)a.adv_ms[2 * a.mb + 1] + 1e-8); }
   const float eps = c.clip, lo = 1.0f - c.clip, hi = 1.0f + c.clip;
-  const bool exact = a.mode == 1;
-  const float u_exact = exact ? (float)a.vfix[0] : 0.0f;
-  const double nwin = exact ? a.vfix[1] : 0.0;
+  const float u_exact = EXACT ? (float)a.vfix[0] : 0.0f;
+  const double nwin = EXACT ? a.vfix[1] : 0.0;
   const double entk = (double)c.ent_coeff / ((double)A * a.Mglobal);
   const double vk = (double)c.v_coef * 0.5 * invM;
+  const int32_t* perm = a.perm + (size_t)a.mb * M;
 
-  for (int tile = rb * (blockDim.x >> 6) + wave; tile < ntiles; tile += nwaves) {
+  // software pipeline of the gather: sample ids two tiles ahead, sample data one tile ahead
+  int tile = rb * RW + wave;
+  Gathered<D> cur, nxt;
+  int smp_n = 0;
+  if (tile < ntiles) {
+    const int pos = tile * TILE + j;
+    gather<D, ROLE>(a, pos < M ? perm[pos] : 0, cur);
+    const int pn = (tile + nwaves) * TILE + j;
+    smp_n = pn < M ? perm[pn] : 0;
+  }
+  for (; tile < ntiles; tile += nwaves) {
     const int pos = tile * TILE + j;
     const bool ok = pos < M;
-    const int smp = ok ? a.perm[(size_t)a.mb * M + pos] : 0;
-    float x[D];
-    if (D == 4) {
-      const float4 xv = reinterpret_cast<const float4*>(a.states)[smp];
-      x[0] = xv.x; x[1] = xv.y; x[2] = xv.z; x[3] = xv.w;
-    } else {
-#pragma unroll
-      for (int i = 0; i < D; ++i) x[i] = a.states[(size_t)D * smp + i];
+    gather<D, ROLE>(a, smp_n, nxt);                       // tile + nwaves (in flight during this tile's math)
+    {
+      const int pn = (tile + 2 * nwaves) * TILE + j;
+      smp_n = pn < M ? perm[pn] : 0;
     }
+    float x[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) x[i] = cur.x[i];
     f32x16 h1[2], h2[2];
     float out[NOUT], dout[NOUT];
+    // opaque per-iteration offset: keeps the loop-invariant weight reads in LDS instead of hoisted into ~130 registers
+    int lds_off = 0;
+    asm volatile("" : "+v"(lds_off));
+    const float* img = img0 + lds_off;
     mlp_forward<D, NOUT, true>(img, x, h1, h2, out, lane);
 
     if constexpr (ROLE == 0) {
       // policy loss + entropy (ppo.jl:213,219-228,242)
       float pr[A], lp[A];
       softmax_logsoftmax<A>(out, pr, lp);
-      const int act = a.actions[smp];
+      const int act = cur.act;
       float nlp = lp[0];
 #pragma unroll
       for (int i = 1; i < A; ++i) nlp = (act == i) ? lp[i] : nlp;
       double Hs = 0.0;
 #pragma unroll
       for (int i = 0; i < A; ++i) Hs += (double)(-(pr[i] * lp[i]));
-      const double Ahat = (double)(a.advantages[smp] - mean_f) / denom;
-      const float ratio = expf(nlp - a.logprobs[smp]);
+      const double Ahat = (double)(cur.f1 - mean_f) * inv_denom;
+      const float ratio = expf(nlp - cur.f0);
       const float rc = fminf(fmaxf(ratio, lo), hi);
       const double pg1 = -Ahat * (double)ratio, pg2 = -Ahat * (double)rc;
       double dnlp, pg;
@@ -119,14 +160,14 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
       if (ok && hf == 0) { ls0 += pg; ls1 += Hs; }
     } else {
       // value loss (ppo.jl:214,231-240)
-      const float v = out[0], R = a.returns[smp], ov = a.values[smp];
+      const float v = out[0], R = cur.f1, ov = cur.f0;
       double dv, term;
       if (c.clip_vloss) {
         const float dvv = v - ov;
         const float cl = fminf(fmaxf(dvv, -eps), eps);
         const float vc = ov + cl;
         const float q = (vc - R) * (vc - R);
-        const bool q_wins = exact ? !(u_exact > q) : true;  // max.(u, q): ties → q
+        const bool q_wins = EXACT ? !(u_exact > q) : true;  // max.(u, q): ties → q
         term = q_wins ? (double)q : (double)u_exact;
         const double inner = (q_wins && dvv >= -eps && dvv <= eps) ? 2.0 * (double)(vc - R) : 0.0;
         dv = vk * (nwin * invM + inner);
@@ -139,7 +180,7 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
       if (ok && hf == 0) {
         ls0 += (double)(v - R * R);
         ls1 += term;
-        if (!exact) a.newv[pos] = v;
+        if (!EXACT) a.newv[pos] = v;
       }
     }
     if (!ok) {
@@ -179,7 +220,7 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
         dW3acc[i] += accw; db3acc[i] += accb;
       }
     }
-    // (3) δ2 = (W3ᵀ·δ3) ⊙ (1 − h2²) in C-fragment registers
+    // (3) δ2 = (W3ᵀ·δ3) ⊙ (1 − h2²) in C-fragment registers (h2 dies here)
     f32x16 d2[2];
     {
 #pragma unroll
@@ -204,47 +245,7 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
 #pragma unroll
         for (int r = 0; r < 16; ++r) d2[mt][r] *= (1.0f - h2[mt][r] * h2[mt][r]);
     }
-    wave_lds_fence();
-    // (4) δ2ᵀ → scratch; db2; B-fragments (δ2 rows on lanes, samples along k: smp(s,hf) = s + 16hf)
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) T[(32 * mt + rowmap(r, hf)) * TSTRIDE + j] = d2[mt][r];
-    wave_lds_fence();
-    f32x4 bfr[2][4];
-    {
-      const f32x4* tr = reinterpret_cast<const f32x4*>(T + lane * TSTRIDE);
-      float s = 0.0f;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) { const f32x4 t4 = tr[q]; s += (t4[0] + t4[1]) + (t4[2] + t4[3]); }
-      db2acc += s;
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const f32x4* fr = reinterpret_cast<const f32x4*>(T + (32 * ni + j) * TSTRIDE + 16 * hf);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bfr[ni][q] = fr[q];
-      }
-    }
-    wave_lds_fence();
-    // h1ᵀ → scratch; A-fragments streamed; dW2ᵀ[mj][ni] += h1[mj-block]·δ2[ni-block]ᵀ over the tile's 32 samples
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) T[(32 * mt + rowmap(r, hf)) * TSTRIDE + j] = h1[mt][r];
-    wave_lds_fence();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(T + (j) * TSTRIDE + 16 * hf + 4 * q);
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(T + (32 + j) * TSTRIDE + 16 * hf + 4 * q);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        dW2t[0][0] = mfma32(a0[e], bfr[0][q][e], dW2t[0][0]);
-        dW2t[0][1] = mfma32(a0[e], bfr[1][q][e], dW2t[0][1]);
-        dW2t[1][0] = mfma32(a1[e], bfr[0][q][e], dW2t[1][0]);
-        dW2t[1][1] = mfma32(a1[e], bfr[1][q][e], dW2t[1][1]);
-      }
-    }
-    // (5) dh1 = W2ᵀ·δ2 (A-fragments of W2ᵀ from LDS, B = δ2 registers); δ1 = dh1 ⊙ (1 − h1²)
+    // (4) dh1 = W2ᵀ·δ2 (A-fragments of W2ᵀ from LDS, B = δ2 registers); δ1 = dh1 ⊙ (1 − h1²)
     f32x16 d1[2];
     {
       f32x16 c0, c1;
@@ -270,7 +271,47 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
       }
     }
     wave_lds_fence();
-    // (6) δ1ᵀ → scratch; lane = row: db1, dW1[lane][c] += Σ_s δ1[lane][s]·x[s][c]
+    // (5) δ2ᵀ → scratch; db2; B-fragments (δ2 rows on lanes, samples along k: smp(s,hf) = s + 16hf) (δ2 dies here)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) T[(32 * mt + rowmap(r, hf)) * TSTRIDE + j] = d2[mt][r];
+    wave_lds_fence();
+    f32x4 bfr[2][4];
+    {
+      const f32x4* tr = reinterpret_cast<const f32x4*>(T + lane * TSTRIDE);
+      float s = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { const f32x4 t4 = tr[q]; s += (t4[0] + t4[1]) + (t4[2] + t4[3]); }
+      db2acc += s;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const f32x4* fr = reinterpret_cast<const f32x4*>(T + (32 * ni + j) * TSTRIDE + 16 * hf);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bfr[ni][q] = fr[q];
+      }
+    }
+    wave_lds_fence();
+    // (6) h1ᵀ → scratch (h1 dies here); A-fragments streamed; dW2ᵀ[mj][ni] += h1[mj-block]·δ2[ni-block]ᵀ over 32 samples
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) T[(32 * mt + rowmap(r, hf)) * TSTRIDE + j] = h1[mt][r];
+    wave_lds_fence();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(T + (j) * TSTRIDE + 16 * hf + 4 * q);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(T + (32 + j) * TSTRIDE + 16 * hf + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dW2t[0][0] = mfma32(a0[e], bfr[0][q][e], dW2t[0][0]);
+        dW2t[0][1] = mfma32(a0[e], bfr[1][q][e], dW2t[0][1]);
+        dW2t[1][0] = mfma32(a1[e], bfr[0][q][e], dW2t[1][0]);
+        dW2t[1][1] = mfma32(a1[e], bfr[1][q][e], dW2t[1][1]);
+      }
+    }
+    wave_lds_fence();
+    // (7) δ1ᵀ → scratch; lane = row: db1, dW1[lane][c] += Σ_s δ1[lane][s]·x[s][c]
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -299,17 +340,18 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
       db1acc += sb;
     }
     wave_lds_fence();
+    cur = nxt;
   }
 
   // ---- block reduction: waves add their accumulators into one LDS image in flat Flux order ------------------
   __syncthreads();
   float* R = smem;  // the weight image is dead now
-  for (int i = tid; i < P::SIZE; i += blockDim.x) R[i] = 0.0f;
+  for (int i = tid; i < P::SIZE; i += NT) R[i] = 0.0f;
   double* lsum = reinterpret_cast<double*>(smem + 6144);  // inside the dead weight image, past R (all LDS stays dynamic)
   ls0 = wave_sum(ls0); ls1 = wave_sum(ls1);
   if (lane == 0) { lsum[wave] = ls0; lsum[8 + wave] = ls1; }
   __syncthreads();
-  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+  for (int w = 0; w < RW; ++w) {
     if (wave == w) {
 #pragma unroll
       for (int mj = 0; mj < 2; ++mj)
@@ -332,52 +374,82 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
     __syncthreads();
   }
   float* gp = a.gpart + ((size_t)ROLE * a.blocks_per_role + rb) * a.gstride;
-  for (int i = tid; i < P::SIZE; i += blockDim.x) gp[i] = R[i];
+  for (int i = tid; i < P::SIZE; i += NT) gp[i] = R[i];
   if (tid == 0) {
     double s0 = 0.0, s1 = 0.0;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { s0 += lsum[w]; s1 += lsum[8 + w]; }
+    for (int w = 0; w < RW; ++w) { s0 += lsum[w]; s1 += lsum[8 + w]; }
     double* lp = a.lpart + ((size_t)ROLE * a.blocks_per_role + rb) * 2;
     lp[0] = s0; lp[1] = s1;
   }
 }
 
+// Speculative pass (assumes u <= 0, see header). One 512-thread block per CU: waves 0-3 run the actor, waves 4-7 the
+// critic. Waves w and w+4 of a block share a SIMD, so every SIMD hosts one actor and one critic wave: their tiles have
+// different lengths, which keeps the two co-resident waves out of lockstep (two waves of the SAME role march through
+// MFMA-heavy and VALU-only phases together and leave the matrix pipe idle ~35 % of the cycles — measured).
 template <int D, int A>
-__global__ void __launch_bounds__(256, 2) update_kernel(UpdateArgs a) {
+__global__ void __launch_bounds__(512, 2) update_kernel(UpdateArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (a.mode == 1) {
-    if (a.vfix[3] == 0.0) return;  // speculation held: nothing to redo
-    update_role<D, A, 1>(a, blockIdx.x, smem);
-  } else if ((blockIdx.x & 1) == 0) {
-    update_role<D, A, 0>(a, blockIdx.x >> 1, smem);
-  } else {
-    update_role<D, A, 1>(a, blockIdx.x >> 1, smem);
-  }
+  constexpr int IA = NetImage<D, A, true>::SIZE, IC = NetImage<D, 1, true>::SIZE;
+  float* scratch = smem + IA + IC;
+  if (threadIdx.x < 64 * RW) update_role<D, A, 0, false>(a, blockIdx.x, smem, scratch);
+  else update_role<D, A, 1, false>(a, blockIdx.x, smem + IA, scratch + RW * SCR_FLOATS);
+}
+// Exact critic-only pass with the known scalar u and count; runs only when stats_kernel raised the flag
+template <int D, int A>
+__global__ void __launch_bounds__(256, 2) update_vfix_kernel(UpdateArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (a.vfix[3] == 0.0) return;  // speculation held: nothing to redo
+  update_role<D, A, 1, true>(a, blockIdx.x, smem, smem + NetImage<D, 1, true>::SIZE);
 }
 
 // Σ over per-block partials in fixed order → flat gradient (+ the loss sums appended for the all-reduce message)
 // msg layout: [P gradient floats][pg_sum, ent_sum, u_sum, q_sum as floats]
-__global__ void reduce_kernel(const float* __restrict__ gpart, const double* __restrict__ lpart, int blocks_per_role,
-                              int gstride, int Pa, int Pc, float* __restrict__ msg, const double* __restrict__ vfix,
-                              int mode) {
-  if (mode == 1 && vfix[3] == 0.0) return;
+// Block = 64 consecutive outputs x 4 groups of partials (group g sums blocks b ≡ g mod 4, then g0+g1+g2+g3):
+// 256-B coalesced rows, 4x the loads in flight of a one-thread-per-output loop, still a fixed summation order.
+template <int MODE>
+__global__ void __launch_bounds__(256) reduce_kernel(const float* __restrict__ gpart, const double* __restrict__ lpart,
+                                                     int blocks_per_role, int gstride, int Pa, int Pc,
+                                                     float* __restrict__ msg, const double* __restrict__ vfix) {
+  if (MODE == 1 && vfix[3] == 0.0) return;
+  __shared__ float sm[4][64];
+  __shared__ double smd[4][4];
   const int P = Pa + Pc;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < P) {
-    const int role = i >= Pa;
-    if (mode == 1 && role == 0) return;
-    const float* g = gpart + (size_t)role * blocks_per_role * gstride + (role ? i - Pa : i);
-    float s = 0.0f;
-    for (int b = 0; b < blocks_per_role; ++b) s += g[(size_t)b * gstride];
-    msg[i] = s;
-  } else if (i < P + 4) {
-    const int which = i - P;  // 0 pg, 1 ent (actor) ; 2 u, 3 q (critic)
-    const int role = which >> 1;
-    if (mode == 1 && role == 0) return;
-    const double* l = lpart + (size_t)role * blocks_per_role * 2 + (which & 1);
-    double s = 0.0;
-    for (int b = 0; b < blocks_per_role; ++b) s += l[b * 2];
-    msg[i] = (float)s;
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + o;
+  float s = 0.0f;
+  bool live = i < P;
+  int role = 0;
+  if (live) {
+    role = i >= Pa;
+    if (MODE == 1 && role == 0) live = false;
   }
+  if (live) {
+    const float* gp = gpart + (size_t)role * blocks_per_role * gstride + (role ? i - Pa : i);
+    int b = g;
+    for (; b + 12 < blocks_per_role; b += 16) {
+      const float v0 = gp[(size_t)b * gstride], v1 = gp[(size_t)(b + 4) * gstride], v2 = gp[(size_t)(b + 8) * gstride],
+                  v3 = gp[(size_t)(b + 12) * gstride];
+      s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; b < blocks_per_role; b += 4) s += gp[(size_t)b * gstride];
+  }
+  sm[g][o] = s;
+  // the four loss sums ride on the last block: thread (which = o < 4, group g)
+  double ds = 0.0;
+  const bool last = blockIdx.x == gridDim.x - 1;
+  if (last && o < 4) {
+    const int which = o, lrole = which >> 1;  // 0 pg, 1 ent (actor) ; 2 u, 3 q (critic)
+    if (!(MODE == 1 && lrole == 0)) {
+      const double* l = lpart + (size_t)lrole * blocks_per_role * 2 + (which & 1);
+      for (int b = g; b < blocks_per_role; b += 4) ds += l[b * 2];
+    }
+    smd[g][o] = ds;
+  }
+  __syncthreads();
+  if (g == 0 && live) msg[i] = (sm[0][o] + sm[1][o]) + (sm[2][o] + sm[3][o]);
+  if (last && g == 0 && o < 4 && !(MODE == 1 && (o >> 1) == 0))
+    msg[P + o] = (float)((smd[0][o] + smd[1][o]) + (smd[2][o] + smd[3][o]));
 }
 
 // "Training Statistics" (ppo.jl:247) from the (all-reduced) sums; raises the value-loss speculation flag
@@ -437,10 +509,14 @@ static int run_update(crl_ppo* h, int mb, int mode) {
   a.gpart = h->gpart; a.lpart = h->lpart; a.newv = h->newv;
   a.mb = mb; a.mode = mode; a.blocks_per_role = h->update_blocks; a.gstride = (int)h->Pa;
   a.Mglobal = (double)h->dc.M * h->world;
-  constexpr int SCR = 64 * TSTRIDE + TILE * 4 + 2 * TILE;
-  const size_t smem = sizeof(float) * (NetImage<4, 2, true>::SIZE + 4 * SCR);
-  const int grid = mode == 1 ? h->update_blocks : 2 * h->update_blocks;
-  hipLaunchKernelGGL((update_kernel<4, 2>), dim3(grid), dim3(256), smem, h->stream, a);
+  const int grid = h->update_blocks;
+  if (mode == 1) {
+    const size_t smem = sizeof(float) * (NetImage<4, 1, true>::SIZE + RW * SCR_FLOATS);
+    hipLaunchKernelGGL((update_vfix_kernel<4, 2>), dim3(grid), dim3(64 * RW), smem, h->stream, a);
+  } else {
+    const size_t smem = sizeof(float) * (NetImage<4, 2, true>::SIZE + NetImage<4, 1, true>::SIZE + 2 * RW * SCR_FLOATS);
+    hipLaunchKernelGGL((update_kernel<4, 2>), dim3(grid), dim3(2 * 64 * RW), smem, h->stream, a);
+  }
   CRL_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -459,8 +535,8 @@ int launch_update(crl_ppo* h, int mb) {
   }
   {
     ProfScope ps(h, CRL_K_REDUCE);
-    hipLaunchKernelGGL(reduce_kernel, dim3((P + 4 + 255) / 256), dim3(256), 0, h->stream, h->gpart, h->lpart, h->update_blocks,
-                       (int)h->Pa, (int)h->Pa, (int)h->Pc, h->comm_buf, h->vfix, 0);
+    hipLaunchKernelGGL(reduce_kernel<0>, dim3((P + 63) / 64), dim3(256), 0, h->stream, h->gpart, h->lpart, h->update_blocks,
+                       (int)h->Pa, (int)h->Pa, (int)h->Pc, h->comm_buf, h->vfix);
     CRL_HIP_CHECK(hipGetLastError());
   }
   if (h->world > 1) {
@@ -481,8 +557,8 @@ int launch_update_finish(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
     hipLaunchKernelGGL(vfix_count_kernel, dim3(1), dim3(1024), 0, h->stream, h->dc, h->perm, mb, h->newv, h->value, h->ret, h->vfix);
     CRL_HIP_CHECK(hipGetLastError());
     if (run_update(h, mb, 1)) return 1;
-    hipLaunchKernelGGL(reduce_kernel, dim3((P + 4 + 255) / 256), dim3(256), 0, h->stream, h->gpart, h->lpart, h->update_blocks,
-                       (int)h->Pa, (int)h->Pa, (int)h->Pc, h->comm_buf, h->vfix, 1);
+    hipLaunchKernelGGL(reduce_kernel<1>, dim3((P + 63) / 64), dim3(256), 0, h->stream, h->gpart, h->lpart, h->update_blocks,
+                       (int)h->Pa, (int)h->Pa, (int)h->Pc, h->comm_buf, h->vfix);
     CRL_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(64), 0, h->stream, h->comm_buf, P, h->dc, Mg, h->adv_ms, mb, h->vfix, stats_slot, 1);
     CRL_HIP_CHECK(hipGetLastError());

@@ -1,0 +1,135 @@
+# CleanRLHip.jl — the Julia shell a CleanRL.jl maintainer drops next to src/algorithms/ppo.jl.
+#
+# It keeps the reference's surface (PPOConfig, ppo, get_action, logprob_actions, gae and the two @info records of
+# src/algorithms/ppo.jl:157,247) and forwards every numeric step to libcleanrl_hip.so through `ccall`.
+# NOT EXECUTED IN THIS REPO'S CI: the build image has no Julia (SURVEY.md F4). The same C entry points are exercised
+# through the ctypes mirror (cleanrl.jl_amd/_lib.py) by tests/; the struct layout below is the one
+# tests/test_host_cpu.py::test_config_struct_matches_header_and_reference_defaults pins (104 bytes).
+module CleanRLHip
+
+export PPOConfig, ppo, get_action, logprob_actions, gae
+
+const libcrl = get(ENV, "CLEANRL_HIP_LIB", joinpath(@__DIR__, "..", "cleanrl.jl_amd", "libcleanrl_hip.so"))
+
+# ppo.jl:1-19 — unchanged
+Base.@kwdef struct PPOConfig
+  total_timesteps::Int = 500_000
+  num_steps::Int = 32
+  num_envs::Int = 4
+  num_minibatches::Int = 4
+  update_epochs::Int = 4
+  lr::Float32 = 2.5f-4
+  gamma::Float32 = 0.99
+  gae_lambda::Float32 = 0.95
+  clip_coef::Float32 = 0.2
+  ent_coeff::Float32 = 0.01
+  v_coef::Float32 = 0.5
+  normalize_advantages::Bool = true
+  clip_value_loss::Bool = true
+  anneal_lr::Bool = true
+end
+
+# crl_ppo_config (include/cleanrl_hip.h) — isbits, C layout
+struct CrlConfig
+  total_timesteps::Int64
+  num_steps::Int32; num_envs::Int32; num_minibatches::Int32; update_epochs::Int32
+  lr::Float32; gamma::Float32; gae_lambda::Float32; clip_coef::Float32; ent_coeff::Float32; v_coef::Float32
+  normalize_advantages::Int32; clip_value_loss::Int32; anneal_lr::Int32
+  obs_dim::Int32; n_act::Int32; hidden::Int32; gae_mode::Int32; env_kind::Int32; stale_obs::Int32
+  env_id_offset::Int32; shuffle_mode::Int32
+  seed::UInt64
+end
+
+struct CrlStats            # crl_ppo_stats
+  loss::Float64; pg_loss::Float64; v_loss::Float64; entropy_loss::Float64
+  adv_mean::Float64; adv_std::Float64; u_value::Float64; n_unclipped_wins::Float64
+end
+struct CrlEpisodeStats     # crl_episode_stats
+  episodes::Float64; return_sum::Float64; length_sum::Float64; return_max::Float64
+end
+
+check(rc::Int32) = rc == 0 || error(unsafe_string(ccall((:crl_last_error, libcrl), Cstring, ())))
+
+mutable struct Agent
+  h::Ptr{Cvoid}
+  config::PPOConfig
+  function Agent(config::PPOConfig; device=0, seed=0x5EED, env_id_offset=0, shuffle_mode=1)
+    c = CrlConfig(config.total_timesteps, config.num_steps, config.num_envs, config.num_minibatches, config.update_epochs,
+                  config.lr, config.gamma, config.gae_lambda, config.clip_coef, config.ent_coeff, config.v_coef,
+                  config.normalize_advantages, config.clip_value_loss, config.anneal_lr,
+                  4, 2, 64, 0, 0, 1, env_id_offset, shuffle_mode, seed)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:crl_ppo_create, libcrl), Int32, (Ref{CrlConfig}, Int32, Ref{Ptr{Cvoid}}), c, device, out))
+    a = new(out[], config)
+    finalizer(x -> ccall((:crl_ppo_destroy, libcrl), Int32, (Ptr{Cvoid},), x.h), a)
+  end
+end
+
+# Flux.params(actor, critic) → one flat Float32 vector in the same order (ppo.jl:196); W is (out,in) column-major
+# exactly as Flux stores it, so `vcat(vec.(Flux.params(actor, critic))...)` is the argument.
+set_params!(a::Agent, flat::Vector{Float32}) =
+  GC.@preserve flat check(ccall((:crl_ppo_write, libcrl), Int32, (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Csize_t), a.h, 9, pointer(flat), sizeof(flat)))
+
+# ppo.jl:21-32 — `actor` is the Agent holding the weights on the GPU; u are the rand() draws of StatsBase.sample
+function get_action(obs::AbstractVecOrMat{Float32}, actor::Agent; u::Vector{Float64}=rand(size(obs, ndims(obs))))
+  n = size(obs, ndims(obs)); o = Array(obs)
+  action = Vector{Int32}(undef, n); logprob = Vector{Float32}(undef, n)
+  GC.@preserve o u action logprob check(ccall((:crl_policy_act, libcrl), Int32,
+    (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float64}, Int32, Ptr{Int32}, Ptr{Float32}, Ptr{Float32}),
+    actor.h, o, u, n, action, logprob, C_NULL))
+  Int.(action) .+ 1, logprob                      # 1-based like Base.OneTo(2) (ppo.jl:26)
+end
+
+# ppo.jl:34-45
+function logprob_actions(obs::AbstractVecOrMat{Float32}, actor::Agent, actions::AbstractVector{Int32})
+  n = size(obs, ndims(obs)); o = Array(obs); a0 = Int32.(actions .- 1)
+  logprob = Vector{Float32}(undef, n); entropy = Matrix{Float32}(undef, 2, n)
+  GC.@preserve o a0 logprob entropy check(ccall((:crl_logprob_actions, libcrl), Int32,
+    (Ptr{Cvoid}, Ptr{Float32}, Ptr{Int32}, Int32, Ptr{Float32}, Ptr{Float32}), actor.h, o, a0, n, logprob, entropy))
+  logprob, entropy
+end
+
+# ppo.jl:48-73 — one env; values [0,k], rewards [1,k], terminals [0,k]. The last slot is 0 (upstream: uninitialised).
+function gae(values::AbstractVector{Float32}, rewards::AbstractVector{Float32}, terminals::AbstractVector{Bool},
+             γ::Float32, λ::Float32; mode::Integer=0, device::Integer=0)
+  k = length(rewards)
+  v = Vector{Float32}(values[1:k]); r = Vector{Float32}(rewards); t = UInt8.(terminals[1:k])   # BitArray → bytes
+  nv = Float32[values[k+1]]; nd = UInt8[terminals[k+1]]
+  adv = Vector{Float32}(undef, k)
+  GC.@preserve v r t nv nd adv check(ccall((:crl_gae, libcrl), Int32,
+    (Int32, Ptr{Float32}, Ptr{Float32}, Ptr{UInt8}, Ptr{Float32}, Ptr{UInt8}, Int32, Int32, Float32, Float32, Int32,
+     Ptr{Float32}, Ptr{Float32}), device, v, r, t, nv, nd, 1, k, γ, λ, mode, adv, C_NULL))
+  adv
+end
+
+# ppo.jl:75 — same signature; the loop body (ppo.jl:117-253) runs on the GPU, one ccall per update
+function ppo(config::PPOConfig=PPOConfig(); device=0, params::Union{Nothing,Vector{Float32}}=nothing)
+  agent = Agent(config; device)
+  params === nothing || set_params!(agent, params)
+  check(ccall((:crl_env_reset, libcrl), Int32, (Ptr{Cvoid},), agent.h))
+  batch_size = config.num_steps * config.num_envs
+  num_updates = config.total_timesteps ÷ batch_size
+  nstats = config.update_epochs * config.num_minibatches
+  stats = Vector{CrlStats}(undef, nstats); ep = Ref{CrlEpisodeStats}()
+  global_step = 0; last_log_step = 0; start_time = time()
+  for update in 1:num_updates
+    GC.@preserve stats check(ccall((:crl_ppo_iterate, libcrl), Int32, (Ptr{Cvoid}, Int32, Ptr{CrlStats}), agent.h, 1, stats))
+    check(ccall((:crl_episode_stats_read, libcrl), Int32, (Ptr{Cvoid}, Ref{CrlEpisodeStats}), agent.h, ep))
+    global_step += batch_size
+    steps_per_sec = trunc(global_step / (time() - start_time))
+    if ep[].episodes > 0
+      episode_return = ep[].return_sum / ep[].episodes; episode_length = ep[].length_sum / ep[].episodes
+      log_step_inc = last_log_step == 0 ? 0 : global_step - last_log_step
+      @info "Episode Statistics" episode_return episode_length global_step steps_per_sec log_step_increment = log_step_inc
+      last_log_step = global_step
+    end
+    for s in stats
+      log_step_inc = last_log_step == 0 ? 0 : global_step - last_log_step
+      @info "Training Statistics" loss = s.loss pg_loss = s.pg_loss v_loss = s.v_loss entropy_loss = s.entropy_loss log_step_increment = log_step_inc
+      last_log_step = global_step
+    end
+  end
+  agent
+end
+
+end # module

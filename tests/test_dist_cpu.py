@@ -1,0 +1,98 @@
+"""N>1 path on CPU: world_size-2 gloo processes check the sharding contract the multi-GPU run relies on, with the CPU
+oracle as the checker (the HIP path itself needs GPUs):
+  * shard r's rollout == envs [r*n,(r+1)*n) of the single-process rollout (global env ids key the RNG streams);
+  * Σ_ranks of gradients computed with the GLOBAL minibatch size and GLOBAL advantage statistics == the single-process
+    gradient of the union minibatch (the all-reduce the library performs, ppo.jl:250 cadence);
+  * the 128-byte communicator id reaches every rank."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oraclelib as O
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, total_envs, k, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import importlib
+    distmod = importlib.import_module("cleanrl_jl_amd.dist")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        uid = distmod.exchange_unique_id(dist, rank, lambda: bytes(range(128)))
+        assert uid == bytes(range(128))
+        n, off = distmod.shard_envs(total_envs, world, rank)
+        cfg = O.make_config(num_envs=n, num_steps=k, env_id_offset=off)
+        st = O.State(cfg)
+        full_cfg = O.make_config(num_envs=total_envs, num_steps=k)
+        params = O.orthogonal_params(full_cfg, 0)
+        st.params[:] = params
+        st.env_init(); st.rollout(); st.compute_gae()
+        # --- shard invariance of the rollout
+        parts = [torch.zeros(n * k, dtype=torch.int32) for _ in range(world)]
+        dist.all_gather(parts, torch.from_numpy(np.ascontiguousarray(st.action.ravel(order="F"))))
+        obs_parts = [torch.zeros(4 * n * k) for _ in range(world)]
+        dist.all_gather(obs_parts, torch.from_numpy(np.ascontiguousarray(st.obs.ravel(order="F"))))
+        # --- data-parallel gradient: local minibatch = first quarter of the local batch
+        B = n * k; M = B // 4
+        mb = np.arange(M, dtype=np.int32)
+        sums = torch.tensor([float(st.adv.ravel(order="F")[mb].astype(np.float64).sum()),
+                             float((st.adv.ravel(order="F")[mb].astype(np.float64) ** 2).sum())], dtype=torch.float64)
+        dist.all_reduce(sums)
+        Mg = distmod.global_minibatch(M, world)
+        mean = sums[0].item() / Mg
+        std = np.sqrt(max((sums[1].item() - Mg * mean * mean) / (Mg - 1), 0.0))
+        g, s = O.loss_grad(cfg, params, st.obs.reshape(4, -1, order="F"), st.action, st.logprob, st.value, st.adv, st.ret, mb,
+                           adv_stats=[np.float32(mean), np.float32(std)])
+        gt = torch.from_numpy(g.astype(np.float64) / world)   # local means → global mean
+        dist.all_reduce(gt)
+        if rank == 0:
+            fst = O.State(full_cfg); fst.params[:] = params
+            fst.env_init(); fst.rollout(); fst.compute_gae()
+            act = fst.action
+            for r in range(world):
+                assert np.array_equal(parts[r].numpy().reshape(n, k, order="F"), act[r * n:(r + 1) * n]), "shard rollout differs"
+                assert np.array_equal(obs_parts[r].numpy().reshape(4, n, k, order="F"), fst.obs[:, r * n:(r + 1) * n])
+            # union minibatch in the full batch's flat indexing b = e + nt*t
+            e = np.arange(B) % n; t = np.arange(B) // n
+            union = np.concatenate([(r * n + e[:M]) + total_envs * t[:M] for r in range(world)]).astype(np.int32)
+            gf, sf = O.loss_grad(full_cfg, params, fst.obs.reshape(4, -1, order="F"), fst.action, fst.logprob, fst.value,
+                                 fst.adv, fst.ret, union)
+            assert abs(sf["adv_mean"] - np.float32(mean)) < 1e-6 and abs(sf["adv_std"] - np.float32(std)) < 1e-5
+            err = np.linalg.norm(gt.numpy() - gf) / np.linalg.norm(gf)
+            assert err < 1e-5, err
+            open(os.path.join(out_dir, "ok"), "w").write("ok")
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharding_matches_single_process(tmp_path):
+    O.build()
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, 16, 32, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()
+
+
+def test_shard_envs_contract():
+    import importlib
+    distmod = importlib.import_module("cleanrl_jl_amd.dist")
+    assert distmod.shard_envs(65536, 8, 3) == (8192, 24576)
+    assert distmod.global_minibatch(262144, 8) == 2097152
+    with pytest.raises(ValueError):
+        distmod.shard_envs(10, 4, 0)
+    with pytest.raises(ValueError):
+        distmod.shard_envs(8, 2, 2)
