@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "ppo_ctx.hpp"
@@ -61,7 +62,8 @@ int comm_unique_id(uint8_t id[128]) {
 int comm_init(crl_ppo* h, const uint8_t id[128], int world, int rank) {
   if (world < 1 || rank < 0 || rank >= world) { set_error("crl_comm_init: bad world/rank"); return 1; }
   h->world = world; h->rank = rank;
-  if (world == 1) return 0;
+  // world 1 needs no communicator; CRL_COMM_FORCE=1 creates one anyway so a 1-GPU box can exercise the RCCL path
+  if (world == 1 && !std::getenv("CRL_COMM_FORCE")) return 0;
   if (load_rccl()) return 1;
   CRL_HIP_CHECK(hipSetDevice(h->device));
   ncclUniqueId u;
@@ -74,8 +76,10 @@ int comm_init(crl_ppo* h, const uint8_t id[128], int world, int rank) {
 }
 
 int comm_allreduce(crl_ppo* h, void* buf, size_t count, bool is_double) {
-  if (h->world == 1) return 0;
-  if (!h->comm) { set_error("all-reduce requested but no communicator attached (crl_comm_init)"); return 1; }
+  if (!h->comm) {
+    if (h->world == 1) return 0;
+    set_error("all-reduce requested but no communicator attached (crl_comm_init)"); return 1;
+  }
   ncclResult_t r = g_rccl.AllReduce(buf, buf, count, is_double ? ncclDouble : ncclFloat, ncclSum,
                                     static_cast<ncclComm_t>(h->comm), h->stream);
   if (r != ncclSuccess) return nccl_fail("ncclAllReduce", r);

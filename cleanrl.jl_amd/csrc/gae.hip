@@ -1,20 +1,20 @@
 // gae.hip — GAE advantages + returns (ppo.jl:48-73,169-181) as a segmented reverse scan.
 //
 // The recurrence A_t = δ_t + c_t·A_{t+1} (δ_t = r_t + γ·nt_{t+1}·v_{t+1} − v_t, c_t = (γλ)·nt_{t+1}) is affine, so the
-// time axis is cut into segments of L=16 steps that run in parallel: each thread owns (env, segment), keeps its 16
+// time axis is cut into segments of L=8/16 steps that run in parallel: each thread owns (env, segment), keeps its L
 // (v, r, done) triples in registers, composes the segment's map A_lo = D + C·A_in, the per-segment maps are folded
 // through LDS, and the thread replays its segment from the resolved carry. One HBM read of value/reward/terminal
 // (9 B) and one write of advantage/return (8 B) per (env, step): 17 B — the algorithmic minimum.
 // Arithmetic is Float64 like the reference's accumulator (ppo.jl:63,65; Q2), stored Float32 (ppo.jl:62).
 // Layout: (nt, k) column-major, env fastest ⇒ lanes of a wave read consecutive envs: coalesced 128/256-B rows.
+#include <cstdlib>
+
 #include "ppo_ctx.hpp"
 
 namespace crl {
 
-constexpr int GAE_L = 16;
-
-template <int EB>
-__global__ void __launch_bounds__(1024) gae_kernel(const float* __restrict__ value, const float* __restrict__ reward,
+template <int EB, int GAE_L>
+__global__ void __launch_bounds__(512) gae_kernel(const float* __restrict__ value, const float* __restrict__ reward,
                                                    const uint8_t* __restrict__ terminal,
                                                    const float* __restrict__ next_value,
                                                    const uint8_t* __restrict__ next_done, int nt, int k, float gamma,
@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(1024) gae_kernel(const float* __restrict__ val
   double* smC = sm + S * EB;
 
   float v[GAE_L + 1], r[GAE_L];
-  uint8_t tm[GAE_L];
+  uint32_t tm[GAE_L];
 #pragma unroll
   for (int i = 0; i < GAE_L; ++i) {
     const int t = lo + i;
@@ -49,27 +49,34 @@ __global__ void __launch_bounds__(1024) gae_kernel(const float* __restrict__ val
   // the bootstrap value follows the LAST buffered step (ppo.jl:174 hcat(value, next_values'))
   const float nv = (ev && next_value) ? next_value[e] : 0.0f;
 
-  // phase 1: compose the segment's affine map
-  double D = 0.0, Cc = 1.0;
-  double dl[GAE_L], cl[GAE_L];
-#pragma unroll
-  for (int i = GAE_L - 1; i >= 0; --i) {
+  // δ_t and c_t of step lo+i from the registers (recomputed in phase 2 rather than kept: 64 fewer VGPRs)
+  auto step_terms = [&](int i, double& delta, double& cc) {
     const int t = lo + i;
     const float vnext = (t + 1 < k) ? v[i + 1] : nv;
     const double nonterm = 1.0 - (double)(tm[i] ? 1 : 0);
-    double delta = (double)r[i] + ((double)gamma * nonterm) * (double)vnext - (double)v[i];
-    double c = (double)gl * nonterm;
+    delta = (double)r[i] + ((double)gamma * nonterm) * (double)vnext - (double)v[i];
+    cc = (double)gl * nonterm;
     // compat (ppo.jl:66): the loop starts at k-1 (1-based) so the last slot keeps carry 0 and is defined as 0
-    const bool dead = (t >= k) || (mode == CRL_GAE_COMPAT && t == k - 1);
-    if (t >= k) { delta = 0.0; c = 1.0; }        // padding steps are the identity map
-    else if (dead) { delta = 0.0; c = 0.0; }
-    dl[i] = delta; cl[i] = c;
+    if (t >= k) { delta = 0.0; cc = 1.0; }                                   // padding steps: identity map
+    else if (mode == CRL_GAE_COMPAT && t == k - 1) { delta = 0.0; cc = 0.0; }
+  };
+  // phase 1: compose the segment's affine map A_lo = D + C·A_in
+  double D = 0.0, Cc = 1.0;
+#pragma unroll
+  for (int i = GAE_L - 1; i >= 0; --i) {
+    double delta, c;
+    step_terms(i, delta, c);
     D = delta + c * D;
     Cc = c * Cc;
   }
   smD[seg * EB + el] = D;
   smC[seg * EB + el] = Cc;
   __syncthreads();
+  // keep the raw f32/u8 registers (not their Float64 conversions) alive across the barrier: the conversions are
+  // redone in phase 2, which halves the register footprint
+#pragma unroll
+  for (int i = 0; i < GAE_L; ++i) asm volatile("" : "+v"(v[i]), "+v"(r[i]), "+v"(tm[i]));
+  asm volatile("" : "+v"(v[GAE_L]));
   // fold the segments above this one (later in time) into the incoming carry
   double A = 0.0;
   for (int s = S - 1; s > seg; --s) A = smD[s * EB + el] + smC[s * EB + el] * A;
@@ -77,7 +84,9 @@ __global__ void __launch_bounds__(1024) gae_kernel(const float* __restrict__ val
 #pragma unroll
   for (int i = GAE_L - 1; i >= 0; --i) {
     const int t = lo + i;
-    A = dl[i] + (cl[i] * A);
+    double delta, c;
+    step_terms(i, delta, c);
+    A = delta + (c * A);
     if (ev && t < k) {
       const size_t idx = (size_t)e + (size_t)nt * t;
       const float a32 = (float)A;
@@ -91,18 +100,29 @@ int launch_gae(hipStream_t st, const float* value, const float* reward, const ui
                const float* next_value, const uint8_t* next_done, int nt, int k, float gamma, float lambda, int mode,
                float* adv, float* ret) {
   if (nt <= 0 || k <= 0) { set_error("gae: empty input"); return 1; }
-  const int S = (k + GAE_L - 1) / GAE_L;
   const float gl = gamma * lambda;  // Float32 product, as `γ * λ` with both T=Float32 (ppo.jl:68)
-  // enough blocks to cover 256 CUs: narrower env tiles when the shard is small
-  int EB = 64;
-  if (S * 64 > 1024 || (nt + 63) / 64 < 512) EB = 32;
-  if (S * EB > 1024) EB = 16;
-  if (S * EB > 1024) { set_error("gae: num_steps > 1024 is not supported"); return 1; }
+  // segment length L and env tile EB: S = ceil(k/L) segments, block = S*EB <= 512 threads.
+  // Short segments + narrow tiles give the most loads in flight; long rollouts fall back to longer segments.
+  static int env_L = -1, env_EB = -1;
+  if (env_L < 0) { const char* e = getenv("CRL_GAE_L"); env_L = e ? atoi(e) : 0; }
+  if (env_EB < 0) { const char* e = getenv("CRL_GAE_EB"); env_EB = e ? atoi(e) : 0; }
+  int L = env_L ? env_L : (k <= 256 ? 8 : 16);
+  int S = (k + L - 1) / L;
+  int EB = env_EB ? env_EB : 64;
+  while (EB > 8 && (S * EB > 512 || (nt + EB - 1) / EB < 1024)) EB >>= 1;
+  if (S * EB > 512 && L == 8) { L = 16; S = (k + L - 1) / L; }
+  if (S * EB > 512) { set_error("gae: num_steps > 1024 is not supported"); return 1; }
   const dim3 block(S * EB), grid((nt + EB - 1) / EB);
   const size_t smem = sizeof(double) * 2 * S * EB;
-  if (EB == 64) hipLaunchKernelGGL(gae_kernel<64>, grid, block, smem, st, value, reward, terminal, next_value, next_done, nt, k, gamma, gl, mode, adv, ret);
-  else if (EB == 32) hipLaunchKernelGGL(gae_kernel<32>, grid, block, smem, st, value, reward, terminal, next_value, next_done, nt, k, gamma, gl, mode, adv, ret);
-  else hipLaunchKernelGGL(gae_kernel<16>, grid, block, smem, st, value, reward, terminal, next_value, next_done, nt, k, gamma, gl, mode, adv, ret);
+#define CRL_GAE_CASE(eb, l)                                                                                          \
+  if (EB == eb && L == l) {                                                                                          \
+    hipLaunchKernelGGL((gae_kernel<eb, l>), grid, block, smem, st, value, reward, terminal, next_value, next_done, nt, \
+                       k, gamma, gl, mode, adv, ret);                                                                \
+  } else
+  CRL_GAE_CASE(64, 8) CRL_GAE_CASE(32, 8) CRL_GAE_CASE(16, 8) CRL_GAE_CASE(8, 8)
+  CRL_GAE_CASE(64, 16) CRL_GAE_CASE(32, 16) CRL_GAE_CASE(16, 16) CRL_GAE_CASE(8, 16)
+  { set_error("gae: unsupported tile configuration"); return 1; }
+#undef CRL_GAE_CASE
   CRL_HIP_CHECK(hipGetLastError());
   return 0;
 }

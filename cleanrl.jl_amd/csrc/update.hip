@@ -539,7 +539,7 @@ int launch_update(crl_ppo* h, int mb) {
                        (int)h->Pa, (int)h->Pa, (int)h->Pc, h->comm_buf, h->vfix);
     CRL_HIP_CHECK(hipGetLastError());
   }
-  if (h->world > 1) {
+  if (h->comm) {
     ProfScope ps(h, CRL_K_ALLREDUCE);
     if (comm_allreduce(h, h->comm_buf, (size_t)P + 4, false)) return 1;
   }

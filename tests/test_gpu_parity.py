@@ -294,3 +294,23 @@ def test_full_size_gae_and_scan_linearity(crl):
     # a terminal at t+1 cuts the scan: advantage at t is exactly δ_t = r_t - v_t
     e, t = np.argwhere(term[:, 1:] == 1)[0]
     assert adv[e, t] == np.float32(np.float64(reward[e, t]) - np.float64(value[e, t]))
+
+
+def test_rccl_path_world1(crl, monkeypatch):
+    """The gradient / advantage-statistics all-reduces go through RCCL (dlopen'ed librccl) even on one GPU when
+    CRL_COMM_FORCE=1: a sum over one rank is the identity, so the iteration must still match the oracle."""
+    monkeypatch.setenv("CRL_COMM_FORCE", "1")
+    nt, k = 8, 128
+    agent = make_agent(crl, nt=nt, k=k, shuffle_mode=0)
+    h = agent.handle
+    h.comm_init(crl.comm_unique_id(), 1, 0)
+    params = agent.get_params()
+    cfgo, st = _oracle_state(nt, k, params)
+    h.env_reset()
+    h.prof_enable(True)
+    gs = h.iterate(1); os_ = st.iterate(10, gen_perm=True)
+    assert h.prof_read()["allreduce"][1] == 16, "one all-reduce per optimiser step (ppo.jl:250 cadence)"
+    for a, b in zip(gs, os_):
+        assert abs(a["loss"] - b["loss"]) <= 2e-5 * max(1.0, abs(b["loss"]))
+    assert np.max(np.abs(h.read(crl._lib.F_PARAMS) - st.params)) < 2e-5
+    agent.close(); st.close()
