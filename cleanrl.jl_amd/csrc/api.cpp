@@ -15,6 +15,12 @@ int comm_unique_id(uint8_t id[128]);
 int comm_init(crl_ppo* h, const uint8_t id[128], int world, int rank);
 int launch_iota(crl_ppo* h);
 
+bool gemm_x3() {
+  static int mode = -1;
+  if (mode < 0) { const char* e = std::getenv("CRL_GEMM"); mode = (e && std::string(e) == "f32") ? 0 : 1; }
+  return mode == 1;
+}
+
 int ensure_stage(crl_ppo* h, size_t bytes) {
   if (h->stage_bytes >= bytes) return 0;
   if (h->stage) CRL_HIP_CHECK(hipFree(h->stage));

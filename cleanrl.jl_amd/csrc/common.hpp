@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace crl {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -9,6 +9,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "mlp_x3.hpp"
 #include "ppo_ctx.hpp"
 
 namespace crl {
@@ -181,15 +182,20 @@ struct RolloutArgs {
   int stagger;  // s_sleep units (64 clocks) by which waves 4-7 of an 8-wave block start late
 };
 
-template <int A>
+template <int A, bool X3>
 __global__ void __launch_bounds__(512, 2) rollout_cartpole_kernel(RolloutArgs a) {
   constexpr int D = 4;
-  using IA = NetImage<D, A, false>;
+  constexpr int IASIZE = X3 ? NetImageX3<D, A, false>::SIZE : NetImage<D, A, false>::SIZE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* imgA0 = smem;
-  float* imgC0 = smem + IA::SIZE;
-  stage_net<D, A, false>(imgA0, a.params, threadIdx.x, blockDim.x);
-  stage_net<D, 1, false>(imgC0, a.params + NetParams<D, A>::SIZE, threadIdx.x, blockDim.x);
+  float* imgC0 = smem + IASIZE;
+  if (X3) {
+    stage_net_x3<D, A, false>(imgA0, a.params, threadIdx.x, blockDim.x);
+    stage_net_x3<D, 1, false>(imgC0, a.params + NetParams<D, A>::SIZE, threadIdx.x, blockDim.x);
+  } else {
+    stage_net<D, A, false>(imgA0, a.params, threadIdx.x, blockDim.x);
+    stage_net<D, 1, false>(imgC0, a.params + NetParams<D, A>::SIZE, threadIdx.x, blockDim.x);
+  }
   __syncthreads();
   const DevCfg& c = a.c;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, hf = lane >> 5;
@@ -232,14 +238,16 @@ __global__ void __launch_bounds__(512, 2) rollout_cartpole_kernel(RolloutArgs a)
     asm volatile("" : "+v"(lds_off));
     const float* imgA = imgA0 + lds_off;
     const float* imgC = imgC0 + lds_off;
-    mlp_forward<D, A, false>(imgA, co, h1, h2, z, lane);             // ppo.jl:127 get_action
+    if (X3) mlp_forward_x3<D, A, false>(imgA, co, h1, h2, z, lane);  // ppo.jl:127 get_action
+    else mlp_forward<D, A, false>(imgA, co, h1, h2, z, lane);
     softmax_logsoftmax<A>(z, p, lp);
     const double u = u53(philox_env(c.seed, gid, gstep, 0));
     const int act = sample_weights<A>(p, u);
     float lpa = lp[0];
 #pragma unroll
     for (int i = 1; i < A; ++i) lpa = (act == i) ? lp[i] : lpa;
-    mlp_forward<D, 1, false>(imgC, co, h1, h2, v, lane);             // ppo.jl:128
+    if (X3) mlp_forward_x3<D, 1, false>(imgC, co, h1, h2, v, lane);  // ppo.jl:128
+    else mlp_forward<D, 1, false>(imgC, co, h1, h2, v, lane);
     const bool done = cartpole_step(s, t_env, act);                  // ppo.jl:130
     const float rew = done ? 0.0f : 1.0f;                            // ppo.jl:132 (RLEnvs: reward 0 on the terminal step)
     if (writer) {                                                    // ppo.jl:133-140 Buffer.add!
@@ -345,8 +353,13 @@ int launch_rollout(crl_ppo* h) {
   a.stagger = wpb == 8 ? stagger_env : 0;
   const int blocks = (tiles + wpb - 1) / wpb;
   ProfScope ps(h, CRL_K_ROLLOUT);
-  const size_t smem = act_smem<4, 2>();
-  hipLaunchKernelGGL((rollout_cartpole_kernel<2>), dim3(blocks), dim3(64 * wpb), smem, h->stream, a);
+  if (gemm_x3()) {
+    const size_t smem = sizeof(float) * (NetImageX3<4, 2, false>::SIZE + NetImageX3<4, 1, false>::SIZE);
+    hipLaunchKernelGGL((rollout_cartpole_kernel<2, true>), dim3(blocks), dim3(64 * wpb), smem, h->stream, a);
+  } else {
+    const size_t smem = act_smem<4, 2>();
+    hipLaunchKernelGGL((rollout_cartpole_kernel<2, false>), dim3(blocks), dim3(64 * wpb), smem, h->stream, a);
+  }
   CRL_HIP_CHECK(hipGetLastError());
   return 0;
 }

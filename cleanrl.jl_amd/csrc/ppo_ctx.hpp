@@ -81,6 +81,8 @@ struct crl_ppo {
 
 namespace crl {
 int ensure_stage(crl_ppo* h, size_t bytes);
+// CRL_GEMM=f32 selects the v_mfma_f32_32x32x2_f32 layers; default is the bf16x3 matrix-pipe path (mlp_x3.hpp)
+bool gemm_x3();
 
 struct ProfScope {
   crl_ppo* h; int id; hipEvent_t a = nullptr, b = nullptr;

@@ -14,7 +14,10 @@
 // Value loss (ppo.jl:231-237, Q4): max.(u, q_b) with the SCALAR u = mean(v - R²) needs u before any critic
 // cotangent exists. q_b ≥ 0, so whenever u ≤ 0 every max picks q_b: the kernel speculates on that, and
 // reduce_kernel raises a flag if u > 0; only then do vfix_count_kernel and a critic-only exact pass rerun.
+#include <cstdlib>
+
 #include "common.hpp"
+#include "mlp_x3.hpp"
 #include "ppo_ctx.hpp"
 
 namespace crl {
@@ -30,7 +33,10 @@ struct UpdateArgs {
   const double* adv_ms;   // [nmb][2] mean, std of the (global) minibatch advantages
   const double* vfix;     // [8] u, #{u > q}, -, flag, sticky flag
   float* gpart; double* lpart; float* newv;
-  int mb, mode, blocks_per_role, gstride;
+  int mb, mode, gstride;
+  int nblk[2];            // blocks working on the actor / the critic
+  int pmax;               // capacity (blocks per role) of the partial buffers
+  int stagger;            // x3 kernel: start delay of waves 4-7 (units of 1024 clocks)
   double Mglobal;         // minibatch size over all ranks (the 1/M of every mean)
 };
 
@@ -57,13 +63,12 @@ __device__ __forceinline__ void gather(const UpdateArgs& a, int smp, Gathered<D>
 
 // One role (actor or critic) = RW waves of the block: `smem` is the role's weight image, `scratch` the first of its
 // RW wave-private tiles. All barriers are block-wide and both roles execute the same number of them.
-constexpr int RW = 4;          // waves per role per block
 constexpr int SCR_FLOATS = 64 * TSTRIDE + TILE * 4 + 2 * TILE;
 
-template <int D, int A, int ROLE, bool EXACT>
+template <int D, int A, int ROLE, bool EXACT, bool X3, int RW>
 __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, float* smem, float* scratch) {
   constexpr int NOUT = ROLE == 0 ? A : 1;
-  using I = NetImage<D, NOUT, true>;
+  using I = typename std::conditional<X3, NetImageX3<D, NOUT, true>, NetImage<D, NOUT, true>>::type;
   using P = NetParams<D, NOUT>;
   constexpr int SCR = SCR_FLOATS;
   static_assert(64 * TSTRIDE + TILE * D + A * TILE <= SCR_FLOATS, "scratch too small");
@@ -75,7 +80,8 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
   float* xs = T + 64 * TSTRIDE;
   float* d3s = xs + TILE * D;
   const float* p = a.params + (ROLE ? NetParams<D, A>::SIZE : 0);
-  stage_net<D, NOUT, true>(img0, p, tid, NT);
+  if (X3) stage_net_x3<D, NOUT, true>(img0, p, tid, NT);
+  else stage_net<D, NOUT, true>(img0, p, tid, NT);
   __syncthreads();
 
   f32x16 dW2t[2][2];  // dW2ᵀ accumulators: [mj = h1-row block][ni = δ2-row block]
@@ -95,7 +101,7 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
   const int M = c.M;
   const double invM = 1.0 / a.Mglobal;
   const int ntiles = (M + TILE - 1) / TILE;
-  const int nwaves = a.blocks_per_role * RW;
+  const int nwaves = a.nblk[ROLE] * RW;
   // role constants
   float mean_f = 0.0f; double inv_denom = 1.0;
   if (ROLE == 0) { mean_f = (float)a.adv_ms[2 * a.mb]; inv_denom = 1.0 / ((double)(float)a.adv_ms[2 * a.mb + 1] + 1e-8); }
@@ -133,7 +139,8 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
     int lds_off = 0;
     asm volatile("" : "+v"(lds_off));
     const float* img = img0 + lds_off;
-    mlp_forward<D, NOUT, true>(img, x, h1, h2, out, lane);
+    if constexpr (X3) mlp_forward_x3<D, NOUT, true>(img, x, h1, h2, out, lane);
+    else mlp_forward<D, NOUT, true>(img, x, h1, h2, out, lane);
 
     if constexpr (ROLE == 0) {
       // policy loss + entropy (ppo.jl:213,219-228,242)
@@ -251,17 +258,21 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
       f32x16 c0, c1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { c0[r] = 0.0f; c1[r] = 0.0f; }
-      const f32x4* w0 = reinterpret_cast<const f32x4*>(img + I::WB2) + lane;
-      const f32x4* w1 = reinterpret_cast<const f32x4*>(img + I::WB2 + 2048) + lane;
+      if constexpr (X3) {
+        dense64_x3(img + I::WB2P, d2, c0, c1, lane);
+      } else {
+        const f32x4* w0 = reinterpret_cast<const f32x4*>(img + I::WB2) + lane;
+        const f32x4* w1 = reinterpret_cast<const f32x4*>(img + I::WB2 + 2048) + lane;
 #pragma unroll
-      for (int s4 = 0; s4 < 8; ++s4) {
-        const f32x4 fa = w0[s4 * 64], fb = w1[s4 * 64];
+        for (int s4 = 0; s4 < 8; ++s4) {
+          const f32x4 fa = w0[s4 * 64], fb = w1[s4 * 64];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int s = s4 * 4 + e;
-          const float b = d2[s >> 4][s & 15];
-          c0 = mfma32(fa[e], b, c0);
-          c1 = mfma32(fb[e], b, c1);
+          for (int e = 0; e < 4; ++e) {
+            const int s = s4 * 4 + e;
+            const float b = d2[s >> 4][s & 15];
+            c0 = mfma32(fa[e], b, c0);
+            c1 = mfma32(fb[e], b, c1);
+          }
         }
       }
 #pragma unroll
@@ -278,17 +289,31 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
       for (int r = 0; r < 16; ++r) T[(32 * mt + rowmap(r, hf)) * TSTRIDE + j] = d2[mt][r];
     wave_lds_fence();
     f32x4 bfr[2][4];
+    P3 bp[2][2];  // x3: δ2ᵀ B-fragment pieces [ni][ks]
     {
       const f32x4* tr = reinterpret_cast<const f32x4*>(T + lane * TSTRIDE);
       float s = 0.0f;
 #pragma unroll
       for (int q = 0; q < 8; ++q) { const f32x4 t4 = tr[q]; s += (t4[0] + t4[1]) + (t4[2] + t4[3]); }
       db2acc += s;
+      if constexpr (X3) {
+        // k-step ks covers samples 16ks + 8hf + (0..7): two b128 reads per fragment, split into bf16 pieces
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const f32x4* fr = reinterpret_cast<const f32x4*>(T + (32 * ni + j) * TSTRIDE + 16 * hf);
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bfr[ni][q] = fr[q];
+          for (int ks = 0; ks < 2; ++ks) {
+            const f32x4* fr = reinterpret_cast<const f32x4*>(T + (32 * ni + j) * TSTRIDE + 16 * ks + 8 * hf);
+            const f32x4 f0 = fr[0], f1 = fr[1];
+            const float xb[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+            bp[ni][ks] = split3(xb);
+          }
+      } else {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const f32x4* fr = reinterpret_cast<const f32x4*>(T + (32 * ni + j) * TSTRIDE + 16 * hf);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bfr[ni][q] = fr[q];
+        }
       }
     }
     wave_lds_fence();
@@ -298,16 +323,34 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
 #pragma unroll
       for (int r = 0; r < 16; ++r) T[(32 * mt + rowmap(r, hf)) * TSTRIDE + j] = h1[mt][r];
     wave_lds_fence();
+    if constexpr (X3) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(T + (j) * TSTRIDE + 16 * hf + 4 * q);
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(T + (32 + j) * TSTRIDE + 16 * hf + 4 * q);
+      for (int ks = 0; ks < 2; ++ks) {
+        P3 ap[2];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        dW2t[0][0] = mfma32(a0[e], bfr[0][q][e], dW2t[0][0]);
-        dW2t[0][1] = mfma32(a0[e], bfr[1][q][e], dW2t[0][1]);
-        dW2t[1][0] = mfma32(a1[e], bfr[0][q][e], dW2t[1][0]);
-        dW2t[1][1] = mfma32(a1[e], bfr[1][q][e], dW2t[1][1]);
+        for (int mj = 0; mj < 2; ++mj) {
+          const f32x4* fr = reinterpret_cast<const f32x4*>(T + (32 * mj + j) * TSTRIDE + 16 * ks + 8 * hf);
+          const f32x4 f0 = fr[0], f1 = fr[1];
+          const float xa[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+          ap[mj] = split3(xa);
+        }
+        dW2t[0][0] = mfma_x3(ap[0], bp[0][ks], dW2t[0][0]);
+        dW2t[0][1] = mfma_x3(ap[0], bp[1][ks], dW2t[0][1]);
+        dW2t[1][0] = mfma_x3(ap[1], bp[0][ks], dW2t[1][0]);
+        dW2t[1][1] = mfma_x3(ap[1], bp[1][ks], dW2t[1][1]);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(T + (j) * TSTRIDE + 16 * hf + 4 * q);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(T + (32 + j) * TSTRIDE + 16 * hf + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dW2t[0][0] = mfma32(a0[e], bfr[0][q][e], dW2t[0][0]);
+          dW2t[0][1] = mfma32(a0[e], bfr[1][q][e], dW2t[0][1]);
+          dW2t[1][0] = mfma32(a1[e], bfr[0][q][e], dW2t[1][0]);
+          dW2t[1][1] = mfma32(a1[e], bfr[1][q][e], dW2t[1][1]);
+        }
       }
     }
     wave_lds_fence();
@@ -373,34 +416,44 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
     }
     __syncthreads();
   }
-  float* gp = a.gpart + ((size_t)ROLE * a.blocks_per_role + rb) * a.gstride;
+  float* gp = a.gpart + ((size_t)ROLE * a.pmax + rb) * a.gstride;
   for (int i = tid; i < P::SIZE; i += NT) gp[i] = R[i];
   if (tid == 0) {
     double s0 = 0.0, s1 = 0.0;
     for (int w = 0; w < RW; ++w) { s0 += lsum[w]; s1 += lsum[8 + w]; }
-    double* lp = a.lpart + ((size_t)ROLE * a.blocks_per_role + rb) * 2;
+    double* lp = a.lpart + ((size_t)ROLE * a.pmax + rb) * 2;
     lp[0] = s0; lp[1] = s1;
   }
 }
 
-// Speculative pass (assumes u <= 0, see header). One 512-thread block per CU: waves 0-3 run the actor, waves 4-7 the
-// critic. Waves w and w+4 of a block share a SIMD, so every SIMD hosts one actor and one critic wave: their tiles have
-// different lengths, which keeps the two co-resident waves out of lockstep (two waves of the SAME role march through
-// MFMA-heavy and VALU-only phases together and leave the matrix pipe idle ~35 % of the cycles — measured).
+// Speculative pass (assumes u <= 0, see header), f32-MFMA flavour. One 512-thread block per CU: waves 0-3 run the actor,
+// waves 4-7 the critic. Waves w and w+4 of a block share a SIMD, so every SIMD hosts one actor and one critic wave:
+// their tiles have different lengths, which keeps the two co-resident waves out of lockstep.
 template <int D, int A>
 __global__ void __launch_bounds__(512, 2) update_kernel(UpdateArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int IA = NetImage<D, A, true>::SIZE, IC = NetImage<D, 1, true>::SIZE;
   float* scratch = smem + IA + IC;
-  if (threadIdx.x < 64 * RW) update_role<D, A, 0, false>(a, blockIdx.x, smem, scratch);
-  else update_role<D, A, 1, false>(a, blockIdx.x, smem + IA, scratch + RW * SCR_FLOATS);
+  if (threadIdx.x < 256) update_role<D, A, 0, false, false, 4>(a, blockIdx.x, smem, scratch);
+  else update_role<D, A, 1, false, false, 4>(a, blockIdx.x, smem + IA, scratch + 4 * SCR_FLOATS);
+}
+// bf16x3 flavour (mlp_x3.hpp): the split weight images are 51 KB per network, so a 512-thread block carries ONE role
+// (blocks [0, nblk[0]) = actor, the rest = critic) and its 8 waves share that image.
+template <int D, int A>
+__global__ void __launch_bounds__(512, 2) update_x3_kernel(UpdateArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= 4) {
+    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+  }
+  if ((int)blockIdx.x < a.nblk[0]) update_role<D, A, 0, false, true, 8>(a, blockIdx.x, smem, smem + NetImageX3<D, A, true>::SIZE);
+  else update_role<D, A, 1, false, true, 8>(a, blockIdx.x - a.nblk[0], smem, smem + NetImageX3<D, 1, true>::SIZE);
 }
 // Exact critic-only pass with the known scalar u and count; runs only when stats_kernel raised the flag
 template <int D, int A>
 __global__ void __launch_bounds__(256, 2) update_vfix_kernel(UpdateArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (a.vfix[3] == 0.0) return;  // speculation held: nothing to redo
-  update_role<D, A, 1, true>(a, blockIdx.x, smem, smem + NetImage<D, 1, true>::SIZE);
+  update_role<D, A, 1, true, false, 4>(a, blockIdx.x, smem, smem + NetImage<D, 1, true>::SIZE);
 }
 
 // Σ over per-block partials in fixed order → flat gradient (+ the loss sums appended for the all-reduce message)
@@ -409,7 +462,7 @@ __global__ void __launch_bounds__(256, 2) update_vfix_kernel(UpdateArgs a) {
 // 256-B coalesced rows, 4x the loads in flight of a one-thread-per-output loop, still a fixed summation order.
 template <int MODE>
 __global__ void __launch_bounds__(256) reduce_kernel(const float* __restrict__ gpart, const double* __restrict__ lpart,
-                                                     int blocks_per_role, int gstride, int Pa, int Pc,
+                                                     int nblkA, int nblkC, int pmax, int gstride, int Pa, int Pc,
                                                      float* __restrict__ msg, const double* __restrict__ vfix) {
   if (MODE == 1 && vfix[3] == 0.0) return;
   __shared__ float sm[4][64];
@@ -425,7 +478,8 @@ __global__ void __launch_bounds__(256) reduce_kernel(const float* __restrict__ g
     if (MODE == 1 && role == 0) live = false;
   }
   if (live) {
-    const float* gp = gpart + (size_t)role * blocks_per_role * gstride + (role ? i - Pa : i);
+    const float* gp = gpart + (size_t)role * pmax * gstride + (role ? i - Pa : i);
+    const int blocks_per_role = role ? nblkC : nblkA;
     int b = g;
     for (; b + 12 < blocks_per_role; b += 16) {
       const float v0 = gp[(size_t)b * gstride], v1 = gp[(size_t)(b + 4) * gstride], v2 = gp[(size_t)(b + 8) * gstride],
@@ -441,8 +495,9 @@ __global__ void __launch_bounds__(256) reduce_kernel(const float* __restrict__ g
   if (last && o < 4) {
     const int which = o, lrole = which >> 1;  // 0 pg, 1 ent (actor) ; 2 u, 3 q (critic)
     if (!(MODE == 1 && lrole == 0)) {
-      const double* l = lpart + (size_t)lrole * blocks_per_role * 2 + (which & 1);
-      for (int b = g; b < blocks_per_role; b += 4) ds += l[b * 2];
+      const double* l = lpart + (size_t)lrole * pmax * 2 + (which & 1);
+      const int nb = lrole ? nblkC : nblkA;
+      for (int b = g; b < nb; b += 4) ds += l[b * 2];
     }
     smd[g][o] = ds;
   }
@@ -501,21 +556,48 @@ __global__ void vfix_count_kernel(DevCfg c, const int32_t* __restrict__ perm, in
   }
 }
 
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
+// block counts of the main pass: {actor, critic}
+static void main_pass_blocks(crl_ppo* h, int* nA, int* nC) {
+  if (gemm_x3()) {
+    // one role per block; the actor tile is a little longer (softmax + Float64 policy-loss terms), so it gets more blocks
+    const int total = 2 * ((h->update_blocks + 1) / 2);
+    static int actor_pct = -1;
+    if (actor_pct < 0) actor_pct = env_int("CRL_X3_ACTOR_PCT", 52);
+    int a = total * actor_pct / 100;
+    if (a < 1) a = 1;
+    if (a > total - 1) a = total - 1;
+    if (total < 2) { *nA = 1; *nC = 1; return; }
+    *nA = a; *nC = total - a;
+  } else {
+    *nA = h->update_blocks; *nC = h->update_blocks;
+  }
+}
+
 static int run_update(crl_ppo* h, int mb, int mode) {
   UpdateArgs a;
   a.c = h->dc; a.params = h->params;
   a.states = h->obs; a.actions = h->action; a.logprobs = h->logprob; a.values = h->value;
   a.advantages = h->adv; a.returns = h->ret; a.perm = h->perm; a.adv_ms = h->adv_ms; a.vfix = h->vfix;
   a.gpart = h->gpart; a.lpart = h->lpart; a.newv = h->newv;
-  a.mb = mb; a.mode = mode; a.blocks_per_role = h->update_blocks; a.gstride = (int)h->Pa;
+  a.mb = mb; a.mode = mode; a.gstride = (int)h->Pa; a.pmax = h->update_blocks; a.stagger = 0;
   a.Mglobal = (double)h->dc.M * h->world;
-  const int grid = h->update_blocks;
   if (mode == 1) {
-    const size_t smem = sizeof(float) * (NetImage<4, 1, true>::SIZE + RW * SCR_FLOATS);
-    hipLaunchKernelGGL((update_vfix_kernel<4, 2>), dim3(grid), dim3(64 * RW), smem, h->stream, a);
+    a.nblk[0] = 0; a.nblk[1] = h->update_blocks;
+    const size_t smem = sizeof(float) * (NetImage<4, 1, true>::SIZE + 4 * SCR_FLOATS);
+    hipLaunchKernelGGL((update_vfix_kernel<4, 2>), dim3(h->update_blocks), dim3(256), smem, h->stream, a);
+  } else if (gemm_x3()) {
+    main_pass_blocks(h, &a.nblk[0], &a.nblk[1]);
+    static int stagger = -1;
+    if (stagger < 0) stagger = env_int("CRL_X3_STAGGER", 3);
+    a.stagger = stagger;
+    const size_t smem = sizeof(float) * (NetImageX3<4, 2, true>::SIZE + 8 * SCR_FLOATS);
+    hipLaunchKernelGGL((update_x3_kernel<4, 2>), dim3(a.nblk[0] + a.nblk[1]), dim3(512), smem, h->stream, a);
   } else {
-    const size_t smem = sizeof(float) * (NetImage<4, 2, true>::SIZE + NetImage<4, 1, true>::SIZE + 2 * RW * SCR_FLOATS);
-    hipLaunchKernelGGL((update_kernel<4, 2>), dim3(grid), dim3(2 * 64 * RW), smem, h->stream, a);
+    main_pass_blocks(h, &a.nblk[0], &a.nblk[1]);
+    const size_t smem = sizeof(float) * (NetImage<4, 2, true>::SIZE + NetImage<4, 1, true>::SIZE + 8 * SCR_FLOATS);
+    hipLaunchKernelGGL((update_kernel<4, 2>), dim3(h->update_blocks), dim3(512), smem, h->stream, a);
   }
   CRL_HIP_CHECK(hipGetLastError());
   return 0;
@@ -527,16 +609,16 @@ int launch_update(crl_ppo* h, int mb) {
     return 1;
   }
   const int P = (int)h->P;
-  const int slot = mb;  // caller indexes stats_dev
-  (void)slot;
   {
     ProfScope ps(h, CRL_K_UPDATE);
     if (run_update(h, mb, 0)) return 1;
   }
   {
+    int nA, nC;
+    main_pass_blocks(h, &nA, &nC);
     ProfScope ps(h, CRL_K_REDUCE);
-    hipLaunchKernelGGL(reduce_kernel<0>, dim3((P + 63) / 64), dim3(256), 0, h->stream, h->gpart, h->lpart, h->update_blocks,
-                       (int)h->Pa, (int)h->Pa, (int)h->Pc, h->comm_buf, h->vfix);
+    hipLaunchKernelGGL(reduce_kernel<0>, dim3((P + 63) / 64), dim3(256), 0, h->stream, h->gpart, h->lpart, nA, nC,
+                       h->update_blocks, (int)h->Pa, (int)h->Pa, (int)h->Pc, h->comm_buf, h->vfix);
     CRL_HIP_CHECK(hipGetLastError());
   }
   if (h->comm) {
@@ -557,8 +639,8 @@ int launch_update_finish(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
     hipLaunchKernelGGL(vfix_count_kernel, dim3(1), dim3(1024), 0, h->stream, h->dc, h->perm, mb, h->newv, h->value, h->ret, h->vfix);
     CRL_HIP_CHECK(hipGetLastError());
     if (run_update(h, mb, 1)) return 1;
-    hipLaunchKernelGGL(reduce_kernel<1>, dim3((P + 63) / 64), dim3(256), 0, h->stream, h->gpart, h->lpart, h->update_blocks,
-                       (int)h->Pa, (int)h->Pa, (int)h->Pc, h->comm_buf, h->vfix);
+    hipLaunchKernelGGL(reduce_kernel<1>, dim3((P + 63) / 64), dim3(256), 0, h->stream, h->gpart, h->lpart, 0, h->update_blocks,
+                       h->update_blocks, (int)h->Pa, (int)h->Pa, (int)h->Pc, h->comm_buf, h->vfix);
     CRL_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(64), 0, h->stream, h->comm_buf, P, h->dc, Mg, h->adv_ms, mb, h->vfix, stats_slot, 1);
     CRL_HIP_CHECK(hipGetLastError());
