@@ -125,11 +125,6 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
   for (; tile < ntiles; tile += nwaves) {
     const int pos = tile * TILE + j;
     const bool ok = pos < M;
-    gather<D, ROLE>(a, smp_n, nxt);                       // tile + nwaves (in flight during this tile's math)
-    {
-      const int pn = (tile + 2 * nwaves) * TILE + j;
-      smp_n = pn < M ? perm[pn] : 0;
-    }
     float x[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) x[i] = cur.x[i];
@@ -195,6 +190,12 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
       for (int i = 0; i < NOUT; ++i) dout[i] = 0.0f;
     }
 
+    // next tile's samples: issued here (after the register-hungry loss section), in flight during the backward pass
+    gather<D, ROLE>(a, smp_n, nxt);
+    {
+      const int pn = (tile + 2 * nwaves) * TILE + j;
+      smp_n = pn < M ? perm[pn] : 0;
+    }
     // ---- backward ------------------------------------------------------------------------------------
     // (1) h2ᵀ, the output cotangents and x into the wave-private scratch
 #pragma unroll
@@ -209,23 +210,30 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
     }
     wave_lds_fence();
     // (2) lane = row: dW3[a][lane] += Σ_s h2[lane][s]·δ3[a][s];  db3[a] += Σ_s δ3[a][s]
+    // (in chunks of 8 samples with scheduling barriers: un-chunked, the compiler hoists all 8+8·NOUT b128 reads and
+    //  their 96 registers on top of h1, h2 and the dW2 accumulators, and spills)
     {
-      f32x4 row[8];
       const f32x4* tr = reinterpret_cast<const f32x4*>(T + lane * TSTRIDE);
+      float accw[NOUT], accb[NOUT];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) row[q] = tr[q];
+      for (int i = 0; i < NOUT; ++i) { accw[i] = 0.0f; accb[i] = 0.0f; }
 #pragma unroll
-      for (int i = 0; i < NOUT; ++i) {
-        const f32x4* dr = reinterpret_cast<const f32x4*>(d3s + i * TILE);
-        float accw = 0.0f, accb = 0.0f;
+      for (int q2 = 0; q2 < 4; ++q2) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const f32x4 dv4 = dr[q];
+        for (int qq = 0; qq < 2; ++qq) {
+          const int q = 2 * q2 + qq;
+          const f32x4 rq = tr[q];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { accw = __builtin_fmaf(row[q][e], dv4[e], accw); accb += dv4[e]; }
+          for (int i = 0; i < NOUT; ++i) {
+            const f32x4 dv4 = reinterpret_cast<const f32x4*>(d3s + i * TILE)[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { accw[i] = __builtin_fmaf(rq[e], dv4[e], accw[i]); accb[i] += dv4[e]; }
+          }
         }
-        dW3acc[i] += accw; db3acc[i] += accb;
+        __builtin_amdgcn_sched_barrier(0);
       }
+#pragma unroll
+      for (int i = 0; i < NOUT; ++i) { dW3acc[i] += accw[i]; db3acc[i] += accb[i]; }
     }
     // (3) δ2 = (W3ᵀ·δ3) ⊙ (1 − h2²) in C-fragment registers (h2 dies here)
     f32x16 d2[2];
@@ -289,7 +297,7 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
       for (int r = 0; r < 16; ++r) T[(32 * mt + rowmap(r, hf)) * TSTRIDE + j] = d2[mt][r];
     wave_lds_fence();
     f32x4 bfr[2][4];
-    P3 bp[2][2];  // x3: δ2ᵀ B-fragment pieces [ni][ks]
+    f32x4 braw[2][2][2];  // x3: raw δ2ᵀ B-fragments [ni][ks][half] (split into bf16 pieces at use: 32 registers, not 48)
     {
       const f32x4* tr = reinterpret_cast<const f32x4*>(T + lane * TSTRIDE);
       float s = 0.0f;
@@ -303,9 +311,7 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
             const f32x4* fr = reinterpret_cast<const f32x4*>(T + (32 * ni + j) * TSTRIDE + 16 * ks + 8 * hf);
-            const f32x4 f0 = fr[0], f1 = fr[1];
-            const float xb[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
-            bp[ni][ks] = split3(xb);
+            braw[ni][ks][0] = fr[0]; braw[ni][ks][1] = fr[1];
           }
       } else {
 #pragma unroll
@@ -334,10 +340,17 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
           const float xa[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
           ap[mj] = split3(xa);
         }
-        dW2t[0][0] = mfma_x3(ap[0], bp[0][ks], dW2t[0][0]);
-        dW2t[0][1] = mfma_x3(ap[0], bp[1][ks], dW2t[0][1]);
-        dW2t[1][0] = mfma_x3(ap[1], bp[0][ks], dW2t[1][0]);
-        dW2t[1][1] = mfma_x3(ap[1], bp[1][ks], dW2t[1][1]);
+        P3 bp[2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const f32x4 f0 = braw[ni][ks][0], f1 = braw[ni][ks][1];
+          const float xb[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+          bp[ni] = split3(xb);
+        }
+        dW2t[0][0] = mfma_x3(ap[0], bp[0], dW2t[0][0]);
+        dW2t[0][1] = mfma_x3(ap[0], bp[1], dW2t[0][1]);
+        dW2t[1][0] = mfma_x3(ap[1], bp[0], dW2t[1][0]);
+        dW2t[1][1] = mfma_x3(ap[1], bp[1], dW2t[1][1]);
       }
     } else {
 #pragma unroll
