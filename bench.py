@@ -136,8 +136,11 @@ def main():
             "config": {"workload": f"PPO CartPole-v1-shaped on-device env, num_envs={args.total_envs} total "
                                    f"({nt_local}/GPU), num_steps={NUM_STEPS}, 2x64 actor+critic MLP, update_epochs=4, "
                                    f"num_minibatches=4, anneal_lr", "global_batch": args.total_envs * NUM_STEPS,
-                       "parallelism": f"dp{world}", "shuffle": args.shuffle},
-            "roofline": {"bound": "mfma", "kernel": "update_kernel (fwd+bwd of one minibatch, actor+critic)",
+                       "parallelism": f"dp{world}", "shuffle": args.shuffle,
+                       "gemm": "f32 results via bf16x3 split products on the bf16 matrix pipe" if os.environ.get("CRL_GEMM", "x3") != "f32"
+                               else "v_mfma_f32_32x32x2_f32"},
+            "roofline": {"bound": "mfma", "kernel": "update_x3_kernel / update_kernel (fwd+bwd of one minibatch, actor+critic)",
+                         "note": "achieved = algorithmic f32 FLOPs (3 x 17,792 per sample) / HIP-event launch time; peak = dense f32 MFMA",
                          "achieved": upd_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": upd_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                          "avg_launch_ms": upd_avg_s * 1e3, "launches": upd_n, "flops_per_launch": UPDATE_FLOPS_PER_SAMPLE * M},

@@ -52,7 +52,7 @@ static bool field_ref(crl_ppo* h, int f, FieldRef* out) {
     case CRL_F_RETURN: *out = {h->ret, B * 4}; return true;
     case CRL_F_PERM: *out = {h->perm, B * 4}; return true;
     case CRL_F_PARAMS: *out = {h->params, P * 4}; return true;
-    case CRL_F_GRADS: *out = {h->grads, P * 4}; return true;
+    case CRL_F_GRADS: *out = {h->comm_buf, P * 4}; return true;
     case CRL_F_ADAM_M: *out = {h->adam_m, P * 4}; return true;
     case CRL_F_ADAM_V: *out = {h->adam_v, P * 4}; return true;
     case CRL_F_ENV_STATE: *out = {h->env_state, nt * d * 4}; return true;
@@ -144,7 +144,7 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
   rc |= dalloc(&h->env_state, nt * d); rc |= dalloc(&h->env_t, nt); rc |= dalloc(&h->cur_obs, nt * d);
   rc |= dalloc(&h->next_done, nt); rc |= dalloc(&h->ep_return, nt); rc |= dalloc(&h->ep_length, nt);
   rc |= dalloc(&h->next_value, nt); rc |= dalloc(&h->ep_stats, 4);
-  rc |= dalloc(&h->params, h->P); rc |= dalloc(&h->grads, h->P); rc |= dalloc(&h->adam_m, h->P); rc |= dalloc(&h->adam_v, h->P);
+  rc |= dalloc(&h->params, h->P); rc |= dalloc(&h->adam_m, h->P); rc |= dalloc(&h->adam_v, h->P);
   rc |= dalloc(&h->betap, 24); rc |= dalloc(&h->perm, B);
   // update grid: two 256-thread blocks per CU, alternating roles; never more waves than tiles
   hipDeviceProp_t prop;
@@ -176,7 +176,7 @@ int32_t crl_ppo_destroy(crl_ppo* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   comm_destroy(h);
   void* ptrs[] = {h->obs, h->action, h->logprob, h->reward, h->terminal, h->value, h->adv, h->ret, h->env_state, h->env_t,
-                  h->cur_obs, h->next_done, h->ep_return, h->ep_length, h->next_value, h->ep_stats, h->params, h->grads,
+                  h->cur_obs, h->next_done, h->ep_return, h->ep_length, h->next_value, h->ep_stats, h->params,
                   h->adam_m, h->adam_v, h->betap, h->perm, h->gpart, h->lpart, h->adv_sums, h->adv_ms, h->newv, h->vfix,
                   h->stats_dev, h->comm_buf, h->stage};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -351,8 +351,7 @@ int32_t crl_adv_stats(crl_ppo* h) {
 }
 
 static int update_step(crl_ppo* h, int mb, double eta, int apply, int slot) {
-  if (launch_update(h, mb)) return 1;
-  if (launch_update_finish(h, mb, h->stats_dev + slot)) return 1;
+  if (launch_update(h, mb, h->stats_dev + slot)) return 1;
   if (apply && launch_optim(h, eta)) return 1;
   return 0;
 }

@@ -106,7 +106,7 @@ int launch_optim(crl_ppo* h, double eta) {
   const int sizes[12] = {hN * d, hN, hN * hN, hN, A * hN, A, hN * d, hN, hN * hN, hN, hN, 1};
   a.off[0] = 0;
   for (int i = 0; i < 12; ++i) a.off[i + 1] = a.off[i] + sizes[i];
-  a.params = h->params; a.grads = h->grads; a.m = h->adam_m; a.v = h->adam_v; a.betap = h->betap;
+  a.params = h->params; a.grads = h->comm_buf; a.m = h->adam_m; a.v = h->adam_v; a.betap = h->betap;
   a.eta = eta; a.thresh = 0.5;
   ProfScope ps(h, CRL_K_OPTIM);
   hipLaunchKernelGGL(clipnorm_adam_kernel, dim3(12), dim3(1024), 0, h->stream, a);

@@ -281,6 +281,101 @@ __global__ void __launch_bounds__(512, 2) rollout_cartpole_kernel(RolloutArgs a)
   }
 }
 
+// Small shards (≤ 512 tiles = 16384 envs, e.g. 8192 envs per GPU under 8-way data parallelism) leave most SIMDs idle and the
+// 128 dependent steps set the time. Here each 32-env tile gets TWO waves: wave 0 runs the actor, the sampling and
+// the env; wave 1 runs the critic on the same observations, handed over through a double-buffered 512-B LDS slot
+// with one s_barrier per step. Step latency drops to the longer of the two halves.
+template <int A>
+__global__ void __launch_bounds__(128) rollout_split_kernel(RolloutArgs a) {
+  constexpr int D = 4;
+  constexpr int IASIZE = NetImageX3<D, A, false>::SIZE, ICSIZE = NetImageX3<D, 1, false>::SIZE;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* imgA0 = smem;
+  float* imgC0 = smem + IASIZE;
+  float4* xch = reinterpret_cast<float4*>(smem + IASIZE + ICSIZE);  // [2][TILE] observations
+  stage_net_x3<D, A, false>(imgA0, a.params, threadIdx.x, blockDim.x);
+  stage_net_x3<D, 1, false>(imgC0, a.params + NetParams<D, A>::SIZE, threadIdx.x, blockDim.x);
+  const DevCfg& c = a.c;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 31, hf = lane >> 5;
+  const int e = blockIdx.x * TILE + j;
+  const bool ok = e < c.nt;
+  const bool writer = ok && hf == 0;
+  const int ee = ok ? e : 0;
+  const uint32_t gid = c.env_id_offset + (uint32_t)ee;
+
+  float s[4] = {0, 0, 0, 0}, co[4] = {0, 0, 0, 0};
+  int t_env = 0, ep_len = 0;
+  uint8_t nd = 0;
+  float ep_ret = 0.0f;
+  double st_n = 0.0, st_ret = 0.0, st_len = 0.0, st_max = 0.0;
+  if (wave == 0) {
+    const float4 sv = reinterpret_cast<const float4*>(a.env_state)[ee];
+    const float4 cv = reinterpret_cast<const float4*>(a.cur_obs)[ee];
+    s[0] = sv.x; s[1] = sv.y; s[2] = sv.z; s[3] = sv.w;
+    co[0] = cv.x; co[1] = cv.y; co[2] = cv.z; co[3] = cv.w;
+    t_env = a.env_t[ee]; nd = a.next_done[ee]; ep_ret = a.ep_return[ee]; ep_len = a.ep_length[ee];
+    if (hf == 0) xch[j] = cv;
+  }
+  __syncthreads();
+
+  for (int step = 0; step < c.k; ++step) {
+    const uint64_t gstep = a.iteration * (uint64_t)c.k + (uint64_t)step;
+    const size_t b = (size_t)ee + (size_t)c.nt * step;
+    int lds_off = 0;
+    asm volatile("" : "+v"(lds_off));  // keep the weight reads in LDS (see rollout_cartpole_kernel)
+    f32x16 h1[2], h2[2];
+    if (wave == 0) {
+      ep_len += 1;                                                   // ppo.jl:125
+      float z[A], p[A], lp[A];
+      mlp_forward_x3<D, A, false>(imgA0 + lds_off, co, h1, h2, z, lane);  // ppo.jl:127 get_action
+      softmax_logsoftmax<A>(z, p, lp);
+      const double u = u53(philox_env(c.seed, gid, gstep, 0));
+      const int act = sample_weights<A>(p, u);
+      float lpa = lp[0];
+#pragma unroll
+      for (int i = 1; i < A; ++i) lpa = (act == i) ? lp[i] : lpa;
+      const bool done = cartpole_step(s, t_env, act);                // ppo.jl:130
+      const float rew = done ? 0.0f : 1.0f;                          // ppo.jl:132
+      if (writer) {                                                  // ppo.jl:133-140 Buffer.add! (value: wave 1)
+        reinterpret_cast<float4*>(a.obs)[b] = make_float4(co[0], co[1], co[2], co[3]);
+        a.action[b] = act; a.logprob[b] = lpa; a.reward[b] = rew; a.terminal[b] = nd;
+      }
+      co[0] = s[0]; co[1] = s[1]; co[2] = s[2]; co[3] = s[3];       // ppo.jl:143
+      nd = done ? 1 : 0;                                             // ppo.jl:144
+      ep_ret += rew;                                                 // ppo.jl:145
+      if (done) {                                                    // ppo.jl:147-165
+        if (writer) { st_n += 1.0; st_ret += (double)ep_ret; st_len += (double)ep_len; st_max = fmax(st_max, (double)ep_ret); }
+        ep_ret = 0.0f; ep_len = 0;
+        cartpole_reset(s, c.seed, gid, gstep, 1);                    // ppo.jl:164
+        t_env = 0;
+        if (!c.stale_obs) { co[0] = s[0]; co[1] = s[1]; co[2] = s[2]; co[3] = s[3]; }
+      }
+      if (hf == 0) xch[((step + 1) & 1) * TILE + j] = make_float4(co[0], co[1], co[2], co[3]);
+    } else {
+      const float4 cv = xch[(step & 1) * TILE + j];
+      const float cx[4] = {cv.x, cv.y, cv.z, cv.w};
+      float v[1];
+      mlp_forward_x3<D, 1, false>(imgC0 + lds_off, cx, h1, h2, v, lane);  // ppo.jl:128
+      if (writer) a.value[b] = v[0];
+    }
+    __syncthreads();
+  }
+  if (wave == 0) {
+    if (writer) {
+      reinterpret_cast<float4*>(a.env_state)[e] = make_float4(s[0], s[1], s[2], s[3]);
+      reinterpret_cast<float4*>(a.cur_obs)[e] = make_float4(co[0], co[1], co[2], co[3]);
+      a.env_t[e] = t_env; a.next_done[e] = nd; a.ep_return[e] = ep_ret; a.ep_length[e] = ep_len;
+    }
+    st_n = wave_sum(st_n); st_ret = wave_sum(st_ret); st_len = wave_sum(st_len);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) st_max = fmax(st_max, __shfl_xor(st_max, o, 64));
+    if (lane == 0 && st_n > 0.0) {
+      atomicAdd(&a.ep_stats[0], st_n); atomicAdd(&a.ep_stats[1], st_ret); atomicAdd(&a.ep_stats[2], st_len);
+      atomicMax(reinterpret_cast<unsigned long long*>(&a.ep_stats[3]), (unsigned long long)__double_as_longlong(st_max));
+    }
+  }
+}
+
 template <int D, int A>
 static size_t act_smem() { return sizeof(float) * (NetImage<D, A, false>::SIZE + NetImage<D, 1, false>::SIZE); }
 
@@ -353,7 +448,12 @@ int launch_rollout(crl_ppo* h) {
   a.stagger = wpb == 8 ? stagger_env : 0;
   const int blocks = (tiles + wpb - 1) / wpb;
   ProfScope ps(h, CRL_K_ROLLOUT);
-  if (gemm_x3()) {
+  const char* split_s = getenv("CRL_ROLLOUT_SPLIT");  // read per launch so tests can exercise both kernels
+  const int split_env = split_s ? atoi(split_s) : 1;
+  if (gemm_x3() && split_env && tiles <= 512) {
+    const size_t smem = sizeof(float) * (NetImageX3<4, 2, false>::SIZE + NetImageX3<4, 1, false>::SIZE + 2 * TILE * 4);
+    hipLaunchKernelGGL((rollout_split_kernel<2>), dim3(tiles), dim3(128), smem, h->stream, a);
+  } else if (gemm_x3()) {
     const size_t smem = sizeof(float) * (NetImageX3<4, 2, false>::SIZE + NetImageX3<4, 1, false>::SIZE);
     hipLaunchKernelGGL((rollout_cartpole_kernel<2, true>), dim3(blocks), dim3(64 * wpb), smem, h->stream, a);
   } else {

@@ -55,7 +55,7 @@ struct crl_ppo {
   float* ep_return = nullptr; int32_t* ep_length = nullptr; float* next_value = nullptr;
   double* ep_stats = nullptr;  // [4] episodes, return_sum, length_sum, return_max
   // optimiser
-  float* params = nullptr; float* grads = nullptr; float* adam_m = nullptr; float* adam_v = nullptr;
+  float* params = nullptr; float* adam_m = nullptr; float* adam_v = nullptr;  // the gradient lives in comm_buf[0..P)
   double* betap = nullptr;     // [24]
   int32_t* perm = nullptr;
   // update workspace
@@ -107,8 +107,7 @@ int launch_next_value(crl_ppo* h);
 int launch_shuffle(crl_ppo* h, uint64_t epoch_id);
 int launch_adv_stats_sums(crl_ppo* h);
 int launch_adv_stats_finish(crl_ppo* h);
-int launch_update(crl_ppo* h, int mb);
-int launch_update_finish(crl_ppo* h, int mb, crl_ppo_stats* stats_slot);
+int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot);
 int launch_optim(crl_ppo* h, double eta);
 int comm_allreduce(crl_ppo* h, void* buf, size_t count, bool is_double);
 void comm_destroy(crl_ppo* h);

@@ -469,6 +469,32 @@ __global__ void __launch_bounds__(256, 2) update_vfix_kernel(UpdateArgs a) {
   update_role<D, A, 1, true, false, 4>(a, blockIdx.x, smem, smem + NetImage<D, 1, true>::SIZE);
 }
 
+// "Training Statistics" (ppo.jl:247) from the (all-reduced) sums msg[P..P+3]; mode 0 also raises the value-loss
+// speculation flag (u > 0), mode 1 is the re-evaluation after the exact critic pass.
+__device__ __forceinline__ void compute_stats(const float* msg, int P, const DevCfg& c, double Mglobal, const double* adv_ms,
+                                              int mb, double* vfix, crl_ppo_stats* out, int mode) {
+  const double pg = (double)msg[P] / Mglobal;
+  const double ent = (double)(float)((double)msg[P + 1] / ((double)c.A * Mglobal));
+  const double u = (double)(float)((double)msg[P + 2] / Mglobal);
+  const double vl = 0.5 * (double)(float)((double)msg[P + 3] / Mglobal);
+  if (mode == 0) {
+    vfix[0] = u;
+    vfix[3] = (c.clip_vloss && u > 0.0) ? 1.0 : 0.0;
+    if (vfix[3] != 0.0) vfix[4] = 1.0;  // sticky: lets a data-parallel run fail loudly (no exact pass there yet)
+    out->n_unclipped_wins = 0.0;
+  } else {
+    out->n_unclipped_wins = vfix[1];
+  }
+  out->pg_loss = pg; out->entropy_loss = ent; out->v_loss = vl; out->u_value = u;
+  out->loss = pg - (double)(c.ent_coeff * (float)ent) + (double)c.v_coef * vl;
+  out->adv_mean = (double)(float)adv_ms[2 * mb]; out->adv_std = (double)(float)adv_ms[2 * mb + 1];
+}
+
+struct StatsArgs {
+  DevCfg c; double Mglobal; const double* adv_ms; int mb; double* vfix; crl_ppo_stats* out;
+  int fused;  // 1: the last block of reduce_kernel also writes the statistics (single-GPU: sums are already global)
+};
+
 // Σ over per-block partials in fixed order → flat gradient (+ the loss sums appended for the all-reduce message)
 // msg layout: [P gradient floats][pg_sum, ent_sum, u_sum, q_sum as floats]
 // Block = 64 consecutive outputs x 4 groups of partials (group g sums blocks b ≡ g mod 4, then g0+g1+g2+g3):
@@ -476,7 +502,8 @@ __global__ void __launch_bounds__(256, 2) update_vfix_kernel(UpdateArgs a) {
 template <int MODE>
 __global__ void __launch_bounds__(256) reduce_kernel(const float* __restrict__ gpart, const double* __restrict__ lpart,
                                                      int nblkA, int nblkC, int pmax, int gstride, int Pa, int Pc,
-                                                     float* __restrict__ msg, const double* __restrict__ vfix) {
+                                                     float* __restrict__ msg, StatsArgs st) {
+  const double* vfix = st.vfix;
   if (MODE == 1 && vfix[3] == 0.0) return;
   __shared__ float sm[4][64];
   __shared__ double smd[4][4];
@@ -518,30 +545,17 @@ __global__ void __launch_bounds__(256) reduce_kernel(const float* __restrict__ g
   if (g == 0 && live) msg[i] = (sm[0][o] + sm[1][o]) + (sm[2][o] + sm[3][o]);
   if (last && g == 0 && o < 4 && !(MODE == 1 && (o >> 1) == 0))
     msg[P + o] = (float)((smd[0][o] + smd[1][o]) + (smd[2][o] + smd[3][o]));
+  if (last && st.fused) {
+    __syncthreads();  // the four sums written above are visible to thread 0 of this block
+    if (threadIdx.x == 0) compute_stats(msg, P, st.c, st.Mglobal, st.adv_ms, st.mb, st.vfix, st.out, MODE);
+  }
 }
 
-// "Training Statistics" (ppo.jl:247) from the (all-reduced) sums; raises the value-loss speculation flag
-__global__ void stats_kernel(const float* __restrict__ msg, int P, DevCfg c, double Mglobal, const double* __restrict__ adv_ms,
-                             int mb, double* __restrict__ vfix, crl_ppo_stats* __restrict__ out, int mode) {
+// data-parallel path: the sums are global only after the all-reduce, so the statistics get their own tiny launch
+__global__ void stats_kernel(const float* __restrict__ msg, int P, StatsArgs st, int mode) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (mode == 1 && vfix[3] == 0.0) return;
-  const double pg = (double)msg[P] / Mglobal;
-  const double ent = (double)(float)((double)msg[P + 1] / ((double)c.A * Mglobal));
-  const double u = (double)(float)((double)msg[P + 2] / Mglobal);
-  double vl;
-  if (mode == 0) {
-    vl = 0.5 * (double)(float)((double)msg[P + 3] / Mglobal);
-    vfix[0] = u;
-    vfix[3] = (c.clip_vloss && u > 0.0) ? 1.0 : 0.0;
-    if (vfix[3] != 0.0) vfix[4] = 1.0;  // sticky: lets a data-parallel run fail loudly (no exact pass there yet)
-    out->n_unclipped_wins = 0.0;
-  } else {
-    vl = 0.5 * (double)(float)((double)msg[P + 3] / Mglobal);
-    out->n_unclipped_wins = vfix[1];
-  }
-  out->pg_loss = pg; out->entropy_loss = ent; out->v_loss = vl; out->u_value = u;
-  out->loss = pg - (double)(c.ent_coeff * (float)ent) + (double)c.v_coef * vl;
-  out->adv_mean = (double)(float)adv_ms[2 * mb]; out->adv_std = (double)(float)adv_ms[2 * mb + 1];
+  if (mode == 1 && st.vfix[3] == 0.0) return;
+  compute_stats(msg, P, st.c, st.Mglobal, st.adv_ms, st.mb, st.vfix, st.out, mode);
 }
 
 // #{b : u > q_b} over the minibatch (only when the speculation flag is up)
@@ -616,12 +630,22 @@ static int run_update(crl_ppo* h, int mb, int mode) {
   return 0;
 }
 
-int launch_update(crl_ppo* h, int mb) {
+static StatsArgs stats_args(crl_ppo* h, int mb, crl_ppo_stats* slot, int fused) {
+  StatsArgs st;
+  st.c = h->dc; st.Mglobal = (double)h->dc.M * h->world; st.adv_ms = h->adv_ms; st.mb = mb; st.vfix = h->vfix; st.out = slot;
+  st.fused = fused;
+  return st;
+}
+
+// One optimiser step's gradient: update pass → fixed-order reduce (+ statistics) → [all-reduce → statistics] →
+// the rare exact value-loss pass (three early-exit launches). The gradient message ends up in comm_buf.
+int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
   if (h->cfg.obs_dim != 4 || h->cfg.n_act != 2 || h->cfg.hidden != 64) {
     set_error("this build of libcleanrl_hip supports obs_dim=4, n_act=2, hidden=64 (2x64 MLP) only");
     return 1;
   }
   const int P = (int)h->P;
+  const bool dp = h->comm != nullptr;
   {
     ProfScope ps(h, CRL_K_UPDATE);
     if (run_update(h, mb, 0)) return 1;
@@ -631,34 +655,26 @@ int launch_update(crl_ppo* h, int mb) {
     main_pass_blocks(h, &nA, &nC);
     ProfScope ps(h, CRL_K_REDUCE);
     hipLaunchKernelGGL(reduce_kernel<0>, dim3((P + 63) / 64), dim3(256), 0, h->stream, h->gpart, h->lpart, nA, nC,
-                       h->update_blocks, (int)h->Pa, (int)h->Pa, (int)h->Pc, h->comm_buf, h->vfix);
+                       h->update_blocks, (int)h->Pa, (int)h->Pa, (int)h->Pc, h->comm_buf, stats_args(h, mb, stats_slot, dp ? 0 : 1));
     CRL_HIP_CHECK(hipGetLastError());
   }
-  if (h->comm) {
-    ProfScope ps(h, CRL_K_ALLREDUCE);
-    if (comm_allreduce(h, h->comm_buf, (size_t)P + 4, false)) return 1;
+  if (dp) {
+    {
+      ProfScope ps(h, CRL_K_ALLREDUCE);
+      if (comm_allreduce(h, h->comm_buf, (size_t)P + 4, false)) return 1;
+    }
+    hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(64), 0, h->stream, h->comm_buf, P, stats_args(h, mb, stats_slot, 0), 0);
+    CRL_HIP_CHECK(hipGetLastError());
   }
-  return 0;
-}
-
-// second half of a step: statistics, the (rare) exact value-loss pass, gradient hand-off
-int launch_update_finish(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
-  const int P = (int)h->P;
-  const double Mg = (double)h->dc.M * h->world;
-  hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(64), 0, h->stream, h->comm_buf, P, h->dc, Mg, h->adv_ms, mb, h->vfix, stats_slot, 0);
-  CRL_HIP_CHECK(hipGetLastError());
   if (h->cfg.clip_value_loss && h->world == 1) {
-    // early-exit launches unless stats_kernel raised the flag (u > 0)
+    // early-exit launches unless the statistics raised the flag (u > 0)
     hipLaunchKernelGGL(vfix_count_kernel, dim3(1), dim3(1024), 0, h->stream, h->dc, h->perm, mb, h->newv, h->value, h->ret, h->vfix);
     CRL_HIP_CHECK(hipGetLastError());
     if (run_update(h, mb, 1)) return 1;
     hipLaunchKernelGGL(reduce_kernel<1>, dim3((P + 63) / 64), dim3(256), 0, h->stream, h->gpart, h->lpart, 0, h->update_blocks,
-                       h->update_blocks, (int)h->Pa, (int)h->Pa, (int)h->Pc, h->comm_buf, h->vfix);
-    CRL_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(64), 0, h->stream, h->comm_buf, P, h->dc, Mg, h->adv_ms, mb, h->vfix, stats_slot, 1);
+                       h->update_blocks, (int)h->Pa, (int)h->Pa, (int)h->Pc, h->comm_buf, stats_args(h, mb, stats_slot, 1));
     CRL_HIP_CHECK(hipGetLastError());
   }
-  CRL_HIP_CHECK(hipMemcpyAsync(h->grads, h->comm_buf, sizeof(float) * P, hipMemcpyDeviceToDevice, h->stream));
   return 0;
 }
 

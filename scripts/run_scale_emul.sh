@@ -1,0 +1,9 @@
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider 2>&1 | grep -E "passed|failed|error" > gpurun_out/test9.log
+for n in 65536 32768 16384 8192; do
+  timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --total-envs $n 2>/dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('envs $n','value %.4g ms %.3f'%(d['value'],d['ms_per_step']), {k:round(v,3) for k,v in d['kernel_ms_per_step'].items()})" >> gpurun_out/scale_emul.txt
+done
+cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof2 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof2.json 2> $GRAFT_REPO_ROOT/gpurun_out/prof2.log
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof3 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --total-envs 8192 > $GRAFT_REPO_ROOT/gpurun_out/prof3.json 2> $GRAFT_REPO_ROOT/gpurun_out/prof3.log
+echo done

@@ -114,8 +114,11 @@ def _oracle_state(nt, k, params, **kw):
     return cfg, st
 
 
+@pytest.mark.parametrize("split", ["1", "0"])
 @pytest.mark.parametrize("nt,stale", [(8, 1), (8, 0), (70, 1)])
-def test_rollout_matches_oracle(crl, nt, stale):
+def test_rollout_matches_oracle(crl, nt, stale, split, monkeypatch):
+    """split=1: two waves per tile (actor+env | critic), the small-shard kernel; split=0: one wave per tile."""
+    monkeypatch.setenv("CRL_ROLLOUT_SPLIT", split)
     k = 128
     agent = make_agent(crl, nt=nt, k=k, stale_obs=stale)
     params = agent.get_params()
