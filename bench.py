@@ -92,6 +92,8 @@ def main():
     h = agent.handle
     if world > 1:
         h.comm_init(crl_dist.exchange_unique_id(dist, rank, crl.comm_unique_id), world, rank)
+    elif os.environ.get("CRL_COMM_FORCE"):
+        h.comm_init(crl.comm_unique_id(), 1, 0)  # 1-GPU box: still route the all-reduces through RCCL
     h.env_reset()
 
     def barrier():

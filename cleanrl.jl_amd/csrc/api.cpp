@@ -207,6 +207,7 @@ int32_t crl_ppo_write(crl_ppo* h, int32_t field, const void* host, size_t nbytes
                                       std::to_string(nbytes) + ", want " + std::to_string(fr.bytes)); return 1; }
   CRL_HIP_CHECK(hipMemcpyAsync(fr.ptr, host, nbytes, hipMemcpyHostToDevice, h->stream));
   CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  if (field == CRL_F_PERM) h->perm_is_bijection = false;  // a caller-supplied permutation has no closed-form inverse
   return 0;
 }
 

@@ -1,4 +1,5 @@
 // optim.hip — advantage statistics (ppo.jl:221) and Optimiser(ClipNorm(0.5), Adam(η)) (ppo.jl:93,250).
+#include "bijection.hpp"
 #include "common.hpp"
 #include "ppo_ctx.hpp"
 
@@ -26,6 +27,38 @@ __global__ void adv_sums_kernel(const float* __restrict__ adv, const int32_t* __
     part[((size_t)mb * gridDim.x + blockIdx.x) * 2 + 1] = t2;
   }
 }
+// Same sums when perm is the keyed bijection: read the advantages IN ORDER (coalesced, 4 B per sample instead of a
+// 64-B sector per random gather) and ask the inverse bijection which minibatch sample x fell into.
+template <int NMB>
+__global__ void adv_sums_inv_kernel(const float* __restrict__ adv, int n, int M, int bits, uint64_t seed, uint64_t epoch,
+                                    double* __restrict__ part /* [nmb][gridDim.x][2] */) {
+  const BijKey key = bij_key(n, bits, seed, epoch);
+  double s[NMB], s2[NMB];
+#pragma unroll
+  for (int m = 0; m < NMB; ++m) { s[m] = 0.0; s2[m] = 0.0; }
+  for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < n; x += gridDim.x * blockDim.x) {
+    const double a = (double)adv[x];
+    const int mb = (int)(bij_inverse(key, (uint32_t)x, (uint32_t)n) / (uint32_t)M);
+#pragma unroll
+    for (int m = 0; m < NMB; ++m) { const bool hit = mb == m; s[m] += hit ? a : 0.0; s2[m] += hit ? a * a : 0.0; }
+  }
+  __shared__ double sm[2][NMB][16];
+  const int w = threadIdx.x >> 6;
+#pragma unroll
+  for (int m = 0; m < NMB; ++m) {
+    const double t = wave_sum(s[m]), t2 = wave_sum(s2[m]);
+    if ((threadIdx.x & 63) == 0) { sm[0][m][w] = t; sm[1][m][w] = t2; }
+  }
+  __syncthreads();
+  if (threadIdx.x < NMB) {
+    const int m = threadIdx.x;
+    double t = 0.0, t2 = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { t += sm[0][m][i]; t2 += sm[1][m][i]; }
+    part[((size_t)m * gridDim.x + blockIdx.x) * 2 + 0] = t;
+    part[((size_t)m * gridDim.x + blockIdx.x) * 2 + 1] = t2;
+  }
+}
+
 __global__ void adv_sums_fold_kernel(const double* __restrict__ part, int nblk, int nmb, double* __restrict__ sums) {
   const int mb = threadIdx.x;
   if (mb >= nmb) return;
@@ -48,8 +81,15 @@ int launch_adv_stats_sums(crl_ppo* h) {
   const int nblk = 64;
   double* part = reinterpret_cast<double*>(h->gpart);  // gpart is idle between optimiser steps
   ProfScope ps(h, CRL_K_ADV_STATS);
-  hipLaunchKernelGGL(adv_sums_kernel, dim3(nblk, h->dc.nmb), dim3(512), 0, h->stream, h->adv, h->perm, h->dc.M, part);
-  hipLaunchKernelGGL(adv_sums_fold_kernel, dim3(1), dim3(64), 0, h->stream, part, nblk, h->dc.nmb, h->adv_sums);
+  int nfold = nblk;
+  if (h->perm_is_bijection && h->dc.nmb == 4) {
+    nfold = 512;
+    hipLaunchKernelGGL((adv_sums_inv_kernel<4>), dim3(nfold), dim3(512), 0, h->stream, h->adv, h->dc.B, h->dc.M, bij_bits(h->dc.B),
+                       h->cfg.seed, h->perm_epoch, part);
+  } else {
+    hipLaunchKernelGGL(adv_sums_kernel, dim3(nblk, h->dc.nmb), dim3(512), 0, h->stream, h->adv, h->perm, h->dc.M, part);
+  }
+  hipLaunchKernelGGL(adv_sums_fold_kernel, dim3(1), dim3(64), 0, h->stream, part, nfold, h->dc.nmb, h->adv_sums);
   CRL_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -58,6 +58,8 @@ struct crl_ppo {
   float* params = nullptr; float* adam_m = nullptr; float* adam_v = nullptr;  // the gradient lives in comm_buf[0..P)
   double* betap = nullptr;     // [24]
   int32_t* perm = nullptr;
+  bool perm_is_bijection = false;  // perm == π_key(epoch): its inverse is computable (adv-stats fast path)
+  uint64_t perm_epoch = 0;
   // update workspace
   int update_blocks = 0;       // blocks per role
   float* gpart = nullptr;      // [2 roles][update_blocks][Pmax] per-block gradient partials

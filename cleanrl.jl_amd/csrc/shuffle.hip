@@ -5,6 +5,7 @@
 //  CRL_SHUFFLE_BIJECTION: throughput mode — perm[p] = π_key(p) with π a keyed bijection of [0,n) (invertible
 //    multiply / xorshift rounds on ceil(log2 n) bits + cycle walking). O(1) per element, no dependence between
 //    elements, one coalesced store each. A pseudo-random permutation, not a uniform draw from S_n.
+#include "bijection.hpp"
 #include "common.hpp"
 #include "ppo_ctx.hpp"
 
@@ -25,38 +26,22 @@ __global__ void iota_kernel(int32_t* __restrict__ perm, int n) {
   if (i < n) perm[i] = i;
 }
 
-__device__ __forceinline__ uint32_t bij_round(uint32_t x, uint32_t mask, int bits, uint32_t k0, uint32_t k1) {
-  // every step is invertible on `bits`-bit words: add key, odd multiply, xorshift
-  x = (x + k0) & mask;
-  x = (x * (k1 | 1u)) & mask;
-  x ^= x >> ((bits + 1) >> 1);
-  x = (x * 0x9E3779B1u) & mask;
-  x ^= x >> ((bits + 2) / 3);
-  return x & mask;
-}
-
 __global__ void bijection_kernel(int32_t* __restrict__ perm, int n, int bits, uint64_t seed, uint64_t epoch) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
-  const u32x4 key = philox(0x51u, (uint32_t)epoch, (uint32_t)(epoch >> 32), 0xB1Du, (uint32_t)seed, (uint32_t)(seed >> 32));
-  const uint32_t mask = bits >= 32 ? 0xFFFFFFFFu : ((1u << bits) - 1u);
-  uint32_t x = (uint32_t)p;
-  do {
-    x = bij_round(x, mask, bits, key.x, key.y);
-    x = bij_round(x, mask, bits, key.z, key.w);
-    x = bij_round(x, mask, bits, key.y ^ 0xA5A5A5A5u, key.x ^ 0x3C3C3C3Cu);
-  } while (x >= (uint32_t)n);  // cycle walking keeps it a bijection of [0,n)
-  perm[p] = (int32_t)x;
+  const BijKey key = bij_key(n, bits, seed, epoch);
+  perm[p] = (int32_t)bij_forward(key, (uint32_t)p, (uint32_t)n);
 }
 
 int launch_shuffle(crl_ppo* h, uint64_t epoch_id) {
   const int n = h->dc.B;
   ProfScope ps(h, CRL_K_SHUFFLE);
   if (h->cfg.shuffle_mode == CRL_SHUFFLE_FISHER_YATES) {
+    h->perm_is_bijection = false;
     hipLaunchKernelGGL(fy_serial_kernel, dim3(1), dim3(64), 0, h->stream, h->perm, n, h->cfg.seed, epoch_id);
   } else {
-    int bits = 1;
-    while ((1ll << bits) < (long long)n) ++bits;
+    const int bits = bij_bits(n);
+    h->perm_epoch = epoch_id; h->perm_is_bijection = true;
     hipLaunchKernelGGL(bijection_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->perm, n, bits, h->cfg.seed, epoch_id);
   }
   CRL_HIP_CHECK(hipGetLastError());

@@ -1,0 +1,5 @@
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider 2>&1 | grep -E "passed|failed|error|Error|assert" | head -20 > gpurun_out/test11.log
+timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('value %.4g ms %.3f'%(d['value'],d['ms_per_step']), {k:round(v,3) for k,v in d['kernel_ms_per_step'].items()})" >> gpurun_out/bench_t.txt
+echo done

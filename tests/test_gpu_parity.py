@@ -317,3 +317,27 @@ def test_rccl_path_world1(crl, monkeypatch):
         assert abs(a["loss"] - b["loss"]) <= 2e-5 * max(1.0, abs(b["loss"]))
     assert np.max(np.abs(h.read(crl._lib.F_PARAMS) - st.params)) < 2e-5
     agent.close(); st.close()
+
+
+@pytest.mark.parametrize("nt,k", [(8, 128), (37, 64), (4096, 128)])
+def test_adv_stats_through_inverse_bijection(crl, nt, k):
+    """With the keyed-bijection shuffle the advantage statistics are summed in sample order and each sample's minibatch
+    comes from the INVERSE bijection; they must equal mean/std over the perm slices (ppo.jl:221)."""
+    rng = np.random.default_rng(nt)
+    agent = make_agent(crl, nt=nt, k=k, shuffle_mode=1)
+    h = agent.handle; F = crl._lib
+    adv = (3 * rng.standard_normal((nt, k)) + 0.7).astype(np.float32)
+    for f, a in ((F.F_ADVANTAGE, adv), (F.F_OBS, rng.standard_normal((4, nt, k)).astype(np.float32)),
+                 (F.F_RETURN, 10 * rng.standard_normal((nt, k)).astype(np.float32))):
+        h.write(f, a)
+    h.shuffle(11)
+    perm = h.read(F.F_PERM)
+    h.adv_stats()
+    M = nt * k // 4
+    flat = adv.ravel(order="F").astype(np.float64)
+    for mb in range(4):
+        st = h.update_minibatch(mb, 0.0, apply_update=False)
+        sl = flat[perm[mb * M:(mb + 1) * M]]
+        assert abs(st["adv_mean"] - np.float32(sl.mean())) < 1e-6
+        assert abs(st["adv_std"] - np.float32(sl.std(ddof=1))) < 1e-5
+    agent.close()
