@@ -106,6 +106,8 @@ int launch_gae(hipStream_t st, const float* value, const float* reward, const ui
   static int env_L = -1, env_EB = -1;
   if (env_L < 0) { const char* e = getenv("CRL_GAE_L"); env_L = e ? atoi(e) : 0; }
   if (env_EB < 0) { const char* e = getenv("CRL_GAE_EB"); env_EB = e ? atoi(e) : 0; }
+  // (a 4-envs-per-thread variant with 16-B loads was measured SLOWER: 38.9 vs 32.1 us at nt=65536 — 182 VGPRs leave only
+  //  2 waves/SIMD; profiles/r01_g_gae_wide_vs_scalar.txt)
   int L = env_L ? env_L : (k <= 256 ? 8 : 16);
   int S = (k + L - 1) / L;
   int EB = env_EB ? env_EB : 64;
