@@ -130,6 +130,18 @@ def main():
         upd_tflops = UPDATE_FLOPS_PER_SAMPLE * M / upd_avg_s / 1e12 if upd_n else 0.0
         gae_bytes = GAE_BYTES_PER_STEP * nt_local * NUM_STEPS + GAE_BYTES_PER_ENV * nt_local
         gae_gbps = gae_bytes / gae_avg_s / 1e9 if gae_n else 0.0
+        # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate
+        # passes of this same command, scripts/final_measure.sh); raw (FETCH+WRITE)*1024 — the guide's x2 FETCH correction
+        # is calibrated for 16-B/lane streams only, these kernels use 4-B and gathered 16-B accesses.
+        traffic = {"update": None, "gae": None}
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_f_pmc_hbm_traffic.json")))
+            if world == 1 and args.total_envs == TOTAL_ENVS:
+                for key, name in (("update", "void crl::update_x3_kernel<4, 2>"), ("gae", "void crl::gae_kernel<32, 8>")):
+                    if name in pm:
+                        traffic[key] = (pm[name]["FETCH_SIZE_KB_per_launch_mean"] + pm[name]["WRITE_SIZE_KB_per_launch_mean"]) * 1024
+        except Exception:
+            pass
         out = {
             "metric": "env-steps/sec (whole node), CartPole PPO num_envs=65536 at 1/2/4/8 GPUs",
             "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -144,10 +156,10 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "update_x3_kernel / update_kernel (fwd+bwd of one minibatch, actor+critic)",
                          "note": "achieved = algorithmic f32 FLOPs (3 x 17,792 per sample) / HIP-event launch time; peak = dense f32 MFMA",
                          "achieved": upd_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": upd_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": upd_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic["update"],
                          "avg_launch_ms": upd_avg_s * 1e3, "launches": upd_n, "flops_per_launch": UPDATE_FLOPS_PER_SAMPLE * M},
             "roofline_gae": {"bound": "hbm", "kernel": "gae_kernel (advantages + returns)", "achieved": gae_gbps,
-                             "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gae_gbps / PEAK_HBM_GBPS, "traffic": None,
+                             "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gae_gbps / PEAK_HBM_GBPS, "traffic": traffic["gae"],
                              "avg_launch_ms": gae_avg_s * 1e3, "launches": gae_n, "bytes_per_launch": gae_bytes},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
             "last_iteration": {"loss": stats[-1]["loss"], "episodes": ep["episodes"],
