@@ -334,9 +334,9 @@ int32_t crl_compute_gae(crl_ppo* h) {
   CRL_GUARD(h);
   const bool fixed = h->cfg.gae_mode == CRL_GAE_FIXED;
   if (fixed && launch_next_value(h)) return 1;
-  ProfScope ps(h, CRL_K_GAE);
+  ProfScope ps(h, CRL_K_GAE, /*attach=*/true);
   return launch_gae(h->stream, h->value, h->reward, h->terminal, fixed ? h->next_value : nullptr, h->next_done, h->dc.nt,
-                    h->dc.k, h->cfg.gamma, h->cfg.gae_lambda, h->cfg.gae_mode, h->adv, h->ret);
+                    h->dc.k, h->cfg.gamma, h->cfg.gae_lambda, h->cfg.gae_mode, h->adv, h->ret, ps.a, ps.b);
 }
 
 int32_t crl_shuffle(crl_ppo* h, uint64_t epoch_id) {

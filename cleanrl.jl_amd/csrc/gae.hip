@@ -7,6 +7,8 @@
 // (9 B) and one write of advantage/return (8 B) per (env, step): 17 B — the algorithmic minimum.
 // Arithmetic is Float64 like the reference's accumulator (ppo.jl:63,65; Q2), stored Float32 (ppo.jl:62).
 // Layout: (nt, k) column-major, env fastest ⇒ lanes of a wave read consecutive envs: coalesced 128/256-B rows.
+#include <hip/hip_ext.h>
+
 #include <cstdlib>
 
 #include "ppo_ctx.hpp"
@@ -98,7 +100,7 @@ __global__ void __launch_bounds__(512) gae_kernel(const float* __restrict__ valu
 
 int launch_gae(hipStream_t st, const float* value, const float* reward, const uint8_t* terminal,
                const float* next_value, const uint8_t* next_done, int nt, int k, float gamma, float lambda, int mode,
-               float* adv, float* ret) {
+               float* adv, float* ret, hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (nt <= 0 || k <= 0) { set_error("gae: empty input"); return 1; }
   const float gl = gamma * lambda;  // Float32 product, as `γ * λ` with both T=Float32 (ppo.jl:68)
   // segment length L and env tile EB: S = ceil(k/L) segments, block = S*EB <= 512 threads.
@@ -118,8 +120,8 @@ int launch_gae(hipStream_t st, const float* value, const float* reward, const ui
   const size_t smem = sizeof(double) * 2 * S * EB;
 #define CRL_GAE_CASE(eb, l)                                                                                          \
   if (EB == eb && L == l) {                                                                                          \
-    hipLaunchKernelGGL((gae_kernel<eb, l>), grid, block, smem, st, value, reward, terminal, next_value, next_done, nt, \
-                       k, gamma, gl, mode, adv, ret);                                                                \
+    hipExtLaunchKernelGGL((gae_kernel<eb, l>), grid, block, smem, st, ev_start, ev_stop, 0, value, reward, terminal,   \
+                          next_value, next_done, nt, k, gamma, gl, mode, adv, ret);                                  \
   } else
   CRL_GAE_CASE(64, 8) CRL_GAE_CASE(32, 8) CRL_GAE_CASE(16, 8) CRL_GAE_CASE(8, 8)
   CRL_GAE_CASE(64, 16) CRL_GAE_CASE(32, 16) CRL_GAE_CASE(16, 16) CRL_GAE_CASE(8, 16)

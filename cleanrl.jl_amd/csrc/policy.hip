@@ -19,6 +19,11 @@ namespace crl {
 // Contraction is off and the promotions to Float64 follow the reference expression (`4 / 3` is a Float64 literal),
 // so this is bit-identical to the CPU oracle.
 // ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_nt4(f32x4* p, float a, float b, float c, float d) {
+  f32x4 v; v[0] = a; v[1] = b; v[2] = c; v[3] = d;
+  __builtin_nontemporal_store(v, p);
+}
+
 __device__ __forceinline__ float sin_poly(float x) {
   float x2 = x * x;
   float p = __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, 2.7557319e-6f, -1.9841270e-4f), 8.3333333e-3f), -1.6666667e-1f);
@@ -251,8 +256,11 @@ __global__ void __launch_bounds__(512, 2) rollout_cartpole_kernel(RolloutArgs a)
     const bool done = cartpole_step(s, t_env, act);                  // ppo.jl:130
     const float rew = done ? 0.0f : 1.0f;                            // ppo.jl:132 (RLEnvs: reward 0 on the terminal step)
     if (writer) {                                                    // ppo.jl:133-140 Buffer.add!
-      reinterpret_cast<float4*>(a.obs)[b] = make_float4(co[0], co[1], co[2], co[3]);
-      a.action[b] = act; a.logprob[b] = lpa; a.reward[b] = rew; a.terminal[b] = nd; a.value[b] = v[0];
+      // obs/action/logprob are next read by the update pass, a full GAE + shuffle later: stream them past the caches
+      // (nontemporal) so the 75 MB the GAE scan needs (value, reward, terminal) stay resident in L2 / Infinity Cache
+      store_nt4(reinterpret_cast<f32x4*>(a.obs) + b, co[0], co[1], co[2], co[3]);
+      __builtin_nontemporal_store(act, a.action + b); __builtin_nontemporal_store(lpa, a.logprob + b);
+      a.reward[b] = rew; a.terminal[b] = nd; a.value[b] = v[0];
     }
     co[0] = s[0]; co[1] = s[1]; co[2] = s[2]; co[3] = s[3];         // ppo.jl:143 next_obs (before reset!, Q7)
     nd = done ? 1 : 0;                                               // ppo.jl:144
@@ -337,8 +345,9 @@ __global__ void __launch_bounds__(128) rollout_split_kernel(RolloutArgs a) {
       const bool done = cartpole_step(s, t_env, act);                // ppo.jl:130
       const float rew = done ? 0.0f : 1.0f;                          // ppo.jl:132
       if (writer) {                                                  // ppo.jl:133-140 Buffer.add! (value: wave 1)
-        reinterpret_cast<float4*>(a.obs)[b] = make_float4(co[0], co[1], co[2], co[3]);
-        a.action[b] = act; a.logprob[b] = lpa; a.reward[b] = rew; a.terminal[b] = nd;
+        store_nt4(reinterpret_cast<f32x4*>(a.obs) + b, co[0], co[1], co[2], co[3]);
+        __builtin_nontemporal_store(act, a.action + b); __builtin_nontemporal_store(lpa, a.logprob + b);
+        a.reward[b] = rew; a.terminal[b] = nd;
       }
       co[0] = s[0]; co[1] = s[1]; co[2] = s[2]; co[3] = s[3];       // ppo.jl:143
       nd = done ? 1 : 0;                                             // ppo.jl:144

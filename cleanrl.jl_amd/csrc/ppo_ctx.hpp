@@ -86,20 +86,28 @@ int ensure_stage(crl_ppo* h, size_t bytes);
 // CRL_GEMM=f32 selects the v_mfma_f32_32x32x2_f32 layers; default is the bf16x3 matrix-pipe path (mlp_x3.hpp)
 bool gemm_x3();
 
+// HIP-event timing of one kernel class. attach=true: the events are handed to hipExtLaunchKernelGGL, which stamps the
+// kernel's own begin/end (what rocprofv3 reports); otherwise they are recorded on the stream around the launch(es).
 struct ProfScope {
-  crl_ppo* h; int id; hipEvent_t a = nullptr, b = nullptr;
-  ProfScope(crl_ppo* h_, int id_) : h(h_), id(id_) {
-    if (h->prof) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, h->stream); }
+  crl_ppo* h; int id; bool attach; hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(crl_ppo* h_, int id_, bool attach_ = false) : h(h_), id(id_), attach(attach_) {
+    if (h->prof) {
+      (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+      if (!attach) (void)hipEventRecord(a, h->stream);
+    }
   }
   ~ProfScope() {
-    if (h->prof) { (void)hipEventRecord(b, h->stream); h->prof_slots[id].pending.emplace_back(a, b); }
+    if (h->prof) {
+      if (!attach) (void)hipEventRecord(b, h->stream);
+      h->prof_slots[id].pending.emplace_back(a, b);
+    }
   }
 };
 
 // kernel launchers (each in its own translation unit)
 int launch_gae(hipStream_t st, const float* value, const float* reward, const uint8_t* terminal,
                const float* next_value, const uint8_t* next_done, int nt, int k, float gamma, float lambda, int mode,
-               float* adv, float* ret);
+               float* adv, float* ret, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 int launch_policy_act(crl_ppo* h, const float* obs_d, const double* u_d, int n, int32_t* action_d, float* logprob_d,
                       float* value_d);
 int launch_logprob_actions(crl_ppo* h, const float* obs_d, const int32_t* act_d, int n, float* logprob_d, float* ent_d);

@@ -14,6 +14,8 @@
 // Value loss (ppo.jl:231-237, Q4): max.(u, q_b) with the SCALAR u = mean(v - R²) needs u before any critic
 // cotangent exists. q_b ≥ 0, so whenever u ≤ 0 every max picks q_b: the kernel speculates on that, and
 // reduce_kernel raises a flag if u > 0; only then do vfix_count_kernel and a critic-only exact pass rerun.
+#include <hip/hip_ext.h>
+
 #include <cstdlib>
 
 #include "common.hpp"
@@ -37,6 +39,7 @@ struct UpdateArgs {
   int nblk[2];            // blocks working on the actor / the critic
   int pmax;               // capacity (blocks per role) of the partial buffers
   int stagger;            // x3 kernel: start delay of waves 4-7 (units of 1024 clocks)
+  int smp_mask;           // timing experiments only (CRL_DEBUG_GATHER_MASK): AND-mask on gathered sample ids; default all ones
   double Mglobal;         // minibatch size over all ranks (the 1/M of every mean)
 };
 
@@ -118,9 +121,9 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
   int smp_n = 0;
   if (tile < ntiles) {
     const int pos = tile * TILE + j;
-    gather<D, ROLE>(a, pos < M ? perm[pos] : 0, cur);
+    gather<D, ROLE>(a, pos < M ? (perm[pos] & a.smp_mask) : 0, cur);
     const int pn = (tile + nwaves) * TILE + j;
-    smp_n = pn < M ? perm[pn] : 0;
+    smp_n = pn < M ? (perm[pn] & a.smp_mask) : 0;
   }
   for (; tile < ntiles; tile += nwaves) {
     const int pos = tile * TILE + j;
@@ -194,7 +197,7 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
     gather<D, ROLE>(a, smp_n, nxt);
     {
       const int pn = (tile + 2 * nwaves) * TILE + j;
-      smp_n = pn < M ? perm[pn] : 0;
+      smp_n = pn < M ? (perm[pn] & a.smp_mask) : 0;
     }
     // ---- backward ------------------------------------------------------------------------------------
     // (1) h2ᵀ, the output cotangents and x into the wave-private scratch
@@ -602,13 +605,14 @@ static void main_pass_blocks(crl_ppo* h, int* nA, int* nC) {
   }
 }
 
-static int run_update(crl_ppo* h, int mb, int mode) {
+static int run_update(crl_ppo* h, int mb, int mode, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
   UpdateArgs a;
   a.c = h->dc; a.params = h->params;
   a.states = h->obs; a.actions = h->action; a.logprobs = h->logprob; a.values = h->value;
   a.advantages = h->adv; a.returns = h->ret; a.perm = h->perm; a.adv_ms = h->adv_ms; a.vfix = h->vfix;
   a.gpart = h->gpart; a.lpart = h->lpart; a.newv = h->newv;
   a.mb = mb; a.mode = mode; a.gstride = (int)h->Pa; a.pmax = h->update_blocks; a.stagger = 0;
+  a.smp_mask = env_int("CRL_DEBUG_GATHER_MASK", 0x7fffffff);
   a.Mglobal = (double)h->dc.M * h->world;
   if (mode == 1) {
     a.nblk[0] = 0; a.nblk[1] = h->update_blocks;
@@ -620,11 +624,11 @@ static int run_update(crl_ppo* h, int mb, int mode) {
     if (stagger < 0) stagger = env_int("CRL_X3_STAGGER", 3);
     a.stagger = stagger;
     const size_t smem = sizeof(float) * (NetImageX3<4, 2, true>::SIZE + 8 * SCR_FLOATS);
-    hipLaunchKernelGGL((update_x3_kernel<4, 2>), dim3(a.nblk[0] + a.nblk[1]), dim3(512), smem, h->stream, a);
+    hipExtLaunchKernelGGL((update_x3_kernel<4, 2>), dim3(a.nblk[0] + a.nblk[1]), dim3(512), smem, h->stream, ev0, ev1, 0, a);
   } else {
     main_pass_blocks(h, &a.nblk[0], &a.nblk[1]);
     const size_t smem = sizeof(float) * (NetImage<4, 2, true>::SIZE + NetImage<4, 1, true>::SIZE + 8 * SCR_FLOATS);
-    hipLaunchKernelGGL((update_kernel<4, 2>), dim3(h->update_blocks), dim3(512), smem, h->stream, a);
+    hipExtLaunchKernelGGL((update_kernel<4, 2>), dim3(h->update_blocks), dim3(512), smem, h->stream, ev0, ev1, 0, a);
   }
   CRL_HIP_CHECK(hipGetLastError());
   return 0;
@@ -647,8 +651,8 @@ int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
   const int P = (int)h->P;
   const bool dp = h->comm != nullptr;
   {
-    ProfScope ps(h, CRL_K_UPDATE);
-    if (run_update(h, mb, 0)) return 1;
+    ProfScope ps(h, CRL_K_UPDATE, /*attach=*/true);
+    if (run_update(h, mb, 0, ps.a, ps.b)) return 1;
   }
   {
     int nA, nC;
