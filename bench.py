@@ -72,6 +72,11 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
+    # stdout carries exactly ONE JSON line (rank 0). Native libraries (RCCL prints a version banner through C stdio,
+    # flushed at exit) must not leak into it: fd 1 is pointed at stderr for the whole run and the JSON goes to the saved fd.
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     import cleanrl_jl_amd as crl
@@ -167,7 +172,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
