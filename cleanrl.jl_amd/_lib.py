@@ -47,12 +47,13 @@ EXPORTS = [
     "crl_sync", "crl_ppo_write", "crl_ppo_read", "crl_policy_act", "crl_logprob_actions", "crl_gae",
     "crl_rollout_store", "crl_env_reset", "crl_rollout_run", "crl_episode_stats_read", "crl_compute_gae",
     "crl_shuffle", "crl_adv_stats", "crl_ppo_update_minibatch", "crl_ppo_iterate", "crl_ppo_iteration",
-    "crl_comm_unique_id", "crl_comm_init", "crl_prof_enable", "crl_prof_read", "crl_prof_reset",
+    "crl_comm_unique_id", "crl_comm_init", "crl_comm_init_external", "crl_adv_stats_local", "crl_adv_stats_finish",
+    "crl_prof_enable", "crl_prof_read", "crl_prof_reset",
 ]
 
 # crl_field
 F_OBS, F_ACTION, F_LOGPROB, F_REWARD, F_TERMINAL, F_VALUE, F_ADVANTAGE, F_RETURN, F_PERM, F_PARAMS, F_GRADS, F_ADAM_M, \
-    F_ADAM_V, F_ENV_STATE, F_CUR_OBS, F_NEXT_DONE, F_ENV_T, F_BETAP = range(18)
+    F_ADAM_V, F_ENV_STATE, F_CUR_OBS, F_NEXT_DONE, F_ENV_T, F_BETAP, F_ADV_SUMS = range(19)
 GAE_COMPAT, GAE_FIXED = 0, 1
 ENV_CARTPOLE, ENV_EXTERNAL = 0, 2
 SHUFFLE_FISHER_YATES, SHUFFLE_BIJECTION = 0, 1
@@ -96,6 +97,9 @@ def load():
     L.crl_ppo_iteration.argtypes = [vp, C.POINTER(C.c_int64)]
     L.crl_comm_unique_id.argtypes = [u8p]
     L.crl_comm_init.argtypes = [vp, u8p, C.c_int32, C.c_int32]
+    L.crl_comm_init_external.argtypes = [vp, C.c_int32, C.c_int32]
+    L.crl_adv_stats_local.argtypes = [vp]
+    L.crl_adv_stats_finish.argtypes = [vp]
     L.crl_prof_enable.argtypes = [vp, C.c_int32]
     L.crl_prof_read.argtypes = [vp, C.c_int32, dp, C.POINTER(C.c_int64)]
     L.crl_prof_reset.argtypes = [vp]
@@ -125,7 +129,7 @@ _FIELD_DTYPES = {
     F_OBS: np.float32, F_ACTION: np.int32, F_LOGPROB: np.float32, F_REWARD: np.float32, F_TERMINAL: np.uint8,
     F_VALUE: np.float32, F_ADVANTAGE: np.float32, F_RETURN: np.float32, F_PERM: np.int32, F_PARAMS: np.float32,
     F_GRADS: np.float32, F_ADAM_M: np.float32, F_ADAM_V: np.float32, F_ENV_STATE: np.float32, F_CUR_OBS: np.float32,
-    F_NEXT_DONE: np.uint8, F_ENV_T: np.int32, F_BETAP: np.float64,
+    F_NEXT_DONE: np.uint8, F_ENV_T: np.int32, F_BETAP: np.float64, F_ADV_SUMS: np.float64,
 }
 
 
@@ -156,7 +160,8 @@ class Handle:
     def _shape(self, f):
         nt, k, d, B, P = self.nt, self.k, self.d, self.B, self.P
         return {F_OBS: (d, nt, k), F_PERM: (B,), F_PARAMS: (P,), F_GRADS: (P,), F_ADAM_M: (P,), F_ADAM_V: (P,),
-                F_ENV_STATE: (d, nt), F_CUR_OBS: (d, nt), F_NEXT_DONE: (nt,), F_ENV_T: (nt,), F_BETAP: (24,)}.get(f, (nt, k))
+                F_ENV_STATE: (d, nt), F_CUR_OBS: (d, nt), F_NEXT_DONE: (nt,), F_ENV_T: (nt,), F_BETAP: (24,),
+                F_ADV_SUMS: (2 * self.cfg.num_minibatches,)}.get(f, (nt, k))
 
     def read(self, f):
         out = np.zeros(self._shape(f), _FIELD_DTYPES[f], order="F")
@@ -238,6 +243,15 @@ class Handle:
     def comm_init(self, unique_id: bytes, world_size: int, rank: int):
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         check(load().crl_comm_init(self._h, buf, world_size, rank))
+
+    def comm_init_external(self, world_size: int, rank: int):
+        check(load().crl_comm_init_external(self._h, world_size, rank))
+
+    def adv_stats_local(self):
+        check(load().crl_adv_stats_local(self._h))
+
+    def adv_stats_finish(self):
+        check(load().crl_adv_stats_finish(self._h))
 
     def prof_enable(self, on=True):
         check(load().crl_prof_enable(self._h, int(on)))

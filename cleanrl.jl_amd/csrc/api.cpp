@@ -60,6 +60,7 @@ static bool field_ref(crl_ppo* h, int f, FieldRef* out) {
     case CRL_F_NEXT_DONE: *out = {h->next_done, nt}; return true;
     case CRL_F_ENV_T: *out = {h->env_t, nt * 4}; return true;
     case CRL_F_BETAP: *out = {h->betap, 24 * 8}; return true;
+    case CRL_F_ADV_SUMS: *out = {h->adv_sums, (size_t)h->dc.nmb * 2 * 8}; return true;
     default: return false;
   }
 }
@@ -351,6 +352,15 @@ int32_t crl_adv_stats(crl_ppo* h) {
   return launch_adv_stats_finish(h);
 }
 
+int32_t crl_adv_stats_local(crl_ppo* h) {
+  CRL_GUARD(h);
+  return launch_adv_stats_sums(h);
+}
+int32_t crl_adv_stats_finish(crl_ppo* h) {
+  CRL_GUARD(h);
+  return launch_adv_stats_finish(h);
+}
+
 static int update_step(crl_ppo* h, int mb, double eta, int apply, int slot) {
   if (launch_update(h, mb, h->stats_dev + slot)) return 1;
   if (apply && launch_optim(h, eta)) return 1;
@@ -417,6 +427,16 @@ int32_t crl_comm_init(crl_ppo* h, const uint8_t id[128], int32_t world_size, int
   CRL_GUARD(h);
   if (comm_init(h, id, world_size, rank)) return 1;
   // num_updates = total_timesteps ÷ (global batch) (ppo.jl:89-91)
+  const int64_t gb = (int64_t)h->dc.B * h->world;
+  h->num_updates = h->cfg.total_timesteps / gb;
+  if (h->num_updates < 1) h->num_updates = 1;
+  return 0;
+}
+
+int32_t crl_comm_init_external(crl_ppo* h, int32_t world_size, int32_t rank) {
+  CRL_GUARD(h);
+  if (world_size < 1 || rank < 0 || rank >= world_size) { set_error("crl_comm_init_external: bad world/rank"); return 1; }
+  h->world = world_size; h->rank = rank; h->external_comm = true;
   const int64_t gb = (int64_t)h->dc.B * h->world;
   h->num_updates = h->cfg.total_timesteps / gb;
   if (h->num_updates < 1) h->num_updates = 1;

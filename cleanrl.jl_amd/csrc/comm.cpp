@@ -77,7 +77,7 @@ int comm_init(crl_ppo* h, const uint8_t id[128], int world, int rank) {
 
 int comm_allreduce(crl_ppo* h, void* buf, size_t count, bool is_double) {
   if (!h->comm) {
-    if (h->world == 1) return 0;
+    if (h->world == 1 || h->external_comm) return 0;
     set_error("all-reduce requested but no communicator attached (crl_comm_init)"); return 1;
   }
   ncclResult_t r = g_rccl.AllReduce(buf, buf, count, is_double ? ncclDouble : ncclFloat, ncclSum,

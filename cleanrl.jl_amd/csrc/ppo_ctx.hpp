@@ -76,6 +76,7 @@ struct crl_ppo {
 
   // RCCL (loaded lazily; world_size 1 = no communicator)
   void* comm = nullptr; int world = 1, rank = 0;
+  bool external_comm = false;  // shards exchanged by the host (crl_comm_init_external): all-reduce calls are no-ops
 
   bool prof = false;
   crl::ProfSlot prof_slots[CRL_K_COUNT];

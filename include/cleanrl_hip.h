@@ -37,7 +37,7 @@ extern "C" {
 #define CRL_ENV_EXTERNAL 2 /* envs stepped by the caller: crl_policy_act + crl_rollout_store */
 /* shuffle mode */
 #define CRL_SHUFFLE_FISHER_YATES 0 /* exact serial Fisher–Yates on device (ppo.jl:194 semantics) */
-#define CRL_SHUFFLE_BLOCKED 1      /* parallel keyed bijection + per-block Fisher–Yates in LDS (throughput path) */
+#define CRL_SHUFFLE_BIJECTION 1     /* perm[p] = keyed bijection of [0,B): O(1) per element, pseudo-random (throughput path) */
 /* rollout / state fields for crl_ppo_read / crl_ppo_write */
 enum crl_field {
   CRL_F_OBS = 0,      /* float  (obs_dim, nt, k)  replay_buffer.jl:15-18 / ppo.jl:96 */
@@ -57,7 +57,8 @@ enum crl_field {
   CRL_F_CUR_OBS = 14,   /* float (obs_dim, nt) next_obs of ppo.jl:114,143 */
   CRL_F_NEXT_DONE = 15, /* uint8 (nt)          next_done of ppo.jl:115,144 */
   CRL_F_ENV_T = 16,     /* int32 (nt) steps since reset */
-  CRL_F_BETAP = 17      /* double (24) Adam running beta powers per array */
+  CRL_F_BETAP = 17,     /* double (24) Adam running beta powers per array */
+  CRL_F_ADV_SUMS = 18   /* double (num_minibatches, 2) Σadv, Σadv² of the current permutation slices (what the ranks all-reduce) */
 };
 
 /* Mirror of PPOConfig (ppo.jl:1-19) + the shapes the reference hard-codes (networks.jl:36, CartPole) */
@@ -143,6 +144,10 @@ int32_t crl_shuffle(crl_ppo* h, uint64_t epoch_id);
 /* per-minibatch advantage mean/std of the current permutation (ppo.jl:221), all num_minibatches at once;
  * all-reduced across ranks when a communicator is attached. Must follow crl_shuffle / a CRL_F_PERM write. */
 int32_t crl_adv_stats(crl_ppo* h);
+/* The two halves of crl_adv_stats for hosts that run the exchange themselves (and for the single-GPU test of the
+ * data-parallel arithmetic): local sums → CRL_F_ADV_SUMS, then mean/std from whatever CRL_F_ADV_SUMS holds. */
+int32_t crl_adv_stats_local(crl_ppo* h);
+int32_t crl_adv_stats_finish(crl_ppo* h);
 /* One `for start in 1:minibatch_size:batch_size` body — ppo.jl:197-251: loss, gradient, (all-reduce), per-array
  * ClipNorm(0.5) + Adam(eta). apply_update=0 stops after the gradient (parity tests). stats may be NULL (no sync). */
 int32_t crl_ppo_update_minibatch(crl_ppo* h, int32_t mb, double eta, int32_t apply_update, crl_ppo_stats* stats);
@@ -156,6 +161,9 @@ int32_t crl_ppo_iteration(const crl_ppo* h, int64_t* it);
  * all-reduced once per optimiser step (ppo.jl:250 cadence) and averaged; ClipNorm/Adam then run replicated. */
 int32_t crl_comm_unique_id(uint8_t id[128]);
 int32_t crl_comm_init(crl_ppo* h, const uint8_t id[128], int32_t world_size, int32_t rank);
+/* Declares this handle one of `world_size` shards WITHOUT attaching a communicator: every 1/M uses the global
+ * minibatch size and the host sums the per-shard gradient messages (CRL_F_GRADS) itself. */
+int32_t crl_comm_init_external(crl_ppo* h, int32_t world_size, int32_t rank);
 
 /* Profiling: HIP-event timing of each kernel class on the handle's stream (bench.py roofline). */
 enum crl_kernel_id { CRL_K_ROLLOUT = 0, CRL_K_GAE = 1, CRL_K_SHUFFLE = 2, CRL_K_ADV_STATS = 3, CRL_K_UPDATE = 4,
