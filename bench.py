@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--total-envs", type=int, default=TOTAL_ENVS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--shuffle", choices=["bijection", "fisher-yates"], default="bijection")
+    ap.add_argument("--shuffle", choices=["bijection", "fisher-yates", "blocked-fy"], default="bijection")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -93,7 +93,8 @@ def main():
     nt_local, env_off = crl_dist.shard_envs(args.total_envs, world, rank)
     cfg = crl.PPOConfig(num_envs=nt_local, num_steps=NUM_STEPS, total_timesteps=args.total_envs * NUM_STEPS * (args.steps + args.warmup))
     agent = crl.Agent(cfg, device=local_rank, env_id_offset=env_off,
-                      shuffle_mode=L.SHUFFLE_BIJECTION if args.shuffle == "bijection" else L.SHUFFLE_FISHER_YATES)
+                      shuffle_mode={"bijection": L.SHUFFLE_BIJECTION, "fisher-yates": L.SHUFFLE_FISHER_YATES,
+                                    "blocked-fy": L.SHUFFLE_BLOCKED_FY}[args.shuffle])
     h = agent.handle
     if world > 1:
         h.comm_init(crl_dist.exchange_unique_id(dist, rank, crl.comm_unique_id), world, rank)

@@ -147,6 +147,7 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
   rc |= dalloc(&h->next_value, nt); rc |= dalloc(&h->ep_stats, 4);
   rc |= dalloc(&h->params, h->P); rc |= dalloc(&h->adam_m, h->P); rc |= dalloc(&h->adam_v, h->P);
   rc |= dalloc(&h->betap, 24); rc |= dalloc(&h->perm, B);
+  if (cfg->shuffle_mode == CRL_SHUFFLE_BLOCKED_FY) { rc |= dalloc(&h->perm_tmp, B); rc |= dalloc(&h->bfy_ws, (size_t)4 * 4096 + 8); }
   // update grid: two 256-thread blocks per CU, alternating roles; never more waves than tiles
   hipDeviceProp_t prop;
   CRL_HIP_CHECK(hipGetDeviceProperties(&prop, device));
@@ -178,7 +179,7 @@ int32_t crl_ppo_destroy(crl_ppo* h) {
   comm_destroy(h);
   void* ptrs[] = {h->obs, h->action, h->logprob, h->reward, h->terminal, h->value, h->adv, h->ret, h->env_state, h->env_t,
                   h->cur_obs, h->next_done, h->ep_return, h->ep_length, h->next_value, h->ep_stats, h->params,
-                  h->adam_m, h->adam_v, h->betap, h->perm, h->gpart, h->lpart, h->adv_sums, h->adv_ms, h->newv, h->vfix,
+                  h->adam_m, h->adam_v, h->betap, h->perm, h->perm_tmp, h->bfy_ws, h->gpart, h->lpart, h->adv_sums, h->adv_ms, h->newv, h->vfix,
                   h->stats_dev, h->comm_buf, h->stage};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int k = 0; k < CRL_K_COUNT; ++k)
@@ -209,6 +210,7 @@ int32_t crl_ppo_write(crl_ppo* h, int32_t field, const void* host, size_t nbytes
   CRL_HIP_CHECK(hipMemcpyAsync(fr.ptr, host, nbytes, hipMemcpyHostToDevice, h->stream));
   CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
   if (field == CRL_F_PERM) h->perm_is_bijection = false;  // a caller-supplied permutation has no closed-form inverse
+  if (field == CRL_F_ENV_STATE || field == CRL_F_CUR_OBS) h->env_ready = true;  // caller-supplied env state
   return 0;
 }
 
@@ -313,11 +315,21 @@ int32_t crl_rollout_store(crl_ppo* h, int32_t step, const float* obs, const int3
 
 int32_t crl_env_reset(crl_ppo* h) {
   CRL_GUARD(h);
-  return launch_env_reset(h);
+  if (launch_env_reset(h)) return 1;
+  h->env_ready = true;
+  return 0;
+}
+
+static int ensure_env(crl_ppo* h) {  // ppo.jl:112-115 runs once before the loop
+  if (h->env_ready) return 0;
+  if (launch_env_reset(h)) return 1;
+  h->env_ready = true;
+  return 0;
 }
 
 int32_t crl_rollout_run(crl_ppo* h) {
   CRL_GUARD(h);
+  if (ensure_env(h)) return 1;
   return launch_rollout(h);
 }
 
@@ -340,9 +352,19 @@ int32_t crl_compute_gae(crl_ppo* h) {
                     h->dc.k, h->cfg.gamma, h->cfg.gae_lambda, h->cfg.gae_mode, h->adv, h->ret, ps.a, ps.b);
 }
 
+static int check_bfy(crl_ppo* h) {
+  if (h->cfg.shuffle_mode != CRL_SHUFFLE_BLOCKED_FY) return 0;
+  uint32_t err = 0;
+  CRL_HIP_CHECK(hipMemcpyAsync(&err, h->bfy_ws + 3 * 4096 + 1, sizeof(err), hipMemcpyDeviceToHost, h->stream));
+  CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  if (err) { set_error("blocked Fisher-Yates: a bucket overflowed its LDS leaf (probability < 1e-200; corrupted state?)"); return 1; }
+  return 0;
+}
+
 int32_t crl_shuffle(crl_ppo* h, uint64_t epoch_id) {
   CRL_GUARD(h);
-  return launch_shuffle(h, epoch_id);
+  if (launch_shuffle(h, epoch_id)) return 1;
+  return check_bfy(h);
 }
 
 int32_t crl_adv_stats(crl_ppo* h) {
@@ -382,6 +404,7 @@ int32_t crl_ppo_iterate(crl_ppo* h, int32_t n_iters, crl_ppo_stats* stats) {
   CRL_GUARD(h);
   if (h->cfg.env_kind != CRL_ENV_CARTPOLE) { set_error("crl_ppo_iterate needs the on-device env (env_kind = CRL_ENV_CARTPOLE)"); return 1; }
   const int E = h->cfg.update_epochs, nmb = h->dc.nmb;
+  if (ensure_env(h)) return 1;
   for (int it = 0; it < n_iters; ++it) {
     double eta = (double)h->cfg.lr;
     if (h->cfg.anneal_lr) {  // ppo.jl:118-121 (update is 1-based)
@@ -403,6 +426,7 @@ int32_t crl_ppo_iterate(crl_ppo* h, int32_t n_iters, crl_ppo_stats* stats) {
     CRL_HIP_CHECK(hipMemcpyAsync(stats, h->stats_dev, sizeof(crl_ppo_stats) * (size_t)E * nmb, hipMemcpyDeviceToHost, h->stream));
     CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
   }
+  if (check_bfy(h)) return 1;
   if (h->world > 1) {
     double vf[8];
     CRL_HIP_CHECK(hipMemcpyAsync(vf, h->vfix, sizeof(vf), hipMemcpyDeviceToHost, h->stream));

@@ -45,6 +45,7 @@ struct crl_ppo {
   hipStream_t stream = nullptr;
   int64_t P = 0, Pa = 0, Pc = 0;  // total / actor / critic parameter counts
   int64_t iteration = 0;
+  bool env_ready = false;          // crl_env_reset has run (crl_ppo_iterate / crl_rollout_run do it on first use)
   int64_t num_updates = 1;
 
   // rollout buffer, Julia (·, nt, k) column-major (replay_buffer.jl:15-18)
@@ -58,6 +59,8 @@ struct crl_ppo {
   float* params = nullptr; float* adam_m = nullptr; float* adam_v = nullptr;  // the gradient lives in comm_buf[0..P)
   double* betap = nullptr;     // [24]
   int32_t* perm = nullptr;
+  int32_t* perm_tmp = nullptr;     // blocked Fisher–Yates: elements grouped by L1 bucket
+  uint32_t* bfy_ws = nullptr;      // blocked Fisher–Yates: totals | offsets | cursors | error flag
   bool perm_is_bijection = false;  // perm == π_key(epoch): its inverse is computable (adv-stats fast path)
   uint64_t perm_epoch = 0;
   // update workspace

@@ -2,6 +2,8 @@
 //  CRL_SHUFFLE_FISHER_YATES: the exact Fisher–Yates loop of Random.shuffle! (for i = n:-1:2, j = rand(1:i), swap),
 //    run by one lane, draws from the Philox stream keyed (seed, epoch): bit-identical to orc_shuffle_fy. It is
 //    inherently serial (one dependent global swap per element), so it is the parity / small-batch mode.
+//  CRL_SHUFFLE_BLOCKED_FY: the same distribution (uniform over S_n), parallel: Rao–Sandelius split into ~64-element
+//    sub-buckets + Fisher–Yates inside each (see below). Exact and deterministic; ~3x the cost of the bijection.
 //  CRL_SHUFFLE_BIJECTION: throughput mode — perm[p] = π_key(p) with π a keyed bijection of [0,n) (invertible
 //    multiply / xorshift rounds on ceil(log2 n) bits + cycle walking). O(1) per element, no dependence between
 //    elements, one coalesced store each. A pseudo-random permutation, not a uniform draw from S_n.
@@ -33,9 +35,148 @@ __global__ void bijection_kernel(int32_t* __restrict__ perm, int n, int bits, ui
   perm[p] = (int32_t)bij_forward(key, (uint32_t)p, (uint32_t)n);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// CRL_SHUFFLE_BLOCKED_FY — an exact, parallel, deterministic shuffle (uniform over S_n like ppo.jl:194's shuffle):
+// Rao–Sandelius split + Fisher–Yates leaves. Every element draws two random digits (d1 < K1, d2 < 256) from its own
+// Philox counter; elements are scattered to their L1 bucket (global, LDS-aggregated atomics), each L1 bucket (≈16 K
+// elements) is split by d2 inside LDS, and every sub-bucket (≈64 elements) is first sorted by value — which makes the
+// result independent of the order the atomics happened to serve — and then shuffled by the textbook Fisher–Yates loop
+// run by one lane. Sub-buckets are concatenated in (d1,d2) order. Bit-identical to orc_shuffle_blocked_fy.
+// ------------------------------------------------------------------------------------------------------
+constexpr int BFY_CHUNK = 8192;     // elements per block in the L1 passes (256 threads x 32)
+constexpr int BFY_CAP = 20480;      // LDS capacity of one L1 bucket (expected 16384, +32 sigma)
+constexpr int BFY_MAXK1 = 4096;
+
+__device__ __forceinline__ void bfy_digits(uint32_t i, uint32_t K1, uint64_t seed, uint64_t epoch, uint32_t& d1, uint32_t& d2) {
+  const u32x4 o = philox(i, (uint32_t)epoch, (uint32_t)(epoch >> 32), 0xB0Cu, (uint32_t)seed, (uint32_t)(seed >> 32));
+  d1 = o.x & (K1 - 1u); d2 = o.y & 255u;
+}
+
+// pass A (SCATTER=false): tot[d1] += count ; pass C (SCATTER=true): S[cur[d1]++] = i with LDS-aggregated reservations
+template <bool SCATTER>
+__global__ void __launch_bounds__(256) bfy_l1_kernel(int n, uint32_t K1, uint64_t seed, uint64_t epoch, uint32_t* __restrict__ tot,
+                                                     uint32_t* __restrict__ cur, int32_t* __restrict__ S) {
+  extern __shared__ uint32_t lds[];   // hist[K1] (+ base[K1] when scattering)
+  uint32_t* hist = lds;
+  uint32_t* base = lds + K1;
+  for (uint32_t d = threadIdx.x; d < K1; d += 256) hist[d] = 0;
+  __syncthreads();
+  uint32_t dig[32];
+  const int i0 = blockIdx.x * BFY_CHUNK + threadIdx.x;
+#pragma unroll 4
+  for (int q = 0; q < 32; ++q) {
+    const int i = i0 + q * 256;
+    uint32_t d1 = 0xFFFFFFFFu, d2;
+    if (i < n) { bfy_digits((uint32_t)i, K1, seed, epoch, d1, d2); atomicAdd(&hist[d1], 1u); }
+    dig[q] = d1;
+  }
+  __syncthreads();
+  if (!SCATTER) {
+    for (uint32_t d = threadIdx.x; d < K1; d += 256) if (hist[d]) atomicAdd(&tot[d], hist[d]);
+    return;
+  }
+  for (uint32_t d = threadIdx.x; d < K1; d += 256) { base[d] = hist[d] ? atomicAdd(&cur[d], hist[d]) : 0u; hist[d] = 0; }
+  __syncthreads();
+#pragma unroll 4
+  for (int q = 0; q < 32; ++q) {
+    const int i = i0 + q * 256;
+    if (i < n) { const uint32_t d1 = dig[q]; S[base[d1] + atomicAdd(&hist[d1], 1u)] = i; }
+  }
+}
+
+// exclusive scan of the K1 bucket totals (one block); cur = off; flags buckets that do not fit the LDS leaf kernel
+__global__ void __launch_bounds__(1024) bfy_scan_kernel(uint32_t K1, const uint32_t* __restrict__ tot, uint32_t* __restrict__ off,
+                                                        uint32_t* __restrict__ cur, uint32_t* __restrict__ err) {
+  __shared__ uint32_t part[1024];
+  const int t = threadIdx.x;
+  const int per = (K1 + 1023) / 1024;
+  uint32_t s = 0;
+  for (int q = 0; q < per; ++q) { const uint32_t d = t * per + q; if (d < K1) { s += tot[d]; if (tot[d] > (uint32_t)BFY_CAP) *err = 1u; } }
+  part[t] = s;
+  __syncthreads();
+  if (t == 0) { uint32_t a = 0; for (int q = 0; q < 1024; ++q) { const uint32_t v = part[q]; part[q] = a; a += v; } }
+  __syncthreads();
+  uint32_t a = part[t];
+  for (int q = 0; q < per; ++q) { const uint32_t d = t * per + q; if (d < K1) { off[d] = a; cur[d] = a; a += tot[d]; } }
+  if (t == 1023) off[K1] = a;
+}
+
+// leaves: one block per L1 bucket
+__global__ void __launch_bounds__(256) bfy_leaf_kernel(uint32_t K1, uint64_t seed, uint64_t epoch, const uint32_t* __restrict__ off,
+                                                       const int32_t* __restrict__ S, int32_t* __restrict__ perm,
+                                                       const uint32_t* __restrict__ err) {
+  if (*err) return;
+  extern __shared__ uint32_t lds[];
+  int32_t* buf = reinterpret_cast<int32_t*>(lds);          // [BFY_CAP]
+  uint32_t* cnt = lds + BFY_CAP;                            // [256]
+  uint32_t* soff = cnt + 256;                               // [257]
+  uint32_t* run = soff + 257;                               // [256]
+  const uint32_t d1 = blockIdx.x;
+  const uint32_t base = off[d1], c = off[d1 + 1] - base;
+  const int t = threadIdx.x;
+  cnt[t] = 0; run[t] = 0;
+  __syncthreads();
+  for (uint32_t idx = t; idx < c; idx += 256) {
+    uint32_t a, d2;
+    bfy_digits((uint32_t)S[base + idx], K1, seed, epoch, a, d2);
+    atomicAdd(&cnt[d2], 1u);
+  }
+  __syncthreads();
+  if (t == 0) { uint32_t a = 0; for (int q = 0; q < 256; ++q) { soff[q] = a; a += cnt[q]; } soff[256] = a; }
+  __syncthreads();
+  for (uint32_t idx = t; idx < c; idx += 256) {
+    const int32_t i = S[base + idx];
+    uint32_t a, d2;
+    bfy_digits((uint32_t)i, K1, seed, epoch, a, d2);
+    buf[soff[d2] + atomicAdd(&run[d2], 1u)] = i;
+  }
+  __syncthreads();
+  {
+    int32_t* m = buf + soff[t];
+    const int n2 = (int)cnt[t];
+    for (int a = 1; a < n2; ++a) {               // canonical order first: ascending element value
+      const int32_t v = m[a];
+      int b = a - 1;
+      while (b >= 0 && m[b] > v) { m[b + 1] = m[b]; --b; }
+      m[b + 1] = v;
+    }
+    const uint32_t g = d1 * 256u + (uint32_t)t;
+    for (int j = n2 - 1; j >= 1; --j) {          // Fisher–Yates (Random.shuffle!: for i = n:-1:2, swap with rand(1:i))
+      const u32x4 o = philox(g, (uint32_t)j, (uint32_t)epoch ^ 0x9E3779B9u, (uint32_t)(epoch >> 32) ^ 0xF15A7E5u, (uint32_t)seed,
+                             (uint32_t)(seed >> 32));
+      const uint64_t r = ((uint64_t)o.x << 32) | o.y;
+      const uint32_t x = (uint32_t)__umul64hi(r, (uint64_t)(j + 1));
+      const int32_t tmp = m[j]; m[j] = m[x]; m[x] = tmp;
+    }
+  }
+  __syncthreads();
+  for (uint32_t idx = t; idx < c; idx += 256) perm[base + idx] = buf[idx];
+}
+
+static int launch_blocked_fy(crl_ppo* h, uint64_t epoch_id) {
+  const int n = h->dc.B;
+  uint32_t K1 = 1;
+  while ((uint64_t)K1 * 16384u < (uint64_t)n) K1 *= 2;
+  if (K1 > (uint32_t)BFY_MAXK1) { set_error("blocked Fisher-Yates supports batches up to 2^26 samples"); return 1; }
+  uint32_t* tot = h->bfy_ws; uint32_t* off = tot + BFY_MAXK1; uint32_t* cur = off + BFY_MAXK1 + 1; uint32_t* err = cur + BFY_MAXK1;
+  CRL_HIP_CHECK(hipMemsetAsync(tot, 0, sizeof(uint32_t) * BFY_MAXK1, h->stream));
+  const int chunks = (n + BFY_CHUNK - 1) / BFY_CHUNK;
+  hipLaunchKernelGGL(bfy_l1_kernel<false>, dim3(chunks), dim3(256), sizeof(uint32_t) * K1, h->stream, n, K1, h->cfg.seed, epoch_id, tot, cur, h->perm_tmp);
+  hipLaunchKernelGGL(bfy_scan_kernel, dim3(1), dim3(1024), 0, h->stream, K1, tot, off, cur, err);
+  hipLaunchKernelGGL(bfy_l1_kernel<true>, dim3(chunks), dim3(256), sizeof(uint32_t) * 2 * K1, h->stream, n, K1, h->cfg.seed, epoch_id, tot, cur, h->perm_tmp);
+  const size_t leaf_lds = sizeof(uint32_t) * (BFY_CAP + 256 + 257 + 256 + 3);
+  hipLaunchKernelGGL(bfy_leaf_kernel, dim3(K1), dim3(256), leaf_lds, h->stream, K1, h->cfg.seed, epoch_id, off, h->perm_tmp, h->perm, err);
+  CRL_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 int launch_shuffle(crl_ppo* h, uint64_t epoch_id) {
   const int n = h->dc.B;
   ProfScope ps(h, CRL_K_SHUFFLE);
+  if (h->cfg.shuffle_mode == CRL_SHUFFLE_BLOCKED_FY) {
+    h->perm_is_bijection = false;
+    return launch_blocked_fy(h, epoch_id);
+  }
   if (h->cfg.shuffle_mode == CRL_SHUFFLE_FISHER_YATES) {
     h->perm_is_bijection = false;
     hipLaunchKernelGGL(fy_serial_kernel, dim3(1), dim3(64), 0, h->stream, h->perm, n, h->cfg.seed, epoch_id);

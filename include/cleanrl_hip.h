@@ -38,6 +38,7 @@ extern "C" {
 /* shuffle mode */
 #define CRL_SHUFFLE_FISHER_YATES 0 /* exact serial Fisher–Yates on device (ppo.jl:194 semantics) */
 #define CRL_SHUFFLE_BIJECTION 1     /* perm[p] = keyed bijection of [0,B): O(1) per element, pseudo-random (throughput path) */
+#define CRL_SHUFFLE_BLOCKED_FY 2    /* exact parallel shuffle: random split into ~64-element buckets + Fisher–Yates in each */
 /* rollout / state fields for crl_ppo_read / crl_ppo_write */
 enum crl_field {
   CRL_F_OBS = 0,      /* float  (obs_dim, nt, k)  replay_buffer.jl:15-18 / ppo.jl:96 */

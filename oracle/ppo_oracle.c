@@ -568,6 +568,41 @@ void orc_shuffle_fy(int32_t* perm, int32_t n, uint64_t seed, uint64_t epoch_id) 
   }
 }
 
+/* Blocked Fisher–Yates (CRL_SHUFFLE_BLOCKED_FY): Rao–Sandelius split into sub-buckets of ~64 elements by two random
+ * digits per element, exact Fisher–Yates inside every sub-bucket, sub-buckets concatenated in id order. A uniform draw
+ * from S_n like ppo.jl:194's shuffle, but parallel; this is the build's own algorithm, restated here so the HIP kernels
+ * can be checked bit for bit. Always starts from the identity (ppo.jl:191 b_inds = 1:batch_size). */
+void orc_shuffle_blocked_fy(int32_t* perm, int32_t n, uint64_t seed, uint64_t epoch_id) {
+  uint32_t K1 = 1;
+  while ((uint64_t)K1 * 16384u < (uint64_t)n) K1 *= 2;
+  const uint32_t G = K1 * 256u;
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32), e0 = (uint32_t)epoch_id, e1 = (uint32_t)(epoch_id >> 32);
+  uint32_t* gid = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)n);
+  uint32_t* off = (uint32_t*)calloc((size_t)G + 1, sizeof(uint32_t));
+  for (int32_t i = 0; i < n; ++i) {
+    uint32_t o[4];
+    orc_philox((uint32_t)i, e0, e1, 0xB0Cu, k0, k1, o);
+    gid[i] = (o[0] & (K1 - 1)) * 256u + (o[1] & 255u);
+    off[gid[i] + 1] += 1;
+  }
+  for (uint32_t g = 0; g < G; ++g) off[g + 1] += off[g];
+  uint32_t* cur = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)G);
+  memcpy(cur, off, sizeof(uint32_t) * (size_t)G);
+  for (int32_t i = 0; i < n; ++i) perm[cur[gid[i]]++] = i; /* ascending i inside each sub-bucket */
+  for (uint32_t g = 0; g < G; ++g) {
+    int32_t* m = perm + off[g];
+    const int32_t cnt = (int32_t)(off[g + 1] - off[g]);
+    for (int32_t j = cnt - 1; j >= 1; --j) {
+      uint32_t o[4];
+      orc_philox(g, (uint32_t)j, e0 ^ 0x9E3779B9u, e1 ^ 0xF15A7E5u, k0, k1, o);
+      const uint64_t r = ((uint64_t)o[0] << 32) | o[1];
+      const uint32_t t = (uint32_t)(((unsigned __int128)r * (uint64_t)(j + 1)) >> 64);
+      const int32_t tmp = m[j]; m[j] = m[t]; m[t] = tmp;
+    }
+  }
+  free(gid); free(off); free(cur);
+}
+
 void orc_update_minibatch(const orc_config* c, orc_state* s, int32_t mb, double eta, orc_stats* st) {
   int B = c->num_envs * c->num_steps, M = B / c->num_minibatches;
   orc_loss_grad(c, s->params, s->obs, s->action, s->logprob, s->value, s->adv, s->ret, s->perm + (size_t)mb * M, M,

@@ -93,6 +93,7 @@ def lib():
         L.orc_rollout.argtypes = [cp, C.POINTER(OrcState)]
         L.orc_compute_gae.argtypes = [cp, C.POINTER(OrcState)]
         L.orc_shuffle_fy.argtypes = [ip, C.c_int32, C.c_uint64, C.c_uint64]
+        L.orc_shuffle_blocked_fy.argtypes = [ip, C.c_int32, C.c_uint64, C.c_uint64]
         L.orc_update_minibatch.argtypes = [cp, C.POINTER(OrcState), C.c_int32, C.c_double, C.POINTER(OrcStats)]
         L.orc_iterate.argtypes = [cp, C.POINTER(OrcState), C.c_int32, C.c_int32, C.POINTER(OrcStats)]
         _lib = L
@@ -265,6 +266,12 @@ class State:
 def shuffle_fy(perm, seed, epoch_id):
     perm = np.ascontiguousarray(perm, np.int32)
     lib().orc_shuffle_fy(_p(perm, C.c_int32), len(perm), seed, epoch_id)
+    return perm
+
+
+def shuffle_blocked_fy(n, seed, epoch_id):
+    perm = np.zeros(n, np.int32)
+    lib().orc_shuffle_blocked_fy(_p(perm, C.c_int32), n, seed, epoch_id)
     return perm
 
 

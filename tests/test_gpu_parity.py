@@ -341,3 +341,92 @@ def test_adv_stats_through_inverse_bijection(crl, nt, k):
         assert abs(st["adv_mean"] - np.float32(sl.mean())) < 1e-6
         assert abs(st["adv_std"] - np.float32(sl.std(ddof=1))) < 1e-5
     agent.close()
+
+
+def test_external_env_path_store_then_update(crl):
+    """The reference's own loop shape (ppo.jl:123-166): the HOST steps the envs, asks the device for actions
+    (crl_policy_act), stores each transition (crl_rollout_store = Buffer.add!), then GAE + one optimiser step on device."""
+    nt, k = 8, 32
+    cfgo = O.make_config(num_envs=nt, num_steps=k)
+    agent = make_agent(crl, nt=nt, k=k, shuffle_mode=0)
+    params = agent.get_params()
+    st = O.State(cfgo); st.params[:] = params; st.env_init()
+    h = agent.handle; F = crl._lib
+    # host-side env loop driven by the oracle's CartPole; actions come from the GPU with the oracle's uniform draws
+    import ctypes as C
+    s = st.env_state; co = st.cur_obs
+    next_done = np.zeros(nt, np.uint8)
+    t_env = np.zeros(nt, np.int32)
+    for step in range(k):
+        u = np.array([O.lib().orc_u53(cfgo.seed, e, step, 0) for e in range(nt)])
+        a, lp, v = h.policy_act(co, u)
+        a_o, lp_o, v_o, margin = O.get_action(cfgo, params, np.asfortranarray(co), u)
+        assert np.array_equal(a[margin > 1e-6], a_o[margin > 1e-6])
+        rew = np.zeros(nt, np.float32); done = np.zeros(nt, np.int32)
+        obs_in = co.copy()
+        for e in range(nt):
+            se = np.ascontiguousarray(s[:, e]); te = t_env[e:e + 1].copy(); de = np.zeros(1, np.int32)
+            O.lib().orc_cartpole_step(O.fptr(se), te.ctypes.data_as(C.POINTER(C.c_int32)), int(a[e]), 500, de.ctypes.data_as(C.POINTER(C.c_int32)))
+            s[:, e] = se; t_env[e] = te[0]; done[e] = de[0]; rew[e] = 0.0 if de[0] else 1.0
+        h.rollout_store(step, obs_in, a, lp, rew, next_done, v)
+        st.obs[:, :, step] = obs_in; st.action[:, step] = a; st.logprob[:, step] = lp; st.reward[:, step] = rew
+        st.terminal[:, step] = next_done; st.value[:, step] = v
+        co[:] = s; next_done = done.astype(np.uint8)
+        for e in range(nt):
+            if done[e]:
+                se = np.zeros(4, np.float32)
+                O.lib().orc_env_reset(C.byref(cfgo), O.fptr(se), e, step, 1); s[:, e] = se; t_env[e] = 0
+    st.next_done[:] = next_done
+    h.write(F.F_NEXT_DONE, next_done)
+    assert np.array_equal(h.read(F.F_OBS), st.obs) and np.array_equal(h.read(F.F_TERMINAL), st.terminal)
+    h.compute_gae(); st.compute_gae()
+    assert rel_err(h.read(F.F_ADVANTAGE), st.adv) < RTOL
+    st.perm[:] = np.random.default_rng(1).permutation(nt * k).astype(np.int32)
+    h.write(F.F_PERM, st.perm)
+    h.adv_stats()
+    gs = h.update_minibatch(1, 2.5e-4, apply_update=True)
+    so = st.update_minibatch(1, 2.5e-4)
+    assert abs(gs["loss"] - so["loss"]) <= 2e-5 * max(1.0, abs(so["loss"]))
+    assert np.max(np.abs(h.read(F.F_PARAMS) - st.params)) < 1e-6
+    # critic(obs) through the Policy object, like `value = critic(next_obs)` (ppo.jl:128)
+    vv = agent.critic(co)
+    assert vv.shape == (1, nt)
+    agent.close(); st.close()
+
+
+@pytest.mark.parametrize("nt,k", [(1, 4), (8, 128), (37, 64), (4096, 128), (65536, 128)])
+def test_shuffle_blocked_fisher_yates_matches_oracle(crl, nt, k):
+    """Exact parallel shuffle (Rao–Sandelius split + Fisher–Yates leaves): bit-identical to its CPU restatement, a
+    permutation, deterministic, and different per epoch."""
+    if (nt * k) % 4:
+        pytest.skip("batch not divisible")
+    agent = make_agent(crl, nt=nt, k=k, shuffle_mode=2, seed=99)
+    h = agent.handle
+    B = nt * k
+    for ep in (0, 5):
+        h.shuffle(ep)
+        p = h.read(crl._lib.F_PERM)
+        assert np.array_equal(p, O.shuffle_blocked_fy(B, 99, ep))
+        assert np.array_equal(np.sort(p), np.arange(B))
+    agent.close()
+
+
+def test_iteration_with_blocked_fisher_yates(crl):
+    """Whole iteration with the exact parallel shuffle: same losses/parameters as the oracle fed the same permutations."""
+    nt, k = 8, 128
+    agent = make_agent(crl, nt=nt, k=k, shuffle_mode=2)
+    params = agent.get_params()
+    cfgo, st = _oracle_state(nt, k, params)
+    h = agent.handle
+    h.env_reset(); h.rollout_run(); h.compute_gae()
+    st.rollout(); st.compute_gae()
+    for ep in range(2):
+        h.shuffle(ep); h.adv_stats()
+        st.perm[:] = O.shuffle_blocked_fy(nt * k, cfgo.seed, ep)
+        assert np.array_equal(h.read(crl._lib.F_PERM), st.perm)
+        for mb in range(4):
+            a = h.update_minibatch(mb, 2.5e-4)
+            b = st.update_minibatch(mb, 2.5e-4)
+            assert abs(a["loss"] - b["loss"]) <= 2e-5 * max(1.0, abs(b["loss"]))
+    assert np.max(np.abs(h.read(crl._lib.F_PARAMS) - st.params)) < 2e-5
+    agent.close(); st.close()

@@ -312,3 +312,15 @@ def test_iterate_runs_and_learns_direction():
 def test_shuffle_fy_is_permutation_and_deterministic():
     a = O.shuffle_fy(np.arange(1000), 1, 0); b = O.shuffle_fy(np.arange(1000), 1, 0); c = O.shuffle_fy(np.arange(1000), 1, 1)
     assert sorted(a.tolist()) == list(range(1000)) and np.array_equal(a, b) and not np.array_equal(a, c)
+
+
+def test_blocked_fisher_yates_is_uniform_over_small_permutations():
+    """Rao–Sandelius split + Fisher–Yates leaves must be uniform over S_n: all 24 permutations of n=4 about equally often."""
+    from collections import Counter
+    c = Counter(tuple(O.shuffle_blocked_fy(4, 7, ep).tolist()) for ep in range(24000))
+    assert len(c) == 24
+    counts = np.array(list(c.values()), np.float64)
+    chi2 = np.sum((counts - 1000.0) ** 2 / 1000.0)
+    assert chi2 < 60.0, chi2          # 23 dof: P(chi2 > 60) ≈ 3e-5
+    p = O.shuffle_blocked_fy(100000, 1, 0)
+    assert np.array_equal(np.sort(p), np.arange(100000)) and abs(p[:25000].mean() / 1e5 - 0.5) < 0.01
