@@ -147,7 +147,7 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
   rc |= dalloc(&h->next_value, nt); rc |= dalloc(&h->ep_stats, 4);
   rc |= dalloc(&h->params, h->P); rc |= dalloc(&h->adam_m, h->P); rc |= dalloc(&h->adam_v, h->P);
   rc |= dalloc(&h->betap, 24); rc |= dalloc(&h->perm, B);
-  if (cfg->shuffle_mode == CRL_SHUFFLE_BLOCKED_FY) { rc |= dalloc(&h->perm_tmp, B); rc |= dalloc(&h->bfy_ws, (size_t)4 * 4096 + 8); }
+  if (cfg->shuffle_mode == CRL_SHUFFLE_BLOCKED_FY) { rc |= dalloc(&h->perm_tmp, B); rc |= dalloc(&h->bfy_ws, (size_t)4 * 16384 + 8); }
   // update grid: two 256-thread blocks per CU, alternating roles; never more waves than tiles
   hipDeviceProp_t prop;
   CRL_HIP_CHECK(hipGetDeviceProperties(&prop, device));
@@ -355,7 +355,7 @@ int32_t crl_compute_gae(crl_ppo* h) {
 static int check_bfy(crl_ppo* h) {
   if (h->cfg.shuffle_mode != CRL_SHUFFLE_BLOCKED_FY) return 0;
   uint32_t err = 0;
-  CRL_HIP_CHECK(hipMemcpyAsync(&err, h->bfy_ws + 3 * 4096 + 1, sizeof(err), hipMemcpyDeviceToHost, h->stream));
+  CRL_HIP_CHECK(hipMemcpyAsync(&err, h->bfy_ws + 3 * 16384 + 1, sizeof(err), hipMemcpyDeviceToHost, h->stream));
   CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
   if (err) { set_error("blocked Fisher-Yates: a bucket overflowed its LDS leaf (probability < 1e-200; corrupted state?)"); return 1; }
   return 0;

@@ -38,14 +38,16 @@ __global__ void bijection_kernel(int32_t* __restrict__ perm, int n, int bits, ui
 // ------------------------------------------------------------------------------------------------------
 // CRL_SHUFFLE_BLOCKED_FY — an exact, parallel, deterministic shuffle (uniform over S_n like ppo.jl:194's shuffle):
 // Rao–Sandelius split + Fisher–Yates leaves. Every element draws two random digits (d1 < K1, d2 < 256) from its own
-// Philox counter; elements are scattered to their L1 bucket (global, LDS-aggregated atomics), each L1 bucket (≈16 K
-// elements) is split by d2 inside LDS, and every sub-bucket (≈64 elements) is first sorted by value — which makes the
-// result independent of the order the atomics happened to serve — and then shuffled by the textbook Fisher–Yates loop
-// run by one lane. Sub-buckets are concatenated in (d1,d2) order. Bit-identical to orc_shuffle_blocked_fy.
+// Philox counter; elements are scattered to their L1 bucket (global, LDS-aggregated atomics), each L1 bucket (≈4 K
+// elements) is split by d2 inside LDS, and every sub-bucket (≈16 elements) is first put in ascending order by a
+// parallel rank count — which makes the result independent of the order the atomics happened to serve — and then
+// shuffled by the textbook Fisher–Yates loop run by one lane. Sub-buckets are concatenated in (d1,d2) order.
+// Bit-identical to orc_shuffle_blocked_fy.
 // ------------------------------------------------------------------------------------------------------
 constexpr int BFY_CHUNK = 8192;     // elements per block in the L1 passes (256 threads x 32)
-constexpr int BFY_CAP = 20480;      // LDS capacity of one L1 bucket (expected 16384, +32 sigma)
-constexpr int BFY_MAXK1 = 4096;
+constexpr int BFY_L1 = 4096;        // expected elements per L1 bucket
+constexpr int BFY_CAP = 5632;       // LDS capacity of one L1 bucket (+24 sigma)
+constexpr int BFY_MAXK1 = 16384;    // batches up to 2^26 samples
 
 __device__ __forceinline__ void bfy_digits(uint32_t i, uint32_t K1, uint64_t seed, uint64_t epoch, uint32_t& d1, uint32_t& d2) {
   const u32x4 o = philox(i, (uint32_t)epoch, (uint32_t)(epoch >> 32), 0xB0Cu, (uint32_t)seed, (uint32_t)(seed >> 32));
@@ -101,46 +103,63 @@ __global__ void __launch_bounds__(1024) bfy_scan_kernel(uint32_t K1, const uint3
   if (t == 1023) off[K1] = a;
 }
 
-// leaves: one block per L1 bucket
-__global__ void __launch_bounds__(256) bfy_leaf_kernel(uint32_t K1, uint64_t seed, uint64_t epoch, const uint32_t* __restrict__ off,
-                                                       const int32_t* __restrict__ S, int32_t* __restrict__ perm,
-                                                       const uint32_t* __restrict__ err) {
+// leaves: one block per L1 bucket; 256 sub-buckets ↔ 256 lanes for the Fisher–Yates tail. No per-thread arrays and no
+// unrolling: a low register count keeps several blocks per CU resident, which hides the dependent Philox→swap chain.
+__global__ void __launch_bounds__(256, 4) bfy_leaf_kernel(uint32_t K1, uint64_t seed, uint64_t epoch, const uint32_t* __restrict__ off,
+                                                          const int32_t* __restrict__ S, int32_t* __restrict__ perm,
+                                                          const uint32_t* __restrict__ err) {
   if (*err) return;
-  extern __shared__ uint32_t lds[];
-  int32_t* buf = reinterpret_cast<int32_t*>(lds);          // [BFY_CAP]
-  uint32_t* cnt = lds + BFY_CAP;                            // [256]
-  uint32_t* soff = cnt + 256;                               // [257]
-  uint32_t* run = soff + 257;                               // [256]
+  __shared__ int32_t buf[BFY_CAP], buf2[BFY_CAP];
+  __shared__ uint8_t dig[BFY_CAP];
+  __shared__ uint32_t cnt[256], soff[257], run[256];
   const uint32_t d1 = blockIdx.x;
   const uint32_t base = off[d1], c = off[d1 + 1] - base;
   const int t = threadIdx.x;
   cnt[t] = 0; run[t] = 0;
   __syncthreads();
+#pragma unroll 1
   for (uint32_t idx = t; idx < c; idx += 256) {
+    const int32_t v = S[base + idx];
     uint32_t a, d2;
-    bfy_digits((uint32_t)S[base + idx], K1, seed, epoch, a, d2);
+    bfy_digits((uint32_t)v, K1, seed, epoch, a, d2);
+    buf2[idx] = v; dig[idx] = (uint8_t)d2;
     atomicAdd(&cnt[d2], 1u);
   }
   __syncthreads();
-  if (t == 0) { uint32_t a = 0; for (int q = 0; q < 256; ++q) { soff[q] = a; a += cnt[q]; } soff[256] = a; }
+  if (t < 64) {   // exclusive scan of 256 counts by one wave: 4 per lane + a wave prefix
+    const uint32_t c0 = cnt[4 * t], c1 = cnt[4 * t + 1], c2 = cnt[4 * t + 2], c3 = cnt[4 * t + 3];
+    uint32_t incl = c0 + c1 + c2 + c3;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o, 64); if (t >= o) incl += y; }
+    const uint32_t excl = incl - (c0 + c1 + c2 + c3);
+    soff[4 * t] = excl; soff[4 * t + 1] = excl + c0; soff[4 * t + 2] = excl + c0 + c1; soff[4 * t + 3] = excl + c0 + c1 + c2;
+    if (t == 63) soff[256] = incl;
+  }
   __syncthreads();
+#pragma unroll 1
   for (uint32_t idx = t; idx < c; idx += 256) {
-    const int32_t i = S[base + idx];
-    uint32_t a, d2;
-    bfy_digits((uint32_t)i, K1, seed, epoch, a, d2);
-    buf[soff[d2] + atomicAdd(&run[d2], 1u)] = i;
+    const uint32_t d2 = dig[idx];
+    buf[soff[d2] + atomicAdd(&run[d2], 1u)] = buf2[idx];
+  }
+  __syncthreads();
+  // canonical order: every element counts the smaller members of its sub-bucket (values are distinct) and moves there
+#pragma unroll 1
+  for (uint32_t idx = t; idx < c; idx += 256) {
+    const int32_t v = buf[idx];
+    uint32_t d2 = 0;                        // the sub-bucket that owns position idx: soff[d2] <= idx < soff[d2+1]
+#pragma unroll
+    for (uint32_t step = 128; step >= 1; step >>= 1) d2 += (soff[d2 + step] <= idx) ? step : 0u;
+    const uint32_t lo = soff[d2], hi = soff[d2 + 1];
+    uint32_t r = 0;
+    for (uint32_t p = lo; p < hi; ++p) r += (buf[p] < v) ? 1u : 0u;
+    buf2[lo + r] = v;
   }
   __syncthreads();
   {
-    int32_t* m = buf + soff[t];
+    int32_t* m = buf2 + soff[t];
     const int n2 = (int)cnt[t];
-    for (int a = 1; a < n2; ++a) {               // canonical order first: ascending element value
-      const int32_t v = m[a];
-      int b = a - 1;
-      while (b >= 0 && m[b] > v) { m[b + 1] = m[b]; --b; }
-      m[b + 1] = v;
-    }
     const uint32_t g = d1 * 256u + (uint32_t)t;
+#pragma unroll 1
     for (int j = n2 - 1; j >= 1; --j) {          // Fisher–Yates (Random.shuffle!: for i = n:-1:2, swap with rand(1:i))
       const u32x4 o = philox(g, (uint32_t)j, (uint32_t)epoch ^ 0x9E3779B9u, (uint32_t)(epoch >> 32) ^ 0xF15A7E5u, (uint32_t)seed,
                              (uint32_t)(seed >> 32));
@@ -150,13 +169,13 @@ __global__ void __launch_bounds__(256) bfy_leaf_kernel(uint32_t K1, uint64_t see
     }
   }
   __syncthreads();
-  for (uint32_t idx = t; idx < c; idx += 256) perm[base + idx] = buf[idx];
+  for (uint32_t idx = t; idx < c; idx += 256) perm[base + idx] = buf2[idx];
 }
 
 static int launch_blocked_fy(crl_ppo* h, uint64_t epoch_id) {
   const int n = h->dc.B;
   uint32_t K1 = 1;
-  while ((uint64_t)K1 * 16384u < (uint64_t)n) K1 *= 2;
+  while ((uint64_t)K1 * (uint64_t)BFY_L1 < (uint64_t)n) K1 *= 2;
   if (K1 > (uint32_t)BFY_MAXK1) { set_error("blocked Fisher-Yates supports batches up to 2^26 samples"); return 1; }
   uint32_t* tot = h->bfy_ws; uint32_t* off = tot + BFY_MAXK1; uint32_t* cur = off + BFY_MAXK1 + 1; uint32_t* err = cur + BFY_MAXK1;
   CRL_HIP_CHECK(hipMemsetAsync(tot, 0, sizeof(uint32_t) * BFY_MAXK1, h->stream));
@@ -164,8 +183,7 @@ static int launch_blocked_fy(crl_ppo* h, uint64_t epoch_id) {
   hipLaunchKernelGGL(bfy_l1_kernel<false>, dim3(chunks), dim3(256), sizeof(uint32_t) * K1, h->stream, n, K1, h->cfg.seed, epoch_id, tot, cur, h->perm_tmp);
   hipLaunchKernelGGL(bfy_scan_kernel, dim3(1), dim3(1024), 0, h->stream, K1, tot, off, cur, err);
   hipLaunchKernelGGL(bfy_l1_kernel<true>, dim3(chunks), dim3(256), sizeof(uint32_t) * 2 * K1, h->stream, n, K1, h->cfg.seed, epoch_id, tot, cur, h->perm_tmp);
-  const size_t leaf_lds = sizeof(uint32_t) * (BFY_CAP + 256 + 257 + 256 + 3);
-  hipLaunchKernelGGL(bfy_leaf_kernel, dim3(K1), dim3(256), leaf_lds, h->stream, K1, h->cfg.seed, epoch_id, off, h->perm_tmp, h->perm, err);
+  hipLaunchKernelGGL(bfy_leaf_kernel, dim3(K1), dim3(256), 0, h->stream, K1, h->cfg.seed, epoch_id, off, h->perm_tmp, h->perm, err);
   CRL_HIP_CHECK(hipGetLastError());
   return 0;
 }

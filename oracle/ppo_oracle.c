@@ -568,13 +568,13 @@ void orc_shuffle_fy(int32_t* perm, int32_t n, uint64_t seed, uint64_t epoch_id) 
   }
 }
 
-/* Blocked Fisher–Yates (CRL_SHUFFLE_BLOCKED_FY): Rao–Sandelius split into sub-buckets of ~64 elements by two random
+/* Blocked Fisher–Yates (CRL_SHUFFLE_BLOCKED_FY): Rao–Sandelius split into sub-buckets of ~16 elements by two random
  * digits per element, exact Fisher–Yates inside every sub-bucket, sub-buckets concatenated in id order. A uniform draw
  * from S_n like ppo.jl:194's shuffle, but parallel; this is the build's own algorithm, restated here so the HIP kernels
  * can be checked bit for bit. Always starts from the identity (ppo.jl:191 b_inds = 1:batch_size). */
 void orc_shuffle_blocked_fy(int32_t* perm, int32_t n, uint64_t seed, uint64_t epoch_id) {
   uint32_t K1 = 1;
-  while ((uint64_t)K1 * 16384u < (uint64_t)n) K1 *= 2;
+  while ((uint64_t)K1 * 4096u < (uint64_t)n) K1 *= 2;
   const uint32_t G = K1 * 256u;
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32), e0 = (uint32_t)epoch_id, e1 = (uint32_t)(epoch_id >> 32);
   uint32_t* gid = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)n);
