@@ -85,6 +85,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # single node: RCCL's bootstrap must not depend on the hostname resolving
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)  # control plane; gradients go over RCCL
     torch.cuda.set_device(local_rank)
 
