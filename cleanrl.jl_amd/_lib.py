@@ -55,7 +55,7 @@ EXPORTS = [
 F_OBS, F_ACTION, F_LOGPROB, F_REWARD, F_TERMINAL, F_VALUE, F_ADVANTAGE, F_RETURN, F_PERM, F_PARAMS, F_GRADS, F_ADAM_M, \
     F_ADAM_V, F_ENV_STATE, F_CUR_OBS, F_NEXT_DONE, F_ENV_T, F_BETAP, F_ADV_SUMS = range(19)
 GAE_COMPAT, GAE_FIXED = 0, 1
-ENV_CARTPOLE, ENV_EXTERNAL = 0, 2
+ENV_CARTPOLE, ENV_SYNTHETIC, ENV_EXTERNAL = 0, 1, 2
 SHUFFLE_FISHER_YATES, SHUFFLE_BIJECTION, SHUFFLE_BLOCKED_FY = 0, 1, 2
 K_ROLLOUT, K_GAE, K_SHUFFLE, K_ADV_STATS, K_UPDATE, K_REDUCE, K_OPTIM, K_ALLREDUCE = range(8)
 KERNEL_NAMES = ["rollout", "gae", "shuffle", "adv_stats", "update", "reduce", "optim", "allreduce"]

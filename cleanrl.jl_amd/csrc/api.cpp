@@ -109,8 +109,23 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
   if (!cfg->normalize_advantages) {
     set_error("normalize_advantages=false is not a valid configuration (the reference errors too: ppo.jl:219-222)"); return 1;
   }
-  if (cfg->obs_dim != 4 || cfg->n_act != 2 || cfg->hidden != 64) {
-    set_error("this build of libcleanrl_hip supports obs_dim=4, n_act=2, hidden=64 (2x64 MLP) only"); return 1;
+  // obs 4 / act 2 / 2x64 (the reference's CartPole shape) runs the fused register-resident kernels; every other
+  // supported shape runs the layer-wise path of wide.hip (CRL_FORCE_WIDE=1 sends the CartPole shape there too)
+  const bool narrow_shape = cfg->obs_dim == 4 && cfg->n_act == 2 && cfg->hidden == 64;
+  const char* fw = getenv("CRL_FORCE_WIDE");
+  const bool wide = !narrow_shape || (fw && atoi(fw) != 0);
+  if (wide) {
+    std::string why;
+    if (!wide_shape_ok(cfg, &why)) { set_error("unsupported network shape: " + why); return 1; }
+  }
+  if (cfg->env_kind == CRL_ENV_CARTPOLE && (cfg->obs_dim != 4 || cfg->n_act != 2)) {
+    set_error("env_kind = CRL_ENV_CARTPOLE needs obs_dim=4, n_act=2 (use CRL_ENV_SYNTHETIC or CRL_ENV_EXTERNAL)"); return 1;
+  }
+  if (cfg->env_kind != CRL_ENV_CARTPOLE && cfg->env_kind != CRL_ENV_SYNTHETIC && cfg->env_kind != CRL_ENV_EXTERNAL) {
+    set_error("unknown env_kind"); return 1;
+  }
+  if (cfg->env_kind == CRL_ENV_SYNTHETIC && !wide) {
+    set_error("env_kind = CRL_ENV_SYNTHETIC runs on the generic-shape path only (set CRL_FORCE_WIDE=1 for the 4/2/64 shape)"); return 1;
   }
   const int64_t B64 = (int64_t)cfg->num_envs * cfg->num_steps;
   if (B64 > (1ll << 30)) { set_error("batch too large"); return 1; }
@@ -124,7 +139,7 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
   CRL_HIP_CHECK(hipSetDevice(device));
   crl_ppo* h = new (std::nothrow) crl_ppo();
   if (!h) { set_error("out of host memory"); return 1; }
-  h->cfg = *cfg; h->device = device;
+  h->cfg = *cfg; h->device = device; h->wide = wide;
   DevCfg& c = h->dc;
   c.nt = cfg->num_envs; c.k = cfg->num_steps; c.B = (int)B64; c.nmb = cfg->num_minibatches; c.M = c.B / c.nmb;
   c.D = cfg->obs_dim; c.A = cfg->n_act; c.gamma = cfg->gamma; c.lambda = cfg->gae_lambda; c.clip = cfg->clip_coef;
@@ -157,12 +172,15 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
   if (ub * 4 > ntiles) ub = (ntiles + 3) / 4;
   if (ub < 1) ub = 1;
   h->update_blocks = ub;
-  rc |= dalloc(&h->gpart, (size_t)2 * ub * h->Pa + 4096); rc |= dalloc(&h->lpart, (size_t)2 * ub * 2);
+  // gpart doubles as the scratch of the advantage-statistics partials (≤ 512 blocks × nmb × 2 doubles)
+  if (!wide) { rc |= dalloc(&h->gpart, (size_t)2 * ub * h->Pa + 4096); rc |= dalloc(&h->lpart, (size_t)2 * ub * 2); }
+  else rc |= dalloc(&h->gpart, (size_t)4 * 512 * (c.nmb > 4 ? c.nmb : 4) + 4096);
   rc |= dalloc(&h->adv_sums, (size_t)c.nmb * 2); rc |= dalloc(&h->adv_ms, (size_t)c.nmb * 2);
   rc |= dalloc(&h->newv, (size_t)c.M); rc |= dalloc(&h->vfix, 8);
   rc |= dalloc(&h->stats_dev, (size_t)cfg->update_epochs * c.nmb);
   rc |= dalloc(&h->comm_buf, (size_t)h->P + 8);
   if (rc) { crl_ppo_destroy(h); return 1; }
+  if (wide && wide_create(h)) { crl_ppo_destroy(h); return 1; }
   double bp[24];
   for (int i = 0; i < 12; ++i) { bp[2 * i] = 0.9; bp[2 * i + 1] = 0.999; }
   CRL_HIP_CHECK(hipMemcpy(h->betap, bp, sizeof(bp), hipMemcpyHostToDevice));
@@ -177,6 +195,7 @@ int32_t crl_ppo_destroy(crl_ppo* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   comm_destroy(h);
+  wide_destroy(h);
   void* ptrs[] = {h->obs, h->action, h->logprob, h->reward, h->terminal, h->value, h->adv, h->ret, h->env_state, h->env_t,
                   h->cur_obs, h->next_done, h->ep_return, h->ep_length, h->next_value, h->ep_stats, h->params,
                   h->adam_m, h->adam_v, h->betap, h->perm, h->perm_tmp, h->bfy_ws, h->gpart, h->lpart, h->adv_sums, h->adv_ms, h->newv, h->vfix,
@@ -209,6 +228,7 @@ int32_t crl_ppo_write(crl_ppo* h, int32_t field, const void* host, size_t nbytes
                                       std::to_string(nbytes) + ", want " + std::to_string(fr.bytes)); return 1; }
   CRL_HIP_CHECK(hipMemcpyAsync(fr.ptr, host, nbytes, hipMemcpyHostToDevice, h->stream));
   CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  if (field == CRL_F_PARAMS) wide_mark_params_changed(h);
   if (field == CRL_F_PERM) h->perm_is_bijection = false;  // a caller-supplied permutation has no closed-form inverse
   if (field == CRL_F_ENV_STATE || field == CRL_F_CUR_OBS) h->env_ready = true;  // caller-supplied env state
   return 0;
@@ -402,7 +422,7 @@ int32_t crl_ppo_update_minibatch(crl_ppo* h, int32_t mb, double eta, int32_t app
 
 int32_t crl_ppo_iterate(crl_ppo* h, int32_t n_iters, crl_ppo_stats* stats) {
   CRL_GUARD(h);
-  if (h->cfg.env_kind != CRL_ENV_CARTPOLE) { set_error("crl_ppo_iterate needs the on-device env (env_kind = CRL_ENV_CARTPOLE)"); return 1; }
+  if (h->cfg.env_kind == CRL_ENV_EXTERNAL) { set_error("crl_ppo_iterate needs an on-device env (CRL_ENV_CARTPOLE or CRL_ENV_SYNTHETIC)"); return 1; }
   const int E = h->cfg.update_epochs, nmb = h->dc.nmb;
   if (ensure_env(h)) return 1;
   for (int it = 0; it < n_iters; ++it) {

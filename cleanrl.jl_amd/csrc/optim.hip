@@ -151,6 +151,7 @@ int launch_optim(crl_ppo* h, double eta) {
   ProfScope ps(h, CRL_K_OPTIM);
   hipLaunchKernelGGL(clipnorm_adam_kernel, dim3(12), dim3(1024), 0, h->stream, a);
   CRL_HIP_CHECK(hipGetLastError());
+  wide_mark_params_changed(h);
   return 0;
 }
 

@@ -9,60 +9,11 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "env.hpp"
 #include "mlp_x3.hpp"
 #include "ppo_ctx.hpp"
 
 namespace crl {
-
-// ------------------------------------------------------------------------------------------------------
-// CartPoleEnv{Float32} step (RLEnvs 0.6.12 semantics; oracle/ppo_oracle.c:orc_cartpole_step is the restatement).
-// Contraction is off and the promotions to Float64 follow the reference expression (`4 / 3` is a Float64 literal),
-// so this is bit-identical to the CPU oracle.
-// ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void store_nt4(f32x4* p, float a, float b, float c, float d) {
-  f32x4 v; v[0] = a; v[1] = b; v[2] = c; v[3] = d;
-  __builtin_nontemporal_store(v, p);
-}
-
-__device__ __forceinline__ float sin_poly(float x) {
-  float x2 = x * x;
-  float p = __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, 2.7557319e-6f, -1.9841270e-4f), 8.3333333e-3f), -1.6666667e-1f);
-  return __builtin_fmaf(x * x2, p, x);
-}
-__device__ __forceinline__ float cos_poly(float x) {
-  float x2 = x * x;
-  float p = __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, 2.4801587e-5f, -1.3888889e-3f), 4.1666667e-2f), -0.5f);
-  return __builtin_fmaf(x2, p, 1.0f);
-}
-
-__device__ __forceinline__ bool cartpole_step(float (&s)[4], int& t, int action) {
-#pragma clang fp contract(off)
-  const float gravity = 9.8f, masspole = 0.1f, totalmass = 1.1f, halflength = 0.5f, pml = 0.05f;
-  const float forcemag = 10.0f, dt = 0.02f, ththr = 0.20943951f, xthr = 2.4f;
-  t += 1;
-  const float force = action == 1 ? forcemag : -forcemag;
-  const float xdot = s[1], theta = s[2], thetadot = s[3];
-  const float costheta = cos_poly(theta), sintheta = sin_poly(theta);
-  const float tmp = (force + (pml * (thetadot * thetadot)) * sintheta) / totalmass;
-  const float num = gravity * sintheta - costheta * tmp;
-  const double den = (double)halflength * (4.0 / 3.0 - (double)((masspole * (costheta * costheta)) / totalmass));
-  const double thetaacc = (double)num / den;
-  const double xacc = (double)tmp - (((double)pml * thetaacc) * (double)costheta) / (double)totalmass;
-  s[0] = s[0] + dt * xdot;
-  s[1] = (float)((double)s[1] + (double)dt * xacc);
-  s[2] = s[2] + dt * thetadot;
-  s[3] = (float)((double)s[3] + (double)dt * thetaacc);
-  return (fabsf(s[0]) > xthr) || (fabsf(s[2]) > ththr) || (t > 500);
-}
-
-__device__ __forceinline__ void cartpole_reset(float (&s)[4], uint64_t seed, uint32_t gid, uint64_t gstep, uint32_t stream) {
-#pragma clang fp contract(off)
-  u32x4 o = philox_env(seed, gid, gstep, stream);
-  s[0] = 0.1f * ((float)(o.x >> 8) * 0x1.0p-24f) - 0.05f;
-  s[1] = 0.1f * ((float)(o.y >> 8) * 0x1.0p-24f) - 0.05f;
-  s[2] = 0.1f * ((float)(o.z >> 8) * 0x1.0p-24f) - 0.05f;
-  s[3] = 0.1f * ((float)(o.w >> 8) * 0x1.0p-24f) - 0.05f;
-}
 
 // ------------------------------------------------------------------------------------------------------
 // get_action / critic on caller-supplied observations (crl_policy_act) — ppo.jl:21-32,128
@@ -404,6 +355,7 @@ static int grid_for_tiles(int n, int wpb) {
 
 int launch_policy_act(crl_ppo* h, const float* obs_d, const double* u_d, int n, int32_t* action_d, float* logprob_d,
                       float* value_d) {
+  if (h->wide) return wide_policy_act(h, obs_d, u_d, n, action_d, logprob_d, value_d);
   if (check_shape(h)) return 1;
   const int wpb = 4;
   const size_t smem = act_smem<4, 2>();
@@ -414,6 +366,7 @@ int launch_policy_act(crl_ppo* h, const float* obs_d, const double* u_d, int n, 
 }
 
 int launch_logprob_actions(crl_ppo* h, const float* obs_d, const int32_t* act_d, int n, float* logprob_d, float* ent_d) {
+  if (h->wide) return wide_logprob_actions(h, obs_d, act_d, n, logprob_d, ent_d);
   if (check_shape(h)) return 1;
   const int wpb = 4;
   const size_t smem = sizeof(float) * NetImage<4, 2, false>::SIZE;
@@ -423,6 +376,7 @@ int launch_logprob_actions(crl_ppo* h, const float* obs_d, const int32_t* act_d,
 }
 
 int launch_next_value(crl_ppo* h) {
+  if (h->wide) return wide_next_value(h);
   if (check_shape(h)) return 1;
   const int wpb = 4;
   const size_t smem = sizeof(float) * NetImage<4, 1, false>::SIZE;
@@ -433,7 +387,8 @@ int launch_next_value(crl_ppo* h) {
 }
 
 int launch_env_reset(crl_ppo* h) {
-  if (h->cfg.env_kind != CRL_ENV_CARTPOLE) { set_error("crl_env_reset: on-device env is CartPole only"); return 1; }
+  if (h->cfg.env_kind == CRL_ENV_SYNTHETIC) return wide_env_reset(h);
+  if (h->cfg.env_kind != CRL_ENV_CARTPOLE) { set_error("crl_env_reset: envs are stepped by the caller (CRL_ENV_EXTERNAL)"); return 1; }
   hipLaunchKernelGGL(env_reset_kernel, dim3((h->dc.nt + 255) / 256), dim3(256), 0, h->stream, h->dc, h->env_state, h->env_t,
                      h->cur_obs, h->next_done, h->ep_return, h->ep_length, h->ep_stats);
   CRL_HIP_CHECK(hipGetLastError());
@@ -441,8 +396,9 @@ int launch_env_reset(crl_ppo* h) {
 }
 
 int launch_rollout(crl_ppo* h) {
+  if (h->cfg.env_kind == CRL_ENV_EXTERNAL) { set_error("crl_rollout_run: envs are stepped by the caller (CRL_ENV_EXTERNAL)"); return 1; }
+  if (h->wide) return wide_rollout(h);
   if (check_shape(h)) return 1;
-  if (h->cfg.env_kind != CRL_ENV_CARTPOLE) { set_error("crl_rollout_run: on-device env is CartPole only"); return 1; }
   CRL_HIP_CHECK(hipMemsetAsync(h->ep_stats, 0, 4 * sizeof(double), h->stream));
   RolloutArgs a;
   a.c = h->dc; a.params = h->params;

@@ -81,6 +81,10 @@ struct crl_ppo {
   void* comm = nullptr; int world = 1, rank = 0;
   bool external_comm = false;  // shards exchanged by the host (crl_comm_init_external): all-reduce calls are no-ops
 
+  // generic-shape path (wide.hip): anything but obs 4 / act 2 / hidden 64, or CRL_FORCE_WIDE=1
+  bool wide = false;
+  void* wide_ws = nullptr;
+
   bool prof = false;
   crl::ProfSlot prof_slots[CRL_K_COUNT];
 };
@@ -124,5 +128,16 @@ int launch_adv_stats_finish(crl_ppo* h);
 int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot);
 int launch_optim(crl_ppo* h, double eta);
 int comm_allreduce(crl_ppo* h, void* buf, size_t count, bool is_double);
+// wide.hip — layer-wise path for other network shapes
+bool wide_shape_ok(const crl_ppo_config* cfg, std::string* why);
+int wide_create(crl_ppo* h);
+void wide_destroy(crl_ppo* h);
+void wide_mark_params_changed(crl_ppo* h);
+int wide_policy_act(crl_ppo* h, const float* obs_d, const double* u_d, int n, int32_t* action_d, float* logprob_d, float* value_d);
+int wide_logprob_actions(crl_ppo* h, const float* obs_d, const int32_t* act_d, int n, float* logprob_d, float* ent_d);
+int wide_next_value(crl_ppo* h);
+int wide_env_reset(crl_ppo* h);
+int wide_rollout(crl_ppo* h);
+int wide_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot);
 void comm_destroy(crl_ppo* h);
 }  // namespace crl

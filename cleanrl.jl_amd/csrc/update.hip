@@ -21,6 +21,7 @@
 #include "common.hpp"
 #include "mlp_x3.hpp"
 #include "ppo_ctx.hpp"
+#include "stats.hpp"
 
 namespace crl {
 
@@ -472,32 +473,6 @@ __global__ void __launch_bounds__(256, 2) update_vfix_kernel(UpdateArgs a) {
   update_role<D, A, 1, true, false, 4>(a, blockIdx.x, smem, smem + NetImage<D, 1, true>::SIZE);
 }
 
-// "Training Statistics" (ppo.jl:247) from the (all-reduced) sums msg[P..P+3]; mode 0 also raises the value-loss
-// speculation flag (u > 0), mode 1 is the re-evaluation after the exact critic pass.
-__device__ __forceinline__ void compute_stats(const float* msg, int P, const DevCfg& c, double Mglobal, const double* adv_ms,
-                                              int mb, double* vfix, crl_ppo_stats* out, int mode) {
-  const double pg = (double)msg[P] / Mglobal;
-  const double ent = (double)(float)((double)msg[P + 1] / ((double)c.A * Mglobal));
-  const double u = (double)(float)((double)msg[P + 2] / Mglobal);
-  const double vl = 0.5 * (double)(float)((double)msg[P + 3] / Mglobal);
-  if (mode == 0) {
-    vfix[0] = u;
-    vfix[3] = (c.clip_vloss && u > 0.0) ? 1.0 : 0.0;
-    if (vfix[3] != 0.0) vfix[4] = 1.0;  // sticky: lets a data-parallel run fail loudly (no exact pass there yet)
-    out->n_unclipped_wins = 0.0;
-  } else {
-    out->n_unclipped_wins = vfix[1];
-  }
-  out->pg_loss = pg; out->entropy_loss = ent; out->v_loss = vl; out->u_value = u;
-  out->loss = pg - (double)(c.ent_coeff * (float)ent) + (double)c.v_coef * vl;
-  out->adv_mean = (double)(float)adv_ms[2 * mb]; out->adv_std = (double)(float)adv_ms[2 * mb + 1];
-}
-
-struct StatsArgs {
-  DevCfg c; double Mglobal; const double* adv_ms; int mb; double* vfix; crl_ppo_stats* out;
-  int fused;  // 1: the last block of reduce_kernel also writes the statistics (single-GPU: sums are already global)
-};
-
 // Σ over per-block partials in fixed order → flat gradient (+ the loss sums appended for the all-reduce message)
 // msg layout: [P gradient floats][pg_sum, ent_sum, u_sum, q_sum as floats]
 // Block = 64 consecutive outputs x 4 groups of partials (group g sums blocks b ≡ g mod 4, then g0+g1+g2+g3):
@@ -644,6 +619,7 @@ static StatsArgs stats_args(crl_ppo* h, int mb, crl_ppo_stats* slot, int fused) 
 // One optimiser step's gradient: update pass → fixed-order reduce (+ statistics) → [all-reduce → statistics] →
 // the rare exact value-loss pass (three early-exit launches). The gradient message ends up in comm_buf.
 int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
+  if (h->wide) return wide_update(h, mb, stats_slot);
   if (h->cfg.obs_dim != 4 || h->cfg.n_act != 2 || h->cfg.hidden != 64) {
     set_error("this build of libcleanrl_hip supports obs_dim=4, n_act=2, hidden=64 (2x64 MLP) only");
     return 1;

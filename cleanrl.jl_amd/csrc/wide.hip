@@ -1,0 +1,995 @@
+// wide.hip — the same PPO hot path (ppo.jl:21-45,123-166,197-251) for network shapes other than the specialised
+// obs 4 / act 2 / 2×64 one: obs_dim ≤ 64, n_act ≤ 16, hidden ∈ {64, 128, 256} (BASELINE config C3: obs 8, act 4, 2×256).
+//
+// A 256-wide layer no longer fits the "whole network in registers + LDS" scheme of update.hip (W2 alone is 256 KB), so
+// this path is layer-wise: activations of a whole minibatch live in HBM as (features, samples) column-major arrays —
+// the reference's own layout — and every dense layer is one tiled v_mfma_f32_32x32x2_f32 GEMM:
+//   forward          Y = act(W·X + b)            wide_dense_kernel<EPI_TANH | EPI_BIAS>
+//   backward (data)  dX = (Wᵀ·dY) ⊙ (1 − X²)     wide_dense_kernel<EPI_DTANH> on a transposed weight copy
+//   backward (weight) dW = dY·Xᵀ, db = Σ dY      wide_wgrad_kernel: the reduction runs over samples, both operands are
+//                                                 read feature-fastest (no transpose anywhere), split over sample
+//                                                 chunks into per-block partials, summed in fixed order afterwards
+//   K ≤ 16 / N ≤ 16 weight gradients (dW1, dW3)  wide_skinny_kernel on the VALU (no MFMA shape fits)
+// At 2×256 a layer is 131 KFLOP per sample against 2 KB of HBM traffic: the MFMA pipe, not HBM, bounds every GEMM.
+// Because the critic forward is its own pass here, the value-loss scalar u = mean(v − R²) (ppo.jl:232, Q4) is known
+// before any cotangent is formed: no speculation and no fix-up pass, and it is exact under data parallelism too.
+#include <hip/hip_ext.h>
+
+#include <cstdlib>
+
+#include "common.hpp"
+#include "env.hpp"
+#include "ppo_ctx.hpp"
+#include "stats.hpp"
+
+namespace crl {
+
+constexpr int WXS = 36;    // LDS stride (floats) of one staged sample row: 32 k + 4 pad → conflict-free ds_read_b128
+constexpr int WLS = 24;    // doubles per loss-kernel block partial: pg, Σ-entropy, Σ(v−R²), Σ value term, db3a[16], db3c
+constexpr int AMAX = 16;
+
+enum { EPI_TANH = 0, EPI_BIAS = 1, EPI_DTANH = 2 };
+
+// ------------------------------------------------------------------------------------------------------
+// Workspace
+// ------------------------------------------------------------------------------------------------------
+struct WideNetPack { int w1, w3, w2t, w3t, size; };  // float offsets of the packed weight copies of one network
+static inline WideNetPack pack_layout(int H, int D8, int O8) {
+  WideNetPack p;
+  p.w1 = 0; p.w3 = p.w1 + H * D8; p.w2t = p.w3 + 32 * H; p.w3t = p.w2t + H * H; p.size = p.w3t + H * O8;
+  return p;
+}
+
+struct WideWs {
+  int H, D, D8, A, A8, Mw;       // Mw = samples the activation buffers hold
+  WideNetPack pk[2]; int pk_base[2];
+  float* pack = nullptr;         // padded / transposed weight copies, rebuilt after every parameter change
+  bool pack_dirty = true;
+  float *h1[2] = {nullptr, nullptr}, *h2[2] = {nullptr, nullptr};  // [H × Mw] tanh activations, actor / critic
+  float* z = nullptr;            // [A8 × Mw] logits, overwritten by their cotangent
+  float* v = nullptr;            // [Mw] critic outputs
+  float* dv8 = nullptr;          // [8 × Mw] critic-output cotangent in row 0 (rows 1-7 zero: K of the head GEMM is padded to 8)
+  float *dA = nullptr, *dB = nullptr;  // [H × Mw] hidden-layer cotangents
+  // gradient partials
+  int S2 = 1, chunk2 = 32, Ss = 1, chunks = 256, nlb = 1;
+  float *pW2[2] = {nullptr, nullptr}, *pB2[2] = {nullptr, nullptr};
+  float *pW1[2] = {nullptr, nullptr}, *pB1[2] = {nullptr, nullptr};
+  float* pW3[2] = {nullptr, nullptr};
+  double* lpart = nullptr;       // [nlb][WLS]
+  double* vpart = nullptr;       // [1024]
+  double* u_dev = nullptr;       // [0] u (reserved), [1] = double(count) under DP
+};
+
+static int walloc(float** p, size_t n) {
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(p), n * sizeof(float));
+  if (e != hipSuccess) { set_error(std::string("hipMalloc (wide workspace): ") + hipGetErrorString(e)); return 1; }
+  return 0;
+}
+
+bool wide_shape_ok(const crl_ppo_config* cfg, std::string* why) {
+  const int H = cfg->hidden;
+  if (H != 64 && H != 128 && H != 256) { *why = "hidden must be 64, 128 or 256"; return false; }
+  if (cfg->obs_dim < 1 || cfg->obs_dim > 64) { *why = "obs_dim must be in 1..64"; return false; }
+  if (cfg->n_act < 2 || cfg->n_act > AMAX) { *why = "n_act must be in 2..16"; return false; }
+  return true;
+}
+
+void wide_destroy(crl_ppo* h) {
+  WideWs* w = static_cast<WideWs*>(h->wide_ws);
+  if (!w) return;
+  void* ptrs[] = {w->pack, w->h1[0], w->h1[1], w->h2[0], w->h2[1], w->z, w->v, w->dv8, w->dA, w->dB, w->pW2[0], w->pW2[1],
+                  w->pB2[0], w->pB2[1], w->pW1[0], w->pW1[1], w->pB1[0], w->pB1[1], w->pW3[0], w->pW3[1], w->lpart, w->vpart,
+                  w->u_dev};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  delete w;
+  h->wide_ws = nullptr;
+}
+
+int wide_create(crl_ppo* h) {
+  WideWs* w = new (std::nothrow) WideWs();
+  if (!w) { set_error("out of host memory"); return 1; }
+  h->wide_ws = w;
+  w->H = h->cfg.hidden; w->D = h->cfg.obs_dim; w->A = h->cfg.n_act;
+  w->D8 = (w->D + 7) & ~7; w->A8 = (w->A + 7) & ~7;
+  const int M = h->dc.M, nt = h->dc.nt;
+  w->Mw = M > nt ? M : nt;
+  w->pk[0] = pack_layout(w->H, w->D8, w->A8);
+  w->pk[1] = pack_layout(w->H, w->D8, 8);
+  w->pk_base[0] = 0; w->pk_base[1] = w->pk[0].size;
+  const size_t H = (size_t)w->H, Mw = (size_t)w->Mw;
+  int rc = 0;
+  rc |= walloc(&w->pack, (size_t)w->pk[0].size + w->pk[1].size);
+  for (int n = 0; n < 2; ++n) { rc |= walloc(&w->h1[n], H * Mw); rc |= walloc(&w->h2[n], H * Mw); }
+  rc |= walloc(&w->z, (size_t)w->A8 * Mw); rc |= walloc(&w->v, Mw); rc |= walloc(&w->dv8, 8 * Mw);
+  rc |= walloc(&w->dA, H * Mw); rc |= walloc(&w->dB, H * Mw);
+  // weight-gradient splits: ≈2048-sample chunks for the MFMA kernel, 512-sample chunks for the VALU kernels
+  int s2 = (M + 2047) / 2048; if (s2 > 512) s2 = 512; if (s2 < 1) s2 = 1;
+  w->S2 = s2; w->chunk2 = (((M + s2 - 1) / s2) + 31) & ~31;
+  int ss = (M + 511) / 512; if (ss > 1024) ss = 1024; if (ss < 1) ss = 1;
+  w->Ss = ss; w->chunks = (M + ss - 1) / ss;
+  w->nlb = (M + 255) / 256;
+  for (int n = 0; n < 2; ++n) {
+    const size_t NO = n ? 1 : (size_t)w->A;
+    rc |= walloc(&w->pW2[n], (size_t)w->S2 * H * H); rc |= walloc(&w->pB2[n], (size_t)w->S2 * H);
+    rc |= walloc(&w->pW1[n], (size_t)w->Ss * H * w->D); rc |= walloc(&w->pB1[n], (size_t)w->Ss * H);
+    rc |= walloc(&w->pW3[n], (size_t)w->Ss * H * NO);
+  }
+  rc |= walloc(reinterpret_cast<float**>(&w->lpart), (size_t)w->nlb * WLS * 2);
+  rc |= walloc(reinterpret_cast<float**>(&w->vpart), 1024 * 2);
+  rc |= walloc(reinterpret_cast<float**>(&w->u_dev), 4 * 2);
+  if (rc) { wide_destroy(h); return 1; }
+  return 0;
+}
+
+void wide_mark_params_changed(crl_ppo* h) {
+  if (h->wide_ws) static_cast<WideWs*>(h->wide_ws)->pack_dirty = true;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Weight packing: W1 → [H × D8] (zero columns beyond obs_dim), W3 → [32 × H] (zero rows beyond n_out),
+// W2ᵀ [H × H], W3ᵀ → [H × O8]. W2 itself is used in place (it already is H × H column-major).
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) wide_pack_kernel(const float* __restrict__ params, float* __restrict__ pack, int H, int D,
+                                                       int D8, int NO, int O8, int pbase, int kbase, WideNetPack pk) {
+  const float* W1 = params + pbase;
+  const float* W2 = W1 + H * D + H;
+  const float* W3 = W2 + H * H + H;
+  float* o = pack + kbase;
+  const int total = pk.size;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    float val;
+    if (i < pk.w3) { const int n = i % H, k = i / H; val = k < D ? W1[n + H * k] : 0.0f; }
+    else if (i < pk.w2t) { const int q = i - pk.w3; const int a = q & 31, k = q >> 5; val = a < NO ? W3[a + NO * k] : 0.0f; }
+    else if (i < pk.w3t) { const int q = i - pk.w2t; const int k = q % H, n = q / H; val = W2[n + H * k]; }
+    else { const int q = i - pk.w3t; const int k = q % H, a = q / H; val = a < NO ? W3[a + NO * k] : 0.0f; }
+    o[i] = val;
+  }
+}
+
+static int ensure_pack(crl_ppo* h) {
+  WideWs* w = static_cast<WideWs*>(h->wide_ws);
+  if (!w->pack_dirty) return 0;
+  for (int n = 0; n < 2; ++n) {
+    const int NO = n ? 1 : w->A, O8 = n ? 8 : w->A8;
+    hipLaunchKernelGGL(wide_pack_kernel, dim3((w->pk[n].size + 255) / 256), dim3(256), 0, h->stream, h->params, w->pack, w->H, w->D,
+                       w->D8, NO, O8, n ? (int)h->Pa : 0, w->pk_base[n], w->pk[n]);
+  }
+  CRL_HIP_CHECK(hipGetLastError());
+  w->pack_dirty = false;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Dense layer: Y[n, m] = epi( Σ_k W[n, k]·X[k, m] ).  256 threads; the block owns NP = 32·WN·TN output rows (all of
+// them) × MB = 32·WM·TM samples; K is walked in slabs of 32 staged through LDS (W slab: a contiguous copy; X slab:
+// one 128-B row piece per sample). Three blocks fit a CU, so one block's staging hides under the others' MFMAs.
+// k-pairing: MFMA step c of an 8-k group takes k = 8j+c from lanes 0-31 and k = 8j+4+c from lanes 32-63, so every lane
+// reads its B operand as one ds_read_b128.
+// ------------------------------------------------------------------------------------------------------
+struct DenseArgs {
+  const float* W; int Kp;                                  // packed [NP × Kp] column-major, Kp % 8 == 0
+  const float* X; int ldx; int Kt; const int32_t* idx;     // sample m's features at X + ldx·(idx ? idx[m] : m), Kt valid
+  const float* bias; const float* S; int lds;              // bias[Nt]; S: stored tanh outputs at the Y positions
+  float* Y; int ldy; int Nt; int M;
+};
+
+template <int WN, int TN, int WM, int TM, int EPI>
+__global__ void __launch_bounds__(256) wide_dense_kernel(DenseArgs a) {
+  constexpr int NP = 32 * WN * TN, MB = 32 * WM * TM;
+  static_assert(WN * WM == 4, "four waves per block");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Wl = smem;            // [32][NP]
+  float* Xl = smem + 32 * NP;  // [MB][WXS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hf = lane >> 5;
+  const int wn = wave % WN, wm = wave / WN;
+  const int m0 = blockIdx.x * MB;
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int x = 0; x < TN; ++x)
+#pragma unroll
+    for (int y = 0; y < TM; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.0f;
+  const bool xfast = ((a.ldx & 3) == 0) && ((a.Kt & 3) == 0);
+
+  for (int k0 = 0; k0 < a.Kp; k0 += 32) {
+    const int ks = (a.Kp - k0) < 32 ? (a.Kp - k0) : 32;
+    {
+      const f32x4* src = reinterpret_cast<const f32x4*>(a.W + (size_t)NP * k0);
+      f32x4* dst = reinterpret_cast<f32x4*>(Wl);
+      const int n4 = NP * ks / 4;
+      for (int i = tid; i < n4; i += 256) dst[i] = src[i];
+    }
+    {
+      const int q4 = ks >> 2, n = MB * q4;
+      for (int i = tid; i < n; i += 256) {
+        const int mm = i / q4, q = i - mm * q4, m = m0 + mm, k = k0 + 4 * q;
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (m < a.M && k < a.Kt) {
+          const size_t row = a.idx ? (size_t)a.idx[m] : (size_t)m;
+          const float* p = a.X + row * (size_t)a.ldx + k;
+          if (xfast) v = *reinterpret_cast<const f32x4*>(p);
+          else {
+            v[0] = p[0];
+            if (k + 1 < a.Kt) v[1] = p[1];
+            if (k + 2 < a.Kt) v[2] = p[2];
+            if (k + 3 < a.Kt) v[3] = p[3];
+          }
+        }
+        *reinterpret_cast<f32x4*>(Xl + mm * WXS + 4 * q) = v;
+      }
+    }
+    __syncthreads();
+    for (int jj = 0; jj < (ks >> 3); ++jj) {
+      f32x4 b[TM];
+#pragma unroll
+      for (int y = 0; y < TM; ++y) b[y] = *reinterpret_cast<const f32x4*>(Xl + ((wm * TM + y) * 32 + j) * WXS + 8 * jj + 4 * hf);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int x = 0; x < TN; ++x) {
+          const float av = Wl[(8 * jj + 4 * hf + c) * NP + (wn * TN + x) * 32 + j];
+#pragma unroll
+          for (int y = 0; y < TM; ++y) acc[x][y] = mfma32(av, b[y][c], acc[x][y]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  const bool yfast = ((a.ldy & 3) == 0) && ((a.Nt & 3) == 0) && (EPI != EPI_DTANH || (a.lds & 3) == 0);
+#pragma unroll
+  for (int x = 0; x < TN; ++x) {
+#pragma unroll
+    for (int y = 0; y < TM; ++y) {
+      const int m = m0 + (wm * TM + y) * 32 + j;
+      if (m >= a.M) continue;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = (wn * TN + x) * 32 + 8 * g + 4 * hf;   // rows n..n+3 = registers 4g..4g+3 (rowmap)
+        if (n >= a.Nt) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[x][y][4 * g + e];
+        if (yfast) {
+          if (EPI == EPI_DTANH) {
+            const f32x4 s = *reinterpret_cast<const f32x4*>(a.S + (size_t)a.lds * m + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.0f - s[e] * s[e]);
+          } else {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += bv[e]; if (EPI == EPI_TANH) v[e] = tanh_fast(v[e]); }
+          }
+          f32x4 o; o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+          *reinterpret_cast<f32x4*>(a.Y + (size_t)a.ldy * m + n) = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (n + e >= a.Nt) continue;
+            float o = v[e];
+            if (EPI == EPI_DTANH) { const float s = a.S[(size_t)a.lds * m + n + e]; o = o * (1.0f - s * s); }
+            else { o += a.bias[n + e]; if (EPI == EPI_TANH) o = tanh_fast(o); }
+            a.Y[(size_t)a.ldy * m + n + e] = o;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int EPI>
+static int dense_launch(hipStream_t st, int NP, const DenseArgs& a) {
+  if (a.M <= 0) return 0;
+  switch (NP) {
+    case 256: hipLaunchKernelGGL((wide_dense_kernel<4, 2, 1, 2, EPI>), dim3((a.M + 63) / 64), dim3(256), sizeof(float) * (32 * 256 + 64 * WXS), st, a); break;
+    case 128: hipLaunchKernelGGL((wide_dense_kernel<4, 1, 1, 2, EPI>), dim3((a.M + 63) / 64), dim3(256), sizeof(float) * (32 * 128 + 64 * WXS), st, a); break;
+    case 64: hipLaunchKernelGGL((wide_dense_kernel<2, 1, 2, 2, EPI>), dim3((a.M + 127) / 128), dim3(256), sizeof(float) * (32 * 64 + 128 * WXS), st, a); break;
+    case 32: hipLaunchKernelGGL((wide_dense_kernel<1, 1, 4, 2, EPI>), dim3((a.M + 255) / 256), dim3(256), sizeof(float) * (32 * 32 + 256 * WXS), st, a); break;
+    default: set_error("wide path: unsupported layer width"); return 1;
+  }
+  CRL_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// flat Flux parameter offsets inside one network
+struct NetOff { int W1, b1, W2, b2, W3, b3, size; };
+static NetOff net_off(int H, int D, int NO) {
+  NetOff o; o.W1 = 0; o.b1 = H * D; o.W2 = o.b1 + H; o.b2 = o.W2 + H * H; o.W3 = o.b2 + H; o.b3 = o.W3 + NO * H; o.size = o.b3 + NO;
+  return o;
+}
+
+// forward of one network over M samples: h1, h2 kept in the workspace, head output to out (ld ldo)
+static int wide_forward(crl_ppo* h, int net, const float* X, int ldx, const int32_t* idx, int M, float* out, int ldo) {
+  WideWs* w = static_cast<WideWs*>(h->wide_ws);
+  const int H = w->H, NO = net ? 1 : w->A;
+  const NetOff o = net_off(H, w->D, NO);
+  const float* P = h->params + (net ? h->Pa : 0);
+  const float* pk = w->pack + w->pk_base[net];
+  DenseArgs a;
+  a.idx = idx; a.S = nullptr; a.lds = 0; a.M = M;
+  a.W = pk + w->pk[net].w1; a.Kp = w->D8; a.X = X; a.ldx = ldx; a.Kt = w->D; a.bias = P + o.b1; a.Y = w->h1[net]; a.ldy = H; a.Nt = H;
+  if (dense_launch<EPI_TANH>(h->stream, H, a)) return 1;
+  a.idx = nullptr;
+  a.W = P + o.W2; a.Kp = H; a.X = w->h1[net]; a.ldx = H; a.Kt = H; a.bias = P + o.b2; a.Y = w->h2[net];
+  if (dense_launch<EPI_TANH>(h->stream, H, a)) return 1;
+  a.W = pk + w->pk[net].w3; a.Kp = H; a.X = w->h2[net]; a.bias = P + o.b3; a.Y = out; a.ldy = ldo; a.Nt = NO;
+  return dense_launch<EPI_BIAS>(h->stream, 32, a);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Weight gradient of a hidden layer: dW[n, k] = Σ_m dY[n, m]·X[k, m], db[n] = Σ_m dY[n, m] over one sample chunk.
+// Block = one (64·TW)² output tile × one chunk; both operands are (feature, sample) arrays, so a 32-sample slab of
+// either is BT contiguous floats per sample and the MFMA operands are read feature-fastest from LDS.
+// ------------------------------------------------------------------------------------------------------
+struct WgradArgs { const float* dY; const float* X; int H; int M; int chunk; float* pW; float* pB; };
+
+template <int TW>
+__global__ void __launch_bounds__(256) wide_wgrad_kernel(WgradArgs a) {
+  constexpr int BT = 64 * TW;
+  __shared__ __attribute__((aligned(16))) float Yl[32 * BT];
+  __shared__ __attribute__((aligned(16))) float Xl[32 * BT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hf = lane >> 5;
+  const int nb = a.H / BT, tnb = blockIdx.y % nb, tkb = blockIdx.y / nb;
+  const int n0 = tnb * BT, kk0 = tkb * BT;
+  const int wn = wave & 1, wk = wave >> 1;
+  f32x16 acc[TW][TW];
+#pragma unroll
+  for (int x = 0; x < TW; ++x)
+#pragma unroll
+    for (int y = 0; y < TW; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.0f;
+  f32x4 bacc = {0.0f, 0.0f, 0.0f, 0.0f};
+  const int c0 = blockIdx.x * a.chunk;
+  const int c1 = (c0 + a.chunk) < a.M ? (c0 + a.chunk) : a.M;
+  for (int m = c0; m < c1; m += 32) {
+    const int mv = (c1 - m) < 32 ? (c1 - m) : 32;
+    for (int i = tid; i < BT * 8; i += 256) {
+      const int p = 4 * i, mm = p / BT, n = p - mm * BT;
+      f32x4 y = {0.0f, 0.0f, 0.0f, 0.0f}, x = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (mm < mv) {
+        y = *reinterpret_cast<const f32x4*>(a.dY + (size_t)a.H * (m + mm) + n0 + n);
+        x = *reinterpret_cast<const f32x4*>(a.X + (size_t)a.H * (m + mm) + kk0 + n);
+      }
+      *reinterpret_cast<f32x4*>(Yl + p) = y;
+      *reinterpret_cast<f32x4*>(Xl + p) = x;
+      bacc += y;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+      const int mm = 2 * s + hf;
+      float av[TW], bv[TW];
+#pragma unroll
+      for (int x = 0; x < TW; ++x) av[x] = Yl[mm * BT + (wn * TW + x) * 32 + j];
+#pragma unroll
+      for (int y = 0; y < TW; ++y) bv[y] = Xl[mm * BT + (wk * TW + y) * 32 + j];
+#pragma unroll
+      for (int x = 0; x < TW; ++x)
+#pragma unroll
+        for (int y = 0; y < TW; ++y) acc[x][y] = mfma32(av[x], bv[y], acc[x][y]);
+    }
+    __syncthreads();
+  }
+  float* pw = a.pW + (size_t)blockIdx.x * a.H * a.H;
+#pragma unroll
+  for (int x = 0; x < TW; ++x)
+#pragma unroll
+    for (int y = 0; y < TW; ++y) {
+      const int k = kk0 + (wk * TW + y) * 32 + j;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + (wn * TW + x) * 32 + 8 * g + 4 * hf;
+        f32x4 o; o[0] = acc[x][y][4 * g]; o[1] = acc[x][y][4 * g + 1]; o[2] = acc[x][y][4 * g + 2]; o[3] = acc[x][y][4 * g + 3];
+        *reinterpret_cast<f32x4*>(pw + (size_t)a.H * k + n) = o;
+      }
+    }
+  if (tkb == 0 && a.pB) {
+    // thread t always staged rows (4t mod BT)..+3: fold the 1024/BT threads that share a row quad, in thread order
+    *reinterpret_cast<f32x4*>(Yl + 4 * tid) = bacc;
+    __syncthreads();
+    if (tid < BT) {
+      const int quad = tid >> 2, e = tid & 3;
+      float s = 0.0f;
+      for (int q = 0; q < 1024 / BT; ++q) s += Yl[4 * (quad + (BT / 4) * q) + e];
+      a.pB[(size_t)blockIdx.x * a.H + n0 + tid] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Skinny weight gradients on the VALU: out[row, s] = Σ_m Big[row, m]·Small[s, m] (+ Σ_m Big[row, m]) with S ≤ 16.
+//   dW1 = dH1·Xᵀ  (Big = dH1, Small = the gathered observations, bias sum = db1)
+//   dW3ᵀ = H2·dZᵀ (Big = H2, Small = the head cotangent)
+// A thread owns one hidden row; the Small values of a sample are wave-uniform (scalar loads).
+// ------------------------------------------------------------------------------------------------------
+struct SkinnyArgs {
+  const float* Big; int H; const float* Small; int lds; const int32_t* idx; int M; int chunk;
+  float* pW; int os_row, os_s, St, wsize; float* pB;
+};
+
+template <int S>
+__global__ void __launch_bounds__(256) wide_skinny_kernel(SkinnyArgs a) {
+  __shared__ float red[256 * (S + 1)];
+  const int tid = threadIdx.x;
+  const int G = 256 / a.H;
+  const int row = tid % a.H;
+  const int g = __builtin_amdgcn_readfirstlane(tid / a.H);
+  float acc[S], bacc = 0.0f;
+#pragma unroll
+  for (int s = 0; s < S; ++s) acc[s] = 0.0f;
+  const int c0 = blockIdx.x * a.chunk;
+  const int c1 = (c0 + a.chunk) < a.M ? (c0 + a.chunk) : a.M;
+#pragma unroll 2
+  for (int m = c0 + g; m < c1; m += G) {
+    const int sr = a.idx ? __builtin_amdgcn_readfirstlane(a.idx[m]) : m;
+    const float* sp = a.Small + (size_t)sr * a.lds;
+    const float big = a.Big[(size_t)a.H * m + row];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const float sv = s < a.St ? sp[s] : 0.0f;
+      acc[s] = __builtin_fmaf(big, sv, acc[s]);
+    }
+    bacc += big;
+  }
+  if (G > 1) {
+#pragma unroll
+    for (int s = 0; s < S; ++s) red[tid * (S + 1) + s] = acc[s];
+    red[tid * (S + 1) + S] = bacc;
+    __syncthreads();
+    if (g == 0) {
+      for (int q = 1; q < G; ++q) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) acc[s] += red[(tid + q * a.H) * (S + 1) + s];
+        bacc += red[(tid + q * a.H) * (S + 1) + S];
+      }
+    }
+  }
+  if (g == 0) {
+    float* pw = a.pW + (size_t)blockIdx.x * a.wsize;
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+      if (s < a.St) pw[row * a.os_row + s * a.os_s] = acc[s];
+    if (a.pB) a.pB[(size_t)blockIdx.x * a.H + row] = bacc;
+  }
+}
+
+static int skinny_launch(hipStream_t st, int blocks, const SkinnyArgs& a) {
+  if (a.St <= 4) hipLaunchKernelGGL(wide_skinny_kernel<4>, dim3(blocks), dim3(256), 0, st, a);
+  else if (a.St <= 8) hipLaunchKernelGGL(wide_skinny_kernel<8>, dim3(blocks), dim3(256), 0, st, a);
+  else if (a.St <= 16) hipLaunchKernelGGL(wide_skinny_kernel<16>, dim3(blocks), dim3(256), 0, st, a);
+  else {
+    // obs_dim up to 64: sixteen columns per launch
+    for (int s0 = 0; s0 < a.St; s0 += 16) {
+      SkinnyArgs b = a;
+      b.Small = a.Small + s0; b.St = (a.St - s0) < 16 ? (a.St - s0) : 16; b.pW = a.pW + (size_t)s0 * a.os_s;
+      if (s0 > 0) b.pB = nullptr;
+      hipLaunchKernelGGL(wide_skinny_kernel<16>, dim3(blocks), dim3(256), 0, st, b);
+    }
+  }
+  CRL_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Per-sample pieces shared by the act / logprob / loss kernels (runtime n_act ≤ 16, same operation order as
+// softmax_logsoftmax<A> and sample_weights<A> in common.hpp)
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void softmax_rt(const float (&z)[AMAX], int A, float (&p)[AMAX], float (&lp)[AMAX]) {
+  float m = z[0];
+#pragma unroll
+  for (int a = 1; a < AMAX; ++a) if (a < A) m = fmaxf(m, z[a]);
+  float s = 0.0f;
+#pragma unroll
+  for (int a = 0; a < AMAX; ++a) if (a < A) { p[a] = expf(z[a] - m); s += p[a]; }
+#pragma unroll
+  for (int a = 0; a < AMAX; ++a) if (a < A) p[a] = p[a] / s;
+  float ls = 0.0f;
+#pragma unroll
+  for (int a = 0; a < AMAX; ++a) if (a < A) { lp[a] = z[a] - m; ls += expf(lp[a]); }
+  const float l = logf(ls);
+#pragma unroll
+  for (int a = 0; a < AMAX; ++a) if (a < A) lp[a] = lp[a] - l;
+}
+__device__ __forceinline__ int sample_rt(const float (&p)[AMAX], int A, double u) {
+  float sw = 0.0f;
+#pragma unroll
+  for (int a = 0; a < AMAX; ++a) if (a < A) sw += p[a];
+  const double t = u * (double)sw;
+  int i = 0;
+  float cw = p[0];
+#pragma unroll
+  for (int a = 1; a < AMAX; ++a) {
+    const bool go = (a < A) && ((double)cw < t) && (i == a - 1);
+    i = go ? a : i;
+    cw = go ? cw + p[a] : cw;
+  }
+  return i;
+}
+__device__ __forceinline__ float pick_rt(const float (&v)[AMAX], int A, int i) {
+  float r = v[0];
+#pragma unroll
+  for (int a = 1; a < AMAX; ++a) if (a < A) r = (i == a) ? v[a] : r;
+  return r;
+}
+__device__ __forceinline__ void load_logits(const float* Z, int A8, int A, size_t m, float (&z)[AMAX]) {
+#pragma unroll
+  for (int a = 0; a < AMAX; ++a) z[a] = a < A ? Z[(size_t)A8 * m + a] : 0.0f;
+}
+
+// get_action on precomputed logits (ppo.jl:23-31) with caller-supplied uniforms
+__global__ void __launch_bounds__(256) wide_sample_kernel(const float* __restrict__ Z, int A8, int A, const float* __restrict__ V,
+                                                         const double* __restrict__ u, int n, int32_t* __restrict__ action,
+                                                         float* __restrict__ logprob, float* __restrict__ value) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= n) return;
+  float z[AMAX], p[AMAX], lp[AMAX];
+  load_logits(Z, A8, A, (size_t)b, z);
+  softmax_rt(z, A, p, lp);
+  const int act = sample_rt(p, A, u[b]);
+  action[b] = act;
+  logprob[b] = pick_rt(lp, A, act);
+  if (value) value[b] = V[b];
+}
+
+// logprob_actions on precomputed logits (ppo.jl:36-44)
+__global__ void __launch_bounds__(256) wide_logprob_kernel(const float* __restrict__ Z, int A8, int A, const int32_t* __restrict__ actions,
+                                                          int n, float* __restrict__ logprob, float* __restrict__ entropy) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= n) return;
+  float z[AMAX], p[AMAX], lp[AMAX];
+  load_logits(Z, A8, A, (size_t)b, z);
+  softmax_rt(z, A, p, lp);
+  logprob[b] = pick_rt(lp, A, actions[b]);
+#pragma unroll
+  for (int a = 0; a < AMAX; ++a) if (a < A) entropy[(size_t)A * b + a] = -(p[a] * lp[a]);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// One rollout step after the two forward passes: sampling, env step, Buffer.add!, episode bookkeeping
+// (ppo.jl:125-165). One thread per env.
+// ------------------------------------------------------------------------------------------------------
+struct WStepArgs {
+  DevCfg c; const float* Z; int A8; const float* V;
+  float* obs; int32_t* action; float* logprob; float* reward; uint8_t* terminal; float* value;
+  float* env_state; int32_t* env_t; float* cur_obs; uint8_t* next_done; float* ep_return; int32_t* ep_length; double* ep_stats;
+  uint64_t iteration; int step;
+};
+
+__global__ void __launch_bounds__(256) wide_step_kernel(WStepArgs a) {
+  const DevCfg& c = a.c;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const bool ok = e < c.nt;
+  double st_n = 0.0, st_ret = 0.0, st_len = 0.0, st_max = 0.0;
+  if (ok) {
+    const int D = c.D, A = c.A;
+    const uint32_t gid = c.env_id_offset + (uint32_t)e;
+    const uint64_t gstep = a.iteration * (uint64_t)c.k + (uint64_t)a.step;
+    const size_t b = (size_t)e + (size_t)c.nt * a.step;
+    int ep_len = a.ep_length[e] + 1;                                   // ppo.jl:125
+    float z[AMAX], p[AMAX], lp[AMAX];
+    load_logits(a.Z, a.A8, A, (size_t)e, z);
+    softmax_rt(z, A, p, lp);                                          // ppo.jl:127 get_action
+    const double u = u53(philox_env(c.seed, gid, gstep, 0));
+    const int act = sample_rt(p, A, u);
+    const float lpa = pick_rt(lp, A, act);
+    float* co = a.cur_obs + (size_t)D * e;
+    float* es = a.env_state + (size_t)D * e;
+    float* ob = a.obs + b * (size_t)D;
+    for (int i = 0; i < D; ++i) ob[i] = co[i];                        // ppo.jl:133-140 Buffer.add!
+    a.action[b] = act; a.logprob[b] = lpa; a.terminal[b] = a.next_done[e]; a.value[b] = a.V[e];
+    bool done; float rew;
+    if (c.env_kind == CRL_ENV_CARTPOLE) {
+      float s[4] = {es[0], es[1], es[2], es[3]};
+      int t_env = a.env_t[e];
+      done = cartpole_step(s, t_env, act);                             // ppo.jl:130
+      rew = done ? 0.0f : 1.0f;                                        // ppo.jl:132
+      for (int i = 0; i < 4; ++i) co[i] = s[i];                        // ppo.jl:143 (before reset!, Q7)
+      if (done) {
+        cartpole_reset(s, c.seed, gid, gstep, 1);                      // ppo.jl:164
+        t_env = 0;
+        if (!c.stale_obs) for (int i = 0; i < 4; ++i) co[i] = s[i];
+      }
+      for (int i = 0; i < 4; ++i) es[i] = s[i];
+      a.env_t[e] = t_env;
+    } else {
+      for (int q = 0; 4 * q < D; ++q) {
+        float o4[4];
+        synth_obs4(c.seed, gid, gstep, q, o4);
+        for (int i = 0; i < 4 && 4 * q + i < D; ++i) { es[4 * q + i] = o4[i]; co[4 * q + i] = o4[i]; }
+      }
+      synth_reward_done(c.seed, gid, gstep, rew, done);
+    }
+    a.reward[b] = rew;
+    a.next_done[e] = done ? 1 : 0;                                     // ppo.jl:144
+    float ep_ret = a.ep_return[e] + rew;                               // ppo.jl:145
+    if (done) {                                                        // ppo.jl:147-165
+      st_n = 1.0; st_ret = (double)ep_ret; st_len = (double)ep_len; st_max = fmax(0.0, (double)ep_ret);
+      ep_ret = 0.0f; ep_len = 0;
+    }
+    a.ep_return[e] = ep_ret; a.ep_length[e] = ep_len;
+  }
+  st_n = wave_sum(st_n);
+  if (st_n > 0.0) {
+    st_ret = wave_sum(st_ret); st_len = wave_sum(st_len);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) st_max = fmax(st_max, __shfl_xor(st_max, o, 64));
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&a.ep_stats[0], st_n); atomicAdd(&a.ep_stats[1], st_ret); atomicAdd(&a.ep_stats[2], st_len);
+      atomicMax(reinterpret_cast<unsigned long long*>(&a.ep_stats[3]), (unsigned long long)__double_as_longlong(st_max));
+    }
+  }
+}
+
+// env construction for the synthetic env (oracle: orc_env_init, gstep = ~0)
+__global__ void __launch_bounds__(256) wide_synth_reset_kernel(DevCfg c, float* env_state, int32_t* env_t, float* cur_obs,
+                                                              uint8_t* next_done, float* ep_return, int32_t* ep_length, double* ep_stats) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e == 0) for (int i = 0; i < 4; ++i) ep_stats[i] = 0.0;
+  if (e >= c.nt) return;
+  const uint32_t gid = c.env_id_offset + (uint32_t)e;
+  for (int q = 0; 4 * q < c.D; ++q) {
+    float o4[4];
+    synth_obs4(c.seed, gid, ~(uint64_t)0, q, o4);
+    for (int i = 0; i < 4 && 4 * q + i < c.D; ++i) { env_state[(size_t)c.D * e + 4 * q + i] = o4[i]; cur_obs[(size_t)c.D * e + 4 * q + i] = o4[i]; }
+  }
+  env_t[e] = 0; next_done[e] = 0; ep_return[e] = 0.0f; ep_length[e] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Value-loss scalar u = mean(newvalue .- mb_returns .^ 2) (ppo.jl:232, Q4) and #{b : u > q_b}
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) wide_vsum_kernel(const float* __restrict__ V, const float* __restrict__ returns,
+                                                       const int32_t* __restrict__ perm, int M, double* __restrict__ vpart) {
+  __shared__ double sm[4];
+  double s = 0.0;
+  for (int pos = blockIdx.x * 256 + threadIdx.x; pos < M; pos += gridDim.x * 256) {
+    const float R = returns[perm[pos]];
+    s += (double)(V[pos] - R * R);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) vpart[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+// vfix[5] = Σ(v − R²) of this shard (all-reduced under DP); vfix[6] (as u64) = 0
+__global__ void __launch_bounds__(64) wide_vsum_final_kernel(const double* __restrict__ vpart, int n, double* vfix) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) s += vpart[i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) { vfix[5] = s; *reinterpret_cast<unsigned long long*>(&vfix[6]) = 0ull; }
+}
+__global__ void __launch_bounds__(256) wide_vcount_kernel(DevCfg c, const float* __restrict__ V, const float* __restrict__ values,
+                                                         const float* __restrict__ returns, const int32_t* __restrict__ perm, int M,
+                                                         double Mglobal, double* vfix) {
+  const float u = (float)(vfix[5] / Mglobal);
+  if (blockIdx.x == 0 && threadIdx.x == 0) vfix[0] = (double)u;
+  if (!(u > 0.0f)) return;   // q_b ≥ 0: no sample can lose against u ≤ 0
+  unsigned long long cnt = 0;
+  for (int pos = blockIdx.x * 256 + threadIdx.x; pos < M; pos += gridDim.x * 256) {
+    const int smp = perm[pos];
+    const float ov = values[smp], R = returns[smp];
+    const float cl = fminf(fmaxf(V[pos] - ov, -c.clip), c.clip);
+    const float vc = ov + cl;
+    const float q = (vc - R) * (vc - R);
+    cnt += (u > q) ? 1ull : 0ull;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(reinterpret_cast<unsigned long long*>(&vfix[6]), cnt);
+}
+__global__ void wide_vcount_to_double_kernel(double* vfix) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) vfix[1] = (double)*reinterpret_cast<unsigned long long*>(&vfix[6]);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Loss terms and output cotangents of one minibatch (ppo.jl:213-244; arithmetic identical to update.hip's tile loop)
+// ------------------------------------------------------------------------------------------------------
+struct WLossArgs {
+  DevCfg c; const int32_t* perm; float* Z; int A8; const float* V; float* dv8;
+  const int32_t* actions; const float* logprobs; const float* values; const float* advantages; const float* returns;
+  const double* adv_ms; int mb; const double* vfix; double Mglobal; double* lpart;
+};
+
+__global__ void __launch_bounds__(256) wide_loss_kernel(WLossArgs a) {
+  const DevCfg& c = a.c;
+  const int A = c.A;
+  const int pos = blockIdx.x * 256 + threadIdx.x;
+  const bool ok = pos < c.M;
+  double sums[4] = {0.0, 0.0, 0.0, 0.0};
+  float dout[AMAX];
+#pragma unroll
+  for (int i = 0; i < AMAX; ++i) dout[i] = 0.0f;
+  float dvf = 0.0f;
+  if (ok) {
+    const int smp = a.perm[pos];
+    const double invM = 1.0 / a.Mglobal;
+    // policy loss + entropy (ppo.jl:213,219-228,242)
+    float z[AMAX], pr[AMAX], lp[AMAX];
+    load_logits(a.Z, a.A8, A, (size_t)pos, z);
+    softmax_rt(z, A, pr, lp);
+    const int act = a.actions[smp];
+    const float nlp = pick_rt(lp, A, act);
+    double Hs = 0.0;
+#pragma unroll
+    for (int i = 0; i < AMAX; ++i) if (i < A) Hs += (double)(-(pr[i] * lp[i]));
+    const float mean_f = (float)a.adv_ms[2 * a.mb];
+    const double inv_denom = 1.0 / ((double)(float)a.adv_ms[2 * a.mb + 1] + 1e-8);
+    const float eps = c.clip, lo = 1.0f - c.clip, hi = 1.0f + c.clip;
+    const double Ahat = (double)(a.advantages[smp] - mean_f) * inv_denom;
+    const float ratio = expf(nlp - a.logprobs[smp]);
+    const float rc = fminf(fmaxf(ratio, lo), hi);
+    const double pg1 = -Ahat * (double)ratio, pg2 = -Ahat * (double)rc;
+    double dnlp, pg;
+    if (pg1 > pg2) { pg = pg1; dnlp = pg1; }
+    else { pg = pg2; dnlp = (ratio >= lo && ratio <= hi) ? pg1 : 0.0; }
+    dnlp *= invM;
+    const double entk = (double)c.ent_coeff / ((double)A * a.Mglobal);
+#pragma unroll
+    for (int i = 0; i < AMAX; ++i)
+      if (i < A) dout[i] = (float)(dnlp * ((i == act ? 1.0 : 0.0) - (double)pr[i]) + entk * (double)pr[i] * ((double)lp[i] + Hs));
+    // value loss (ppo.jl:214,231-240)
+    const float v = a.V[pos], R = a.returns[smp], ov = a.values[smp];
+    const double vk = (double)c.v_coef * 0.5 * invM;
+    double dv, term;
+    if (c.clip_vloss) {
+      const float u = (float)a.vfix[0];
+      const double nwin = a.vfix[1];
+      const float dvv = v - ov;
+      const float cl = fminf(fmaxf(dvv, -eps), eps);
+      const float vc = ov + cl;
+      const float q = (vc - R) * (vc - R);
+      const bool q_wins = !(u > q);  // max.(u, q): ties → q
+      term = q_wins ? (double)q : (double)u;
+      const double inner = (q_wins && dvv >= -eps && dvv <= eps) ? 2.0 * (double)(vc - R) : 0.0;
+      dv = vk * (nwin * invM + inner);
+    } else {
+      const float e = v - R;
+      term = (double)(e * e);
+      dv = vk * 2.0 * (double)e;
+    }
+    dvf = (float)dv;
+    sums[0] = pg; sums[1] = Hs; sums[2] = (double)(v - R * R); sums[3] = term;
+    // cotangents, K padded to a multiple of 8 with zeros for the head's backward GEMM
+#pragma unroll
+    for (int i = 0; i < AMAX; ++i) if (i < a.A8) a.Z[(size_t)a.A8 * pos + i] = dout[i];   // dout[i] = 0 for i ≥ A
+    f32x4 d0 = {dvf, 0.0f, 0.0f, 0.0f}, d1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    reinterpret_cast<f32x4*>(a.dv8)[2 * (size_t)pos] = d0;
+    reinterpret_cast<f32x4*>(a.dv8)[2 * (size_t)pos + 1] = d1;
+  }
+  // block partials: 4 loss sums, db3 of the actor (Σ dZ) and of the critic (Σ dv)
+  __shared__ double sm[4][WLS];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { const double s = wave_sum(sums[q]); if (lane == 0) sm[wave][q] = s; }
+#pragma unroll
+  for (int i = 0; i < AMAX; ++i) {
+    if (i < A) { const double s = wave_sum((double)dout[i]); if (lane == 0) sm[wave][4 + i] = s; }
+  }
+  { const double s = wave_sum((double)dvf); if (lane == 0) sm[wave][4 + AMAX] = s; }
+  __syncthreads();
+  if (threadIdx.x < 4 + AMAX + 1) {
+    const int q = threadIdx.x;
+    const bool live = q < 4 || q == 4 + AMAX || (q - 4) < A;
+    a.lpart[(size_t)blockIdx.x * WLS + q] = live ? (sm[0][q] + sm[1][q]) + (sm[2][q] + sm[3][q]) : 0.0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Fixed-order sum of all partials → flat Flux-ordered gradient + the four loss sums (the all-reduce message)
+// ------------------------------------------------------------------------------------------------------
+struct WRedArgs {
+  const float* part[12]; int nparts[12]; int off[13];
+  const double* lpart; int nlb; float* out; int P; int A;
+};
+
+__global__ void __launch_bounds__(256) wide_reduce_kernel(WRedArgs a) {
+  if (blockIdx.x == gridDim.x - 1) {
+    // loss sums and head-bias gradients: 4 + 16 + 1 quantities over nlb block partials
+    __shared__ double sm[256];
+    for (int q = 0; q < 4 + AMAX + 1; ++q) {
+      const bool live = q < 4 || q == 4 + AMAX || (q - 4) < a.A;
+      if (!live) continue;
+      double s = 0.0;
+      for (int i = threadIdx.x; i < a.nlb; i += 256) s += a.lpart[(size_t)i * WLS + q];
+      sm[threadIdx.x] = s;
+      __syncthreads();
+      for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) {
+        const float f = (float)sm[0];
+        if (q < 4) a.out[a.P + q] = f;
+        else if (q == 4 + AMAX) a.out[a.off[11]] = f;
+        else a.out[a.off[5] + (q - 4)] = f;
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.P) return;
+  int arr = 0;
+#pragma unroll
+  for (int k = 1; k < 12; ++k) arr = (i >= a.off[k]) ? k : arr;
+  const float* p = a.part[arr];
+  if (!p) return;
+  const int size = a.off[arr + 1] - a.off[arr], idx = i - a.off[arr];
+  double s = 0.0;
+  for (int q = 0; q < a.nparts[arr]; ++q) s += (double)p[(size_t)q * size + idx];
+  a.out[i] = (float)s;
+}
+
+__global__ void wide_stats_kernel(const float* __restrict__ msg, int P, StatsArgs st) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  compute_stats(msg, P, st.c, st.Mglobal, st.adv_ms, st.mb, st.vfix, st.out, 1);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Launchers
+// ------------------------------------------------------------------------------------------------------
+int wide_policy_act(crl_ppo* h, const float* obs_d, const double* u_d, int n, int32_t* action_d, float* logprob_d, float* value_d) {
+  WideWs* w = static_cast<WideWs*>(h->wide_ws);
+  if (ensure_pack(h)) return 1;
+  for (int o = 0; o < n; o += w->Mw) {
+    const int m = (n - o) < w->Mw ? (n - o) : w->Mw;
+    if (wide_forward(h, 0, obs_d + (size_t)w->D * o, w->D, nullptr, m, w->z, w->A8)) return 1;
+    if (value_d && wide_forward(h, 1, obs_d + (size_t)w->D * o, w->D, nullptr, m, w->v, 1)) return 1;
+    hipLaunchKernelGGL(wide_sample_kernel, dim3((m + 255) / 256), dim3(256), 0, h->stream, w->z, w->A8, w->A, w->v, u_d + o, m,
+                       action_d + o, logprob_d + o, value_d ? value_d + o : nullptr);
+    CRL_HIP_CHECK(hipGetLastError());
+  }
+  return 0;
+}
+
+int wide_logprob_actions(crl_ppo* h, const float* obs_d, const int32_t* act_d, int n, float* logprob_d, float* ent_d) {
+  WideWs* w = static_cast<WideWs*>(h->wide_ws);
+  if (ensure_pack(h)) return 1;
+  for (int o = 0; o < n; o += w->Mw) {
+    const int m = (n - o) < w->Mw ? (n - o) : w->Mw;
+    if (wide_forward(h, 0, obs_d + (size_t)w->D * o, w->D, nullptr, m, w->z, w->A8)) return 1;
+    hipLaunchKernelGGL(wide_logprob_kernel, dim3((m + 255) / 256), dim3(256), 0, h->stream, w->z, w->A8, w->A, act_d + o, m,
+                       logprob_d + o, ent_d + (size_t)w->A * o);
+    CRL_HIP_CHECK(hipGetLastError());
+  }
+  return 0;
+}
+
+int wide_next_value(crl_ppo* h) {
+  if (ensure_pack(h)) return 1;
+  WideWs* w = static_cast<WideWs*>(h->wide_ws);
+  return wide_forward(h, 1, h->cur_obs, w->D, nullptr, h->dc.nt, h->next_value, 1);
+}
+
+int wide_env_reset(crl_ppo* h) {
+  hipLaunchKernelGGL(wide_synth_reset_kernel, dim3((h->dc.nt + 255) / 256), dim3(256), 0, h->stream, h->dc, h->env_state, h->env_t,
+                     h->cur_obs, h->next_done, h->ep_return, h->ep_length, h->ep_stats);
+  CRL_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int wide_rollout(crl_ppo* h) {
+  WideWs* w = static_cast<WideWs*>(h->wide_ws);
+  if (ensure_pack(h)) return 1;
+  CRL_HIP_CHECK(hipMemsetAsync(h->ep_stats, 0, 4 * sizeof(double), h->stream));
+  WStepArgs a;
+  a.c = h->dc; a.Z = w->z; a.A8 = w->A8; a.V = w->v;
+  a.obs = h->obs; a.action = h->action; a.logprob = h->logprob; a.reward = h->reward; a.terminal = h->terminal; a.value = h->value;
+  a.env_state = h->env_state; a.env_t = h->env_t; a.cur_obs = h->cur_obs; a.next_done = h->next_done;
+  a.ep_return = h->ep_return; a.ep_length = h->ep_length; a.ep_stats = h->ep_stats; a.iteration = (uint64_t)h->iteration;
+  ProfScope ps(h, CRL_K_ROLLOUT);
+  for (int step = 0; step < h->dc.k; ++step) {
+    if (wide_forward(h, 0, h->cur_obs, w->D, nullptr, h->dc.nt, w->z, w->A8)) return 1;   // ppo.jl:127
+    if (wide_forward(h, 1, h->cur_obs, w->D, nullptr, h->dc.nt, w->v, 1)) return 1;       // ppo.jl:128
+    a.step = step;
+    hipLaunchKernelGGL(wide_step_kernel, dim3((h->dc.nt + 255) / 256), dim3(256), 0, h->stream, a);
+    CRL_HIP_CHECK(hipGetLastError());
+  }
+  return 0;
+}
+
+// backward of one network: head cotangent (K padded to 8, ld ldd) → all six parameter-gradient partials
+static int wide_backward(crl_ppo* h, int net, const float* dOut, int ldd, const int32_t* idx) {
+  WideWs* w = static_cast<WideWs*>(h->wide_ws);
+  const int H = w->H, NO = net ? 1 : w->A, M = h->dc.M;
+  const NetOff o = net_off(H, w->D, NO);
+  (void)o;
+  const float* pk = w->pack + w->pk_base[net];
+  // δ2 = (W3ᵀ·δ3) ⊙ (1 − h2²)
+  DenseArgs d;
+  d.idx = nullptr; d.bias = nullptr; d.M = M;
+  d.W = pk + w->pk[net].w3t; d.Kp = ldd; d.X = dOut; d.ldx = ldd; d.Kt = ldd; d.S = w->h2[net]; d.lds = H; d.Y = w->dA; d.ldy = H; d.Nt = H;
+  if (dense_launch<EPI_DTANH>(h->stream, H, d)) return 1;
+  // dW3[a, k] = Σ δ3[a]·h2[k]
+  SkinnyArgs s;
+  s.Big = w->h2[net]; s.H = H; s.Small = dOut; s.lds = ldd; s.idx = nullptr; s.M = M; s.chunk = w->chunks;
+  s.pW = w->pW3[net]; s.os_row = NO; s.os_s = 1; s.St = NO; s.wsize = H * NO; s.pB = nullptr;
+  if (skinny_launch(h->stream, w->Ss, s)) return 1;
+  // dW2 = δ2·h1ᵀ, db2 = Σ δ2
+  WgradArgs g;
+  g.dY = w->dA; g.X = w->h1[net]; g.H = H; g.M = M; g.chunk = w->chunk2; g.pW = w->pW2[net]; g.pB = w->pB2[net];
+  if (H >= 128) { const int nb = H / 128; hipLaunchKernelGGL(wide_wgrad_kernel<2>, dim3(w->S2, nb * nb), dim3(256), 0, h->stream, g); }
+  else hipLaunchKernelGGL(wide_wgrad_kernel<1>, dim3(w->S2, 1), dim3(256), 0, h->stream, g);
+  CRL_HIP_CHECK(hipGetLastError());
+  // δ1 = (W2ᵀ·δ2) ⊙ (1 − h1²)
+  d.W = pk + w->pk[net].w2t; d.Kp = H; d.X = w->dA; d.ldx = H; d.Kt = H; d.S = w->h1[net]; d.Y = w->dB;
+  if (dense_launch<EPI_DTANH>(h->stream, H, d)) return 1;
+  // dW1 = δ1·xᵀ, db1 = Σ δ1
+  s.Big = w->dB; s.Small = h->obs; s.lds = w->D; s.idx = idx; s.pW = w->pW1[net]; s.os_row = 1; s.os_s = H; s.St = w->D;
+  s.wsize = H * w->D; s.pB = w->pB1[net];
+  return skinny_launch(h->stream, w->Ss, s);
+}
+
+// One optimiser step's gradient (ppo.jl:197-244): forward → u → loss → backward → fixed-order reduce → [all-reduce] →
+// statistics. The gradient message ends up in comm_buf like in update.hip.
+int wide_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
+  WideWs* w = static_cast<WideWs*>(h->wide_ws);
+  if (ensure_pack(h)) return 1;
+  const int M = h->dc.M, P = (int)h->P;
+  const int32_t* perm = h->perm + (size_t)mb * M;
+  const double Mglobal = (double)M * h->world;
+  const bool dp = h->world > 1;
+  if (dp && h->external_comm && h->cfg.clip_value_loss) {
+    set_error("wide path: clip_value_loss under host-side exchange (crl_comm_init_external) is not supported; use crl_comm_init");
+    return 1;
+  }
+  ProfScope* ps = new ProfScope(h, CRL_K_UPDATE);
+  struct PsGuard { ProfScope*& p; ~PsGuard() { delete p; } } psg{ps};
+  if (wide_forward(h, 1, h->obs, w->D, perm, M, w->v, 1)) return 1;
+  if (wide_forward(h, 0, h->obs, w->D, perm, M, w->z, w->A8)) return 1;
+  if (h->cfg.clip_value_loss) {
+    int nb = (M + 255) / 256; if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(wide_vsum_kernel, dim3(nb), dim3(256), 0, h->stream, w->v, h->ret, perm, M, w->vpart);
+    hipLaunchKernelGGL(wide_vsum_final_kernel, dim3(1), dim3(64), 0, h->stream, w->vpart, nb, h->vfix);
+    CRL_HIP_CHECK(hipGetLastError());
+    if (dp && comm_allreduce(h, h->vfix + 5, 1, true)) return 1;
+    hipLaunchKernelGGL(wide_vcount_kernel, dim3(nb), dim3(256), 0, h->stream, h->dc, w->v, h->value, h->ret, perm, M, Mglobal, h->vfix);
+    hipLaunchKernelGGL(wide_vcount_to_double_kernel, dim3(1), dim3(1), 0, h->stream, h->vfix);
+    CRL_HIP_CHECK(hipGetLastError());
+    if (dp && comm_allreduce(h, h->vfix + 1, 1, true)) return 1;
+  }
+  {
+    WLossArgs a;
+    a.c = h->dc; a.perm = perm; a.Z = w->z; a.A8 = w->A8; a.V = w->v; a.dv8 = w->dv8;
+    a.actions = h->action; a.logprobs = h->logprob; a.values = h->value; a.advantages = h->adv; a.returns = h->ret;
+    a.adv_ms = h->adv_ms; a.mb = mb; a.vfix = h->vfix; a.Mglobal = Mglobal; a.lpart = w->lpart;
+    hipLaunchKernelGGL(wide_loss_kernel, dim3(w->nlb), dim3(256), 0, h->stream, a);
+    CRL_HIP_CHECK(hipGetLastError());
+  }
+  if (wide_backward(h, 0, w->z, w->A8, perm)) return 1;
+  if (wide_backward(h, 1, w->dv8, 8, perm)) return 1;
+  delete ps; ps = nullptr;
+  {
+    WRedArgs r;
+    const int H = w->H, D = w->D, A = w->A;
+    const int sizes[12] = {H * D, H, H * H, H, A * H, A, H * D, H, H * H, H, H, 1};
+    r.off[0] = 0;
+    for (int i = 0; i < 12; ++i) r.off[i + 1] = r.off[i] + sizes[i];
+    for (int n = 0; n < 2; ++n) {
+      const int b = 6 * n;
+      r.part[b + 0] = w->pW1[n]; r.nparts[b + 0] = w->Ss;
+      r.part[b + 1] = w->pB1[n]; r.nparts[b + 1] = w->Ss;
+      r.part[b + 2] = w->pW2[n]; r.nparts[b + 2] = w->S2;
+      r.part[b + 3] = w->pB2[n]; r.nparts[b + 3] = w->S2;
+      r.part[b + 4] = w->pW3[n]; r.nparts[b + 4] = w->Ss;
+      r.part[b + 5] = nullptr; r.nparts[b + 5] = 0;
+    }
+    r.lpart = w->lpart; r.nlb = w->nlb; r.out = h->comm_buf; r.P = P; r.A = A;
+    ProfScope pr(h, CRL_K_REDUCE);
+    hipLaunchKernelGGL(wide_reduce_kernel, dim3((P + 255) / 256 + 1), dim3(256), 0, h->stream, r);
+    CRL_HIP_CHECK(hipGetLastError());
+  }
+  if (dp) {
+    ProfScope pa(h, CRL_K_ALLREDUCE);
+    if (comm_allreduce(h, h->comm_buf, (size_t)P + 4, false)) return 1;
+  }
+  StatsArgs st;
+  st.c = h->dc; st.Mglobal = Mglobal; st.adv_ms = h->adv_ms; st.mb = mb; st.vfix = h->vfix; st.out = stats_slot; st.fused = 0;
+  hipLaunchKernelGGL(wide_stats_kernel, dim3(1), dim3(64), 0, h->stream, h->comm_buf, P, st);
+  CRL_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace crl

@@ -34,6 +34,7 @@ extern "C" {
 #define CRL_GAE_FIXED 1  /* loop from k with the bootstrap value (CleanRL-python semantics) */
 /* env_kind */
 #define CRL_ENV_CARTPOLE 0 /* CartPoleEnv(T=Float32, max_steps=500) ppo.jl:82 */
+#define CRL_ENV_SYNTHETIC 1 /* stateless generator for shapes the reference has no env for: obs ~ U(-1,1)^d, reward ~ U(-1,1), done ~ B(1/200) */
 #define CRL_ENV_EXTERNAL 2 /* envs stepped by the caller: crl_policy_act + crl_rollout_store */
 /* shuffle mode */
 #define CRL_SHUFFLE_FISHER_YATES 0 /* exact serial Fisher–Yates on device (ppo.jl:194 semantics) */

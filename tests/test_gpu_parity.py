@@ -275,8 +275,8 @@ def test_errors_are_reported_not_thrown(crl):
         crl.Agent(crl.PPOConfig(normalize_advantages=False))
     with pytest.raises(crl.CrlError, match="divisible"):
         crl.Agent(crl.PPOConfig(num_envs=3, num_steps=5, num_minibatches=4))
-    with pytest.raises(crl.CrlError, match="2x64"):
-        crl.Agent(crl.PPOConfig(), hidden=256)
+    with pytest.raises(crl.CrlError, match="hidden must be"):
+        crl.Agent(crl.PPOConfig(), hidden=96)
     agent = make_agent(crl)
     with pytest.raises(crl.CrlError, match="out of range"):
         agent.handle.update_minibatch(9, 1e-3)

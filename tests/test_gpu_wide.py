@@ -1,0 +1,203 @@
+"""Parity of the generic-shape ("wide", layer-wise MFMA GEMM) HIP path against the CPU oracle: BASELINE configs[2]
+(C3: LunarLander-shaped obs 8 / act 4, 2x256 MLP) and other shapes the fused 4/2/64 kernels do not cover.
+Same bars as test_gpu_parity.py: bit-exact integer fields, float32 within 1e-5 relative."""
+import numpy as np
+import pytest
+
+import oraclelib as O
+from test_gpu_parity import ATOL, RTOL, _grad_close, crl, rel_err  # noqa: F401  (crl is the module fixture)
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(8, 4, 256), (6, 3, 128), (4, 2, 64), (17, 16, 64), (3, 5, 256)]
+
+
+def make_wide(crl, nt, k, D, A, Hd, params=None, **kw):
+    cfg = crl.PPOConfig(num_envs=nt, num_steps=k, total_timesteps=nt * k * 10, **{a: b for a, b in kw.items() if a in
+                        ("num_minibatches", "update_epochs", "clip_value_loss", "anneal_lr", "lr")})
+    shape = {a: b for a, b in kw.items() if a in ("gae_mode", "shuffle_mode", "stale_obs", "env_id_offset", "seed")}
+    return crl.Agent(cfg, params=params, obs_dim=D, n_act=A, hidden=Hd, env_kind=crl._lib.ENV_SYNTHETIC, **shape)
+
+
+def ocfg(nt, k, D, A, Hd, **kw):
+    return O.make_config(num_envs=nt, num_steps=k, obs_dim=D, n_act=A, hidden=Hd, env_kind=1, **kw)
+
+
+def spread_params(cfg, seed):
+    rng = np.random.default_rng(seed)
+    params = O.orthogonal_params(cfg, seed) + (0.05 * rng.standard_normal(O.lib().orc_param_count(cfg))).astype(np.float32)
+    off = O.param_offsets(cfg)
+    params[off[4]:off[5]] *= 30   # spread the logits: every action occurs
+    return params
+
+
+@pytest.fixture(autouse=True)
+def force_wide(monkeypatch):
+    monkeypatch.setenv("CRL_FORCE_WIDE", "1")   # sends the 4/2/64 shape down the generic path too
+
+
+@pytest.mark.parametrize("D,A,Hd", SHAPES)
+@pytest.mark.parametrize("n", [1, 33, 300])
+def test_wide_policy_act_and_logprob_match_oracle(crl, D, A, Hd, n):
+    rng = np.random.default_rng(n + D)
+    cfg = ocfg(8, 16, D, A, Hd)
+    params = spread_params(cfg, 3)
+    agent = make_wide(crl, 8, 16, D, A, Hd, params=params)
+    obs = np.asfortranarray(rng.standard_normal((D, n)).astype(np.float32))
+    u = rng.random(n)
+    a_o, lp_o, v_o, margin = O.get_action(cfg, params, obs, u)
+    a_g, lp_g, v_g = agent.handle.policy_act(obs, u)
+    safe = margin > 1e-6
+    assert np.array_equal(a_g[safe], a_o[safe]), "action indices must be bit-exact away from CDF knots"
+    assert safe.mean() > 0.98 and len(set(a_o.tolist())) >= min(A, 2 if n > 1 else 1)
+    same = a_g == a_o
+    assert rel_err(lp_g[same], lp_o[same]) < RTOL and rel_err(v_g, v_o) < RTOL
+    acts = rng.integers(0, A, n).astype(np.int32)
+    lp_o2, ent_o = O.logprob_actions(cfg, params, obs, acts)
+    lp_g2, ent_g = crl.logprob_actions(obs, agent.actor, acts + 1)
+    assert ent_g.shape == (A, n) and rel_err(lp_g2, lp_o2) < RTOL and rel_err(ent_g, ent_o) < RTOL
+    agent.close()
+
+
+@pytest.mark.parametrize("D,A,Hd,nt,k", [(8, 4, 256, 70, 16), (6, 3, 128, 8, 32), (4, 2, 64, 33, 8)])
+def test_wide_rollout_matches_oracle(crl, D, A, Hd, nt, k):
+    cfg = ocfg(nt, k, D, A, Hd)
+    params = spread_params(cfg, 5)
+    agent = make_wide(crl, nt, k, D, A, Hd, params=params)
+    st = O.State(cfg); st.params[:] = params; st.env_init()
+    h = agent.handle; F = crl._lib
+    h.env_reset()
+    assert np.array_equal(h.read(F.F_CUR_OBS), st.cur_obs)
+    h.rollout_run(); st.rollout()
+    assert np.array_equal(h.read(F.F_ACTION), st.action), f"{np.sum(h.read(F.F_ACTION) != st.action)} actions differ"
+    assert np.array_equal(h.read(F.F_OBS), st.obs) and np.array_equal(h.read(F.F_REWARD), st.reward)
+    assert np.array_equal(h.read(F.F_TERMINAL), st.terminal) and np.array_equal(h.read(F.F_NEXT_DONE), st.next_done)
+    assert rel_err(h.read(F.F_LOGPROB), st.logprob) < RTOL and rel_err(h.read(F.F_VALUE), st.value) < RTOL
+    es = h.episode_stats(); n_ep, ret_sum, len_sum = st.episode_stats
+    assert es["episodes"] == n_ep and es["length_sum"] == len_sum and abs(es["return_sum"] - ret_sum) < 1e-4 * max(1, abs(ret_sum))
+    h.compute_gae(); st.compute_gae()
+    assert rel_err(h.read(F.F_ADVANTAGE), st.adv) < RTOL and rel_err(h.read(F.F_RETURN), st.ret) < RTOL
+    agent.close(); st.close()
+
+
+def inject(crl, agent, st, rng, D, A, ret_scale=10.0):
+    nt, k = st.cfg.num_envs, st.cfg.num_steps
+    st.obs[:] = rng.standard_normal((D, nt, k)).astype(np.float32)
+    st.action[:] = rng.integers(0, A, (nt, k))
+    st.logprob[:] = (np.log(1.0 / A) + 0.3 * rng.standard_normal((nt, k))).astype(np.float32)
+    st.value[:] = rng.standard_normal((nt, k)).astype(np.float32) * (1.0 if ret_scale > 1 else 0.05)
+    st.adv[:] = (2 * rng.standard_normal((nt, k))).astype(np.float32)
+    st.ret[:] = (ret_scale * rng.standard_normal((nt, k))).astype(np.float32)
+    st.perm[:] = rng.permutation(nt * k).astype(np.int32)
+    h = agent.handle; F = crl._lib
+    for f, a in ((F.F_OBS, st.obs), (F.F_ACTION, st.action), (F.F_LOGPROB, st.logprob), (F.F_VALUE, st.value),
+                 (F.F_ADVANTAGE, st.adv), (F.F_RETURN, st.ret), (F.F_PERM, st.perm)):
+        h.write(f, a)
+
+
+@pytest.mark.parametrize("D,A,Hd,nt,k,ret_scale,clipv", [
+    (8, 4, 256, 8, 128, 10.0, True), (8, 4, 256, 8, 128, 0.05, True), (8, 4, 256, 37, 64, 3.0, False),
+    (6, 3, 128, 16, 64, 10.0, True), (4, 2, 64, 8, 128, 0.05, True), (17, 16, 64, 64, 36, 10.0, True),
+    (3, 5, 256, 5, 520, 10.0, True)])
+def test_wide_update_gradient_matches_oracle(crl, D, A, Hd, nt, k, ret_scale, clipv):
+    """ret_scale = 0.05 drives u = mean(v - R²) > 0 (Q4): here the exact count is known before the loss kernel runs."""
+    rng = np.random.default_rng(nt + k + D)
+    cfg = ocfg(nt, k, D, A, Hd, clip_value_loss=clipv)
+    params = O.orthogonal_params(cfg, 5) + (0.05 * rng.standard_normal(O.lib().orc_param_count(cfg))).astype(np.float32)
+    off = O.param_offsets(cfg)
+    if ret_scale < 1:
+        params[off[11]] = 0.3
+    agent = make_wide(crl, nt, k, D, A, Hd, params=params, clip_value_loss=clipv)
+    st = O.State(cfg); st.params[:] = params
+    inject(crl, agent, st, rng, D, A, ret_scale)
+    h = agent.handle
+    h.adv_stats()
+    M = nt * k // 4
+    for mb in (0, 3):
+        gs = h.update_minibatch(mb, 2.5e-4, apply_update=False)
+        g_gpu = h.read(crl._lib.F_GRADS)
+        g_orc, so = O.loss_grad(cfg, params, st.obs.reshape(D, -1, order="F"), st.action, st.logprob, st.value, st.adv, st.ret,
+                                st.perm[mb * M:(mb + 1) * M])
+        if ret_scale < 1 and clipv:
+            assert so["n_unclipped_wins"] > 0 and gs["n_unclipped_wins"] == so["n_unclipped_wins"]
+        for key in ("loss", "pg_loss", "v_loss", "entropy_loss"):
+            assert abs(gs[key] - so[key]) <= RTOL * max(1.0, abs(so[key])), (key, gs[key], so[key])
+        _grad_close(g_gpu, g_orc, off)
+    agent.close(); st.close()
+
+
+def test_wide_and_fused_paths_agree_on_the_cartpole_shape(crl, monkeypatch):
+    """Same 4/2/64 minibatch through update.hip (fused, bf16x3) and wide.hip (layer-wise f32 MFMA)."""
+    from test_gpu_parity import _inject_batch, make_agent
+    rng = np.random.default_rng(9)
+    nt, k = 64, 128
+    cfgo = O.make_config(num_envs=nt, num_steps=k)
+    params = O.orthogonal_params(cfgo, 5) + (0.05 * rng.standard_normal(O.lib().orc_param_count(cfgo))).astype(np.float32)
+    grads = {}
+    for force in ("0", "1"):
+        monkeypatch.setenv("CRL_FORCE_WIDE", force)
+        agent = make_agent(crl, nt=nt, k=k, params=params)
+        st = O.State(cfgo); st.params[:] = params
+        _inject_batch(crl, agent, st, np.random.default_rng(10))
+        agent.handle.adv_stats()
+        gs = agent.handle.update_minibatch(1, 2.5e-4, apply_update=True)
+        grads[force] = (agent.handle.read(crl._lib.F_GRADS).copy(), gs, agent.handle.read(crl._lib.F_PARAMS).copy())
+        agent.close(); st.close()
+    _grad_close(grads["1"][0], grads["0"][0], O.param_offsets(cfgo), tol=2e-5)
+    assert abs(grads["1"][1]["loss"] - grads["0"][1]["loss"]) < 1e-5
+    assert np.max(np.abs(grads["1"][2] - grads["0"][2])) < 1e-6
+
+
+@pytest.mark.parametrize("D,A,Hd,nt,k", [(8, 4, 256, 16, 32), (4, 2, 64, 8, 128)])
+def test_wide_full_iteration_matches_oracle(crl, D, A, Hd, nt, k):
+    """Whole ppo.jl:117-253 loop body on the synthetic env, exact Fisher–Yates, two iterations."""
+    cfg = ocfg(nt, k, D, A, Hd)
+    params = spread_params(cfg, 7)
+    off = O.param_offsets(cfg)
+    params[off[4]:off[5]] /= 10
+    agent = make_wide(crl, nt, k, D, A, Hd, params=params, shuffle_mode=0)
+    st = O.State(cfg); st.params[:] = params; st.env_init()
+    h = agent.handle; F = crl._lib
+    h.env_reset()
+    for it in range(2):
+        gs = h.iterate(1)
+        os_ = st.iterate(10, gen_perm=True)
+        assert np.array_equal(h.read(F.F_PERM), st.perm)
+        acts = h.read(F.F_ACTION)
+        assert np.array_equal(acts, st.action), f"iteration {it}: {np.sum(acts != st.action)} actions differ"
+        assert rel_err(h.read(F.F_ADVANTAGE), st.adv) < RTOL
+        for a, b in zip(gs, os_):
+            for key in ("loss", "pg_loss", "v_loss", "entropy_loss"):
+                assert abs(a[key] - b[key]) <= 2e-5 * max(1.0, abs(b[key])), (it, key, a[key], b[key])
+        assert np.max(np.abs(h.read(F.F_PARAMS) - st.params)) < 2e-5
+    agent.close(); st.close()
+
+
+def test_wide_rejects_unsupported_shapes(crl):
+    for kw, msg in ((dict(hidden=96), "hidden"), (dict(n_act=17, hidden=256), "n_act"), (dict(obs_dim=65, hidden=256), "obs_dim")):
+        with pytest.raises(crl.CrlError, match=msg):
+            crl.Agent(crl.PPOConfig(), env_kind=crl._lib.ENV_SYNTHETIC, **kw)
+    with pytest.raises(crl.CrlError, match="CARTPOLE"):
+        crl.Agent(crl.PPOConfig(), obs_dim=8, n_act=4, hidden=256)       # CartPole dynamics need obs 4 / act 2
+
+
+def test_c3_full_size_properties(crl):
+    """BASELINE configs[2] at full size (num_envs=16384, num_steps=128, obs 8 / act 4 / 2x256): the oracle needs minutes
+    here, so: run-to-run bit-identical gradients (fixed-order reductions), lr = 0 leaves the parameters untouched,
+    finite non-zero gradient, and the rollout's integer fields equal the oracle's on the first 64 envs' first steps."""
+    nt, k, D, A, Hd = 16384, 128, 8, 4, 256
+    cfg = ocfg(64, 4, D, A, Hd)
+    params = spread_params(cfg, 11)
+    agent = make_wide(crl, nt, k, D, A, Hd, params=params, shuffle_mode=1)
+    h = agent.handle; F = crl._lib
+    h.env_reset(); h.rollout_run(); h.compute_gae(); h.shuffle(1); h.adv_stats()
+    st = O.State(cfg); st.params[:] = params; st.env_init(); st.rollout()
+    acts = h.read(F.F_ACTION)
+    assert np.array_equal(acts[:64, :4], st.action) and np.array_equal(h.read(F.F_OBS)[:, :64, :4], st.obs)
+    p0 = h.read(F.F_PARAMS)
+    s1 = h.update_minibatch(1, 0.0, apply_update=True); g1 = h.read(F.F_GRADS)
+    assert np.array_equal(h.read(F.F_PARAMS), p0)
+    s2 = h.update_minibatch(1, 0.0, apply_update=False); g2 = h.read(F.F_GRADS)
+    assert np.array_equal(g1, g2) and s1["loss"] == s2["loss"]
+    assert np.isfinite(g1).all() and np.linalg.norm(g1) > 0
+    agent.close(); st.close()
