@@ -62,7 +62,15 @@ def main():
     ap.add_argument("--total-envs", type=int, default=TOTAL_ENVS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shuffle", choices=["bijection", "fisher-yates", "blocked-fy"], default="bijection")
+    ap.add_argument("--workload", choices=["cartpole", "c3"], default="cartpole",
+                    help="cartpole = the headline workload (BASELINE metric); c3 = BASELINE configs[2]: LunarLander-shaped obs 8 / "
+                         "act 4, 2x256 MLP, num_envs=16384 on the synthetic env (a side measurement, not the driver's line)")
     args = ap.parse_args()
+    c3 = args.workload == "c3"
+    if c3 and args.total_envs == TOTAL_ENVS:
+        args.total_envs = 16384
+    fwd_flops = 272896 if c3 else FWD_FLOPS_PER_SAMPLE
+    upd_flops = 3 * fwd_flops
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -93,7 +101,8 @@ def main():
     crl_dist = importlib.import_module("cleanrl_jl_amd.dist")
     nt_local, env_off = crl_dist.shard_envs(args.total_envs, world, rank)
     cfg = crl.PPOConfig(num_envs=nt_local, num_steps=NUM_STEPS, total_timesteps=args.total_envs * NUM_STEPS * (args.steps + args.warmup))
-    agent = crl.Agent(cfg, device=local_rank, env_id_offset=env_off,
+    shape = dict(obs_dim=8, n_act=4, hidden=256, env_kind=L.ENV_SYNTHETIC) if c3 else {}
+    agent = crl.Agent(cfg, device=local_rank, env_id_offset=env_off, **shape,
                       shuffle_mode={"bijection": L.SHUFFLE_BIJECTION, "fisher-yates": L.SHUFFLE_FISHER_YATES,
                                     "blocked-fy": L.SHUFFLE_BLOCKED_FY}[args.shuffle])
     h = agent.handle
@@ -134,7 +143,7 @@ def main():
         gae_ms, gae_n = prof["gae"]
         upd_avg_s = upd_ms / max(upd_n, 1) * 1e-3
         gae_avg_s = gae_ms / max(gae_n, 1) * 1e-3
-        upd_tflops = UPDATE_FLOPS_PER_SAMPLE * M / upd_avg_s / 1e12 if upd_n else 0.0
+        upd_tflops = upd_flops * M / upd_avg_s / 1e12 if upd_n else 0.0
         gae_bytes = GAE_BYTES_PER_STEP * nt_local * NUM_STEPS + GAE_BYTES_PER_ENV * nt_local
         gae_gbps = gae_bytes / gae_avg_s / 1e9 if gae_n else 0.0
         # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate
@@ -143,28 +152,34 @@ def main():
         traffic = {"update": None, "gae": None}
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_f_pmc_hbm_traffic.json")))
-            if world == 1 and args.total_envs == TOTAL_ENVS:
+            if world == 1 and args.total_envs == TOTAL_ENVS and not c3:
                 for key, name in (("update", "void crl::update_x3_kernel<4, 2>"), ("gae", "void crl::gae_kernel<32, 8>")):
                     if name in pm:
                         traffic[key] = (pm[name]["FETCH_SIZE_KB_per_launch_mean"] + pm[name]["WRITE_SIZE_KB_per_launch_mean"]) * 1024
         except Exception:
             pass
         out = {
-            "metric": "env-steps/sec (whole node), CartPole PPO num_envs=65536 at 1/2/4/8 GPUs",
+            "metric": "env-steps/sec (whole node), CartPole PPO num_envs=65536 at 1/2/4/8 GPUs" if not c3 else
+                      "env-steps/sec, PPO LunarLander-shaped (obs 8 / act 4, 2x256) num_envs=16384 (BASELINE configs[2], side measurement)",
             "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"PPO CartPole-v1-shaped on-device env, num_envs={args.total_envs} total "
-                                   f"({nt_local}/GPU), num_steps={NUM_STEPS}, 2x64 actor+critic MLP, update_epochs=4, "
-                                   f"num_minibatches=4, anneal_lr", "global_batch": args.total_envs * NUM_STEPS,
+            "config": {"workload": (f"PPO CartPole-v1-shaped on-device env, num_envs={args.total_envs} total "
+                                    f"({nt_local}/GPU), num_steps={NUM_STEPS}, 2x64 actor+critic MLP, update_epochs=4, "
+                                    f"num_minibatches=4, anneal_lr") if not c3 else
+                                   (f"PPO LunarLander-shaped synthetic env (obs 8, act 4), num_envs={args.total_envs} total "
+                                    f"({nt_local}/GPU), num_steps={NUM_STEPS}, 2x256 actor+critic MLP, update_epochs=4, "
+                                    f"num_minibatches=4, anneal_lr"), "global_batch": args.total_envs * NUM_STEPS,
                        "parallelism": f"dp{world}", "shuffle": args.shuffle,
-                       "gemm": "f32 results via bf16x3 split products on the bf16 matrix pipe" if os.environ.get("CRL_GEMM", "x3") != "f32"
-                               else "v_mfma_f32_32x32x2_f32"},
-            "roofline": {"bound": "mfma", "kernel": "update_x3_kernel / update_kernel (fwd+bwd of one minibatch, actor+critic)",
-                         "note": "achieved = algorithmic f32 FLOPs (3 x 17,792 per sample) / HIP-event launch time; peak = dense f32 MFMA",
+                       "gemm": "v_mfma_f32_32x32x2_f32 (layer-wise)" if c3 else
+                               ("f32 results via bf16x3 split products on the bf16 matrix pipe" if os.environ.get("CRL_GEMM", "x3") != "f32"
+                                else "v_mfma_f32_32x32x2_f32")},
+            "roofline": {"bound": "mfma", "kernel": "update_x3_kernel / update_kernel (fwd+bwd of one minibatch, actor+critic)" if not c3 else
+                                   "wide.hip: all forward/backward launches of one minibatch (HIP events around the group)",
+                         "note": f"achieved = algorithmic f32 FLOPs (3 x {fwd_flops:,} per sample) / HIP-event launch time; peak = dense f32 MFMA",
                          "achieved": upd_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": upd_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic["update"],
-                         "avg_launch_ms": upd_avg_s * 1e3, "launches": upd_n, "flops_per_launch": UPDATE_FLOPS_PER_SAMPLE * M},
+                         "avg_launch_ms": upd_avg_s * 1e3, "launches": upd_n, "flops_per_launch": upd_flops * M},
             "roofline_gae": {"bound": "hbm", "kernel": "gae_kernel (advantages + returns)", "achieved": gae_gbps,
                              "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gae_gbps / PEAK_HBM_GBPS, "traffic": traffic["gae"],
                              "avg_launch_ms": gae_avg_s * 1e3, "launches": gae_n, "bytes_per_launch": gae_bytes},
@@ -172,7 +187,7 @@ def main():
             "last_iteration": {"loss": stats[-1]["loss"], "episodes": ep["episodes"],
                                "mean_episode_return": ep["return_sum"] / max(ep["episodes"], 1.0)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not c3:
             out["cpu_baseline"] = cpu_baseline()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:

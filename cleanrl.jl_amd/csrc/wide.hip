@@ -192,19 +192,22 @@ __global__ void __launch_bounds__(256) wide_dense_kernel(DenseArgs a) {
       for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.0f;
   const bool xfast = ((a.ldx & 3) == 0) && ((a.Kt & 3) == 0);
 
-  for (int k0 = 0; k0 < a.Kp; k0 += 32) {
+  // software pipeline: slab s+1 travels global → registers while slab s is multiplied out of LDS
+  constexpr int WR = NP / 32, XR = MB / 32;   // float4 per thread per slab
+  f32x4 wr[WR], xr[XR];
+  auto fetch = [&](int k0) {
     const int ks = (a.Kp - k0) < 32 ? (a.Kp - k0) : 32;
-    {
-      const f32x4* src = reinterpret_cast<const f32x4*>(a.W + (size_t)NP * k0);
-      f32x4* dst = reinterpret_cast<f32x4*>(Wl);
-      const int n4 = NP * ks / 4;
-      for (int i = tid; i < n4; i += 256) dst[i] = src[i];
-    }
-    {
-      const int q4 = ks >> 2, n = MB * q4;
-      for (int i = tid; i < n; i += 256) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.W + (size_t)NP * k0);
+    const int n4 = NP * ks / 4;
+#pragma unroll
+    for (int u = 0; u < WR; ++u) { const int i = tid + 256 * u; if (i < n4) wr[u] = src[i]; }
+    const int q4 = ks >> 2, n = MB * q4;
+#pragma unroll
+    for (int u = 0; u < XR; ++u) {
+      const int i = tid + 256 * u;
+      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (i < n) {
         const int mm = i / q4, q = i - mm * q4, m = m0 + mm, k = k0 + 4 * q;
-        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
         if (m < a.M && k < a.Kt) {
           const size_t row = a.idx ? (size_t)a.idx[m] : (size_t)m;
           const float* p = a.X + row * (size_t)a.ldx + k;
@@ -216,25 +219,102 @@ __global__ void __launch_bounds__(256) wide_dense_kernel(DenseArgs a) {
             if (k + 3 < a.Kt) v[3] = p[3];
           }
         }
-        *reinterpret_cast<f32x4*>(Xl + mm * WXS + 4 * q) = v;
       }
+      xr[u] = v;
     }
-    __syncthreads();
-    for (int jj = 0; jj < (ks >> 3); ++jj) {
-      f32x4 b[TM];
+  };
+  auto stash = [&](int k0) {
+    const int ks = (a.Kp - k0) < 32 ? (a.Kp - k0) : 32;
+    f32x4* dst = reinterpret_cast<f32x4*>(Wl);
+    const int n4 = NP * ks / 4;
 #pragma unroll
-      for (int y = 0; y < TM; ++y) b[y] = *reinterpret_cast<const f32x4*>(Xl + ((wm * TM + y) * 32 + j) * WXS + 8 * jj + 4 * hf);
+    for (int u = 0; u < WR; ++u) { const int i = tid + 256 * u; if (i < n4) dst[i] = wr[u]; }
+    const int q4 = ks >> 2, n = MB * q4;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
+    for (int u = 0; u < XR; ++u) {
+      const int i = tid + 256 * u;
+      if (i < n) { const int mm = i / q4, q = i - mm * q4; *reinterpret_cast<f32x4*>(Xl + mm * WXS + 4 * q) = xr[u]; }
+    }
+  };
+
+  if (xfast && (a.Kp & 31) == 0 && a.Kt == a.Kp) {
+    // whole 32-k slabs of an aligned activation array (every hidden-layer GEMM): per-thread source pointers and LDS
+    // slots are fixed for the whole K walk — one pointer bump per load, no index arithmetic in the loop
+    const f32x4* wsrc[WR]; const f32x4* xsrc[XR]; bool xok[XR];
 #pragma unroll
-        for (int x = 0; x < TN; ++x) {
-          const float av = Wl[(8 * jj + 4 * hf + c) * NP + (wn * TN + x) * 32 + j];
+    for (int u = 0; u < WR; ++u) wsrc[u] = reinterpret_cast<const f32x4*>(a.W) + tid + 256 * u;
 #pragma unroll
-          for (int y = 0; y < TM; ++y) acc[x][y] = mfma32(av, b[y][c], acc[x][y]);
+    for (int u = 0; u < XR; ++u) {
+      const int i = tid + 256 * u, mm = i >> 3, q = i & 7, m = m0 + mm;
+      xok[u] = m < a.M;
+      const size_t row = xok[u] ? (a.idx ? (size_t)a.idx[m] : (size_t)m) : 0;
+      xsrc[u] = reinterpret_cast<const f32x4*>(a.X + row * (size_t)a.ldx) + q;
+    }
+    f32x4* wdst = reinterpret_cast<f32x4*>(Wl) + tid;
+    float* xdst = Xl + (tid >> 3) * WXS + 4 * (tid & 7);      // slot of u = 0; u adds 32 rows
+    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int nslab = a.Kp >> 5;
+#pragma unroll
+    for (int u = 0; u < WR; ++u) wr[u] = wsrc[u][0];
+#pragma unroll
+    for (int u = 0; u < XR; ++u) xr[u] = xok[u] ? xsrc[u][0] : zero4;
+    for (int sl = 0; sl < nslab; ++sl) {
+      if (sl) __syncthreads();
+#pragma unroll
+      for (int u = 0; u < WR; ++u) wdst[256 * u] = wr[u];
+#pragma unroll
+      for (int u = 0; u < XR; ++u) *reinterpret_cast<f32x4*>(xdst + 32 * u * WXS) = xr[u];
+      __syncthreads();
+      if (sl + 1 < nslab) {
+#pragma unroll
+        for (int u = 0; u < WR; ++u) wr[u] = wsrc[u][(size_t)(sl + 1) * (NP * 8)];
+#pragma unroll
+        for (int u = 0; u < XR; ++u) xr[u] = xok[u] ? xsrc[u][(sl + 1) * 8] : zero4;
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        f32x4 b[TM];
+#pragma unroll
+        for (int y = 0; y < TM; ++y) b[y] = *reinterpret_cast<const f32x4*>(Xl + ((wm * TM + y) * 32 + j) * WXS + 8 * jj + 4 * hf);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+          for (int x = 0; x < TN; ++x) {
+            const float av = Wl[(8 * jj + 4 * hf + c) * NP + (wn * TN + x) * 32 + j];
+#pragma unroll
+            for (int y = 0; y < TM; ++y) acc[x][y] = mfma32(av, b[y][c], acc[x][y]);
+          }
         }
       }
     }
+  } else {
+    fetch(0);
+    stash(0);
     __syncthreads();
+    for (int k0 = 0; k0 < a.Kp; k0 += 32) {
+      const int ks = (a.Kp - k0) < 32 ? (a.Kp - k0) : 32;
+      const bool more = k0 + 32 < a.Kp;
+      if (more) fetch(k0 + 32);
+      for (int jj = 0; jj < (ks >> 3); ++jj) {
+        f32x4 b[TM];
+#pragma unroll
+        for (int y = 0; y < TM; ++y) b[y] = *reinterpret_cast<const f32x4*>(Xl + ((wm * TM + y) * 32 + j) * WXS + 8 * jj + 4 * hf);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+          for (int x = 0; x < TN; ++x) {
+            const float av = Wl[(8 * jj + 4 * hf + c) * NP + (wn * TN + x) * 32 + j];
+#pragma unroll
+            for (int y = 0; y < TM; ++y) acc[x][y] = mfma32(av, b[y][c], acc[x][y]);
+          }
+        }
+      }
+      if (more) {
+        __syncthreads();
+        stash(k0 + 32);
+        __syncthreads();
+      }
+    }
   }
 
   const bool yfast = ((a.ldy & 3) == 0) && ((a.Nt & 3) == 0) && (EPI != EPI_DTANH || (a.lds & 3) == 0);
@@ -282,7 +362,11 @@ template <int EPI>
 static int dense_launch(hipStream_t st, int NP, const DenseArgs& a) {
   if (a.M <= 0) return 0;
   switch (NP) {
-    case 256: hipLaunchKernelGGL((wide_dense_kernel<4, 2, 1, 2, EPI>), dim3((a.M + 63) / 64), dim3(256), sizeof(float) * (32 * 256 + 64 * WXS), st, a); break;
+    case 256:
+      // small batches (rollout: M = num_envs): 32-sample tiles so that at least two blocks land on every CU
+      if (a.M <= 32768) hipLaunchKernelGGL((wide_dense_kernel<4, 2, 1, 1, EPI>), dim3((a.M + 31) / 32), dim3(256), sizeof(float) * (32 * 256 + 32 * WXS), st, a);
+      else hipLaunchKernelGGL((wide_dense_kernel<4, 2, 1, 2, EPI>), dim3((a.M + 63) / 64), dim3(256), sizeof(float) * (32 * 256 + 64 * WXS), st, a);
+      break;
     case 128: hipLaunchKernelGGL((wide_dense_kernel<4, 1, 1, 2, EPI>), dim3((a.M + 63) / 64), dim3(256), sizeof(float) * (32 * 128 + 64 * WXS), st, a); break;
     case 64: hipLaunchKernelGGL((wide_dense_kernel<2, 1, 2, 2, EPI>), dim3((a.M + 127) / 128), dim3(256), sizeof(float) * (32 * 64 + 128 * WXS), st, a); break;
     case 32: hipLaunchKernelGGL((wide_dense_kernel<1, 1, 4, 2, EPI>), dim3((a.M + 255) / 256), dim3(256), sizeof(float) * (32 * 32 + 256 * WXS), st, a); break;
@@ -343,21 +427,43 @@ __global__ void __launch_bounds__(256) wide_wgrad_kernel(WgradArgs a) {
   f32x4 bacc = {0.0f, 0.0f, 0.0f, 0.0f};
   const int c0 = blockIdx.x * a.chunk;
   const int c1 = (c0 + a.chunk) < a.M ? (c0 + a.chunk) : a.M;
+  // thread t stages float4 slots t, t+256, … of the [32][BT] slab: slot → (sample p / BT, rows p % BT); BT·8 slots / 256
+  // threads = BT/32 per thread, each a fixed (sample offset, row) pair — pointers are set up once
+  constexpr int NU = BT / 32;
+  int soff[NU], mmu[NU];   // element offset of the slot inside a slab (rows relative to the block's first row)
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int p = 4 * (tid + 256 * u), mm = p / BT, n = p - mm * BT;
+    mmu[u] = mm;
+    soff[u] = a.H * mm + n;
+  }
+  const float* ybase = a.dY + (size_t)a.H * c0 + n0;
+  const float* xbase = a.X + (size_t)a.H * c0 + kk0;
+  const bool do_bias = (tkb == 0) && a.pB;
+  const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 yr[NU], xr[NU];
+  auto fetch = [&](int m) {
+    const int mv = c1 - m;   // samples left in the chunk
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const bool ok = mmu[u] < mv;
+      const size_t off = (size_t)a.H * (m - c0);   // wave-uniform
+      yr[u] = ok ? *reinterpret_cast<const f32x4*>(ybase + off + soff[u]) : zero4;
+      xr[u] = ok ? *reinterpret_cast<const f32x4*>(xbase + off + soff[u]) : zero4;
+    }
+  };
+  if (c0 < c1) fetch(c0);
   for (int m = c0; m < c1; m += 32) {
-    const int mv = (c1 - m) < 32 ? (c1 - m) : 32;
-    for (int i = tid; i < BT * 8; i += 256) {
-      const int p = 4 * i, mm = p / BT, n = p - mm * BT;
-      f32x4 y = {0.0f, 0.0f, 0.0f, 0.0f}, x = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (mm < mv) {
-        y = *reinterpret_cast<const f32x4*>(a.dY + (size_t)a.H * (m + mm) + n0 + n);
-        x = *reinterpret_cast<const f32x4*>(a.X + (size_t)a.H * (m + mm) + kk0 + n);
-      }
-      *reinterpret_cast<f32x4*>(Yl + p) = y;
-      *reinterpret_cast<f32x4*>(Xl + p) = x;
-      bacc += y;
+    if (m != c0) __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      *reinterpret_cast<f32x4*>(Yl + 4 * (tid + 256 * u)) = yr[u];
+      *reinterpret_cast<f32x4*>(Xl + 4 * (tid + 256 * u)) = xr[u];
+      if (do_bias) bacc += yr[u];
     }
     __syncthreads();
-#pragma unroll 4
+    if (m + 32 < c1) fetch(m + 32);
+#pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int mm = 2 * s + hf;
       float av[TW], bv[TW];
@@ -370,8 +476,8 @@ __global__ void __launch_bounds__(256) wide_wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int y = 0; y < TW; ++y) acc[x][y] = mfma32(av[x], bv[y], acc[x][y]);
     }
-    __syncthreads();
   }
+  __syncthreads();
   float* pw = a.pW + (size_t)blockIdx.x * a.H * a.H;
 #pragma unroll
   for (int x = 0; x < TW; ++x)
@@ -409,63 +515,88 @@ struct SkinnyArgs {
   float* pW; int os_row, os_s, St, wsize; float* pB;
 };
 
-template <int S>
+template <int S, bool UNI>
 __global__ void __launch_bounds__(256) wide_skinny_kernel(SkinnyArgs a) {
-  __shared__ float red[256 * (S + 1)];
+  // a thread owns 4 consecutive hidden rows (one 16-B load per sample); R4 = H/4 threads cover a sample and the
+  // block's 256/R4 groups take samples round-robin. UNI (H = 256): a group is a whole wave, Small goes through SGPRs.
+  __shared__ __attribute__((aligned(16))) float red[256 * 4];
   const int tid = threadIdx.x;
-  const int G = 256 / a.H;
-  const int row = tid % a.H;
-  const int g = __builtin_amdgcn_readfirstlane(tid / a.H);
-  float acc[S], bacc = 0.0f;
+  const int R4 = a.H >> 2, G = 256 / R4;
+  const int r4 = tid % R4;
+  int g = tid / R4;
+  if (UNI) g = __builtin_amdgcn_readfirstlane(g);
+  f32x4 acc[S], bacc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-  for (int s = 0; s < S; ++s) acc[s] = 0.0f;
+  for (int s = 0; s < S; ++s) acc[s] = bacc;
   const int c0 = blockIdx.x * a.chunk;
   const int c1 = (c0 + a.chunk) < a.M ? (c0 + a.chunk) : a.M;
-#pragma unroll 2
-  for (int m = c0 + g; m < c1; m += G) {
-    const int sr = a.idx ? __builtin_amdgcn_readfirstlane(a.idx[m]) : m;
-    const float* sp = a.Small + (size_t)sr * a.lds;
-    const float big = a.Big[(size_t)a.H * m + row];
+  for (int m = c0 + g; m < c1; m += 4 * G) {
+    f32x4 big[4];
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-      const float sv = s < a.St ? sp[s] : 0.0f;
-      acc[s] = __builtin_fmaf(big, sv, acc[s]);
+    for (int u = 0; u < 4; ++u) {
+      const int mu = m + u * G;
+      big[u] = bacc * 0.0f;
+      if (mu < c1) big[u] = *reinterpret_cast<const f32x4*>(a.Big + (size_t)a.H * mu + 4 * r4);
     }
-    bacc += big;
-  }
-  if (G > 1) {
 #pragma unroll
-    for (int s = 0; s < S; ++s) red[tid * (S + 1) + s] = acc[s];
-    red[tid * (S + 1) + S] = bacc;
-    __syncthreads();
-    if (g == 0) {
-      for (int q = 1; q < G; ++q) {
+    for (int u = 0; u < 4; ++u) {
+      const int mu = m + u * G;
+      if (mu < c1) {
+        int sr = a.idx ? a.idx[mu] : mu;
+        if (UNI) sr = __builtin_amdgcn_readfirstlane(sr);
+        const float* sp = a.Small + (size_t)sr * a.lds;
 #pragma unroll
-        for (int s = 0; s < S; ++s) acc[s] += red[(tid + q * a.H) * (S + 1) + s];
-        bacc += red[(tid + q * a.H) * (S + 1) + S];
+        for (int s = 0; s < S; ++s) {
+          const float sv = s < a.St ? sp[s] : 0.0f;
+          acc[s] += big[u] * sv;
+        }
+        bacc += big[u];
       }
     }
   }
-  if (g == 0) {
-    float* pw = a.pW + (size_t)blockIdx.x * a.wsize;
+  // fold the G groups in group order, one float4 column at a time
 #pragma unroll
-    for (int s = 0; s < S; ++s)
-      if (s < a.St) pw[row * a.os_row + s * a.os_s] = acc[s];
-    if (a.pB) a.pB[(size_t)blockIdx.x * a.H + row] = bacc;
+  for (int s = 0; s <= S; ++s) {
+    if (s == S && !a.pB) break;
+    f32x4 v = s < S ? acc[s < S ? s : 0] : bacc;
+    if (G > 1) {
+      __syncthreads();
+      *reinterpret_cast<f32x4*>(red + 4 * tid) = v;
+      __syncthreads();
+      if (g == 0)
+        for (int q = 1; q < G; ++q) v += *reinterpret_cast<const f32x4*>(red + 4 * (tid + q * R4));
+    }
+    if (g == 0) {
+      if (s < S) {
+        if (s < a.St) {
+          float* pw = a.pW + (size_t)blockIdx.x * a.wsize + (size_t)s * a.os_s;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pw[(4 * r4 + e) * a.os_row] = v[e];
+        }
+      } else {
+        *reinterpret_cast<f32x4*>(a.pB + (size_t)blockIdx.x * a.H + 4 * r4) = v;
+      }
+    }
   }
 }
 
+template <int S>
+static void skinny_go(hipStream_t st, int blocks, const SkinnyArgs& a) {
+  if (a.H == 256) hipLaunchKernelGGL((wide_skinny_kernel<S, true>), dim3(blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((wide_skinny_kernel<S, false>), dim3(blocks), dim3(256), 0, st, a);
+}
+
 static int skinny_launch(hipStream_t st, int blocks, const SkinnyArgs& a) {
-  if (a.St <= 4) hipLaunchKernelGGL(wide_skinny_kernel<4>, dim3(blocks), dim3(256), 0, st, a);
-  else if (a.St <= 8) hipLaunchKernelGGL(wide_skinny_kernel<8>, dim3(blocks), dim3(256), 0, st, a);
-  else if (a.St <= 16) hipLaunchKernelGGL(wide_skinny_kernel<16>, dim3(blocks), dim3(256), 0, st, a);
+  if (a.St <= 4) skinny_go<4>(st, blocks, a);
+  else if (a.St <= 8) skinny_go<8>(st, blocks, a);
+  else if (a.St <= 16) skinny_go<16>(st, blocks, a);
   else {
     // obs_dim up to 64: sixteen columns per launch
     for (int s0 = 0; s0 < a.St; s0 += 16) {
       SkinnyArgs b = a;
       b.Small = a.Small + s0; b.St = (a.St - s0) < 16 ? (a.St - s0) : 16; b.pW = a.pW + (size_t)s0 * a.os_s;
       if (s0 > 0) b.pB = nullptr;
-      hipLaunchKernelGGL(wide_skinny_kernel<16>, dim3(blocks), dim3(256), 0, st, b);
+      skinny_go<16>(st, blocks, b);
     }
   }
   CRL_HIP_CHECK(hipGetLastError());
@@ -809,17 +940,29 @@ __global__ void __launch_bounds__(256) wide_reduce_kernel(WRedArgs a) {
     }
     return;
   }
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.P) return;
+  // 64 elements per block, 4 threads per element: thread (e, pg) sums partials pg, pg+4, …; folded in pg order
+  __shared__ double fold[256];
+  const int e = threadIdx.x & 63, pg = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + e;
+  const bool live = i < a.P;
   int arr = 0;
 #pragma unroll
-  for (int k = 1; k < 12; ++k) arr = (i >= a.off[k]) ? k : arr;
-  const float* p = a.part[arr];
-  if (!p) return;
-  const int size = a.off[arr + 1] - a.off[arr], idx = i - a.off[arr];
+  for (int k = 1; k < 12; ++k) arr = (live && i >= a.off[k]) ? k : arr;
+  const float* p = live ? a.part[arr] : nullptr;
   double s = 0.0;
-  for (int q = 0; q < a.nparts[arr]; ++q) s += (double)p[(size_t)q * size + idx];
-  a.out[i] = (float)s;
+  if (p) {
+    const int size = a.off[arr + 1] - a.off[arr], idx = i - a.off[arr], np = a.nparts[arr];
+    int q = pg;
+    for (; q + 12 < np; q += 16) {
+      const float v0 = p[(size_t)q * size + idx], v1 = p[(size_t)(q + 4) * size + idx];
+      const float v2 = p[(size_t)(q + 8) * size + idx], v3 = p[(size_t)(q + 12) * size + idx];
+      s += (double)v0; s += (double)v1; s += (double)v2; s += (double)v3;
+    }
+    for (; q < np; q += 4) s += (double)p[(size_t)q * size + idx];
+  }
+  fold[threadIdx.x] = s;
+  __syncthreads();
+  if (pg == 0 && p) a.out[i] = (float)(((fold[e] + fold[64 + e]) + fold[128 + e]) + fold[192 + e]);
 }
 
 __global__ void wide_stats_kernel(const float* __restrict__ msg, int P, StatsArgs st) {
@@ -930,8 +1073,8 @@ int wide_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
   const int M = h->dc.M, P = (int)h->P;
   const int32_t* perm = h->perm + (size_t)mb * M;
   const double Mglobal = (double)M * h->world;
-  const bool dp = h->world > 1;
-  if (dp && h->external_comm && h->cfg.clip_value_loss) {
+  const bool dp = h->comm != nullptr || h->external_comm;   // a forced 1-rank communicator still goes through RCCL
+  if (h->external_comm && h->world > 1 && h->cfg.clip_value_loss) {
     set_error("wide path: clip_value_loss under host-side exchange (crl_comm_init_external) is not supported; use crl_comm_init");
     return 1;
   }
@@ -978,7 +1121,7 @@ int wide_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
     }
     r.lpart = w->lpart; r.nlb = w->nlb; r.out = h->comm_buf; r.P = P; r.A = A;
     ProfScope pr(h, CRL_K_REDUCE);
-    hipLaunchKernelGGL(wide_reduce_kernel, dim3((P + 255) / 256 + 1), dim3(256), 0, h->stream, r);
+    hipLaunchKernelGGL(wide_reduce_kernel, dim3((P + 63) / 64 + 1), dim3(256), 0, h->stream, r);
     CRL_HIP_CHECK(hipGetLastError());
   }
   if (dp) {

@@ -15,15 +15,20 @@ def crl():
     return crl
 
 
-def test_two_shards_equal_one_handle(crl):
+@pytest.mark.parametrize("path", ["fused", "wide"])
+def test_two_shards_equal_one_handle(crl, path):
+    """fused = the 4/2/64 kernels of update.hip; wide = the layer-wise path on the C3 shape (obs 8 / act 4 / 2x256) with
+    the plain value loss (the clipped one needs two extra scalar all-reduces that only the in-library RCCL path does)."""
     L = crl._lib
     NT, k, W = 16, 128, 2
     n = NT // W
-    cfg_full = crl.PPOConfig(num_envs=NT, num_steps=k, total_timesteps=NT * k * 10)
-    cfg_sh = crl.PPOConfig(num_envs=n, num_steps=k, total_timesteps=NT * k * 10)
-    full = crl.Agent(cfg_full)
+    extra = {} if path == "fused" else dict(clip_value_loss=False)
+    shape = {} if path == "fused" else dict(obs_dim=8, n_act=4, hidden=256, env_kind=L.ENV_SYNTHETIC)
+    cfg_full = crl.PPOConfig(num_envs=NT, num_steps=k, total_timesteps=NT * k * 10, **extra)
+    cfg_sh = crl.PPOConfig(num_envs=n, num_steps=k, total_timesteps=NT * k * 10, **extra)
+    full = crl.Agent(cfg_full, **shape)
     params = full.get_params()
-    shards = [crl.Agent(cfg_sh, params=params, env_id_offset=r * n) for r in range(W)]
+    shards = [crl.Agent(cfg_sh, params=params, env_id_offset=r * n, **shape) for r in range(W)]
     for r, a in enumerate(shards):
         a.handle.comm_init_external(W, r)
     for a in [full] + shards:

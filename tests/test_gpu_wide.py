@@ -201,3 +201,24 @@ def test_c3_full_size_properties(crl):
     assert np.array_equal(g1, g2) and s1["loss"] == s2["loss"]
     assert np.isfinite(g1).all() and np.linalg.norm(g1) > 0
     agent.close(); st.close()
+
+
+def test_wide_rccl_path_world1(crl, monkeypatch):
+    """C3 shape with a forced 1-rank RCCL communicator: the gradient message, the advantage statistics AND the two extra
+    value-loss scalars (Σ(v − R²), #{u > q}) travel through ncclAllReduce; a sum over one rank is the identity."""
+    monkeypatch.setenv("CRL_COMM_FORCE", "1")
+    D, A, Hd, nt, k = 8, 4, 256, 16, 32
+    cfg = ocfg(nt, k, D, A, Hd)
+    params = spread_params(cfg, 7)
+    agent = make_wide(crl, nt, k, D, A, Hd, params=params, shuffle_mode=0)
+    h = agent.handle
+    h.comm_init(crl.comm_unique_id(), 1, 0)
+    st = O.State(cfg); st.params[:] = params; st.env_init()
+    h.env_reset()
+    h.prof_enable(True)
+    gs = h.iterate(1); os_ = st.iterate(10, gen_perm=True)
+    assert h.prof_read()["allreduce"][1] == 16
+    for a, b in zip(gs, os_):
+        assert abs(a["loss"] - b["loss"]) <= 2e-5 * max(1.0, abs(b["loss"]))
+    assert np.max(np.abs(h.read(crl._lib.F_PARAMS) - st.params)) < 2e-5
+    agent.close(); st.close()
