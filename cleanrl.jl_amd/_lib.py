@@ -49,7 +49,24 @@ EXPORTS = [
     "crl_shuffle", "crl_adv_stats", "crl_ppo_update_minibatch", "crl_ppo_iterate", "crl_ppo_iteration",
     "crl_comm_unique_id", "crl_comm_init", "crl_comm_init_external", "crl_adv_stats_local", "crl_adv_stats_finish",
     "crl_prof_enable", "crl_prof_read", "crl_prof_reset",
+    "crl_a2c_create", "crl_a2c_destroy", "crl_a2c_param_count", "crl_a2c_write_params", "crl_a2c_read_params",
+    "crl_a2c_read_env", "crl_a2c_read_buffer", "crl_a2c_run_until_update", "crl_a2c_discounted_future_rewards",
 ]
+
+
+class CrlA2CConfig(C.Structure):
+    """crl_a2c_config — mirror of A2CConfig (a2c.jl:1-10)."""
+    _fields_ = [("lr", C.c_double), ("total_timesteps", C.c_int64), ("min_replay_size", C.c_int32), ("max_steps", C.c_int32),
+                ("gamma", C.c_double), ("seed", C.c_uint64)]
+
+
+class CrlA2CTrainStats(C.Structure):
+    _fields_ = [("actor_loss", C.c_double), ("critic_loss", C.c_double), ("n", C.c_int32), ("trained", C.c_int32)]
+
+
+class CrlA2CEpisode(C.Structure):
+    _fields_ = [("episode_return", C.c_double), ("episode_length", C.c_int64), ("global_step", C.c_int64)]
+
 
 # crl_field
 F_OBS, F_ACTION, F_LOGPROB, F_REWARD, F_TERMINAL, F_VALUE, F_ADVANTAGE, F_RETURN, F_PERM, F_PARAMS, F_GRADS, F_ADAM_M, \
@@ -103,6 +120,16 @@ def load():
     L.crl_prof_enable.argtypes = [vp, C.c_int32]
     L.crl_prof_read.argtypes = [vp, C.c_int32, dp, C.POINTER(C.c_int64)]
     L.crl_prof_reset.argtypes = [vp]
+    i64p = C.POINTER(C.c_int64)
+    L.crl_a2c_create.argtypes = [C.POINTER(CrlA2CConfig), C.c_int32, C.POINTER(vp)]
+    L.crl_a2c_destroy.argtypes = [vp]
+    L.crl_a2c_param_count.argtypes = [vp, i64p]
+    L.crl_a2c_write_params.argtypes = [vp, fp, C.c_size_t]
+    L.crl_a2c_read_params.argtypes = [vp, fp, C.c_size_t]
+    L.crl_a2c_read_env.argtypes = [vp, dp, i64p, ip]
+    L.crl_a2c_read_buffer.argtypes = [vp, dp, ip, dp, u8p, C.c_int32]
+    L.crl_a2c_run_until_update.argtypes = [vp, C.c_int64, C.POINTER(CrlA2CTrainStats), C.POINTER(CrlA2CEpisode), C.c_int32, ip, i64p]
+    L.crl_a2c_discounted_future_rewards.argtypes = [C.c_int32, dp, u8p, C.c_int32, C.c_double, C.c_double, dp]
     for name in EXPORTS:
         if name not in ("crl_version", "crl_last_error"):
             getattr(L, name).restype = C.c_int32
@@ -286,3 +313,62 @@ def gae_host(value, reward, terminal, next_value, next_done, gamma, lam, mode=GA
                          _ptr(nv, C.c_float) if nv is not None else None, _ptr(nd, C.c_uint8) if nd is not None else None,
                          nt, k, gamma, lam, mode, _ptr(adv, C.c_float), _ptr(ret, C.c_float)))
     return adv, ret
+
+
+class A2CHandle:
+    """Owns one crl_a2c* (include/cleanrl_hip.h, A2C block): networks, optimiser state, replay buffer and env on one GPU."""
+
+    def __init__(self, cfg: CrlA2CConfig, device=0):
+        self._L = load()
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        check(self._L.crl_a2c_create(C.byref(cfg), device, C.byref(self._h)))
+        n = C.c_int64()
+        check(self._L.crl_a2c_param_count(self._h, C.byref(n)))
+        self.param_count = n.value
+
+    def close(self):
+        if self._h:
+            self._L.crl_a2c_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def write_params(self, p):
+        p = np.ascontiguousarray(p, np.float32)
+        check(self._L.crl_a2c_write_params(self._h, _ptr(p, C.c_float), p.size))
+
+    def read_params(self):
+        p = np.zeros(self.param_count, np.float32)
+        check(self._L.crl_a2c_read_params(self._h, _ptr(p, C.c_float), p.size))
+        return p
+
+    def env(self):
+        s = np.zeros(4, np.float64); g = C.c_int64(); n = C.c_int32()
+        check(self._L.crl_a2c_read_env(self._h, _ptr(s, C.c_double), C.byref(g), C.byref(n)))
+        return s, g.value, n.value
+
+    def buffer(self):
+        cap = 2 * self.cfg.min_replay_size
+        st = np.zeros((4, cap), np.float64, order="F"); a = np.zeros(cap, np.int32); r = np.zeros(cap, np.float64); t = np.zeros(cap, np.uint8)
+        check(self._L.crl_a2c_read_buffer(self._h, _ptr(st, C.c_double), _ptr(a, C.c_int32), _ptr(r, C.c_double), _ptr(t, C.c_uint8), cap))
+        n = self.env()[2]
+        return st[:, :n], a[:n], r[:n], t[:n]
+
+    def run_until_update(self, max_env_steps=1 << 40, max_eps=4096):
+        ts = CrlA2CTrainStats(); eps = (CrlA2CEpisode * max_eps)(); n = C.c_int32(); taken = C.c_int64()
+        check(self._L.crl_a2c_run_until_update(self._h, max_env_steps, C.byref(ts), eps, max_eps, C.byref(n), C.byref(taken)))
+        episodes = [(eps[i].episode_return, eps[i].episode_length, eps[i].global_step) for i in range(n.value)]
+        return taken.value, dict(actor_loss=ts.actor_loss, critic_loss=ts.critic_loss, n=ts.n, trained=bool(ts.trained)), episodes
+
+
+def a2c_discounted_future_rewards_host(rewards, terminals, final_value, gamma, device=0):
+    r = np.ascontiguousarray(rewards, np.float64); t = np.ascontiguousarray(terminals, np.uint8)
+    out = np.zeros(r.size, np.float64)
+    check(load().crl_a2c_discounted_future_rewards(device, _ptr(r, C.c_double), _ptr(t, C.c_uint8), r.size, float(final_value),
+                                                   float(gamma), _ptr(out, C.c_double)))
+    return out

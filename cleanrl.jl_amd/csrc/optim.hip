@@ -105,14 +105,14 @@ int launch_adv_stats_finish(crl_ppo* h) {
 // independently (Q9): one block per array, Float64 scalar math, Float32 state — oracle: orc_clipnorm_adam.
 // ------------------------------------------------------------------------------------------------------
 struct OptimArgs {
-  int off[13];
+  int off[13]; int arr0;
   float* params; const float* grads; float* m; float* v; double* betap;
   double eta, thresh;
 };
 
 __global__ void __launch_bounds__(1024) clipnorm_adam_kernel(OptimArgs a) {
 #pragma clang fp contract(off)
-  const int arr = blockIdx.x;
+  const int arr = blockIdx.x + a.arr0;
   const int lo = a.off[arr], hi = a.off[arr + 1];
   __shared__ double sm[16];
   double ss = 0.0;
@@ -147,11 +147,24 @@ int launch_optim(crl_ppo* h, double eta) {
   a.off[0] = 0;
   for (int i = 0; i < 12; ++i) a.off[i + 1] = a.off[i] + sizes[i];
   a.params = h->params; a.grads = h->comm_buf; a.m = h->adam_m; a.v = h->adam_v; a.betap = h->betap;
-  a.eta = eta; a.thresh = 0.5;
+  a.eta = eta; a.thresh = 0.5; a.arr0 = 0;
   ProfScope ps(h, CRL_K_OPTIM);
   hipLaunchKernelGGL(clipnorm_adam_kernel, dim3(12), dim3(1024), 0, h->stream, a);
   CRL_HIP_CHECK(hipGetLastError());
   wide_mark_params_changed(h);
+  return 0;
+}
+
+
+// Optimiser(ClipNorm(0.5), Adam(η)) over parameter arrays [a0, a1) of a flat 12-array layout (A2C updates the critic's and
+// the actor's arrays in separate calls, a2c.jl:88,98)
+int launch_clipnorm_adam_range(hipStream_t st, float* params, const float* grads, float* m, float* v, double* betap,
+                               const int* off13, int a0, int a1, double eta) {
+  OptimArgs a;
+  for (int i = 0; i < 13; ++i) a.off[i] = off13[i];
+  a.params = params; a.grads = grads; a.m = m; a.v = v; a.betap = betap; a.eta = eta; a.thresh = 0.5; a.arr0 = a0;
+  hipLaunchKernelGGL(clipnorm_adam_kernel, dim3(a1 - a0), dim3(1024), 0, st, a);
+  CRL_HIP_CHECK(hipGetLastError());
   return 0;
 }
 

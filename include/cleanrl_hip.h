@@ -174,6 +174,45 @@ int32_t crl_prof_enable(crl_ppo* h, int32_t on);
 int32_t crl_prof_read(crl_ppo* h, int32_t kernel_id, double* total_ms, int64_t* launches);
 int32_t crl_prof_reset(crl_ppo* h);
 
+/* =====================================================================================================
+ * A2C: src/algorithms/a2c.jl on the GPU. One on-device CartPoleEnv{Float64}; the reference's
+ * numeric regime (Float32 weights, Float64 observations ⇒ Float64 activations / losses / cotangents, a2c.jl:35,55-56)
+ * is kept: these kernels are plain Float64 VALU code — a training batch is ≤ 2·min_replay_size samples of a 2x64 MLP
+ * (≈0.1 GFLOP), nothing for the matrix pipes to win.
+ * ===================================================================================================== */
+typedef struct crl_a2c_config {   /* A2CConfig, a2c.jl:1-10 */
+  double lr;                      /* a2c.jl:4 */
+  int64_t total_timesteps;        /* a2c.jl:6 */
+  int32_t min_replay_size;        /* a2c.jl:7; must be >= max_steps + 1 so the 2x buffer never wraps inside an update batch */
+  int32_t max_steps;              /* a2c.jl:35 CartPoleEnv(max_steps=500) */
+  double gamma;                   /* a2c.jl:9 */
+  uint64_t seed;
+} crl_a2c_config;
+typedef struct crl_a2c_train_stats { double actor_loss, critic_loss; int32_t n, trained; } crl_a2c_train_stats;  /* a2c.jl:100 */
+typedef struct crl_a2c_episode { double episode_return; int64_t episode_length, global_step; } crl_a2c_episode;  /* a2c.jl:106 */
+typedef struct crl_a2c crl_a2c;
+
+/* a2c.jl:32-52: networks (parameters are uploaded by crl_a2c_write_params, same flat layout as PPO: obs 4 / act 2 / 2x64),
+ * Optimiser(ClipNorm(0.5), Adam(lr)) state, ReplayBuffer(capacity = 2*min_replay_size), reset!(env). */
+int32_t crl_a2c_create(const crl_a2c_config* cfg, int32_t device, crl_a2c** out);
+int32_t crl_a2c_destroy(crl_a2c* h);
+int32_t crl_a2c_param_count(const crl_a2c* h, int64_t* n);
+int32_t crl_a2c_write_params(crl_a2c* h, const float* params, size_t n);
+int32_t crl_a2c_read_params(crl_a2c* h, float* params, size_t n);
+/* env state (4 doubles), global_step, current buffer size */
+int32_t crl_a2c_read_env(crl_a2c* h, double* state4, int64_t* global_step, int32_t* rb_size);
+/* replay buffer columns 1..size (a2c.jl:77 `x[:, 1:rb.size]`): state (4,size) Float64, action 0-based, reward, terminal */
+int32_t crl_a2c_read_buffer(crl_a2c* h, double* state, int32_t* action, double* reward, uint8_t* terminal, int32_t capacity);
+/* a2c.jl:53-111 `for global_step in 1:total_timesteps` body, run on the device until ONE training update has happened
+ * (stats->trained = 1), max_env_steps were taken, or total_timesteps is reached. "Episode Statistics" records
+ * (a2c.jl:106) of the episodes that ended are written to eps[0..*n_eps) (at most max_eps; later ones are dropped).
+ * *steps_taken = env steps of this call. */
+int32_t crl_a2c_run_until_update(crl_a2c* h, int64_t max_env_steps, crl_a2c_train_stats* stats, crl_a2c_episode* eps,
+                                 int32_t max_eps, int32_t* n_eps, int64_t* steps_taken);
+/* discounted_future_rewards(rewards, terminals, final_value, γ) (a2c.jl:13-24) on host vectors */
+int32_t crl_a2c_discounted_future_rewards(int32_t device, const double* rewards, const uint8_t* terminals, int32_t n,
+                                          double final_value, double gamma, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,9 +47,8 @@ class OrcState(C.Structure):
 
 
 def build(force=False):
-    src = os.path.join(_ROOT, "oracle", "ppo_oracle.c")
-    hdr = os.path.join(_ROOT, "oracle", "ppo_oracle.h")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    srcs = [os.path.join(_ROOT, "oracle", f) for f in ("ppo_oracle.c", "ppo_oracle.h", "a2c_oracle.c", "a2c_oracle.h")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle"), "-s"])
     return _SO
 
@@ -300,3 +299,116 @@ def orthogonal_params(cfg, seed=0):
         W = orth(sh[0], sh[1], sh[2])
         out[o[i]:o[i + 1]] = W.ravel(order="F")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# A2C oracle (oracle/a2c_oracle.c — a2c.jl restated)
+# ---------------------------------------------------------------------------------------------------------
+class A2CConfigC(C.Structure):
+    _fields_ = [("lr", C.c_double), ("total_timesteps", C.c_int64), ("min_replay_size", C.c_int32), ("gamma", C.c_double),
+                ("obs_dim", C.c_int32), ("n_act", C.c_int32), ("hidden", C.c_int32), ("max_steps", C.c_int32),
+                ("seed", C.c_uint64)]
+
+
+class A2CTrainStats(C.Structure):
+    _fields_ = [("actor_loss", C.c_double), ("critic_loss", C.c_double), ("n", C.c_int32), ("trained", C.c_int32)]
+
+
+class A2CEpisode(C.Structure):
+    _fields_ = [("episode_return", C.c_double), ("episode_length", C.c_int64), ("global_step", C.c_int64)]
+
+
+_a2c_ready = False
+
+
+def a2c_lib():
+    global _a2c_ready
+    L = lib()
+    if not _a2c_ready:
+        dp, fp, ip, u8p = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+        cp = C.POINTER(A2CConfigC)
+        L.a2c_create.restype = C.c_void_p; L.a2c_create.argtypes = [cp]
+        L.a2c_destroy.argtypes = [C.c_void_p]
+        L.a2c_param_count.restype = C.c_int32; L.a2c_param_count.argtypes = [C.c_void_p]
+        L.a2c_set_params.argtypes = [C.c_void_p, fp]; L.a2c_get_params.argtypes = [C.c_void_p, fp]
+        L.a2c_get_env.argtypes = [C.c_void_p, dp, C.POINTER(C.c_int64), ip]
+        L.a2c_get_buffer.argtypes = [C.c_void_p, dp, ip, dp, u8p]
+        L.a2c_run_until_update.restype = C.c_int64
+        L.a2c_run_until_update.argtypes = [C.c_void_p, C.c_int64, C.POINTER(A2CTrainStats), C.POINTER(A2CEpisode), C.c_int32, ip]
+        L.a2c_discounted_future_rewards.argtypes = [dp, u8p, C.c_int32, C.c_double, C.c_double, dp]
+        for f in (L.a2c_tanh_fast, L.a2c_sin, L.a2c_cos):
+            f.restype = C.c_double; f.argtypes = [C.c_double]
+        L.a2c_forward.argtypes = [cp, fp, C.c_int, dp, dp]
+        L.a2c_loss_grads.argtypes = [cp, fp, dp, ip, dp, C.c_int32, fp, dp, dp, dp]
+        L.a2c_cartpole_step.argtypes = [dp, ip, C.c_int32, C.c_int32, ip]
+        _a2c_ready = True
+    return L
+
+
+def a2c_config(lr=1e-4, total_timesteps=1_000_000, min_replay_size=512, gamma=0.99, obs_dim=4, n_act=2, hidden=64,
+               max_steps=500, seed=0x5EED):
+    return A2CConfigC(lr, total_timesteps, min_replay_size, gamma, obs_dim, n_act, hidden, max_steps, seed)
+
+
+def a2c_discounted_future_rewards(rewards, terminals, final_value, gamma):
+    r = np.ascontiguousarray(rewards, np.float64); t = np.ascontiguousarray(terminals, np.uint8)
+    out = np.zeros(len(r), np.float64)
+    a2c_lib().a2c_discounted_future_rewards(_p(r, C.c_double), _p(t, C.c_uint8), len(r), final_value, gamma, _p(out, C.c_double))
+    return out
+
+
+def a2c_forward(cfg, params, net, x):
+    params = np.ascontiguousarray(params, np.float32); x = np.ascontiguousarray(x, np.float64)
+    out = np.zeros(1 if net else cfg.n_act, np.float64)
+    a2c_lib().a2c_forward(C.byref(cfg), _p(params, C.c_float), net, _p(x, C.c_double), _p(out, C.c_double))
+    return out
+
+
+def a2c_loss_grads(cfg, params, states, actions, returns):
+    params = np.ascontiguousarray(params, np.float32)
+    states = np.asfortranarray(states, np.float64); actions = np.ascontiguousarray(actions, np.int32)
+    returns = np.ascontiguousarray(returns, np.float64)
+    n = len(actions)
+    grads = np.zeros(len(params), np.float32); adv = np.zeros(n, np.float64)
+    cl, al = C.c_double(), C.c_double()
+    a2c_lib().a2c_loss_grads(C.byref(cfg), _p(params, C.c_float), states.ctypes.data_as(C.POINTER(C.c_double)), _p(actions, C.c_int32),
+                             _p(returns, C.c_double), n, _p(grads, C.c_float), C.byref(cl), C.byref(al), _p(adv, C.c_double))
+    return grads, cl.value, al.value, adv
+
+
+class A2CState:
+    def __init__(self, cfg, params):
+        self.cfg = cfg
+        self.L = a2c_lib()
+        self.ptr = self.L.a2c_create(C.byref(cfg))
+        self.P = self.L.a2c_param_count(self.ptr)
+        self.set_params(params)
+
+    def set_params(self, p):
+        p = np.ascontiguousarray(p, np.float32); assert len(p) == self.P
+        self.L.a2c_set_params(self.ptr, _p(p, C.c_float))
+
+    def get_params(self):
+        p = np.zeros(self.P, np.float32); self.L.a2c_get_params(self.ptr, _p(p, C.c_float)); return p
+
+    def env(self):
+        s = np.zeros(4, np.float64); g = C.c_int64(); n = C.c_int32()
+        self.L.a2c_get_env(self.ptr, _p(s, C.c_double), C.byref(g), C.byref(n))
+        return s, g.value, n.value
+
+    def buffer(self):
+        _, _, n = self.env()
+        d = self.cfg.obs_dim
+        st = np.zeros((d, n), np.float64, order="F"); a = np.zeros(n, np.int32); r = np.zeros(n, np.float64); t = np.zeros(n, np.uint8)
+        self.L.a2c_get_buffer(self.ptr, st.ctypes.data_as(C.POINTER(C.c_double)), _p(a, C.c_int32), _p(r, C.c_double), _p(t, C.c_uint8))
+        return st, a, r, t
+
+    def run_until_update(self, max_env_steps=1 << 40, max_eps=4096):
+        ts = A2CTrainStats(); eps = (A2CEpisode * max_eps)(); n = C.c_int32()
+        taken = self.L.a2c_run_until_update(self.ptr, max_env_steps, C.byref(ts), eps, max_eps, C.byref(n))
+        episodes = [(eps[i].episode_return, eps[i].episode_length, eps[i].global_step) for i in range(n.value)]
+        return taken, dict(actor_loss=ts.actor_loss, critic_loss=ts.critic_loss, n=ts.n, trained=bool(ts.trained)), episodes
+
+    def close(self):
+        if self.ptr:
+            self.L.a2c_destroy(self.ptr); self.ptr = None

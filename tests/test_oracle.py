@@ -172,11 +172,13 @@ def _random_batch(cfg, B, rng, ret_scale=10.0):
     return states, actions, old_lp, old_v, adv, ret
 
 
+@pytest.mark.parametrize("shape", [(4, 2, 64), (8, 4, 256), (6, 3, 128)])
 @pytest.mark.parametrize("ret_scale,clipv", [(10.0, True), (0.05, True), (3.0, False)])
-def test_loss_grad_matches_torch_autograd(ret_scale, clipv):
-    """ret_scale=0.05 forces u = mean(v - R^2) > 0 for many samples: the rare unclipped-wins branch (Q4)."""
+def test_loss_grad_matches_torch_autograd(ret_scale, clipv, shape):
+    """ret_scale=0.05 forces u = mean(v - R^2) > 0 for many samples: the rare unclipped-wins branch (Q4).
+    Shapes: the reference's CartPole nets, BASELINE C3 (obs 8 / act 4 / 2x256) and an odd one."""
     rng = np.random.default_rng(3)
-    cfg = O.make_config(num_envs=8, num_steps=16, hidden=64, clip_value_loss=clipv)
+    cfg = O.make_config(num_envs=8, num_steps=16, obs_dim=shape[0], n_act=shape[1], hidden=shape[2], clip_value_loss=clipv)
     params = O.orthogonal_params(cfg, 1)
     params += (0.05 * rng.standard_normal(params.shape)).astype(np.float32)  # non-zero biases, bigger actor head
     off = O.param_offsets(cfg)
