@@ -132,4 +132,44 @@ function ppo(config::PPOConfig=PPOConfig(); device=0, params::Union{Nothing,Vect
   agent
 end
 
+# ------------------------------------------------------------------------------------------------------
+# a2c.jl — same names: A2CConfig keeps the reference's fields (a2c.jl:1-10); the loop body runs on the GPU
+# ------------------------------------------------------------------------------------------------------
+struct CrlA2CConfig       # include/cleanrl_hip.h crl_a2c_config
+  lr::Float64; total_timesteps::Int64; min_replay_size::Int32; max_steps::Int32; gamma::Float64; seed::UInt64
+end
+struct CrlA2CTrainStats; actor_loss::Float64; critic_loss::Float64; n::Int32; trained::Int32; end
+struct CrlA2CEpisode; episode_return::Float64; episode_length::Int64; global_step::Int64; end
+
+# a2c.jl:13-24 — same signature
+function discounted_future_rewards(rewards::Vector{Float64}, terminals::Vector{Bool}, final_value::Float64, γ::Float64; device=0)
+  out = similar(rewards); t = UInt8.(terminals)
+  GC.@preserve rewards t out check(ccall((:crl_a2c_discounted_future_rewards, libcrl), Int32,
+    (Int32, Ptr{Float64}, Ptr{UInt8}, Int32, Float64, Float64, Ptr{Float64}), device, rewards, t, length(rewards), final_value, γ, out))
+  out
+end
+
+# a2c.jl:29 — same signature; `config` is the reference's A2CConfig
+function a2c(config; device=0, seed=UInt64(0x5EED), params::Vector{Float32})
+  cfg = CrlA2CConfig(config.lr, config.total_timesteps, config.min_replay_size, 500, config.gamma, seed)
+  h = Ref{Ptr{Cvoid}}(C_NULL)
+  check(ccall((:crl_a2c_create, libcrl), Int32, (Ref{CrlA2CConfig}, Int32, Ref{Ptr{Cvoid}}), cfg, device, h))
+  GC.@preserve params check(ccall((:crl_a2c_write_params, libcrl), Int32, (Ptr{Cvoid}, Ptr{Float32}, Csize_t), h[], params, length(params)))
+  stats = Ref{CrlA2CTrainStats}(); eps = Vector{CrlA2CEpisode}(undef, 4096); n_eps = Ref{Int32}(0); taken = Ref{Int64}(0)
+  start_time = time(); global_step = 0
+  while global_step < config.total_timesteps
+    GC.@preserve eps check(ccall((:crl_a2c_run_until_update, libcrl), Int32,
+      (Ptr{Cvoid}, Int64, Ref{CrlA2CTrainStats}, Ptr{CrlA2CEpisode}, Int32, Ref{Int32}, Ref{Int64}),
+      h[], typemax(Int64), stats, eps, length(eps), n_eps, taken))
+    taken[] == 0 && break
+    global_step += taken[]
+    for e in @view eps[1:n_eps[]]
+      steps_per_sec = trunc(e.global_step / (time() - start_time))
+      @info "Episode Statistics" episode_return = e.episode_return episode_length = e.episode_length global_step = e.global_step steps_per_sec
+    end
+    stats[].trained == 1 && @info "Training Statistics" actor_loss = stats[].actor_loss critic_loss = stats[].critic_loss
+  end
+  check(ccall((:crl_a2c_destroy, libcrl), Int32, (Ptr{Cvoid},), h[]))
+end
+
 end # module
