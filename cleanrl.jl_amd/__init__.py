@@ -8,8 +8,9 @@ from ._lib import CrlError, Handle, comm_unique_id, device_count
 from .logger import make_logger
 from .networks import make_actor_critic
 from .a2c import A2CAgent, A2CConfig, a2c, discounted_future_rewards
+from .dqn import DQNAgent, DQNConfig, dqn, linear_schedule, make_nn
 from .ppo import Agent, Policy, PPOConfig, gae, get_action, logprob_actions, ppo, train
 
 __all__ = ["_lib", "CrlError", "Handle", "comm_unique_id", "device_count", "make_logger", "make_actor_critic", "Agent",
            "Policy", "PPOConfig", "gae", "get_action", "logprob_actions", "ppo", "train", "A2CAgent", "A2CConfig", "a2c",
-           "discounted_future_rewards"]
+           "discounted_future_rewards", "DQNAgent", "DQNConfig", "dqn", "linear_schedule", "make_nn"]

@@ -51,7 +51,33 @@ EXPORTS = [
     "crl_prof_enable", "crl_prof_read", "crl_prof_reset",
     "crl_a2c_create", "crl_a2c_destroy", "crl_a2c_param_count", "crl_a2c_write_params", "crl_a2c_read_params",
     "crl_a2c_read_env", "crl_a2c_read_buffer", "crl_a2c_run_until_update", "crl_a2c_discounted_future_rewards",
+    "crl_dqn_create", "crl_dqn_destroy", "crl_dqn_write_params", "crl_dqn_read_params", "crl_dqn_status_read", "crl_dqn_run",
+    "crl_dqn_q_values",
 ]
+
+DQN_PARAM_COUNT = 10934
+
+
+class CrlDQNConfig(C.Structure):
+    """crl_dqn_config — mirror of DQNConfig (dqn.jl:1-19)."""
+    _fields_ = [("log_frequency", C.c_int64), ("total_timesteps", C.c_int64), ("buffer_size", C.c_int64), ("min_buff_size", C.c_int64),
+                ("lr", C.c_double), ("train_freq", C.c_int64), ("target_net_freq", C.c_int64), ("batch_size", C.c_int64),
+                ("gamma", C.c_double), ("epsilon_start", C.c_double), ("epsilon_end", C.c_double), ("epsilon_duration", C.c_double),
+                ("max_steps", C.c_int32), ("pad", C.c_int32), ("seed", C.c_uint64)]
+
+
+class CrlDQNEpisode(C.Structure):
+    _fields_ = [("episode_return", C.c_double), ("episode_length", C.c_int64), ("global_step", C.c_int64), ("epsilon", C.c_double)]
+
+
+class CrlDQNLossRecord(C.Structure):
+    _fields_ = [("global_step", C.c_int64), ("loss", C.c_double)]
+
+
+class CrlDQNStatus(C.Structure):
+    _fields_ = [("env_state", C.c_double * 4), ("global_step", C.c_int64), ("rb_size", C.c_int64), ("n_updates", C.c_int64),
+                ("last_loss", C.c_double)]
+
 
 
 class CrlA2CConfig(C.Structure):
@@ -130,6 +156,13 @@ def load():
     L.crl_a2c_read_buffer.argtypes = [vp, dp, ip, dp, u8p, C.c_int32]
     L.crl_a2c_run_until_update.argtypes = [vp, C.c_int64, C.POINTER(CrlA2CTrainStats), C.POINTER(CrlA2CEpisode), C.c_int32, ip, i64p]
     L.crl_a2c_discounted_future_rewards.argtypes = [C.c_int32, dp, u8p, C.c_int32, C.c_double, C.c_double, dp]
+    L.crl_dqn_create.argtypes = [C.POINTER(CrlDQNConfig), C.c_int32, C.POINTER(vp)]
+    L.crl_dqn_destroy.argtypes = [vp]
+    L.crl_dqn_write_params.argtypes = [vp, fp, C.c_size_t]
+    L.crl_dqn_read_params.argtypes = [vp, fp, fp, C.c_size_t]
+    L.crl_dqn_status_read.argtypes = [vp, C.POINTER(CrlDQNStatus)]
+    L.crl_dqn_run.argtypes = [vp, C.c_int64, C.POINTER(CrlDQNEpisode), C.c_int32, ip, C.POINTER(CrlDQNLossRecord), C.c_int32, ip, i64p]
+    L.crl_dqn_q_values.argtypes = [vp, dp, C.c_int32, dp]
     for name in EXPORTS:
         if name not in ("crl_version", "crl_last_error"):
             getattr(L, name).restype = C.c_int32
@@ -372,3 +405,54 @@ def a2c_discounted_future_rewards_host(rewards, terminals, final_value, gamma, d
     check(load().crl_a2c_discounted_future_rewards(device, _ptr(r, C.c_double), _ptr(t, C.c_uint8), r.size, float(final_value),
                                                    float(gamma), _ptr(out, C.c_double)))
     return out
+
+
+class DQNHandle:
+    """Owns one crl_dqn* (include/cleanrl_hip.h, DQN block)."""
+
+    def __init__(self, cfg: CrlDQNConfig, device=0):
+        self._L = load()
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        check(self._L.crl_dqn_create(C.byref(cfg), device, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self._L.crl_dqn_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def write_params(self, p):
+        p = np.ascontiguousarray(p, np.float32)
+        check(self._L.crl_dqn_write_params(self._h, _ptr(p, C.c_float), p.size))
+
+    def read_params(self):
+        q = np.zeros(DQN_PARAM_COUNT, np.float32); t = np.zeros(DQN_PARAM_COUNT, np.float32)
+        check(self._L.crl_dqn_read_params(self._h, _ptr(q, C.c_float), _ptr(t, C.c_float), q.size))
+        return q, t
+
+    def status(self):
+        st = CrlDQNStatus()
+        check(self._L.crl_dqn_status_read(self._h, C.byref(st)))
+        return dict(state=np.array(list(st.env_state)), global_step=st.global_step, rb_size=st.rb_size, n_updates=st.n_updates,
+                    last_loss=st.last_loss)
+
+    def run(self, max_env_steps, max_eps=8192, max_losses=4096):
+        eps = (CrlDQNEpisode * max_eps)(); ls = (CrlDQNLossRecord * max_losses)(); ne = C.c_int32(); nl = C.c_int32(); taken = C.c_int64()
+        check(self._L.crl_dqn_run(self._h, max_env_steps, eps, max_eps, C.byref(ne), ls, max_losses, C.byref(nl), C.byref(taken)))
+        return (taken.value, [(eps[i].episode_return, eps[i].episode_length, eps[i].global_step, eps[i].epsilon) for i in range(ne.value)],
+                [(ls[i].global_step, ls[i].loss) for i in range(nl.value)])
+
+    def q_values(self, obs):
+        obs = np.asfortranarray(obs, np.float64)
+        if obs.ndim == 1:
+            obs = obs[:, None]
+        n = obs.shape[1]
+        q = np.zeros((2, n), np.float64, order="F")
+        check(self._L.crl_dqn_q_values(self._h, _ptr(obs, C.c_double), n, _ptr(q, C.c_double)))
+        return q

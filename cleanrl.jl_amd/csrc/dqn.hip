@@ -1,0 +1,477 @@
+// dqn.hip — src/algorithms/dqn.jl on the GPU (C ABI: the crl_dqn_* block of include/cleanrl_hip.h).
+//
+// The reference interleaves ONE CartPoleEnv{Float64} step with a 120-sample update every train_freq steps. The whole
+// `for global_step` body (dqn.jl:57-119) runs here as ONE persistent 1024-thread workgroup per call: ε-greedy action
+// (q_net forward only on greedy steps), env step, ring-buffer add, episode bookkeeping, and — every train_freq steps — the
+// minibatch draw without replacement, both forwards, TD target, Flux.mse, the pullbacks, Adam and the hard target copy.
+// Float64 arithmetic with Float32 weights like the reference (see a2c.hip); relu has no transcendental, every sum runs
+// in the oracle's order with contraction off ⇒ the run is BIT-IDENTICAL to oracle/dqn_oracle.c.
+// An update is ≈5 MFLOP: spreading it over more CUs would cost a grid-wide barrier per layer per step; one CU's
+// 16 waves with __syncthreads() is the latency-optimal shape for a loop whose steps all depend on the previous one.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "common.hpp"
+#include "ppo_ctx.hpp"
+
+struct crl_dqn;
+
+namespace crl {
+
+constexpr int QH1 = 120, QH2 = 84, QD = 4, QA = 2;
+constexpr int QoW1 = 0, Qob1 = QH1 * QD, QoW2 = Qob1 + QH1, Qob2 = QoW2 + QH2 * QH1, QoW3 = Qob2 + QH2, Qob3 = QoW3 + QA * QH2;
+constexpr int QP = Qob3 + QA;
+static_assert(QP == CRL_DQN_PARAM_COUNT, "parameter count");
+constexpr int DQN_MAX_EPS = 8192, DQN_MAX_LOSSES = 4096, DQN_MAX_BATCH = 1024, DQN_MAX_CAP = 1 << 18;
+
+struct DQNCtl {
+  double env[4]; double episode_return, last_loss;
+  int64_t global_step, episode_length, n_updates, taken, ptr, size;
+  int32_t env_t, n_eps, n_losses, pad;
+};
+
+struct DQNDev {
+  crl_dqn_config cfg;
+  float *q, *t, *grads, *m, *v; double* betap;
+  DQNCtl* ctl; crl_dqn_episode* eps; crl_dqn_loss_record* losses;
+  double *rb_state, *rb_next, *rb_reward; int32_t* rb_action; uint8_t* rb_terminal;
+  double *H1, *H2, *Q, *dz, *sq, *d2, *d1;   // [2][120·k], [2][84·k], [2][2·k], [k], [k], [84·k], [120·k]
+};
+
+// CartPoleEnv{Float64}: shared with a2c.hip's restatement (oracle: a2c_cartpole_step)
+__device__ __forceinline__ double dq_sin64(double x) {
+  const double c[10] = {-1.0 / 6, 1.0 / 120, -1.0 / 5040, 1.0 / 362880, -1.0 / 39916800, 1.0 / 6227020800.0,
+                        -1.0 / 1307674368000.0, 1.0 / 355687428096000.0, -1.0 / 121645100408832000.0,
+                        1.0 / 51090942171709440000.0};
+  const double x2 = x * x;
+  double p = c[9];
+#pragma unroll
+  for (int i = 8; i >= 0; --i) p = __builtin_fma(p, x2, c[i]);
+  return __builtin_fma(x * x2, p, x);
+}
+__device__ __forceinline__ double dq_cos64(double x) {
+  const double c[10] = {-0.5, 1.0 / 24, -1.0 / 720, 1.0 / 40320, -1.0 / 3628800, 1.0 / 479001600.0,
+                        -1.0 / 87178291200.0, 1.0 / 20922789888000.0, -1.0 / 6402373705728000.0,
+                        1.0 / 2432902008176640000.0};
+  const double x2 = x * x;
+  double p = c[9];
+#pragma unroll
+  for (int i = 8; i >= 0; --i) p = __builtin_fma(p, x2, c[i]);
+  return __builtin_fma(x2, p, 1.0);
+}
+__device__ __forceinline__ bool dq_cartpole_step(double* s, int& t, int action, int max_steps) {
+#pragma clang fp contract(off)
+  const double gravity = 9.8, masspole = 0.1, totalmass = 1.1, halflength = 0.5, pml = 0.05;
+  const double forcemag = 10.0, dt = 0.02, ththr = 12.0 * 2.0 * 3.141592653589793 / 360.0, xthr = 2.4;
+  t += 1;
+  const double force = action == 1 ? forcemag : -forcemag;
+  const double xdot = s[1], theta = s[2], thetadot = s[3];
+  const double costheta = dq_cos64(theta), sintheta = dq_sin64(theta);
+  const double tmp = (force + pml * thetadot * thetadot * sintheta) / totalmass;
+  const double thetaacc = (gravity * sintheta - costheta * tmp) / (halflength * (4.0 / 3.0 - masspole * costheta * costheta / totalmass));
+  const double xacc = tmp - pml * thetaacc * costheta / totalmass;
+  s[0] += dt * xdot;
+  s[1] += dt * xacc;
+  s[2] += dt * thetadot;
+  s[3] += dt * thetaacc;
+  return (fabs(s[0]) > xthr) || (fabs(s[2]) > ththr) || (t > max_steps);
+}
+__device__ __forceinline__ void dq_env_reset(double* s, uint64_t seed, uint64_t gstep, uint32_t stream) {
+#pragma clang fp contract(off)
+  for (int i = 0; i < 4; ++i) s[i] = 0.1 * u53(philox_env(seed, (uint32_t)i, gstep, stream)) - 0.05;
+}
+__device__ __forceinline__ double dq_linear_schedule(double start_e, double end_e, double duration, double t) {
+#pragma clang fp contract(off)
+  const double slope = (end_e - start_e) / duration;
+  const double v = slope * t + start_e;
+  return v > end_e ? v : end_e;
+}
+
+__global__ void __launch_bounds__(1024) dqn_run_kernel(DQNDev a, int64_t max_env_steps) {
+#pragma clang fp contract(off)
+  __shared__ DQNCtl c;
+  __shared__ double obs[QD], h1s[QH1], h2s[QH2], qs[QA];
+  __shared__ int go, need_q, train, action_s, got, cbase;
+  __shared__ double eps_s;
+  __shared__ uint32_t bitmap[DQN_MAX_CAP / 32];
+  __shared__ int cand[1024];
+  __shared__ int idx[DQN_MAX_BATCH];
+  const int tid = threadIdx.x, nth = blockDim.x;
+  const int k = (int)a.cfg.batch_size;
+  if (tid == 0) { c = *a.ctl; c.n_eps = 0; c.n_losses = 0; c.taken = 0; }
+  __syncthreads();
+  while (true) {
+    if (tid == 0) {
+      go = (c.taken < max_env_steps && c.global_step < a.cfg.total_timesteps) ? 1 : 0;
+      if (go) {
+        c.global_step += 1; c.taken += 1;                                            // dqn.jl:57
+        const uint64_t gstep = (uint64_t)c.global_step;
+        for (int i = 0; i < QD; ++i) obs[i] = c.env[i];                              // dqn.jl:58
+        eps_s = dq_linear_schedule(a.cfg.epsilon_start, a.cfg.epsilon_end, a.cfg.epsilon_duration, (double)c.global_step);
+        if (u53(philox_env(a.cfg.seed, 0u, gstep, 0u)) < eps_s) {                    // dqn.jl:61-62
+          need_q = 0;
+          action_s = (int)(philox_env(a.cfg.seed, 0u, gstep, 4u).x >> 31);
+        } else need_q = 1;
+      }
+    }
+    __syncthreads();
+    if (!go) break;
+    const uint64_t gstep = (uint64_t)c.global_step;
+    if (need_q) {                                                                    // dqn.jl:64 qs = q_net(obs)
+      if (tid < QH1) {
+        double acc = 0.0;
+        for (int kk = 0; kk < QD; ++kk) acc += (double)a.q[QoW1 + tid + QH1 * kk] * obs[kk];
+        acc += (double)a.q[Qob1 + tid];
+        h1s[tid] = acc > 0.0 ? acc : 0.0;
+      }
+      __syncthreads();
+      if (tid < QH2) {
+        double acc = 0.0;
+        for (int kk = 0; kk < QH1; ++kk) acc += (double)a.q[QoW2 + tid + QH2 * kk] * h1s[kk];
+        acc += (double)a.q[Qob2 + tid];
+        h2s[tid] = acc > 0.0 ? acc : 0.0;
+      }
+      __syncthreads();
+      if (tid < QA) {
+        double acc = 0.0;
+        for (int kk = 0; kk < QH2; ++kk) acc += (double)a.q[QoW3 + tid + QA * kk] * h2s[kk];
+        qs[tid] = acc + (double)a.q[Qob3 + tid];
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const int action = need_q ? (qs[1] > qs[0] ? 1 : 0) : action_s;               // dqn.jl:65 argmax: first maximum
+      const bool done = dq_cartpole_step(c.env, c.env_t, action, a.cfg.max_steps);  // dqn.jl:68
+      const double rew = done ? 0.0 : 1.0;
+      const size_t p = (size_t)c.ptr;                                                // dqn.jl:71-78 Buffer.add!
+      for (int i = 0; i < QD; ++i) { a.rb_state[QD * p + i] = obs[i]; a.rb_next[QD * p + i] = c.env[i]; }
+      a.rb_action[p] = action; a.rb_reward[p] = rew; a.rb_terminal[p] = done ? 1 : 0;
+      c.ptr = c.ptr + 1 >= a.cfg.buffer_size ? 0 : c.ptr + 1;
+      c.size = c.size + 1 > a.cfg.buffer_size ? a.cfg.buffer_size : c.size + 1;
+      c.episode_return += rew; c.episode_length += 1;                               // dqn.jl:81-82
+      if (done) {                                                                    // dqn.jl:83-90
+        if (c.n_eps < DQN_MAX_EPS) {
+          a.eps[c.n_eps].episode_return = c.episode_return; a.eps[c.n_eps].episode_length = c.episode_length;
+          a.eps[c.n_eps].global_step = c.global_step; a.eps[c.n_eps].epsilon = eps_s;
+        }
+        c.n_eps += 1;
+        c.episode_length = 0; c.episode_return = 0.0;
+        dq_env_reset(c.env, a.cfg.seed, gstep, 1); c.env_t = 0;
+      }
+      train = (c.global_step > a.cfg.min_buff_size && c.global_step % a.cfg.train_freq == 0) ? 1 : 0;   // dqn.jl:93
+      got = 0; cbase = 0;
+    }
+    __syncthreads();
+    if (!train) continue;
+
+    // ---- Buffer.sample(rb, batch_size) (dqn.jl:94): self-avoiding draws, candidates in counter order ----
+    const int n = (int)c.size;
+    for (int w = tid; w < (n + 31) / 32; w += nth) bitmap[w] = 0u;
+    __syncthreads();
+    while (got < k) {
+      {
+        const uint32_t cc = (uint32_t)(cbase + tid);
+        const u32x4 o = philox(cc, (uint32_t)gstep, (uint32_t)(gstep >> 32), 0xD9u, (uint32_t)a.cfg.seed, (uint32_t)(a.cfg.seed >> 32));
+        cand[tid] = (int)(((uint64_t)o.x * (uint64_t)n) >> 32);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int g = got;
+        for (int i = 0; i < nth && g < k; ++i) {
+          const int j = cand[i];
+          if (!((bitmap[j >> 5] >> (j & 31)) & 1u)) { bitmap[j >> 5] |= 1u << (j & 31); idx[g++] = j; }
+        }
+        got = g; cbase += nth;
+      }
+      __syncthreads();
+    }
+
+    // ---- forward: target_net(next_state) and q_net(state) (dqn.jl:99,104) ----
+    for (int o = tid; o < 2 * QH1 * k; o += nth) {
+      const int net = o / (QH1 * k), r = o - net * (QH1 * k), b = r / QH1, i = r - b * QH1;
+      const float* p = net ? a.t : a.q;
+      const double* x = (net ? a.rb_next : a.rb_state) + (size_t)QD * idx[b];
+      double acc = 0.0;
+      for (int kk = 0; kk < QD; ++kk) acc += (double)p[QoW1 + i + QH1 * kk] * x[kk];
+      acc += (double)p[Qob1 + i];
+      a.H1[(size_t)net * QH1 * k + r] = acc > 0.0 ? acc : 0.0;
+    }
+    __syncthreads();
+    for (int o = tid; o < 2 * QH2 * k; o += nth) {
+      const int net = o / (QH2 * k), r = o - net * (QH2 * k), b = r / QH2, j = r - b * QH2;
+      const float* p = net ? a.t : a.q;
+      const double* h = a.H1 + (size_t)net * QH1 * k + (size_t)QH1 * b;
+      double acc = 0.0;
+      for (int kk = 0; kk < QH1; ++kk) acc += (double)p[QoW2 + j + QH2 * kk] * h[kk];
+      acc += (double)p[Qob2 + j];
+      a.H2[(size_t)net * QH2 * k + r] = acc > 0.0 ? acc : 0.0;
+    }
+    __syncthreads();
+    for (int o = tid; o < 2 * QA * k; o += nth) {
+      const int net = o / (QA * k), r = o - net * (QA * k), b = r / QA, aa = r - b * QA;
+      const float* p = net ? a.t : a.q;
+      const double* h = a.H2 + (size_t)net * QH2 * k + (size_t)QH2 * b;
+      double acc = 0.0;
+      for (int kk = 0; kk < QH2; ++kk) acc += (double)p[QoW3 + aa + QA * kk] * h[kk];
+      a.Q[(size_t)net * QA * k + r] = acc + (double)p[Qob3 + aa];
+    }
+    __syncthreads();
+    // ---- TD target, mse, output cotangent (dqn.jl:99-107) ----
+    for (int b = tid; b < k; b += nth) {
+      const double tq0 = a.Q[(size_t)QA * k + QA * b], tq1 = a.Q[(size_t)QA * k + QA * b + 1];
+      const double next_q = tq1 > tq0 ? tq1 : tq0;
+      const double td = a.rb_reward[idx[b]] + a.cfg.gamma * next_q * (1.0 - (double)a.rb_terminal[idx[b]]);
+      const double diff = td - a.Q[QA * b + a.rb_action[idx[b]]];
+      a.sq[b] = diff * diff;
+      a.dz[b] = -2.0 * diff / (double)k;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double loss = 0.0;
+      for (int b = 0; b < k; ++b) loss += a.sq[b];
+      c.last_loss = loss / (double)k;
+    }
+    // ---- pullbacks ----
+    for (int o = tid; o < QH2 * k; o += nth) {
+      const int b = o / QH2, j = o - b * QH2;
+      const double s = (double)a.q[QoW3 + a.rb_action[idx[b]] + QA * j] * a.dz[b];
+      a.d2[o] = a.H2[o] > 0.0 ? s : 0.0;
+    }
+    __syncthreads();
+    for (int o = tid; o < QH1 * k; o += nth) {
+      const int b = o / QH1, kk = o - b * QH1;
+      const double* dd = a.d2 + (size_t)QH2 * b;
+      double s = 0.0;
+      for (int j = 0; j < QH2; ++j) s += (double)a.q[QoW2 + j + QH2 * kk] * dd[j];
+      a.d1[o] = a.H1[o] > 0.0 ? s : 0.0;
+    }
+    __syncthreads();
+    for (int p = tid; p < QP; p += nth) {     // one parameter per thread, samples summed in sample order
+      double g = 0.0;
+      if (p < Qob1) { const int i = p % QH1, kk = p / QH1; for (int b = 0; b < k; ++b) g += a.d1[(size_t)QH1 * b + i] * a.rb_state[(size_t)QD * idx[b] + kk]; }
+      else if (p < QoW2) { const int i = p - Qob1; for (int b = 0; b < k; ++b) g += a.d1[(size_t)QH1 * b + i]; }
+      else if (p < Qob2) { const int r = p - QoW2, j = r % QH2, kk = r / QH2; for (int b = 0; b < k; ++b) g += a.d2[(size_t)QH2 * b + j] * a.H1[(size_t)QH1 * b + kk]; }
+      else if (p < QoW3) { const int j = p - Qob2; for (int b = 0; b < k; ++b) g += a.d2[(size_t)QH2 * b + j]; }
+      else if (p < Qob3) { const int r = p - QoW3, aa = r % QA, j = r / QA; for (int b = 0; b < k; ++b) if (a.rb_action[idx[b]] == aa) g += a.dz[b] * a.H2[(size_t)QH2 * b + j]; }
+      else { const int aa = p - Qob3; for (int b = 0; b < k; ++b) if (a.rb_action[idx[b]] == aa) g += a.dz[b]; }
+      a.grads[p] = (float)g;
+    }
+    __syncthreads();
+    // ---- Flux Adam(lr) (dqn.jl:41,109): per-array β powers, Float32 state, Float64 scalar math ----
+    for (int p = tid; p < QP; p += nth) {
+      const int arr = p < Qob1 ? 0 : p < QoW2 ? 1 : p < Qob2 ? 2 : p < QoW3 ? 3 : p < Qob3 ? 4 : 5;
+      const double b1 = 0.9, b2 = 0.999, epsn = 1e-8;
+      const double bp0 = a.betap[2 * arr], bp1 = a.betap[2 * arr + 1];
+      const double gg = (double)a.grads[p];
+      const float mi = (float)(b1 * (double)a.m[p] + (1 - b1) * gg);
+      const float vi = (float)(b2 * (double)a.v[p] + (1 - b2) * gg * gg);
+      a.m[p] = mi; a.v[p] = vi;
+      const double delta = (double)mi / (1 - bp0) / (sqrt((double)vi / (1 - bp1)) + epsn) * a.cfg.lr;
+      a.q[p] = a.q[p] - (float)delta;
+    }
+    __syncthreads();
+    if (tid < 12) a.betap[tid] = a.betap[tid] * ((tid & 1) ? 0.999 : 0.9);
+    if (c.global_step % a.cfg.target_net_freq == 0)                                  // dqn.jl:111-113
+      for (int p = tid; p < QP; p += nth) a.t[p] = a.q[p];
+    if (tid == 0) {
+      c.n_updates += 1;
+      if (c.global_step % a.cfg.log_frequency == 0) {                                // dqn.jl:115-117
+        if (c.n_losses < DQN_MAX_LOSSES) { a.losses[c.n_losses].global_step = c.global_step; a.losses[c.n_losses].loss = c.last_loss; }
+        c.n_losses += 1;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *a.ctl = c;
+}
+
+__global__ void dqn_init_kernel(DQNDev a) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  DQNCtl c;
+  memset(&c, 0, sizeof(c));
+  dq_env_reset(c.env, a.cfg.seed, 0, 2);                                             // dqn.jl:56 reset!(env)
+  *a.ctl = c;
+}
+
+// q_net(obs) on caller-supplied observations: one thread per (observation, layer unit) would be overkill — a wave per
+// observation, lanes striding the units
+__global__ void __launch_bounds__(128) dqn_q_kernel(const float* __restrict__ q, const double* __restrict__ obs, int n, double* __restrict__ out) {
+#pragma clang fp contract(off)
+  __shared__ double h1s[QH1], h2s[QH2];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (b >= n) return;
+  if (tid < QH1) {
+    double acc = 0.0;
+    for (int kk = 0; kk < QD; ++kk) acc += (double)q[QoW1 + tid + QH1 * kk] * obs[(size_t)QD * b + kk];
+    acc += (double)q[Qob1 + tid];
+    h1s[tid] = acc > 0.0 ? acc : 0.0;
+  }
+  __syncthreads();
+  if (tid < QH2) {
+    double acc = 0.0;
+    for (int kk = 0; kk < QH1; ++kk) acc += (double)q[QoW2 + tid + QH2 * kk] * h1s[kk];
+    acc += (double)q[Qob2 + tid];
+    h2s[tid] = acc > 0.0 ? acc : 0.0;
+  }
+  __syncthreads();
+  if (tid < QA) {
+    double acc = 0.0;
+    for (int kk = 0; kk < QH2; ++kk) acc += (double)q[QoW3 + tid + QA * kk] * h2s[kk];
+    out[(size_t)QA * b + tid] = acc + (double)q[Qob3 + tid];
+  }
+}
+
+}  // namespace crl
+
+struct crl_dqn {
+  crl_dqn_config cfg;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  crl::DQNDev d;
+  void* stage = nullptr; size_t stage_bytes = 0;
+};
+
+using namespace crl;
+
+#define DQN_GUARD(h)                                          \
+  if (!(h)) { set_error("null crl_dqn handle"); return 1; }   \
+  CRL_HIP_CHECK(hipSetDevice((h)->device));
+
+template <typename T>
+static int qalloc(T** p, size_t n) {
+  CRL_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)));
+  CRL_HIP_CHECK(hipMemset(*p, 0, n * sizeof(T)));
+  return 0;
+}
+
+extern "C" {
+
+int32_t crl_dqn_create(const crl_dqn_config* cfg, int32_t device, crl_dqn** out) {
+  if (!cfg || !out) { set_error("crl_dqn_create: null argument"); return 1; }
+  *out = nullptr;
+  if (cfg->batch_size < 1 || cfg->batch_size > DQN_MAX_BATCH) { set_error("crl_dqn_create: batch_size must be in 1..1024"); return 1; }
+  if (cfg->buffer_size < cfg->batch_size || cfg->buffer_size > DQN_MAX_CAP) { set_error("crl_dqn_create: buffer_size must be in batch_size..262144"); return 1; }
+  if (cfg->min_buff_size < cfg->batch_size) {
+    set_error("crl_dqn_create: min_buff_size must be >= batch_size (Buffer.sample asserts n <= rb.size, replay_buffer.jl:41)"); return 1;
+  }
+  if (cfg->train_freq < 1 || cfg->target_net_freq < 1 || cfg->log_frequency < 1 || cfg->max_steps < 1 || cfg->total_timesteps < 0 ||
+      !(cfg->epsilon_duration > 0.0)) { set_error("crl_dqn_create: bad frequencies / sizes"); return 1; }
+  int ndev = 0;
+  CRL_HIP_CHECK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) { set_error("crl_dqn_create: no such HIP device (no GPU → no CPU fallback)"); return 1; }
+  CRL_HIP_CHECK(hipSetDevice(device));
+  crl_dqn* h = new (std::nothrow) crl_dqn();
+  if (!h) { set_error("out of host memory"); return 1; }
+  h->cfg = *cfg; h->device = device;
+  memset(&h->d, 0, sizeof(h->d));
+  h->d.cfg = *cfg;
+  hipError_t se = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (se != hipSuccess) { set_error(std::string("hipStreamCreate: ") + hipGetErrorString(se)); delete h; return 1; }
+  const size_t cap = (size_t)cfg->buffer_size, k = (size_t)cfg->batch_size;
+  DQNDev& d = h->d;
+  int rc = 0;
+  rc |= qalloc(&d.q, QP); rc |= qalloc(&d.t, QP); rc |= qalloc(&d.grads, QP); rc |= qalloc(&d.m, QP); rc |= qalloc(&d.v, QP);
+  rc |= qalloc(&d.betap, 12); rc |= qalloc(&d.ctl, 1); rc |= qalloc(&d.eps, DQN_MAX_EPS); rc |= qalloc(&d.losses, DQN_MAX_LOSSES);
+  rc |= qalloc(&d.rb_state, cap * QD); rc |= qalloc(&d.rb_next, cap * QD); rc |= qalloc(&d.rb_reward, cap);
+  rc |= qalloc(&d.rb_action, cap); rc |= qalloc(&d.rb_terminal, cap);
+  rc |= qalloc(&d.H1, 2 * QH1 * k); rc |= qalloc(&d.H2, 2 * QH2 * k); rc |= qalloc(&d.Q, 2 * QA * k);
+  rc |= qalloc(&d.dz, k); rc |= qalloc(&d.sq, k); rc |= qalloc(&d.d2, QH2 * k); rc |= qalloc(&d.d1, QH1 * k);
+  if (rc) { crl_dqn_destroy(h); return 1; }
+  double bp[12];
+  for (int i = 0; i < 6; ++i) { bp[2 * i] = 0.9; bp[2 * i + 1] = 0.999; }
+  CRL_HIP_CHECK(hipMemcpy(d.betap, bp, sizeof(bp), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(dqn_init_kernel, dim3(1), dim3(1), 0, h->stream, d);
+  CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  *out = h;
+  return 0;
+}
+
+int32_t crl_dqn_destroy(crl_dqn* h) {
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  DQNDev& d = h->d;
+  void* ptrs[] = {d.q, d.t, d.grads, d.m, d.v, d.betap, d.ctl, d.eps, d.losses, d.rb_state, d.rb_next, d.rb_reward, d.rb_action,
+                  d.rb_terminal, d.H1, d.H2, d.Q, d.dz, d.sq, d.d2, d.d1, h->stage};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return 0;
+}
+
+int32_t crl_dqn_write_params(crl_dqn* h, const float* q_params, size_t n) {
+  DQN_GUARD(h);
+  if (!q_params || n != (size_t)QP) { set_error("crl_dqn_write_params: expected 10934 floats"); return 1; }
+  CRL_HIP_CHECK(hipMemcpyAsync(h->d.q, q_params, n * 4, hipMemcpyHostToDevice, h->stream));
+  CRL_HIP_CHECK(hipMemcpyAsync(h->d.t, q_params, n * 4, hipMemcpyHostToDevice, h->stream));   // dqn.jl:40 deepcopy(q_net)
+  CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+int32_t crl_dqn_read_params(crl_dqn* h, float* q_params, float* target_params, size_t n) {
+  DQN_GUARD(h);
+  if (!q_params || n != (size_t)QP) { set_error("crl_dqn_read_params: expected 10934 floats"); return 1; }
+  CRL_HIP_CHECK(hipMemcpyAsync(q_params, h->d.q, n * 4, hipMemcpyDeviceToHost, h->stream));
+  if (target_params) CRL_HIP_CHECK(hipMemcpyAsync(target_params, h->d.t, n * 4, hipMemcpyDeviceToHost, h->stream));
+  CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+int32_t crl_dqn_status_read(crl_dqn* h, crl_dqn_status* out) {
+  DQN_GUARD(h);
+  if (!out) { set_error("null argument"); return 1; }
+  DQNCtl c;
+  CRL_HIP_CHECK(hipMemcpyAsync(&c, h->d.ctl, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+  CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < 4; ++i) out->env_state[i] = c.env[i];
+  out->global_step = c.global_step; out->rb_size = c.size; out->n_updates = c.n_updates; out->last_loss = c.last_loss;
+  return 0;
+}
+
+int32_t crl_dqn_run(crl_dqn* h, int64_t max_env_steps, crl_dqn_episode* eps, int32_t max_eps, int32_t* n_eps,
+                    crl_dqn_loss_record* losses, int32_t max_losses, int32_t* n_losses, int64_t* steps_taken) {
+  DQN_GUARD(h);
+  if (!n_eps || !n_losses || max_eps < 0 || max_losses < 0 || (max_eps > 0 && !eps) || (max_losses > 0 && !losses)) {
+    set_error("crl_dqn_run: bad arguments"); return 1;
+  }
+  *n_eps = 0; *n_losses = 0;
+  if (steps_taken) *steps_taken = 0;
+  if (max_env_steps <= 0) return 0;
+  hipLaunchKernelGGL(dqn_run_kernel, dim3(1), dim3(1024), 0, h->stream, h->d, max_env_steps);
+  CRL_HIP_CHECK(hipGetLastError());
+  DQNCtl c;
+  CRL_HIP_CHECK(hipMemcpyAsync(&c, h->d.ctl, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+  CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  if (steps_taken) *steps_taken = c.taken;
+  int ne = c.n_eps < DQN_MAX_EPS ? c.n_eps : DQN_MAX_EPS; if (ne > max_eps) ne = max_eps;
+  int nl = c.n_losses < DQN_MAX_LOSSES ? c.n_losses : DQN_MAX_LOSSES; if (nl > max_losses) nl = max_losses;
+  if (ne > 0) CRL_HIP_CHECK(hipMemcpyAsync(eps, h->d.eps, sizeof(crl_dqn_episode) * (size_t)ne, hipMemcpyDeviceToHost, h->stream));
+  if (nl > 0) CRL_HIP_CHECK(hipMemcpyAsync(losses, h->d.losses, sizeof(crl_dqn_loss_record) * (size_t)nl, hipMemcpyDeviceToHost, h->stream));
+  CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  *n_eps = ne; *n_losses = nl;
+  return 0;
+}
+
+int32_t crl_dqn_q_values(crl_dqn* h, const double* obs, int32_t n, double* q) {
+  DQN_GUARD(h);
+  if (n < 0 || (n > 0 && (!obs || !q))) { set_error("crl_dqn_q_values: bad arguments"); return 1; }
+  if (n == 0) return 0;
+  const size_t N = (size_t)n, need = N * (QD + QA) * 8;
+  if (h->stage_bytes < need) {
+    if (h->stage) CRL_HIP_CHECK(hipFree(h->stage));
+    h->stage = nullptr; h->stage_bytes = 0;
+    CRL_HIP_CHECK(hipMalloc(&h->stage, need));
+    h->stage_bytes = need;
+  }
+  double* so = static_cast<double*>(h->stage);
+  double* sq = so + N * QD;
+  CRL_HIP_CHECK(hipMemcpyAsync(so, obs, N * QD * 8, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(dqn_q_kernel, dim3(n), dim3(128), 0, h->stream, h->d.q, so, n, sq);
+  CRL_HIP_CHECK(hipGetLastError());
+  CRL_HIP_CHECK(hipMemcpyAsync(q, sq, N * QA * 8, hipMemcpyDeviceToHost, h->stream));
+  CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+}  // extern "C"

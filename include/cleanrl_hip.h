@@ -213,6 +213,40 @@ int32_t crl_a2c_run_until_update(crl_a2c* h, int64_t max_env_steps, crl_a2c_trai
 int32_t crl_a2c_discounted_future_rewards(int32_t device, const double* rewards, const uint8_t* terminals, int32_t n,
                                           double final_value, double gamma, double* out);
 
+/* =====================================================================================================
+ * DQN: src/algorithms/dqn.jl on the GPU. One on-device CartPoleEnv{Float64} (max_steps = 200),
+ * q / target networks Chain(Dense(4,120,relu), Dense(120,84,relu), Dense(84,2)) (dqn.jl:22-26) with Float32 weights and
+ * Float64 arithmetic like the reference, replay ring, ε-greedy schedule, minibatch drawn without replacement, TD target,
+ * Flux.mse, Adam (no ClipNorm), hard target copy — the whole `for global_step` loop runs in one persistent launch per call.
+ * ===================================================================================================== */
+typedef struct crl_dqn_config {   /* DQNConfig, dqn.jl:1-19 */
+  int64_t log_frequency, total_timesteps, buffer_size, min_buff_size;
+  double lr;
+  int64_t train_freq, target_net_freq, batch_size;
+  double gamma, epsilon_start, epsilon_end, epsilon_duration;
+  int32_t max_steps;              /* dqn.jl:37 CartPoleEnv(): 200 */
+  int32_t pad;
+  uint64_t seed;
+} crl_dqn_config;
+typedef struct crl_dqn_episode { double episode_return; int64_t episode_length, global_step; double epsilon; } crl_dqn_episode; /* dqn.jl:88 */
+typedef struct crl_dqn_loss_record { int64_t global_step; double loss; } crl_dqn_loss_record;                                  /* dqn.jl:116 */
+typedef struct crl_dqn_status { double env_state[4]; int64_t global_step, rb_size, n_updates; double last_loss; } crl_dqn_status;
+typedef struct crl_dqn crl_dqn;
+#define CRL_DQN_PARAM_COUNT 10934 /* W1(120,4) b1 W2(84,120) b2 W3(2,84) b3 — Flux.params(q_net) order, (out,in) col-major */
+
+int32_t crl_dqn_create(const crl_dqn_config* cfg, int32_t device, crl_dqn** out);          /* dqn.jl:34-56 */
+int32_t crl_dqn_destroy(crl_dqn* h);
+int32_t crl_dqn_write_params(crl_dqn* h, const float* q_params, size_t n);                  /* q_net; target_net = deepcopy(q_net) */
+int32_t crl_dqn_read_params(crl_dqn* h, float* q_params, float* target_params, size_t n);   /* target_params may be NULL */
+int32_t crl_dqn_status_read(crl_dqn* h, crl_dqn_status* out);
+/* dqn.jl:57-119: up to max_env_steps iterations of the loop (or to total_timesteps) in ONE launch. Episode records
+ * (dqn.jl:88) and the "Training Statistics" losses of steps that are multiples of log_frequency (dqn.jl:115-117) come
+ * back in eps / losses (entries beyond max_* are dropped). */
+int32_t crl_dqn_run(crl_dqn* h, int64_t max_env_steps, crl_dqn_episode* eps, int32_t max_eps, int32_t* n_eps,
+                    crl_dqn_loss_record* losses, int32_t max_losses, int32_t* n_losses, int64_t* steps_taken);
+/* q_net(obs) for n observations (4, n) Float64 → (2, n) Float64 (dqn.jl:64) */
+int32_t crl_dqn_q_values(crl_dqn* h, const double* obs, int32_t n, double* q);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,7 +47,7 @@ class OrcState(C.Structure):
 
 
 def build(force=False):
-    srcs = [os.path.join(_ROOT, "oracle", f) for f in ("ppo_oracle.c", "ppo_oracle.h", "a2c_oracle.c", "a2c_oracle.h")]
+    srcs = [os.path.join(_ROOT, "oracle", f) for f in ("ppo_oracle.c", "ppo_oracle.h", "a2c_oracle.c", "a2c_oracle.h", "dqn_oracle.c", "dqn_oracle.h")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle"), "-s"])
     return _SO
@@ -412,3 +412,119 @@ class A2CState:
     def close(self):
         if self.ptr:
             self.L.a2c_destroy(self.ptr); self.ptr = None
+
+
+# ---------------------------------------------------------------------------------------------------------
+# DQN oracle (oracle/dqn_oracle.c — dqn.jl restated)
+# ---------------------------------------------------------------------------------------------------------
+DQN_P = 120 * 4 + 120 + 84 * 120 + 84 + 2 * 84 + 2
+DQN_OFF = np.cumsum([0, 480, 120, 10080, 84, 168, 2])
+
+
+class DQNConfigC(C.Structure):
+    _fields_ = [("log_frequency", C.c_int64), ("total_timesteps", C.c_int64), ("buffer_size", C.c_int64), ("min_buff_size", C.c_int64),
+                ("lr", C.c_double), ("train_freq", C.c_int64), ("target_net_freq", C.c_int64), ("batch_size", C.c_int64),
+                ("gamma", C.c_double), ("epsilon_start", C.c_double), ("epsilon_end", C.c_double), ("epsilon_duration", C.c_double),
+                ("max_steps", C.c_int32), ("pad", C.c_int32), ("seed", C.c_uint64)]
+
+
+class DQNEpisode(C.Structure):
+    _fields_ = [("episode_return", C.c_double), ("episode_length", C.c_int64), ("global_step", C.c_int64), ("epsilon", C.c_double)]
+
+
+class DQNLossRecord(C.Structure):
+    _fields_ = [("global_step", C.c_int64), ("loss", C.c_double)]
+
+
+_dqn_ready = False
+
+
+def dqn_lib():
+    global _dqn_ready
+    L = lib()
+    if not _dqn_ready:
+        dp, fp, ip, u8p, i64p = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.POINTER(C.c_int64)
+        cp = C.POINTER(DQNConfigC)
+        L.dqn_create.restype = C.c_void_p; L.dqn_create.argtypes = [cp]
+        L.dqn_destroy.argtypes = [C.c_void_p]
+        L.dqn_set_params.argtypes = [C.c_void_p, fp]; L.dqn_get_params.argtypes = [C.c_void_p, fp, fp]
+        L.dqn_get_env.argtypes = [C.c_void_p, dp, i64p, i64p, dp, i64p]
+        L.dqn_run.restype = C.c_int64
+        L.dqn_run.argtypes = [C.c_void_p, C.c_int64, C.POINTER(DQNEpisode), C.c_int32, ip, C.POINTER(DQNLossRecord), C.c_int32, ip]
+        L.dqn_linear_schedule.restype = C.c_double; L.dqn_linear_schedule.argtypes = [C.c_double] * 4
+        L.dqn_forward.argtypes = [fp, dp, dp]
+        L.dqn_loss_grads.restype = C.c_double
+        L.dqn_loss_grads.argtypes = [fp, fp, dp, dp, ip, dp, u8p, C.c_int32, C.c_double, fp]
+        L.dqn_sample_indices.argtypes = [C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, ip]
+        _dqn_ready = True
+    return L
+
+
+def dqn_config(log_frequency=1000, total_timesteps=500_000, buffer_size=10_000, min_buff_size=200, lr=1e-4, train_freq=10,
+               target_net_freq=100, batch_size=120, gamma=0.99, epsilon_start=1.0, epsilon_end=0.05, epsilon_duration=10_000.0,
+               max_steps=200, seed=0x5EED):
+    return DQNConfigC(log_frequency, total_timesteps, buffer_size, min_buff_size, lr, train_freq, target_net_freq, batch_size, gamma,
+                      epsilon_start, epsilon_end, epsilon_duration, max_steps, 0, seed)
+
+
+def dqn_params(seed=0):
+    """Flux Dense default init [3P-memory]: glorot_uniform Float32 weights, zero biases. Flux's RNG stream is not
+    reproducible here — weights are an INPUT of both sides."""
+    rng = np.random.default_rng(seed)
+    out = np.zeros(DQN_P, np.float32)
+    for i, (rows, cols) in zip((0, 2, 4), ((120, 4), (84, 120), (2, 84))):
+        lim = np.sqrt(6.0 / (rows + cols))
+        out[DQN_OFF[i]:DQN_OFF[i + 1]] = rng.uniform(-lim, lim, rows * cols).astype(np.float32)
+    return out
+
+
+def dqn_forward(params, x):
+    params = np.ascontiguousarray(params, np.float32); x = np.ascontiguousarray(x, np.float64)
+    q = np.zeros(2, np.float64)
+    dqn_lib().dqn_forward(_p(params, C.c_float), _p(x, C.c_double), _p(q, C.c_double))
+    return q
+
+
+def dqn_loss_grads(q_params, t_params, state, next_state, action, reward, terminal, gamma):
+    qp = np.ascontiguousarray(q_params, np.float32); tp = np.ascontiguousarray(t_params, np.float32)
+    st = np.asfortranarray(state, np.float64); nx = np.asfortranarray(next_state, np.float64)
+    a = np.ascontiguousarray(action, np.int32); r = np.ascontiguousarray(reward, np.float64); t = np.ascontiguousarray(terminal, np.uint8)
+    g = np.zeros(DQN_P, np.float32)
+    loss = dqn_lib().dqn_loss_grads(_p(qp, C.c_float), _p(tp, C.c_float), st.ctypes.data_as(C.POINTER(C.c_double)),
+                                    nx.ctypes.data_as(C.POINTER(C.c_double)), _p(a, C.c_int32), _p(r, C.c_double), _p(t, C.c_uint8),
+                                    len(a), gamma, _p(g, C.c_float))
+    return loss, g
+
+
+def dqn_sample_indices(seed, gstep, n, k):
+    out = np.zeros(k, np.int32)
+    dqn_lib().dqn_sample_indices(seed, gstep, n, k, _p(out, C.c_int32))
+    return out
+
+
+class DQNState:
+    def __init__(self, cfg, params):
+        self.cfg = cfg; self.L = dqn_lib()
+        self.ptr = self.L.dqn_create(C.byref(cfg))
+        p = np.ascontiguousarray(params, np.float32); assert p.size == DQN_P
+        self.L.dqn_set_params(self.ptr, _p(p, C.c_float))
+
+    def params(self):
+        q = np.zeros(DQN_P, np.float32); t = np.zeros(DQN_P, np.float32)
+        self.L.dqn_get_params(self.ptr, _p(q, C.c_float), _p(t, C.c_float))
+        return q, t
+
+    def env(self):
+        s = np.zeros(4, np.float64); g = C.c_int64(); n = C.c_int64(); ll = C.c_double(); nu = C.c_int64()
+        self.L.dqn_get_env(self.ptr, _p(s, C.c_double), C.byref(g), C.byref(n), C.byref(ll), C.byref(nu))
+        return dict(state=s, global_step=g.value, rb_size=n.value, last_loss=ll.value, n_updates=nu.value)
+
+    def run(self, max_env_steps, max_eps=8192, max_losses=4096):
+        eps = (DQNEpisode * max_eps)(); ls = (DQNLossRecord * max_losses)(); ne = C.c_int32(); nl = C.c_int32()
+        taken = self.L.dqn_run(self.ptr, max_env_steps, eps, max_eps, C.byref(ne), ls, max_losses, C.byref(nl))
+        return (taken, [(eps[i].episode_return, eps[i].episode_length, eps[i].global_step, eps[i].epsilon) for i in range(ne.value)],
+                [(ls[i].global_step, ls[i].loss) for i in range(nl.value)])
+
+    def close(self):
+        if self.ptr:
+            self.L.dqn_destroy(self.ptr); self.ptr = None
