@@ -25,7 +25,7 @@ constexpr int QH1 = 120, QH2 = 84, QD = 4, QA = 2;
 constexpr int QoW1 = 0, Qob1 = QH1 * QD, QoW2 = Qob1 + QH1, Qob2 = QoW2 + QH2 * QH1, QoW3 = Qob2 + QH2, Qob3 = QoW3 + QA * QH2;
 constexpr int QP = Qob3 + QA;
 static_assert(QP == CRL_DQN_PARAM_COUNT, "parameter count");
-constexpr int DQN_MAX_EPS = 8192, DQN_MAX_LOSSES = 4096, DQN_MAX_BATCH = 1024, DQN_MAX_CAP = 1 << 18;
+constexpr int DQN_MAX_EPS = 8192, DQN_MAX_LOSSES = 4096, DQN_MAX_BATCH = 1024, DQN_MAX_CAP = 1 << 16;
 
 struct DQNCtl {
   double env[4]; double episode_return, last_loss;
@@ -99,8 +99,13 @@ __global__ void __launch_bounds__(1024) dqn_run_kernel(DQNDev a, int64_t max_env
   __shared__ uint32_t bitmap[DQN_MAX_CAP / 32];
   __shared__ int cand[1024];
   __shared__ int idx[DQN_MAX_BATCH];
+  // both networks live in LDS for the whole call (2 x 43.7 KB): every dot product below reads its weights from there;
+  // Adam and the target copy write LDS and HBM
+  __shared__ float wq[QP];
+  __shared__ float wt[QP];
   const int tid = threadIdx.x, nth = blockDim.x;
   const int k = (int)a.cfg.batch_size;
+  for (int p = tid; p < QP; p += nth) { wq[p] = a.q[p]; wt[p] = a.t[p]; }
   if (tid == 0) { c = *a.ctl; c.n_eps = 0; c.n_losses = 0; c.taken = 0; }
   __syncthreads();
   while (true) {
@@ -123,22 +128,22 @@ __global__ void __launch_bounds__(1024) dqn_run_kernel(DQNDev a, int64_t max_env
     if (need_q) {                                                                    // dqn.jl:64 qs = q_net(obs)
       if (tid < QH1) {
         double acc = 0.0;
-        for (int kk = 0; kk < QD; ++kk) acc += (double)a.q[QoW1 + tid + QH1 * kk] * obs[kk];
-        acc += (double)a.q[Qob1 + tid];
+        for (int kk = 0; kk < QD; ++kk) acc += (double)wq[QoW1 + tid + QH1 * kk] * obs[kk];
+        acc += (double)wq[Qob1 + tid];
         h1s[tid] = acc > 0.0 ? acc : 0.0;
       }
       __syncthreads();
       if (tid < QH2) {
         double acc = 0.0;
-        for (int kk = 0; kk < QH1; ++kk) acc += (double)a.q[QoW2 + tid + QH2 * kk] * h1s[kk];
-        acc += (double)a.q[Qob2 + tid];
+        for (int kk = 0; kk < QH1; ++kk) acc += (double)wq[QoW2 + tid + QH2 * kk] * h1s[kk];
+        acc += (double)wq[Qob2 + tid];
         h2s[tid] = acc > 0.0 ? acc : 0.0;
       }
       __syncthreads();
       if (tid < QA) {
         double acc = 0.0;
-        for (int kk = 0; kk < QH2; ++kk) acc += (double)a.q[QoW3 + tid + QA * kk] * h2s[kk];
-        qs[tid] = acc + (double)a.q[Qob3 + tid];
+        for (int kk = 0; kk < QH2; ++kk) acc += (double)wq[QoW3 + tid + QA * kk] * h2s[kk];
+        qs[tid] = acc + (double)wq[Qob3 + tid];
       }
       __syncthreads();
     }
@@ -192,7 +197,7 @@ __global__ void __launch_bounds__(1024) dqn_run_kernel(DQNDev a, int64_t max_env
     // ---- forward: target_net(next_state) and q_net(state) (dqn.jl:99,104) ----
     for (int o = tid; o < 2 * QH1 * k; o += nth) {
       const int net = o / (QH1 * k), r = o - net * (QH1 * k), b = r / QH1, i = r - b * QH1;
-      const float* p = net ? a.t : a.q;
+      const float* p = net ? wt : wq;
       const double* x = (net ? a.rb_next : a.rb_state) + (size_t)QD * idx[b];
       double acc = 0.0;
       for (int kk = 0; kk < QD; ++kk) acc += (double)p[QoW1 + i + QH1 * kk] * x[kk];
@@ -202,9 +207,10 @@ __global__ void __launch_bounds__(1024) dqn_run_kernel(DQNDev a, int64_t max_env
     __syncthreads();
     for (int o = tid; o < 2 * QH2 * k; o += nth) {
       const int net = o / (QH2 * k), r = o - net * (QH2 * k), b = r / QH2, j = r - b * QH2;
-      const float* p = net ? a.t : a.q;
+      const float* p = net ? wt : wq;
       const double* h = a.H1 + (size_t)net * QH1 * k + (size_t)QH1 * b;
       double acc = 0.0;
+#pragma unroll 8
       for (int kk = 0; kk < QH1; ++kk) acc += (double)p[QoW2 + j + QH2 * kk] * h[kk];
       acc += (double)p[Qob2 + j];
       a.H2[(size_t)net * QH2 * k + r] = acc > 0.0 ? acc : 0.0;
@@ -212,9 +218,10 @@ __global__ void __launch_bounds__(1024) dqn_run_kernel(DQNDev a, int64_t max_env
     __syncthreads();
     for (int o = tid; o < 2 * QA * k; o += nth) {
       const int net = o / (QA * k), r = o - net * (QA * k), b = r / QA, aa = r - b * QA;
-      const float* p = net ? a.t : a.q;
+      const float* p = net ? wt : wq;
       const double* h = a.H2 + (size_t)net * QH2 * k + (size_t)QH2 * b;
       double acc = 0.0;
+#pragma unroll 4
       for (int kk = 0; kk < QH2; ++kk) acc += (double)p[QoW3 + aa + QA * kk] * h[kk];
       a.Q[(size_t)net * QA * k + r] = acc + (double)p[Qob3 + aa];
     }
@@ -237,7 +244,7 @@ __global__ void __launch_bounds__(1024) dqn_run_kernel(DQNDev a, int64_t max_env
     // ---- pullbacks ----
     for (int o = tid; o < QH2 * k; o += nth) {
       const int b = o / QH2, j = o - b * QH2;
-      const double s = (double)a.q[QoW3 + a.rb_action[idx[b]] + QA * j] * a.dz[b];
+      const double s = (double)wq[QoW3 + a.rb_action[idx[b]] + QA * j] * a.dz[b];
       a.d2[o] = a.H2[o] > 0.0 ? s : 0.0;
     }
     __syncthreads();
@@ -245,7 +252,8 @@ __global__ void __launch_bounds__(1024) dqn_run_kernel(DQNDev a, int64_t max_env
       const int b = o / QH1, kk = o - b * QH1;
       const double* dd = a.d2 + (size_t)QH2 * b;
       double s = 0.0;
-      for (int j = 0; j < QH2; ++j) s += (double)a.q[QoW2 + j + QH2 * kk] * dd[j];
+#pragma unroll 6
+      for (int j = 0; j < QH2; ++j) s += (double)wq[QoW2 + j + QH2 * kk] * dd[j];
       a.d1[o] = a.H1[o] > 0.0 ? s : 0.0;
     }
     __syncthreads();
@@ -253,7 +261,9 @@ __global__ void __launch_bounds__(1024) dqn_run_kernel(DQNDev a, int64_t max_env
       double g = 0.0;
       if (p < Qob1) { const int i = p % QH1, kk = p / QH1; for (int b = 0; b < k; ++b) g += a.d1[(size_t)QH1 * b + i] * a.rb_state[(size_t)QD * idx[b] + kk]; }
       else if (p < QoW2) { const int i = p - Qob1; for (int b = 0; b < k; ++b) g += a.d1[(size_t)QH1 * b + i]; }
-      else if (p < Qob2) { const int r = p - QoW2, j = r % QH2, kk = r / QH2; for (int b = 0; b < k; ++b) g += a.d2[(size_t)QH2 * b + j] * a.H1[(size_t)QH1 * b + kk]; }
+      else if (p < Qob2) { const int r = p - QoW2, j = r % QH2, kk = r / QH2; 
+#pragma unroll 8
+        for (int b = 0; b < k; ++b) g += a.d2[(size_t)QH2 * b + j] * a.H1[(size_t)QH1 * b + kk]; }
       else if (p < QoW3) { const int j = p - Qob2; for (int b = 0; b < k; ++b) g += a.d2[(size_t)QH2 * b + j]; }
       else if (p < Qob3) { const int r = p - QoW3, aa = r % QA, j = r / QA; for (int b = 0; b < k; ++b) if (a.rb_action[idx[b]] == aa) g += a.dz[b] * a.H2[(size_t)QH2 * b + j]; }
       else { const int aa = p - Qob3; for (int b = 0; b < k; ++b) if (a.rb_action[idx[b]] == aa) g += a.dz[b]; }
@@ -270,12 +280,13 @@ __global__ void __launch_bounds__(1024) dqn_run_kernel(DQNDev a, int64_t max_env
       const float vi = (float)(b2 * (double)a.v[p] + (1 - b2) * gg * gg);
       a.m[p] = mi; a.v[p] = vi;
       const double delta = (double)mi / (1 - bp0) / (sqrt((double)vi / (1 - bp1)) + epsn) * a.cfg.lr;
-      a.q[p] = a.q[p] - (float)delta;
+      const float np_ = wq[p] - (float)delta;
+      wq[p] = np_; a.q[p] = np_;
     }
     __syncthreads();
     if (tid < 12) a.betap[tid] = a.betap[tid] * ((tid & 1) ? 0.999 : 0.9);
     if (c.global_step % a.cfg.target_net_freq == 0)                                  // dqn.jl:111-113
-      for (int p = tid; p < QP; p += nth) a.t[p] = a.q[p];
+      for (int p = tid; p < QP; p += nth) { const float w = wq[p]; wt[p] = w; a.t[p] = w; }
     if (tid == 0) {
       c.n_updates += 1;
       if (c.global_step % a.cfg.log_frequency == 0) {                                // dqn.jl:115-117
@@ -353,7 +364,7 @@ int32_t crl_dqn_create(const crl_dqn_config* cfg, int32_t device, crl_dqn** out)
   if (!cfg || !out) { set_error("crl_dqn_create: null argument"); return 1; }
   *out = nullptr;
   if (cfg->batch_size < 1 || cfg->batch_size > DQN_MAX_BATCH) { set_error("crl_dqn_create: batch_size must be in 1..1024"); return 1; }
-  if (cfg->buffer_size < cfg->batch_size || cfg->buffer_size > DQN_MAX_CAP) { set_error("crl_dqn_create: buffer_size must be in batch_size..262144"); return 1; }
+  if (cfg->buffer_size < cfg->batch_size || cfg->buffer_size > DQN_MAX_CAP) { set_error("crl_dqn_create: buffer_size must be in batch_size..65536"); return 1; }
   if (cfg->min_buff_size < cfg->batch_size) {
     set_error("crl_dqn_create: min_buff_size must be >= batch_size (Buffer.sample asserts n <= rb.size, replay_buffer.jl:41)"); return 1;
   }
