@@ -19,6 +19,7 @@
 
 #include "common.hpp"
 #include "env.hpp"
+#include "mlp_x3.hpp"
 #include "ppo_ctx.hpp"
 #include "stats.hpp"
 
@@ -33,10 +34,14 @@ enum { EPI_TANH = 0, EPI_BIAS = 1, EPI_DTANH = 2 };
 // ------------------------------------------------------------------------------------------------------
 // Workspace
 // ------------------------------------------------------------------------------------------------------
-struct WideNetPack { int w1, w3, w2t, w3t, size; };  // float offsets of the packed weight copies of one network
+struct WideNetPack { int w1, w3, w2t, w3t, x3f, x3b, size; };  // float offsets of the packed weight copies of one network
+constexpr int X3_SLAB_BF16 = 3 * 2 * 8 * 64 * 8;   // one 32-k slab of a 256-row matrix as bf16x3 A-fragments: [piece][kstep][ntile][lane][8]
 static inline WideNetPack pack_layout(int H, int D8, int O8) {
   WideNetPack p;
-  p.w1 = 0; p.w3 = p.w1 + H * D8; p.w2t = p.w3 + 32 * H; p.w3t = p.w2t + H * H; p.size = p.w3t + H * O8;
+  p.w1 = 0; p.w3 = p.w1 + H * D8; p.w2t = p.w3 + 32 * H; p.w3t = p.w2t + H * H;
+  p.x3f = p.w3t + H * O8;
+  const int x3 = H == 256 ? (H / 32) * X3_SLAB_BF16 / 2 : 0;   // floats
+  p.x3b = p.x3f + x3; p.size = p.x3b + x3;
   return p;
 }
 
@@ -135,7 +140,7 @@ __global__ void __launch_bounds__(256) wide_pack_kernel(const float* __restrict_
   const float* W2 = W1 + H * D + H;
   const float* W3 = W2 + H * H + H;
   float* o = pack + kbase;
-  const int total = pk.size;
+  const int total = pk.x3f;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     float val;
     if (i < pk.w3) { const int n = i % H, k = i / H; val = k < D ? W1[n + H * k] : 0.0f; }
@@ -146,17 +151,83 @@ __global__ void __launch_bounds__(256) wide_pack_kernel(const float* __restrict_
   }
 }
 
+// bf16x3 A-fragments of W2 (dir 0: rows = outputs) and W2ᵀ (dir 1: rows = inputs) for wide_dense_x3_kernel:
+// element e of lane l in (slab s, piece, kstep, ntile) is A[32·ntile + (l & 31)][32 s + 16 kstep + 8 (l >> 5) + e]
+__global__ void __launch_bounds__(256) wide_pack_x3_kernel(const float* __restrict__ params, float* __restrict__ pack, int pbase,
+                                                          int kbase, WideNetPack pk) {
+  constexpr int H = 256;
+  const int t = blockIdx.x * 256 + threadIdx.x;          // (dir, s, kstep, ntile, lane)
+  if (t >= 2 * 8 * 2 * 8 * 64) return;
+  const int lane = t & 63, ntile = (t >> 6) & 7, kstep = (t >> 9) & 1, sl = (t >> 10) & 7, dir = t >> 13;
+  const int n = 32 * ntile + (lane & 31), k0 = 32 * sl + 16 * kstep + 8 * (lane >> 5);
+  float x[8];
+  const float* W = params + pbase;   // pbase = flat offset of this network's W2
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] = dir ? W[(k0 + e) + H * n] : W[n + H * (k0 + e)];
+  const P3 p3 = split3(x);
+  __bf16* dst = reinterpret_cast<__bf16*>(pack + kbase + (dir ? pk.x3b : pk.x3f)) + (size_t)sl * X3_SLAB_BF16;
+  const int fr = (kstep * 8 + ntile) * 64 + lane;        // fragment index inside one piece of the slab
+  reinterpret_cast<bf16x8*>(dst)[0 * 1024 + fr] = p3.hi;
+  reinterpret_cast<bf16x8*>(dst)[1 * 1024 + fr] = p3.mid;
+  reinterpret_cast<bf16x8*>(dst)[2 * 1024 + fr] = p3.lo;
+}
+
+static bool wide_x3() {   // CRL_WIDE_GEMM=f32 keeps every GEMM on v_mfma_f32_32x32x2_f32
+  static int mode = -1;
+  if (mode < 0) { const char* e = getenv("CRL_WIDE_GEMM"); mode = (e && std::string(e) == "f32") ? 0 : 1; }
+  return mode == 1;
+}
+
 static int ensure_pack(crl_ppo* h) {
   WideWs* w = static_cast<WideWs*>(h->wide_ws);
   if (!w->pack_dirty) return 0;
   for (int n = 0; n < 2; ++n) {
     const int NO = n ? 1 : w->A, O8 = n ? 8 : w->A8;
-    hipLaunchKernelGGL(wide_pack_kernel, dim3((w->pk[n].size + 255) / 256), dim3(256), 0, h->stream, h->params, w->pack, w->H, w->D,
+    hipLaunchKernelGGL(wide_pack_kernel, dim3((w->pk[n].x3f + 255) / 256), dim3(256), 0, h->stream, h->params, w->pack, w->H, w->D,
                        w->D8, NO, O8, n ? (int)h->Pa : 0, w->pk_base[n], w->pk[n]);
+    if (w->H == 256)
+      hipLaunchKernelGGL(wide_pack_x3_kernel, dim3(2 * 8 * 2 * 8 * 64 / 256), dim3(256), 0, h->stream, h->params, w->pack,
+                         (n ? (int)h->Pa : 0) + w->H * w->D + w->H, w->pk_base[n], w->pk[n]);
   }
   CRL_HIP_CHECK(hipGetLastError());
   w->pack_dirty = false;
   return 0;
+}
+
+// Epilogue store of one 32×32 accumulator tile with full 128-B lines: the C fragment holds 4 consecutive rows per
+// register quad but one SAMPLE per lane, so a direct store scatters 16-B pieces over 64 lines per instruction. The tile
+// goes through a wave-private [32][36] LDS scratch instead and comes back row-major: 8 lanes write one sample's 32 rows
+// (128 B), a wave instruction covers 8 whole lines. S (the stored tanh outputs) is read the same way.
+template <int EPI>
+__device__ __forceinline__ void tile_out(float* scr, const f32x16& acc, int lane, int n0, int mbase, int M, const float* bias,
+                                         const float* S, int lds, float* Y, int ldy) {
+  const int j = lane & 31, hf = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 o; o[0] = acc[4 * g]; o[1] = acc[4 * g + 1]; o[2] = acc[4 * g + 2]; o[3] = acc[4 * g + 3];
+    *reinterpret_cast<f32x4*>(scr + j * 36 + 8 * g + 4 * hf) = o;
+  }
+  wave_lds_fence();
+  const int c = lane & 7, n = n0 + 4 * c;
+  f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (EPI != EPI_DTANH) bv = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int m = (lane >> 3) + 8 * it, gm = mbase + m;
+    f32x4 v = *reinterpret_cast<const f32x4*>(scr + m * 36 + 4 * c);
+    if (gm < M) {
+      if (EPI == EPI_DTANH) {
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(S + (size_t)lds * gm + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.0f - sv[e] * sv[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += bv[e]; if (EPI == EPI_TANH) v[e] = tanh_fast(v[e]); }
+      }
+      *reinterpret_cast<f32x4*>(Y + (size_t)ldy * gm + n) = v;
+    }
+  }
+  wave_lds_fence();
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -318,6 +389,17 @@ __global__ void __launch_bounds__(256) wide_dense_kernel(DenseArgs a) {
   }
 
   const bool yfast = ((a.ldy & 3) == 0) && ((a.Nt & 3) == 0) && (EPI != EPI_DTANH || (a.lds & 3) == 0);
+  if (yfast && a.Nt == NP) {
+    // every row tile is complete: line-coalesced stores through a wave-private LDS scratch (the operand slabs are dead)
+    __syncthreads();
+    float* scr = smem + wave * (32 * 36);
+#pragma unroll
+    for (int x = 0; x < TN; ++x)
+#pragma unroll
+      for (int y = 0; y < TM; ++y)
+        tile_out<EPI>(scr, acc[x][y], lane, (wn * TN + x) * 32, m0 + (wm * TM + y) * 32, a.M, a.bias, a.S, a.lds, a.Y, a.ldy);
+    return;
+  }
 #pragma unroll
   for (int x = 0; x < TN; ++x) {
 #pragma unroll
@@ -328,34 +410,147 @@ __global__ void __launch_bounds__(256) wide_dense_kernel(DenseArgs a) {
       for (int g = 0; g < 4; ++g) {
         const int n = (wn * TN + x) * 32 + 8 * g + 4 * hf;   // rows n..n+3 = registers 4g..4g+3 (rowmap)
         if (n >= a.Nt) continue;
-        float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[x][y][4 * g + e];
-        if (yfast) {
-          if (EPI == EPI_DTANH) {
-            const f32x4 s = *reinterpret_cast<const f32x4*>(a.S + (size_t)a.lds * m + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.0f - s[e] * s[e]);
-          } else {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] += bv[e]; if (EPI == EPI_TANH) v[e] = tanh_fast(v[e]); }
-          }
-          f32x4 o; o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
-          *reinterpret_cast<f32x4*>(a.Y + (size_t)a.ldy * m + n) = o;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (n + e >= a.Nt) continue;
-            float o = v[e];
-            if (EPI == EPI_DTANH) { const float s = a.S[(size_t)a.lds * m + n + e]; o = o * (1.0f - s * s); }
-            else { o += a.bias[n + e]; if (EPI == EPI_TANH) o = tanh_fast(o); }
-            a.Y[(size_t)a.ldy * m + n + e] = o;
-          }
+        for (int e = 0; e < 4; ++e) {
+          if (n + e >= a.Nt) continue;
+          float o = acc[x][y][4 * g + e];
+          if (EPI == EPI_DTANH) { const float sv = a.S[(size_t)a.lds * m + n + e]; o = o * (1.0f - sv * sv); }
+          else { o += a.bias[n + e]; if (EPI == EPI_TANH) o = tanh_fast(o); }
+          a.Y[(size_t)a.ldy * m + n + e] = o;
         }
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// The same dense layer for the 256×256 hidden GEMMs on the bf16 matrix pipe at f32 accuracy (bf16x3, mlp_x3.hpp):
+// W comes pre-split into A-fragments (wide_pack_x3_kernel, once per optimiser step) and is copied slab by slab into LDS
+// as it stands; activations are split into their three bf16 pieces while they are stashed into LDS (each element once
+// per block, reused by all 8 row tiles). 48 v_mfma_f32_32x32x16_bf16 per wave and slab (1,536 matrix-pipe cycles that
+// overlap the VALU) replace 64 v_mfma_f32_32x32x2_f32 (4,096 cycles that do not).
+// ------------------------------------------------------------------------------------------------------
+struct DenseX3Args {
+  const float* Wx3;                      // [K/32 slabs][piece][kstep][ntile][lane][8] bf16
+  const float* X; int K;                 // X: [K × M] column-major, ld = K = 256
+  const float* bias; const float* S;     // epilogue operands (ld 256)
+  float* Y; int M;
+};
+constexpr int X3ROW = 40;                // bf16 per staged sample row per piece: 32 k + 8 pad (80 B: conflict-free b128)
+
+__device__ __forceinline__ void split3x4(const f32x4 v, uint2& h, uint2& m, uint2& l) {
+  const uint32_t h0 = cvt_pk_bf16(v[0], v[1]), h1 = cvt_pk_bf16(v[2], v[3]);
+  const float r0 = v[0] - __uint_as_float(h0 << 16), r1 = v[1] - __uint_as_float(h0 & 0xFFFF0000u);
+  const float r2 = v[2] - __uint_as_float(h1 << 16), r3 = v[3] - __uint_as_float(h1 & 0xFFFF0000u);
+  const uint32_t m0 = cvt_pk_bf16(r0, r1), m1 = cvt_pk_bf16(r2, r3);
+  const float s0 = r0 - __uint_as_float(m0 << 16), s1 = r1 - __uint_as_float(m0 & 0xFFFF0000u);
+  const float s2 = r2 - __uint_as_float(m1 << 16), s3 = r3 - __uint_as_float(m1 & 0xFFFF0000u);
+  h = make_uint2(h0, h1); m = make_uint2(m0, m1); l = make_uint2(cvt_pk_bf16(s0, s1), cvt_pk_bf16(s2, s3));
+}
+
+template <int EPI, int TM, int NW>
+__global__ void __launch_bounds__(64 * NW) wide_dense_x3_kernel(DenseX3Args a) {
+  // NW waves share one W slab; a wave owns TN = 8/NW row tiles × TM sample tiles
+  constexpr int NT = 64 * NW, TN = 8 / NW, MB = 32 * TM;
+  constexpr int WR = X3_SLAB_BF16 * 2 / 16 / NT;               // 16-B pieces of the W slab per thread (12 or 6)
+  constexpr int XR = (MB * 8 + NT - 1) / NT;                   // float4 pieces of the X slab per thread
+  extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
+  __bf16* Wl = reinterpret_cast<__bf16*>(smx);                 // one slab of A-fragments (48 KB)
+  __bf16* Xl = Wl + X3_SLAB_BF16;                              // [piece][MB][X3ROW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hf = lane >> 5;
+  const int m0 = blockIdx.x * MB;
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int x = 0; x < TN; ++x)
+#pragma unroll
+    for (int y = 0; y < TM; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.0f;
+  const u32x4v* wsrc = reinterpret_cast<const u32x4v*>(a.Wx3) + tid;
+  const f32x4* xsrc[XR]; bool xok[XR];
+#pragma unroll
+  for (int u = 0; u < XR; ++u) {
+    const int i = tid + NT * u, mm = i >> 3, q = i & 7, m = m0 + mm;
+    xok[u] = (i < MB * 8) && (m < a.M);
+    xsrc[u] = reinterpret_cast<const f32x4*>(a.X + (size_t)(xok[u] ? m : 0) * a.K) + q;
+  }
+  u32x4v wr[WR]; f32x4 xr[XR];
+  const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int u = 0; u < WR; ++u) wr[u] = wsrc[NT * u];
+#pragma unroll
+  for (int u = 0; u < XR; ++u) xr[u] = xok[u] ? xsrc[u][0] : zero4;
+  const int nslab = a.K >> 5;
+  for (int sl = 0; sl < nslab; ++sl) {
+    if (sl) __syncthreads();
+#pragma unroll
+    for (int u = 0; u < WR; ++u) reinterpret_cast<u32x4v*>(Wl)[tid + NT * u] = wr[u];
+#pragma unroll
+    for (int u = 0; u < XR; ++u) {
+      const int i = tid + NT * u, mm = i >> 3, q = i & 7;
+      if (i < MB * 8) {
+        uint2 h, m, l;
+        split3x4(xr[u], h, m, l);
+        *reinterpret_cast<uint2*>(Xl + (0 * MB + mm) * X3ROW + 4 * q) = h;
+        *reinterpret_cast<uint2*>(Xl + (1 * MB + mm) * X3ROW + 4 * q) = m;
+        *reinterpret_cast<uint2*>(Xl + (2 * MB + mm) * X3ROW + 4 * q) = l;
+      }
+    }
+    __syncthreads();
+    if (sl + 1 < nslab) {
+#pragma unroll
+      for (int u = 0; u < WR; ++u) wr[u] = wsrc[(size_t)(sl + 1) * (X3_SLAB_BF16 / 8) + NT * u];
+#pragma unroll
+      for (int u = 0; u < XR; ++u) xr[u] = xok[u] ? xsrc[u][(sl + 1) * 8] : zero4;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      P3 af[TN], bf[TM];
+#pragma unroll
+      for (int x = 0; x < TN; ++x) {
+        const int fr = (ks * 8 + TN * wave + x) * 64 + lane;
+        af[x].hi = reinterpret_cast<const bf16x8*>(Wl)[0 * 1024 + fr];
+        af[x].mid = reinterpret_cast<const bf16x8*>(Wl)[1 * 1024 + fr];
+        af[x].lo = reinterpret_cast<const bf16x8*>(Wl)[2 * 1024 + fr];
+      }
+#pragma unroll
+      for (int y = 0; y < TM; ++y) {
+        const int off = (32 * y + j) * X3ROW + 16 * ks + 8 * hf;
+        bf[y].hi = *reinterpret_cast<const bf16x8*>(Xl + 0 * MB * X3ROW + off);
+        bf[y].mid = *reinterpret_cast<const bf16x8*>(Xl + 1 * MB * X3ROW + off);
+        bf[y].lo = *reinterpret_cast<const bf16x8*>(Xl + 2 * MB * X3ROW + off);
+      }
+#pragma unroll
+      for (int x = 0; x < TN; ++x)
+#pragma unroll
+        for (int y = 0; y < TM; ++y) acc[x][y] = mfma_x3(af[x], bf[y], acc[x][y]);
+    }
+  }
+  __syncthreads();
+  float* scr = reinterpret_cast<float*>(smx) + wave * (32 * 36);
+#pragma unroll
+  for (int x = 0; x < TN; ++x)
+#pragma unroll
+    for (int y = 0; y < TM; ++y)
+      tile_out<EPI>(scr, acc[x][y], lane, (TN * wave + x) * 32, m0 + 32 * y, a.M, a.bias, a.S, 256, a.Y, 256);
+}
+
+template <int EPI>
+static int dense_x3_launch(hipStream_t st, const DenseX3Args& a) {
+  if (a.M <= 0) return 0;
+  static int nw = -1;
+  if (nw < 0) { const char* e = getenv("CRL_WIDE_X3_WAVES"); nw = e ? atoi(e) : 8; }
+  if (a.M <= 32768) {
+    const size_t smem = X3_SLAB_BF16 * 2 + 3 * 32 * X3ROW * 2;
+    if (nw == 8) hipLaunchKernelGGL((wide_dense_x3_kernel<EPI, 1, 8>), dim3((a.M + 31) / 32), dim3(512), smem, st, a);
+    else hipLaunchKernelGGL((wide_dense_x3_kernel<EPI, 1, 4>), dim3((a.M + 31) / 32), dim3(256), smem, st, a);
+  } else {
+    const size_t smem = X3_SLAB_BF16 * 2 + 3 * 64 * X3ROW * 2;
+    if (nw == 8) hipLaunchKernelGGL((wide_dense_x3_kernel<EPI, 2, 8>), dim3((a.M + 63) / 64), dim3(512), smem, st, a);
+    else hipLaunchKernelGGL((wide_dense_x3_kernel<EPI, 2, 4>), dim3((a.M + 63) / 64), dim3(256), smem, st, a);
+  }
+  CRL_HIP_CHECK(hipGetLastError());
+  return 0;
 }
 
 template <int EPI>
@@ -395,8 +590,15 @@ static int wide_forward(crl_ppo* h, int net, const float* X, int ldx, const int3
   a.W = pk + w->pk[net].w1; a.Kp = w->D8; a.X = X; a.ldx = ldx; a.Kt = w->D; a.bias = P + o.b1; a.Y = w->h1[net]; a.ldy = H; a.Nt = H;
   if (dense_launch<EPI_TANH>(h->stream, H, a)) return 1;
   a.idx = nullptr;
-  a.W = P + o.W2; a.Kp = H; a.X = w->h1[net]; a.ldx = H; a.Kt = H; a.bias = P + o.b2; a.Y = w->h2[net];
-  if (dense_launch<EPI_TANH>(h->stream, H, a)) return 1;
+  if (H == 256 && wide_x3()) {
+    DenseX3Args x;
+    x.Wx3 = pk + w->pk[net].x3f; x.X = w->h1[net]; x.K = H; x.bias = P + o.b2; x.S = nullptr; x.Y = w->h2[net]; x.M = M;
+    if (dense_x3_launch<EPI_TANH>(h->stream, x)) return 1;
+  } else {
+    a.W = P + o.W2; a.Kp = H; a.X = w->h1[net]; a.ldx = H; a.Kt = H; a.bias = P + o.b2; a.Y = w->h2[net];
+    if (dense_launch<EPI_TANH>(h->stream, H, a)) return 1;
+  }
+  a.ldx = H; a.Kt = H;
   a.W = pk + w->pk[net].w3; a.Kp = H; a.X = w->h2[net]; a.bias = P + o.b3; a.Y = out; a.ldy = ldo; a.Nt = NO;
   return dense_launch<EPI_BIAS>(h->stream, 32, a);
 }
@@ -1057,8 +1259,14 @@ static int wide_backward(crl_ppo* h, int net, const float* dOut, int ldd, const 
   else hipLaunchKernelGGL(wide_wgrad_kernel<1>, dim3(w->S2, 1), dim3(256), 0, h->stream, g);
   CRL_HIP_CHECK(hipGetLastError());
   // δ1 = (W2ᵀ·δ2) ⊙ (1 − h1²)
-  d.W = pk + w->pk[net].w2t; d.Kp = H; d.X = w->dA; d.ldx = H; d.Kt = H; d.S = w->h1[net]; d.Y = w->dB;
-  if (dense_launch<EPI_DTANH>(h->stream, H, d)) return 1;
+  if (H == 256 && wide_x3()) {
+    DenseX3Args x;
+    x.Wx3 = pk + w->pk[net].x3b; x.X = w->dA; x.K = H; x.bias = nullptr; x.S = w->h1[net]; x.Y = w->dB; x.M = M;
+    if (dense_x3_launch<EPI_DTANH>(h->stream, x)) return 1;
+  } else {
+    d.W = pk + w->pk[net].w2t; d.Kp = H; d.X = w->dA; d.ldx = H; d.Kt = H; d.S = w->h1[net]; d.Y = w->dB;
+    if (dense_launch<EPI_DTANH>(h->stream, H, d)) return 1;
+  }
   // dW1 = δ1·xᵀ, db1 = Σ δ1
   s.Big = w->dB; s.Small = h->obs; s.lds = w->D; s.idx = idx; s.pW = w->pW1[net]; s.os_row = 1; s.os_s = H; s.St = w->D;
   s.wsize = H * w->D; s.pB = w->pB1[net];

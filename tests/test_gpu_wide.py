@@ -12,6 +12,16 @@ pytestmark = pytest.mark.gpu
 SHAPES = [(8, 4, 256), (6, 3, 128), (4, 2, 64), (17, 16, 64), (3, 5, 256)]
 
 
+def rel_err_s(a, b):
+    """rel_err with the absolute floor scaled to the array's magnitude: |a-b| <= RTOL*|b| + ATOL*max(1, max|b|).
+    Log-probabilities here come from logits spread to ±5 (the actor head is scaled x30 so that all 4 actions occur): they
+    are differences of numbers that large, and float32 summation-order noise on a 256-term dot product (both the
+    v_mfma_f32 and the bf16x3 flavour measure ~4e-7 mean, 9e-6 max absolute) is relative to THAT scale."""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    floor = ATOL / RTOL * max(1.0, float(np.max(np.abs(b)))) if b.size else 1.0
+    return np.max(np.abs(a - b) / (np.abs(b) + floor)) if a.size else 0.0
+
+
 def make_wide(crl, nt, k, D, A, Hd, params=None, **kw):
     cfg = crl.PPOConfig(num_envs=nt, num_steps=k, total_timesteps=nt * k * 10, **{a: b for a, b in kw.items() if a in
                         ("num_minibatches", "update_epochs", "clip_value_loss", "anneal_lr", "lr")})
@@ -51,11 +61,11 @@ def test_wide_policy_act_and_logprob_match_oracle(crl, D, A, Hd, n):
     assert np.array_equal(a_g[safe], a_o[safe]), "action indices must be bit-exact away from CDF knots"
     assert safe.mean() > 0.98 and len(set(a_o.tolist())) >= min(A, 2 if n > 1 else 1)
     same = a_g == a_o
-    assert rel_err(lp_g[same], lp_o[same]) < RTOL and rel_err(v_g, v_o) < RTOL
+    assert rel_err_s(lp_g[same], lp_o[same]) < RTOL and rel_err(v_g, v_o) < RTOL
     acts = rng.integers(0, A, n).astype(np.int32)
     lp_o2, ent_o = O.logprob_actions(cfg, params, obs, acts)
     lp_g2, ent_g = crl.logprob_actions(obs, agent.actor, acts + 1)
-    assert ent_g.shape == (A, n) and rel_err(lp_g2, lp_o2) < RTOL and rel_err(ent_g, ent_o) < RTOL
+    assert ent_g.shape == (A, n) and rel_err_s(lp_g2, lp_o2) < RTOL and rel_err(ent_g, ent_o) < RTOL
     agent.close()
 
 
@@ -72,7 +82,7 @@ def test_wide_rollout_matches_oracle(crl, D, A, Hd, nt, k):
     assert np.array_equal(h.read(F.F_ACTION), st.action), f"{np.sum(h.read(F.F_ACTION) != st.action)} actions differ"
     assert np.array_equal(h.read(F.F_OBS), st.obs) and np.array_equal(h.read(F.F_REWARD), st.reward)
     assert np.array_equal(h.read(F.F_TERMINAL), st.terminal) and np.array_equal(h.read(F.F_NEXT_DONE), st.next_done)
-    assert rel_err(h.read(F.F_LOGPROB), st.logprob) < RTOL and rel_err(h.read(F.F_VALUE), st.value) < RTOL
+    assert rel_err_s(h.read(F.F_LOGPROB), st.logprob) < RTOL and rel_err(h.read(F.F_VALUE), st.value) < RTOL
     es = h.episode_stats(); n_ep, ret_sum, len_sum = st.episode_stats
     assert es["episodes"] == n_ep and es["length_sum"] == len_sum and abs(es["return_sum"] - ret_sum) < 1e-4 * max(1, abs(ret_sum))
     h.compute_gae(); st.compute_gae()
