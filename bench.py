@@ -61,7 +61,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--total-envs", type=int, default=TOTAL_ENVS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--shuffle", choices=["bijection", "fisher-yates", "blocked-fy"], default="bijection")
+    ap.add_argument("--shuffle", choices=["bijection", "fisher-yates", "blocked-fy"], default="blocked-fy",
+                    help="blocked-fy = exact parallel Fisher-Yates (uniform over S_B like the reference shuffle; default); "
+                         "bijection = keyed pseudo-random permutation (faster, not a uniform draw); fisher-yates = serial exact")
     ap.add_argument("--workload", choices=["cartpole", "c3"], default="cartpole",
                     help="cartpole = the headline workload (BASELINE metric); c3 = BASELINE configs[2]: LunarLander-shaped obs 8 / "
                          "act 4, 2x256 MLP, num_envs=16384 on the synthetic env (a side measurement, not the driver's line)")
@@ -151,7 +153,7 @@ def main():
         # is calibrated for 16-B/lane streams only, these kernels use 4-B and gathered 16-B accesses.
         traffic = {"update": None, "gae": None}
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_f_pmc_hbm_traffic.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_l_pmc_hbm_traffic.json")))
             if world == 1 and args.total_envs == TOTAL_ENVS and not c3:
                 for key, name in (("update", "void crl::update_x3_kernel<4, 2>"), ("gae", "void crl::gae_kernel<32, 8>")):
                     if name in pm:

@@ -1273,21 +1273,10 @@ static int wide_backward(crl_ppo* h, int net, const float* dOut, int ldd, const 
   return skinny_launch(h->stream, w->Ss, s);
 }
 
-// One optimiser step's gradient (ppo.jl:197-244): forward → u → loss → backward → fixed-order reduce → [all-reduce] →
-// statistics. The gradient message ends up in comm_buf like in update.hip.
-int wide_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
+// forward → u → loss → backward of one minibatch; leaves the per-chunk gradient partials in the workspace
+static int wide_grad_passes(crl_ppo* h, int mb, const int32_t* perm, double Mglobal, bool dp) {
   WideWs* w = static_cast<WideWs*>(h->wide_ws);
-  if (ensure_pack(h)) return 1;
-  const int M = h->dc.M, P = (int)h->P;
-  const int32_t* perm = h->perm + (size_t)mb * M;
-  const double Mglobal = (double)M * h->world;
-  const bool dp = h->comm != nullptr || h->external_comm;   // a forced 1-rank communicator still goes through RCCL
-  if (h->external_comm && h->world > 1 && h->cfg.clip_value_loss) {
-    set_error("wide path: clip_value_loss under host-side exchange (crl_comm_init_external) is not supported; use crl_comm_init");
-    return 1;
-  }
-  ProfScope* ps = new ProfScope(h, CRL_K_UPDATE);
-  struct PsGuard { ProfScope*& p; ~PsGuard() { delete p; } } psg{ps};
+  const int M = h->dc.M;
   if (wide_forward(h, 1, h->obs, w->D, perm, M, w->v, 1)) return 1;
   if (wide_forward(h, 0, h->obs, w->D, perm, M, w->z, w->A8)) return 1;
   if (h->cfg.clip_value_loss) {
@@ -1311,7 +1300,26 @@ int wide_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
   }
   if (wide_backward(h, 0, w->z, w->A8, perm)) return 1;
   if (wide_backward(h, 1, w->dv8, 8, perm)) return 1;
-  delete ps; ps = nullptr;
+  return 0;
+}
+
+// One optimiser step's gradient (ppo.jl:197-244): forward → u → loss → backward → fixed-order reduce → [all-reduce] →
+// statistics. The gradient message ends up in comm_buf like in update.hip.
+int wide_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
+  WideWs* w = static_cast<WideWs*>(h->wide_ws);
+  if (ensure_pack(h)) return 1;
+  const int M = h->dc.M, P = (int)h->P;
+  const int32_t* perm = h->perm + (size_t)mb * M;
+  const double Mglobal = (double)M * h->world;
+  const bool dp = h->comm != nullptr || h->external_comm;   // a forced 1-rank communicator still goes through RCCL
+  if (h->external_comm && h->world > 1 && h->cfg.clip_value_loss) {
+    set_error("wide path: clip_value_loss under host-side exchange (crl_comm_init_external) is not supported; use crl_comm_init");
+    return 1;
+  }
+  {
+    ProfScope ps(h, CRL_K_UPDATE);   // HIP events around the whole forward / loss / backward group of this minibatch
+    if (wide_grad_passes(h, mb, perm, Mglobal, dp)) return 1;
+  }
   {
     WRedArgs r;
     const int H = w->H, D = w->D, A = w->A;
