@@ -217,7 +217,8 @@ int32_t crl_a2c_discounted_future_rewards(int32_t device, const double* rewards,
  * DQN: src/algorithms/dqn.jl on the GPU. One on-device CartPoleEnv{Float64} (max_steps = 200),
  * q / target networks Chain(Dense(4,120,relu), Dense(120,84,relu), Dense(84,2)) (dqn.jl:22-26) with Float32 weights and
  * Float64 arithmetic like the reference, replay ring, ε-greedy schedule, minibatch drawn without replacement, TD target,
- * Flux.mse, Adam (no ClipNorm), hard target copy — the whole `for global_step` loop runs in one persistent launch per call.
+ * Flux.mse, Adam (no ClipNorm), hard target copy — a call enqueues the whole chunk of the `for global_step` loop (one fixed
+ * ten-launch cycle per train_freq steps) and reads nothing back until it ends.
  * ===================================================================================================== */
 typedef struct crl_dqn_config {   /* DQNConfig, dqn.jl:1-19 */
   int64_t log_frequency, total_timesteps, buffer_size, min_buff_size;
@@ -239,7 +240,7 @@ int32_t crl_dqn_destroy(crl_dqn* h);
 int32_t crl_dqn_write_params(crl_dqn* h, const float* q_params, size_t n);                  /* q_net; target_net = deepcopy(q_net) */
 int32_t crl_dqn_read_params(crl_dqn* h, float* q_params, float* target_params, size_t n);   /* target_params may be NULL */
 int32_t crl_dqn_status_read(crl_dqn* h, crl_dqn_status* out);
-/* dqn.jl:57-119: up to max_env_steps iterations of the loop (or to total_timesteps) in ONE launch. Episode records
+/* dqn.jl:57-119: up to max_env_steps iterations of the loop (or to total_timesteps), enqueued without host read-backs. Episode records
  * (dqn.jl:88) and the "Training Statistics" losses of steps that are multiples of log_frequency (dqn.jl:115-117) come
  * back in eps / losses (entries beyond max_* are dropped). */
 int32_t crl_dqn_run(crl_dqn* h, int64_t max_env_steps, crl_dqn_episode* eps, int32_t max_eps, int32_t* n_eps,
