@@ -37,7 +37,7 @@ class PPOConfig:
 
 
 def _crl_config(config: PPOConfig, *, obs_dim=4, n_act=2, hidden=64, gae_mode=L.GAE_COMPAT, env_kind=L.ENV_CARTPOLE,
-                stale_obs=True, env_id_offset=0, shuffle_mode=L.SHUFFLE_BIJECTION, seed=0x5EED, num_envs=None):
+                stale_obs=True, env_id_offset=0, shuffle_mode=L.SHUFFLE_BLOCKED_FY, seed=0x5EED, num_envs=None):
     return L.CrlConfig(config.total_timesteps, config.num_steps, config.num_envs if num_envs is None else num_envs,
                        config.num_minibatches, config.update_epochs, config.lr, config.gamma, config.gae_lambda,
                        config.clip_coef, config.ent_coeff, config.v_coef, int(config.normalize_advantages),

@@ -79,3 +79,20 @@ def test_product_package_never_touches_the_oracle():
                 src = open(os.path.join(dp, f)).read()
                 code = "\n".join(l for l in src.splitlines() if not l.strip().startswith(("//", "#", "*", "/*")))
                 assert "oraclelib" not in code and "libppo_oracle" not in code and "ppo_oracle.h" not in code, f
+
+
+def test_argparse_struct_mirrors_config_parser():
+    """config_parser.jl:18-40: one --field option per struct field, defaults from the struct, same struct type back."""
+    import cleanrl_jl_amd as crl
+    from cleanrl_jl_amd.config_parser import argparse_struct
+    cfg = argparse_struct(crl.PPOConfig(), ["--num_envs", "64", "--lr", "0.001", "--anneal_lr", "false"])
+    assert isinstance(cfg, crl.PPOConfig) and cfg.num_envs == 64 and cfg.lr == 0.001 and cfg.anneal_lr is False
+    assert cfg.num_steps == crl.PPOConfig().num_steps and cfg.clip_value_loss is True
+    d = argparse_struct(crl.DQNConfig(), ["--log_frequencey", "50", "--epsilon_duration", "300"])
+    assert d.log_frequencey == 50 and d.epsilon_duration == 300.0 and isinstance(d, crl.DQNConfig)
+    a = argparse_struct(crl.A2CConfig(run_name="x"), [])
+    assert a == crl.A2CConfig(run_name="x")
+    with pytest.raises(SystemExit):
+        argparse_struct(crl.PPOConfig(), ["--no_such_field", "1"])
+    with pytest.raises(TypeError):
+        argparse_struct({"a": 1}, [])
