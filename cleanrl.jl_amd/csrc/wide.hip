@@ -707,6 +707,126 @@ __global__ void __launch_bounds__(256) wide_wgrad_kernel(WgradArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// The same weight gradient on the bf16 matrix pipe (bf16x3) for 256-wide layers. The reduction runs over SAMPLES, so an
+// MFMA operand needs 8 consecutive samples of one row — the strided direction of the (feature, sample) arrays. The
+// staging loads are therefore shaped as 4×4 blocks per thread (4 consecutive rows × 4 consecutive samples: four 16-B
+// loads), which a thread can transpose in its own registers: each row's 4 samples are split into bf16 hi/mid/lo and
+// written with one ds_write_b64 per piece into row-major [row][sample] LDS images (row stride 80 B: conflict-free
+// b128 fragment reads). No f32 copy of the slab ever exists in LDS.
+// ------------------------------------------------------------------------------------------------------
+template <int WNB>   // output tile = (64·WNB rows of dY) × (128 rows of X); 2·WNB waves, each 2×2 MFMA tiles
+__global__ void __launch_bounds__(128 * WNB) wide_wgrad_x3_kernel(WgradArgs a) {
+  constexpr int BN = 64 * WNB, BK = 128, NT = 128 * WNB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smw[];
+  __bf16* Yp = reinterpret_cast<__bf16*>(smw);                 // [3][BN][X3ROW]
+  __bf16* Xp = Yp + 3 * BN * X3ROW;                            // [3][BK][X3ROW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hf = lane >> 5;
+  const int nbn = a.H / BN;
+  const int tnb = blockIdx.y % nbn, tkb = blockIdx.y / nbn;
+  const int n0 = tnb * BN, kk0 = tkb * BK;
+  const int wn = wave % WNB, wk = wave / WNB;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.0f;
+  const int c0 = blockIdx.x * a.chunk;
+  const int c1 = (c0 + a.chunk) < a.M ? (c0 + a.chunk) : a.M;
+  // staging role of this thread: rows 32·wave + 4·ql .. +3, samples 4·sg .. +3 of the slab's 32 (X: the first 4 waves)
+  const int ql = lane & 7, sg = lane >> 3;
+  const int rrow = 32 * wave + 4 * ql;
+  const bool stage_x = wave < BK / 32;
+  const float* ybase = a.dY + (size_t)a.H * c0 + n0 + rrow;
+  const float* xbase = a.X + (size_t)a.H * c0 + kk0 + rrow;
+  const bool do_bias = (tkb == 0) && a.pB;
+  const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 yr[4], xr[4], bacc = zero4;
+  auto fetch = [&](int m) {
+    const size_t off = (size_t)a.H * (m - c0 + 4 * sg);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool ok = m + 4 * sg + e < c1;
+      yr[e] = ok ? *reinterpret_cast<const f32x4*>(ybase + off + (size_t)a.H * e) : zero4;
+      xr[e] = (ok && stage_x) ? *reinterpret_cast<const f32x4*>(xbase + off + (size_t)a.H * e) : zero4;
+    }
+  };
+  if (c0 < c1) fetch(c0);
+  for (int m = c0; m < c1; m += 32) {
+    if (m != c0) __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {          // row rrow + e: its four samples sit in component e of the four loads
+      f32x4 vy;
+      vy[0] = yr[0][e]; vy[1] = yr[1][e]; vy[2] = yr[2][e]; vy[3] = yr[3][e];
+      uint2 h, mm, l;
+      split3x4(vy, h, mm, l);
+      *reinterpret_cast<uint2*>(Yp + (0 * BN + rrow + e) * X3ROW + 4 * sg) = h;
+      *reinterpret_cast<uint2*>(Yp + (1 * BN + rrow + e) * X3ROW + 4 * sg) = mm;
+      *reinterpret_cast<uint2*>(Yp + (2 * BN + rrow + e) * X3ROW + 4 * sg) = l;
+      if (stage_x) {
+        f32x4 vx;
+        vx[0] = xr[0][e]; vx[1] = xr[1][e]; vx[2] = xr[2][e]; vx[3] = xr[3][e];
+        split3x4(vx, h, mm, l);
+        *reinterpret_cast<uint2*>(Xp + (0 * BK + rrow + e) * X3ROW + 4 * sg) = h;
+        *reinterpret_cast<uint2*>(Xp + (1 * BK + rrow + e) * X3ROW + 4 * sg) = mm;
+        *reinterpret_cast<uint2*>(Xp + (2 * BK + rrow + e) * X3ROW + 4 * sg) = l;
+      }
+    }
+    if (do_bias) bacc += (yr[0] + yr[1]) + (yr[2] + yr[3]);
+    __syncthreads();
+    if (m + 32 < c1) fetch(m + 32);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      P3 af[2], bf[2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        const int off = ((wn * 2 + x) * 32 + j) * X3ROW + 16 * ks + 8 * hf;
+        af[x].hi = *reinterpret_cast<const bf16x8*>(Yp + 0 * BN * X3ROW + off);
+        af[x].mid = *reinterpret_cast<const bf16x8*>(Yp + 1 * BN * X3ROW + off);
+        af[x].lo = *reinterpret_cast<const bf16x8*>(Yp + 2 * BN * X3ROW + off);
+      }
+#pragma unroll
+      for (int y = 0; y < 2; ++y) {
+        const int off = ((wk * 2 + y) * 32 + j) * X3ROW + 16 * ks + 8 * hf;
+        bf[y].hi = *reinterpret_cast<const bf16x8*>(Xp + 0 * BK * X3ROW + off);
+        bf[y].mid = *reinterpret_cast<const bf16x8*>(Xp + 1 * BK * X3ROW + off);
+        bf[y].lo = *reinterpret_cast<const bf16x8*>(Xp + 2 * BK * X3ROW + off);
+      }
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = mfma_x3(af[x], bf[y], acc[x][y]);
+    }
+  }
+  __syncthreads();
+  float* pw = a.pW + (size_t)blockIdx.x * a.H * a.H;
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const int k = kk0 + (wk * 2 + y) * 32 + j;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + (wn * 2 + x) * 32 + 8 * g + 4 * hf;
+        f32x4 o; o[0] = acc[x][y][4 * g]; o[1] = acc[x][y][4 * g + 1]; o[2] = acc[x][y][4 * g + 2]; o[3] = acc[x][y][4 * g + 3];
+        *reinterpret_cast<f32x4*>(pw + (size_t)a.H * k + n) = o;
+      }
+    }
+  if (do_bias) {
+    // fold the 8 sample groups of a wave (lanes ql + 8·sg) in group order; lanes with sg = 0 own rows rrow..rrow+3
+    float* scr = reinterpret_cast<float*>(smw);
+    *reinterpret_cast<f32x4*>(scr + 4 * tid) = bacc;
+    __syncthreads();
+    if (sg == 0) {
+      f32x4 sacc = bacc;
+      for (int q = 1; q < 8; ++q) sacc += *reinterpret_cast<const f32x4*>(scr + 4 * (tid + 8 * q));
+      *reinterpret_cast<f32x4*>(a.pB + (size_t)blockIdx.x * a.H + n0 + rrow) = sacc;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Skinny weight gradients on the VALU: out[row, s] = Σ_m Big[row, m]·Small[s, m] (+ Σ_m Big[row, m]) with S ≤ 16.
 //   dW1 = dH1·Xᵀ  (Big = dH1, Small = the gathered observations, bias sum = db1)
 //   dW3ᵀ = H2·dZᵀ (Big = H2, Small = the head cotangent)
@@ -1255,7 +1375,14 @@ static int wide_backward(crl_ppo* h, int net, const float* dOut, int ldd, const 
   // dW2 = δ2·h1ᵀ, db2 = Σ δ2
   WgradArgs g;
   g.dY = w->dA; g.X = w->h1[net]; g.H = H; g.M = M; g.chunk = w->chunk2; g.pW = w->pW2[net]; g.pB = w->pB2[net];
-  if (H >= 128) { const int nb = H / 128; hipLaunchKernelGGL(wide_wgrad_kernel<2>, dim3(w->S2, nb * nb), dim3(256), 0, h->stream, g); }
+  if (H == 256 && wide_x3()) {
+    // 256×128 output tiles (dY read twice, X once: 1.5 GB per launch at C3) unless CRL_WIDE_WGRAD_TILE=128 (2 GB)
+    static int tile = -1;
+    if (tile < 0) { const char* e = getenv("CRL_WIDE_WGRAD_TILE"); tile = e ? atoi(e) : 256; }
+    if (tile == 256) hipLaunchKernelGGL(wide_wgrad_x3_kernel<4>, dim3(w->S2, 2), dim3(512), 3 * (256 + 128) * X3ROW * 2, h->stream, g);
+    else hipLaunchKernelGGL(wide_wgrad_x3_kernel<2>, dim3(w->S2, 4), dim3(256), 3 * (128 + 128) * X3ROW * 2, h->stream, g);
+  }
+  else if (H >= 128) { const int nb = H / 128; hipLaunchKernelGGL(wide_wgrad_kernel<2>, dim3(w->S2, nb * nb), dim3(256), 0, h->stream, g); }
   else hipLaunchKernelGGL(wide_wgrad_kernel<1>, dim3(w->S2, 1), dim3(256), 0, h->stream, g);
   CRL_HIP_CHECK(hipGetLastError());
   // δ1 = (W2ᵀ·δ2) ⊙ (1 − h1²)
