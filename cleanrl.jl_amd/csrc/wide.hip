@@ -29,7 +29,7 @@ constexpr int WXS = 36;    // LDS stride (floats) of one staged sample row: 32 k
 constexpr int WLS = 24;    // doubles per loss-kernel block partial: pg, Σ-entropy, Σ(v−R²), Σ value term, db3a[16], db3c
 constexpr int AMAX = 16;
 
-enum { EPI_TANH = 0, EPI_BIAS = 1, EPI_DTANH = 2 };
+enum { EPI_TANH = 0, EPI_BIAS = 1, EPI_DTANH = 2, EPI_STORE = 3 };
 
 // ------------------------------------------------------------------------------------------------------
 // Workspace
@@ -178,6 +178,15 @@ static bool wide_x3() {   // CRL_WIDE_GEMM=f32 keeps every GEMM on v_mfma_f32_32
   return mode == 1;
 }
 
+static bool wide_x3_fused_head() {   // CRL_WIDE_FUSE_HEAD=0 keeps the heads as their own (padded-MFMA) launches
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("CRL_WIDE_FUSE_HEAD"); const char* nw = getenv("CRL_WIDE_X3_WAVES");
+    mode = (!(e && atoi(e) == 0) && !(nw && atoi(nw) != 8)) ? 1 : 0;
+  }
+  return mode == 1;
+}
+
 static int ensure_pack(crl_ppo* h) {
   WideWs* w = static_cast<WideWs*>(h->wide_ws);
   if (!w->pack_dirty) return 0;
@@ -210,7 +219,7 @@ __device__ __forceinline__ void tile_out(float* scr, const f32x16& acc, int lane
   wave_lds_fence();
   const int c = lane & 7, n = n0 + 4 * c;
   f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
-  if (EPI != EPI_DTANH) bv = *reinterpret_cast<const f32x4*>(bias + n);
+  if (EPI == EPI_TANH || EPI == EPI_BIAS) bv = *reinterpret_cast<const f32x4*>(bias + n);
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int m = (lane >> 3) + 8 * it, gm = mbase + m;
@@ -220,7 +229,7 @@ __device__ __forceinline__ void tile_out(float* scr, const f32x16& acc, int lane
         const f32x4 sv = *reinterpret_cast<const f32x4*>(S + (size_t)lds * gm + n);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.0f - sv[e] * sv[e]);
-      } else {
+      } else if (EPI == EPI_TANH || EPI == EPI_BIAS) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] += bv[e]; if (EPI == EPI_TANH) v[e] = tanh_fast(v[e]); }
       }
@@ -435,6 +444,8 @@ struct DenseX3Args {
   const float* X; int K;                 // X: [K × M] column-major, ld = K = 256
   const float* bias; const float* S;     // epilogue operands (ld 256)
   float* Y; int M;
+  // optional fused head (EPI_TANH, 8-wave variant): Z[a, m] = Σ_n W3[a, n]·Y[n, m] + b3[a] while the tile is at hand
+  const float* W3t; const float* b3; float* Z; int A; int ldz;   // W3t: [256 × ·] column-major (ld 256); Z null = no head
 };
 constexpr int X3ROW = 40;                // bf16 per staged sample row per piece: 32 k + 8 pad (80 B: conflict-free b128)
 
@@ -446,6 +457,32 @@ __device__ __forceinline__ void split3x4(const f32x4 v, uint2& h, uint2& m, uint
   const float s0 = r0 - __uint_as_float(m0 << 16), s1 = r1 - __uint_as_float(m0 & 0xFFFF0000u);
   const float s2 = r2 - __uint_as_float(m1 << 16), s3 = r3 - __uint_as_float(m1 & 0xFFFF0000u);
   h = make_uint2(h0, h1); m = make_uint2(m0, m1); l = make_uint2(cvt_pk_bf16(s0, s1), cvt_pk_bf16(s2, s3));
+}
+
+// tanh epilogue that also accumulates the head's partial dot products of this 32-row tile while the values still sit in
+// the C fragment (lane = sample, registers = rows): hp[m_local][a] += Σ_{n in tile} W3[a, n]·tanh(acc + b)[n, m]. One
+// cross-half exchange per output instead of a lane reduction; the tile is then stored line-coalesced by tile_out.
+__device__ __forceinline__ void tile_tanh_head(float* scr, f32x16 acc, int lane, int n0, int mloc0, int mbase, int M,
+                                               const float* bias, float* Y, const float* W3t, int A, float* hp, int hs) {
+  const int j = lane & 31, hf = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0 + 8 * g + 4 * hf);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[4 * g + e] = tanh_fast(acc[4 * g + e] + bv[e]);
+  }
+  for (int aa = 0; aa < A; ++aa) {
+    float p = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(W3t + (size_t)256 * aa + n0 + 8 * g + 4 * hf);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) p = __builtin_fmaf(w[e], acc[4 * g + e], p);
+    }
+    p += xor32(p);
+    if (hf == 0) hp[(mloc0 + j) * hs + aa] += p;
+  }
+  tile_out<EPI_STORE>(scr, acc, lane, n0, mbase, M, nullptr, nullptr, 0, Y, 256);
 }
 
 template <int EPI, int TM, int NW>
@@ -528,6 +565,26 @@ __global__ void __launch_bounds__(64 * NW) wide_dense_x3_kernel(DenseX3Args a) {
   }
   __syncthreads();
   float* scr = reinterpret_cast<float*>(smx) + wave * (32 * 36);
+  if (EPI == EPI_TANH && NW == 8 && a.Z) {
+    // fused head: per-wave partials over its 32 rows, then a fixed-order fold over the 8 waves
+    const int hs = a.ldz;
+    float* hp_all = reinterpret_cast<float*>(smx) + NW * (32 * 36);
+    float* hp = hp_all + wave * (MB * hs);
+    for (int i = lane; i < MB * hs; i += 64) hp[i] = 0.0f;
+    wave_lds_fence();
+#pragma unroll
+    for (int y = 0; y < TM; ++y)
+      tile_tanh_head(scr, acc[0][y], lane, wave * 32, 32 * y, m0 + 32 * y, a.M, a.bias, a.Y, a.W3t, a.A, hp, hs);
+    __syncthreads();
+    for (int i = tid; i < MB * a.A; i += NT) {
+      const int m = i / a.A, aa = i - m * a.A;
+      float z = 0.0f;
+#pragma unroll
+      for (int w8 = 0; w8 < NW; ++w8) z += hp_all[w8 * (MB * hs) + m * hs + aa];
+      if (m0 + m < a.M) a.Z[(size_t)a.ldz * (m0 + m) + aa] = z + a.b3[aa];
+    }
+    return;
+  }
 #pragma unroll
   for (int x = 0; x < TN; ++x)
 #pragma unroll
@@ -540,12 +597,16 @@ static int dense_x3_launch(hipStream_t st, const DenseX3Args& a) {
   if (a.M <= 0) return 0;
   static int nw = -1;
   if (nw < 0) { const char* e = getenv("CRL_WIDE_X3_WAVES"); nw = e ? atoi(e) : 8; }
+  const size_t head32 = a.Z ? (size_t)8 * 32 * 36 * 4 + (size_t)8 * 32 * a.ldz * 4 : 0;
+  const size_t head64 = a.Z ? (size_t)8 * 32 * 36 * 4 + (size_t)8 * 64 * a.ldz * 4 : 0;
   if (a.M <= 32768) {
-    const size_t smem = X3_SLAB_BF16 * 2 + 3 * 32 * X3ROW * 2;
+    size_t smem = X3_SLAB_BF16 * 2 + 3 * 32 * X3ROW * 2;
+    if (head32 > smem) smem = head32;
     if (nw == 8) hipLaunchKernelGGL((wide_dense_x3_kernel<EPI, 1, 8>), dim3((a.M + 31) / 32), dim3(512), smem, st, a);
     else hipLaunchKernelGGL((wide_dense_x3_kernel<EPI, 1, 4>), dim3((a.M + 31) / 32), dim3(256), smem, st, a);
   } else {
-    const size_t smem = X3_SLAB_BF16 * 2 + 3 * 64 * X3ROW * 2;
+    size_t smem = X3_SLAB_BF16 * 2 + 3 * 64 * X3ROW * 2;
+    if (head64 > smem) smem = head64;
     if (nw == 8) hipLaunchKernelGGL((wide_dense_x3_kernel<EPI, 2, 8>), dim3((a.M + 63) / 64), dim3(512), smem, st, a);
     else hipLaunchKernelGGL((wide_dense_x3_kernel<EPI, 2, 4>), dim3((a.M + 63) / 64), dim3(256), smem, st, a);
   }
@@ -593,7 +654,10 @@ static int wide_forward(crl_ppo* h, int net, const float* X, int ldx, const int3
   if (H == 256 && wide_x3()) {
     DenseX3Args x;
     x.Wx3 = pk + w->pk[net].x3f; x.X = w->h1[net]; x.K = H; x.bias = P + o.b2; x.S = nullptr; x.Y = w->h2[net]; x.M = M;
+    const bool fuse = wide_x3_fused_head();
+    x.W3t = pk + w->pk[net].w3t; x.b3 = P + o.b3; x.Z = fuse ? out : nullptr; x.A = NO; x.ldz = ldo;
     if (dense_x3_launch<EPI_TANH>(h->stream, x)) return 1;
+    if (fuse) return 0;   // the head came out of the layer-2 epilogue
   } else {
     a.W = P + o.W2; a.Kp = H; a.X = w->h1[net]; a.ldx = H; a.Kt = H; a.bias = P + o.b2; a.Y = w->h2[net];
     if (dense_launch<EPI_TANH>(h->stream, H, a)) return 1;
@@ -1389,6 +1453,7 @@ static int wide_backward(crl_ppo* h, int net, const float* dOut, int ldd, const 
   if (H == 256 && wide_x3()) {
     DenseX3Args x;
     x.Wx3 = pk + w->pk[net].x3b; x.X = w->dA; x.K = H; x.bias = nullptr; x.S = w->h1[net]; x.Y = w->dB; x.M = M;
+    x.W3t = nullptr; x.b3 = nullptr; x.Z = nullptr; x.A = 0; x.ldz = 0;
     if (dense_x3_launch<EPI_DTANH>(h->stream, x)) return 1;
   } else {
     d.W = pk + w->pk[net].w2t; d.Kp = H; d.X = w->dA; d.ldx = H; d.Kt = H; d.S = w->h1[net]; d.Y = w->dB;
