@@ -162,7 +162,11 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
   rc |= dalloc(&h->next_value, nt); rc |= dalloc(&h->ep_stats, 4);
   rc |= dalloc(&h->params, h->P); rc |= dalloc(&h->adam_m, h->P); rc |= dalloc(&h->adam_v, h->P);
   rc |= dalloc(&h->betap, 24); rc |= dalloc(&h->perm, B);
-  if (cfg->shuffle_mode == CRL_SHUFFLE_BLOCKED_FY) { rc |= dalloc(&h->perm_tmp, B); rc |= dalloc(&h->bfy_ws, (size_t)4 * 16384 + 8); }
+  if (cfg->shuffle_mode == CRL_SHUFFLE_BLOCKED_FY) {
+    rc |= dalloc(&h->perm_tmp, B); rc |= dalloc(&h->bfy_ws, (size_t)4 * 16384 + 8);
+    size_t k1 = 1; while (k1 * 4096 < B) k1 *= 2;
+    rc |= dalloc(&h->bfy_adv_part, (size_t)c.nmb * k1 * 2);
+  }
   // update grid: two 256-thread blocks per CU, alternating roles; never more waves than tiles
   hipDeviceProp_t prop;
   CRL_HIP_CHECK(hipGetDeviceProperties(&prop, device));
@@ -198,7 +202,7 @@ int32_t crl_ppo_destroy(crl_ppo* h) {
   wide_destroy(h);
   void* ptrs[] = {h->obs, h->action, h->logprob, h->reward, h->terminal, h->value, h->adv, h->ret, h->env_state, h->env_t,
                   h->cur_obs, h->next_done, h->ep_return, h->ep_length, h->next_value, h->ep_stats, h->params,
-                  h->adam_m, h->adam_v, h->betap, h->perm, h->perm_tmp, h->bfy_ws, h->gpart, h->lpart, h->adv_sums, h->adv_ms, h->newv, h->vfix,
+                  h->adam_m, h->adam_v, h->betap, h->perm, h->perm_tmp, h->bfy_ws, h->bfy_adv_part, h->gpart, h->lpart, h->adv_sums, h->adv_ms, h->newv, h->vfix,
                   h->stats_dev, h->comm_buf, h->stage};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int k = 0; k < CRL_K_COUNT; ++k)
@@ -229,7 +233,8 @@ int32_t crl_ppo_write(crl_ppo* h, int32_t field, const void* host, size_t nbytes
   CRL_HIP_CHECK(hipMemcpyAsync(fr.ptr, host, nbytes, hipMemcpyHostToDevice, h->stream));
   CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
   if (field == CRL_F_PARAMS) wide_mark_params_changed(h);
-  if (field == CRL_F_PERM) h->perm_is_bijection = false;  // a caller-supplied permutation has no closed-form inverse
+  if (field == CRL_F_PERM) h->perm_is_bijection = false;
+  if (field == CRL_F_PERM || field == CRL_F_ADVANTAGE) h->bfy_adv_parts = 0;  // a caller-supplied permutation has no closed-form inverse
   if (field == CRL_F_ENV_STATE || field == CRL_F_CUR_OBS) h->env_ready = true;  // caller-supplied env state
   return 0;
 }
@@ -435,7 +440,7 @@ int32_t crl_ppo_iterate(crl_ppo* h, int32_t n_iters, crl_ppo_stats* stats) {
     if (crl_compute_gae(h)) return 1;
     if (h->cfg.shuffle_mode == CRL_SHUFFLE_FISHER_YATES && launch_iota(h)) return 1;  // ppo.jl:191
     for (int ep = 0; ep < E; ++ep) {
-      if (launch_shuffle(h, (uint64_t)h->iteration * (uint64_t)E + (uint64_t)ep)) return 1;
+      if (launch_shuffle(h, (uint64_t)h->iteration * (uint64_t)E + (uint64_t)ep, /*with_adv_sums=*/true)) return 1;
       if (crl_adv_stats(h)) return 1;
       for (int mb = 0; mb < nmb; ++mb)
         if (update_step(h, mb, eta, 1, ep * nmb + mb)) return 1;

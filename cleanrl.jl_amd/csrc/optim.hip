@@ -59,12 +59,20 @@ __global__ void adv_sums_inv_kernel(const float* __restrict__ adv, int n, int M,
   }
 }
 
-__global__ void adv_sums_fold_kernel(const double* __restrict__ part, int nblk, int nmb, double* __restrict__ sums) {
-  const int mb = threadIdx.x;
+// one block per minibatch: thread t sums partials t, t+256, … in order, then a fixed tree over the 256 threads
+__global__ void __launch_bounds__(256) adv_sums_fold_kernel(const double* __restrict__ part, int nblk, int nmb, double* __restrict__ sums) {
+  const int mb = blockIdx.x, t = threadIdx.x;
   if (mb >= nmb) return;
-  double t = 0.0, t2 = 0.0;
-  for (int b = 0; b < nblk; ++b) { t += part[((size_t)mb * nblk + b) * 2]; t2 += part[((size_t)mb * nblk + b) * 2 + 1]; }
-  sums[2 * mb] = t; sums[2 * mb + 1] = t2;
+  __shared__ double sm[2][256];
+  double a = 0.0, a2 = 0.0;
+  for (int b = t; b < nblk; b += 256) { a += part[((size_t)mb * nblk + b) * 2]; a2 += part[((size_t)mb * nblk + b) * 2 + 1]; }
+  sm[0][t] = a; sm[1][t] = a2;
+  __syncthreads();
+  for (int w = 128; w >= 1; w >>= 1) {
+    if (t < w) { sm[0][t] += sm[0][t + w]; sm[1][t] += sm[1][t + w]; }
+    __syncthreads();
+  }
+  if (t == 0) { sums[2 * mb] = sm[0][0]; sums[2 * mb + 1] = sm[1][0]; }
 }
 // mean / corrected std (StatsBase mean/std, ppo.jl:221) from the (all-reduced) sums; n = global minibatch size
 __global__ void adv_finish_kernel(const double* __restrict__ sums, int nmb, double n, double* __restrict__ ms) {
@@ -78,6 +86,14 @@ __global__ void adv_finish_kernel(const double* __restrict__ sums, int nmb, doub
 }
 
 int launch_adv_stats_sums(crl_ppo* h) {
+  if (h->bfy_adv_parts > 0) {
+    // the blocked Fisher–Yates leaves already summed their slices (shuffle.hip): only the fixed-order fold is left
+    ProfScope ps(h, CRL_K_ADV_STATS);
+    hipLaunchKernelGGL(adv_sums_fold_kernel, dim3(h->dc.nmb), dim3(256), 0, h->stream, h->bfy_adv_part, h->bfy_adv_parts, h->dc.nmb, h->adv_sums);
+    CRL_HIP_CHECK(hipGetLastError());
+    h->bfy_adv_parts = 0;
+    return 0;
+  }
   const int nblk = 64;
   double* part = reinterpret_cast<double*>(h->gpart);  // gpart is idle between optimiser steps
   ProfScope ps(h, CRL_K_ADV_STATS);
@@ -89,7 +105,7 @@ int launch_adv_stats_sums(crl_ppo* h) {
   } else {
     hipLaunchKernelGGL(adv_sums_kernel, dim3(nblk, h->dc.nmb), dim3(512), 0, h->stream, h->adv, h->perm, h->dc.M, part);
   }
-  hipLaunchKernelGGL(adv_sums_fold_kernel, dim3(1), dim3(64), 0, h->stream, part, nfold, h->dc.nmb, h->adv_sums);
+  hipLaunchKernelGGL(adv_sums_fold_kernel, dim3(h->dc.nmb), dim3(256), 0, h->stream, part, nfold, h->dc.nmb, h->adv_sums);
   CRL_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -61,6 +61,8 @@ struct crl_ppo {
   int32_t* perm = nullptr;
   int32_t* perm_tmp = nullptr;     // blocked Fisher–Yates: elements grouped by L1 bucket
   uint32_t* bfy_ws = nullptr;      // blocked Fisher–Yates: totals | offsets | cursors | error flag
+  double* bfy_adv_part = nullptr;  // [nmb][K1][2] Σadv, Σadv² per leaf block, left behind by a fused shuffle (crl_ppo_iterate)
+  int bfy_adv_parts = 0;           // K1 when the partials above belong to the current permutation, else 0
   bool perm_is_bijection = false;  // perm == π_key(epoch): its inverse is computable (adv-stats fast path)
   uint64_t perm_epoch = 0;
   // update workspace
@@ -122,7 +124,7 @@ int launch_logprob_actions(crl_ppo* h, const float* obs_d, const int32_t* act_d,
 int launch_env_reset(crl_ppo* h);
 int launch_rollout(crl_ppo* h);
 int launch_next_value(crl_ppo* h);
-int launch_shuffle(crl_ppo* h, uint64_t epoch_id);
+int launch_shuffle(crl_ppo* h, uint64_t epoch_id, bool with_adv_sums = false);
 int launch_adv_stats_sums(crl_ppo* h);
 int launch_adv_stats_finish(crl_ppo* h);
 int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot);

@@ -105,9 +105,13 @@ __global__ void __launch_bounds__(1024) bfy_scan_kernel(uint32_t K1, const uint3
 
 // leaves: one block per L1 bucket; 256 sub-buckets ↔ 256 lanes for the Fisher–Yates tail. No per-thread arrays and no
 // unrolling: a low register count keeps several blocks per CU resident, which hides the dependent Philox→swap chain.
+// With adv != nullptr the block also leaves Σadv, Σadv² of its slice per minibatch in part[mb][bucket][2] (Float64, fixed
+// order): the advantage statistics of ppo.jl:221 then need no separate gather pass over the permutation. Requires
+// M >= BFY_CAP so that a bucket touches at most two minibatches.
 __global__ void __launch_bounds__(256, 4) bfy_leaf_kernel(uint32_t K1, uint64_t seed, uint64_t epoch, const uint32_t* __restrict__ off,
                                                           const int32_t* __restrict__ S, int32_t* __restrict__ perm,
-                                                          const uint32_t* __restrict__ err) {
+                                                          const uint32_t* __restrict__ err, const float* __restrict__ adv, int M,
+                                                          int nmb, double* __restrict__ part) {
   if (*err) return;
   __shared__ int32_t buf[BFY_CAP], buf2[BFY_CAP];
   __shared__ uint8_t dig[BFY_CAP];
@@ -169,10 +173,40 @@ __global__ void __launch_bounds__(256, 4) bfy_leaf_kernel(uint32_t K1, uint64_t 
     }
   }
   __syncthreads();
-  for (uint32_t idx = t; idx < c; idx += 256) perm[base + idx] = buf2[idx];
+  if (!adv) {
+    for (uint32_t idx = t; idx < c; idx += 256) perm[base + idx] = buf2[idx];
+    return;
+  }
+  const int mb0 = (int)(base / (uint32_t)M);
+  const uint32_t cut = (uint32_t)(mb0 + 1) * (uint32_t)M;     // first position of the next minibatch
+  // phase 1: all gathers in flight together (results parked in the dead `buf`), phase 2: ordered sums from LDS
+  float* abuf = reinterpret_cast<float*>(buf);
+#pragma unroll 8
+  for (uint32_t idx = t; idx < c; idx += 256) {
+    const int32_t v = buf2[idx];
+    perm[base + idx] = v;
+    abuf[idx] = adv[v];
+  }
+  double sa = 0.0, sa2 = 0.0, sb = 0.0, sb2 = 0.0;
+  for (uint32_t idx = t; idx < c; idx += 256) {
+    const double a = (double)abuf[idx];
+    if (base + idx < cut) { sa += a; sa2 += a * a; } else { sb += a; sb2 += a * a; }
+  }
+  __shared__ double red[4][4];
+  sa = wave_sum(sa); sa2 = wave_sum(sa2); sb = wave_sum(sb); sb2 = wave_sum(sb2);
+  if ((t & 63) == 0) { red[t >> 6][0] = sa; red[t >> 6][1] = sa2; red[t >> 6][2] = sb; red[t >> 6][3] = sb2; }
+  __syncthreads();
+  if (t < nmb) {
+    double v0 = 0.0, v1 = 0.0;
+    if (t == mb0) { v0 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]); v1 = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]); }
+    else if (t == mb0 + 1) { v0 = (red[0][2] + red[1][2]) + (red[2][2] + red[3][2]); v1 = (red[0][3] + red[1][3]) + (red[2][3] + red[3][3]); }
+    part[((size_t)t * K1 + d1) * 2] = v0; part[((size_t)t * K1 + d1) * 2 + 1] = v1;
+  }
 }
 
-static int launch_blocked_fy(crl_ppo* h, uint64_t epoch_id) {
+// fused = also leave the per-minibatch advantage sums in h->bfy_adv_part (crl_ppo_iterate only: there the advantages are
+// final before the shuffle runs)
+static int launch_blocked_fy(crl_ppo* h, uint64_t epoch_id, bool fused) {
   const int n = h->dc.B;
   uint32_t K1 = 1;
   while ((uint64_t)K1 * (uint64_t)BFY_L1 < (uint64_t)n) K1 *= 2;
@@ -183,17 +217,21 @@ static int launch_blocked_fy(crl_ppo* h, uint64_t epoch_id) {
   hipLaunchKernelGGL(bfy_l1_kernel<false>, dim3(chunks), dim3(256), sizeof(uint32_t) * K1, h->stream, n, K1, h->cfg.seed, epoch_id, tot, cur, h->perm_tmp);
   hipLaunchKernelGGL(bfy_scan_kernel, dim3(1), dim3(1024), 0, h->stream, K1, tot, off, cur, err);
   hipLaunchKernelGGL(bfy_l1_kernel<true>, dim3(chunks), dim3(256), sizeof(uint32_t) * 2 * K1, h->stream, n, K1, h->cfg.seed, epoch_id, tot, cur, h->perm_tmp);
-  hipLaunchKernelGGL(bfy_leaf_kernel, dim3(K1), dim3(256), 0, h->stream, K1, h->cfg.seed, epoch_id, off, h->perm_tmp, h->perm, err);
+  const bool fuse = fused && h->bfy_adv_part && h->dc.M >= BFY_CAP && h->dc.nmb <= 256;
+  hipLaunchKernelGGL(bfy_leaf_kernel, dim3(K1), dim3(256), 0, h->stream, K1, h->cfg.seed, epoch_id, off, h->perm_tmp, h->perm, err,
+                     fuse ? h->adv : nullptr, h->dc.M, h->dc.nmb, h->bfy_adv_part);
   CRL_HIP_CHECK(hipGetLastError());
+  h->bfy_adv_parts = fuse ? (int)K1 : 0;
   return 0;
 }
 
-int launch_shuffle(crl_ppo* h, uint64_t epoch_id) {
+int launch_shuffle(crl_ppo* h, uint64_t epoch_id, bool with_adv_sums) {
   const int n = h->dc.B;
   ProfScope ps(h, CRL_K_SHUFFLE);
+  h->bfy_adv_parts = 0;
   if (h->cfg.shuffle_mode == CRL_SHUFFLE_BLOCKED_FY) {
     h->perm_is_bijection = false;
-    return launch_blocked_fy(h, epoch_id);
+    return launch_blocked_fy(h, epoch_id, with_adv_sums);
   }
   if (h->cfg.shuffle_mode == CRL_SHUFFLE_FISHER_YATES) {
     h->perm_is_bijection = false;
