@@ -326,3 +326,63 @@ def test_blocked_fisher_yates_is_uniform_over_small_permutations():
     assert chi2 < 60.0, chi2          # 23 dof: P(chi2 > 60) ≈ 3e-5
     p = O.shuffle_blocked_fy(100000, 1, 0)
     assert np.array_equal(np.sort(p), np.arange(100000)) and abs(p[:25000].mean() / 1e5 - 0.5) < 0.01
+
+
+# ---- property tests (hypothesis): size-independent invariants of the restatements -------------------------------
+from hypothesis import given, settings, strategies as hst  # noqa: E402
+
+
+@settings(max_examples=40, deadline=None)
+@given(hst.integers(1, 9), hst.integers(1, 40), hst.integers(0, 2**31 - 1), hst.integers(0, 1))
+def test_gae_property_matches_float64_recurrence(nt, k, seed, mode):
+    """ppo.jl:48-73 as a plain Float64 recurrence in numpy, ragged shapes, both modes."""
+    rng = np.random.default_rng(seed)
+    value = np.asfortranarray((rng.standard_normal((nt, k)) * 5).astype(np.float32))
+    reward = np.asfortranarray(rng.standard_normal((nt, k)).astype(np.float32))
+    term = np.asfortranarray((rng.random((nt, k)) < 0.2).astype(np.uint8))
+    nv = rng.standard_normal(nt).astype(np.float32); nd = (rng.random(nt) < 0.3).astype(np.uint8)
+    adv, ret = O.gae_batch(value, reward, term, nv, nd, 0.99, 0.95, mode)
+    gl = np.float64(np.float32(0.99) * np.float32(0.95)); g = np.float64(np.float32(0.99))
+    ref = np.zeros((nt, k), np.float32)
+    for e in range(nt):
+        acc = 0.0
+        last = k - 1 if mode == 1 else k - 2          # compat: loop k-1:-1:1, slot k stays 0
+        for t in range(last, -1, -1):
+            v_next = nv[e] if t == k - 1 else value[e, t + 1]
+            nonterm = 1.0 - float(nd[e] if t == k - 1 else term[e, t + 1])
+            delta = np.float64(reward[e, t]) + g * nonterm * np.float64(v_next) - np.float64(value[e, t])
+            acc = delta + gl * nonterm * acc
+            ref[e, t] = np.float32(acc)
+    assert np.array_equal(adv, ref)
+    assert np.array_equal(ret, adv + value)
+
+
+@settings(max_examples=30, deadline=None)
+@given(hst.integers(1, 3000), hst.integers(0, 2**31 - 1), hst.integers(0, 1000))
+def test_shuffles_are_permutations(n, seed, epoch):
+    fy = O.shuffle_fy(np.arange(n, dtype=np.int32), seed, epoch)
+    bf = O.shuffle_blocked_fy(n, seed, epoch)
+    assert np.array_equal(np.sort(fy), np.arange(n)) and np.array_equal(np.sort(bf), np.arange(n))
+    if n > 64:
+        assert not np.array_equal(fy, np.arange(n)) and not np.array_equal(bf, np.arange(n))
+
+
+@settings(max_examples=30, deadline=None)
+@given(hst.integers(1, 400), hst.integers(0, 2**31 - 1), hst.floats(0.5, 0.999))
+def test_a2c_returns_property(n, seed, gamma):
+    """a2c.jl:13-24: G_j = t_j ? 0 : r_j + γ·G_{j+1}, seeded from the bootstrap unless the last step is terminal."""
+    rng = np.random.default_rng(seed)
+    r = rng.random(n); t = (rng.random(n) < 0.1).astype(np.uint8)
+    g = O.a2c_discounted_future_rewards(r, t, 2.5, gamma)
+    nxt = 2.5
+    for j in range(n - 1, -1, -1):
+        nxt = 0.0 if t[j] else r[j] + gamma * nxt
+        assert g[j] == nxt
+
+
+@settings(max_examples=25, deadline=None)
+@given(hst.integers(1, 600), hst.integers(0, 2**31 - 1), hst.integers(0, 10**6))
+def test_dqn_sampler_property(n, seed, gstep):
+    k = max(1, min(120, n // 2 + 1))
+    idx = O.dqn_sample_indices(seed, gstep, n, k)
+    assert len(set(idx.tolist())) == k and 0 <= idx.min() and idx.max() < n
