@@ -48,7 +48,7 @@ EXPORTS = [
     "crl_rollout_store", "crl_env_reset", "crl_rollout_run", "crl_episode_stats_read", "crl_compute_gae",
     "crl_shuffle", "crl_adv_stats", "crl_ppo_update_minibatch", "crl_ppo_iterate", "crl_ppo_iteration",
     "crl_comm_unique_id", "crl_comm_init", "crl_comm_init_external", "crl_adv_stats_local", "crl_adv_stats_finish",
-    "crl_prof_enable", "crl_prof_read", "crl_prof_reset",
+    "crl_prof_enable", "crl_prof_read", "crl_prof_reset", "crl_ppo_exact_reruns",
     "crl_a2c_create", "crl_a2c_destroy", "crl_a2c_param_count", "crl_a2c_write_params", "crl_a2c_read_params",
     "crl_a2c_read_env", "crl_a2c_read_buffer", "crl_a2c_run_until_update", "crl_a2c_discounted_future_rewards",
     "crl_dqn_create", "crl_dqn_destroy", "crl_dqn_write_params", "crl_dqn_read_params", "crl_dqn_status_read", "crl_dqn_run",
@@ -147,6 +147,7 @@ def load():
     L.crl_prof_read.argtypes = [vp, C.c_int32, dp, C.POINTER(C.c_int64)]
     L.crl_prof_reset.argtypes = [vp]
     i64p = C.POINTER(C.c_int64)
+    L.crl_ppo_exact_reruns.argtypes = [vp, i64p]
     L.crl_a2c_create.argtypes = [C.POINTER(CrlA2CConfig), C.c_int32, C.POINTER(vp)]
     L.crl_a2c_destroy.argtypes = [vp]
     L.crl_a2c_param_count.argtypes = [vp, i64p]
@@ -299,6 +300,12 @@ class Handle:
         it = C.c_int64()
         check(load().crl_ppo_iteration(self._h, C.byref(it)))
         return it.value
+
+    @property
+    def exact_reruns(self):
+        n = C.c_int64()
+        check(load().crl_ppo_exact_reruns(self._h, C.byref(n)))
+        return n.value
 
     def comm_init(self, unique_id: bytes, world_size: int, rank: int):
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)

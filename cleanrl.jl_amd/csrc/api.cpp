@@ -183,6 +183,7 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
   rc |= dalloc(&h->newv, (size_t)c.M); rc |= dalloc(&h->vfix, 8);
   rc |= dalloc(&h->stats_dev, (size_t)cfg->update_epochs * c.nmb);
   rc |= dalloc(&h->comm_buf, (size_t)h->P + 8);
+  rc |= dalloc(&h->snap, (size_t)3 * h->P); rc |= dalloc(&h->snap_betap, 24);
   if (rc) { crl_ppo_destroy(h); return 1; }
   if (wide && wide_create(h)) { crl_ppo_destroy(h); return 1; }
   double bp[24];
@@ -203,7 +204,7 @@ int32_t crl_ppo_destroy(crl_ppo* h) {
   void* ptrs[] = {h->obs, h->action, h->logprob, h->reward, h->terminal, h->value, h->adv, h->ret, h->env_state, h->env_t,
                   h->cur_obs, h->next_done, h->ep_return, h->ep_length, h->next_value, h->ep_stats, h->params,
                   h->adam_m, h->adam_v, h->betap, h->perm, h->perm_tmp, h->bfy_ws, h->bfy_adv_part, h->gpart, h->lpart, h->adv_sums, h->adv_ms, h->newv, h->vfix,
-                  h->stats_dev, h->comm_buf, h->stage};
+                  h->stats_dev, h->comm_buf, h->snap, h->snap_betap, h->stage};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int k = 0; k < CRL_K_COUNT; ++k)
     for (auto& pr : h->prof_slots[k].pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -438,12 +439,44 @@ int32_t crl_ppo_iterate(crl_ppo* h, int32_t n_iters, crl_ppo_stats* stats) {
     }
     if (launch_rollout(h)) return 1;
     if (crl_compute_gae(h)) return 1;
-    if (h->cfg.shuffle_mode == CRL_SHUFFLE_FISHER_YATES && launch_iota(h)) return 1;  // ppo.jl:191
-    for (int ep = 0; ep < E; ++ep) {
-      if (launch_shuffle(h, (uint64_t)h->iteration * (uint64_t)E + (uint64_t)ep, /*with_adv_sums=*/true)) return 1;
-      if (crl_adv_stats(h)) return 1;
-      for (int mb = 0; mb < nmb; ++mb)
-        if (update_step(h, mb, eta, 1, ep * nmb + mb)) return 1;
+    // Data parallel + clipped value loss: the fused kernels speculate on u = mean(v − R²) ≤ 0 (Q4). If the (global,
+    // sticky) flag says the speculation failed somewhere in this iteration, the update phase is re-run from a snapshot
+    // with the exact, slower step (launch_update_exact_dp). Every rank sees the same flag, so every rank re-runs.
+    const bool guard = h->comm != nullptr && !h->wide && h->cfg.clip_value_loss;
+    if (guard) {
+      const size_t P = (size_t)h->P;
+      CRL_HIP_CHECK(hipMemcpyAsync(h->snap, h->params, P * 4, hipMemcpyDeviceToDevice, h->stream));
+      CRL_HIP_CHECK(hipMemcpyAsync(h->snap + P, h->adam_m, P * 4, hipMemcpyDeviceToDevice, h->stream));
+      CRL_HIP_CHECK(hipMemcpyAsync(h->snap + 2 * P, h->adam_v, P * 4, hipMemcpyDeviceToDevice, h->stream));
+      CRL_HIP_CHECK(hipMemcpyAsync(h->snap_betap, h->betap, 24 * 8, hipMemcpyDeviceToDevice, h->stream));
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+      const bool exact = pass == 1;
+      if (h->cfg.shuffle_mode == CRL_SHUFFLE_FISHER_YATES && launch_iota(h)) return 1;  // ppo.jl:191
+      for (int ep = 0; ep < E; ++ep) {
+        if (launch_shuffle(h, (uint64_t)h->iteration * (uint64_t)E + (uint64_t)ep, /*with_adv_sums=*/true)) return 1;
+        if (crl_adv_stats(h)) return 1;
+        for (int mb = 0; mb < nmb; ++mb) {
+          if (exact) {
+            if (launch_update_exact_dp(h, mb, h->stats_dev + ep * nmb + mb)) return 1;
+            if (launch_optim(h, eta)) return 1;
+          } else if (update_step(h, mb, eta, 1, ep * nmb + mb)) return 1;
+        }
+      }
+      if (exact) CRL_HIP_CHECK(hipMemsetAsync(h->vfix + 4, 0, sizeof(double), h->stream));   // handled: lower the sticky flag
+      if (!guard || exact) break;
+      double sticky = 0.0;
+      CRL_HIP_CHECK(hipMemcpyAsync(&sticky, h->vfix + 4, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+      if (sticky == 0.0) break;
+      const size_t P = (size_t)h->P;
+      CRL_HIP_CHECK(hipMemcpyAsync(h->params, h->snap, P * 4, hipMemcpyDeviceToDevice, h->stream));
+      CRL_HIP_CHECK(hipMemcpyAsync(h->adam_m, h->snap + P, P * 4, hipMemcpyDeviceToDevice, h->stream));
+      CRL_HIP_CHECK(hipMemcpyAsync(h->adam_v, h->snap + 2 * P, P * 4, hipMemcpyDeviceToDevice, h->stream));
+      CRL_HIP_CHECK(hipMemcpyAsync(h->betap, h->snap_betap, 24 * 8, hipMemcpyDeviceToDevice, h->stream));
+      CRL_HIP_CHECK(hipMemsetAsync(h->vfix + 4, 0, sizeof(double), h->stream));
+      wide_mark_params_changed(h);
+      h->exact_reruns += 1;
     }
     h->iteration += 1;
   }
@@ -452,15 +485,23 @@ int32_t crl_ppo_iterate(crl_ppo* h, int32_t n_iters, crl_ppo_stats* stats) {
     CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
   }
   if (check_bfy(h)) return 1;
-  if (h->world > 1) {
+  if (h->world > 1 && h->external_comm && !h->wide) {
+    // host-side exchange (crl_comm_init_external) cannot run the exact re-pass: fail loudly rather than train on a
+    // speculative critic gradient
     double vf[8];
     CRL_HIP_CHECK(hipMemcpyAsync(vf, h->vfix, sizeof(vf), hipMemcpyDeviceToHost, h->stream));
     CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
     if (vf[4] != 0.0) {
-      set_error("value-loss branch u = mean(v - R^2) > 0 was taken in a data-parallel run; its exact pass is single-GPU only in this build");
+      set_error("value-loss branch u = mean(v - R^2) > 0 was taken under host-side gradient exchange; use crl_comm_init (RCCL) for the exact pass");
       return 1;
     }
   }
+  return 0;
+}
+
+int32_t crl_ppo_exact_reruns(const crl_ppo* h, int64_t* n) {
+  if (!h || !n) { set_error("null argument"); return 1; }
+  *n = h->exact_reruns;
   return 0;
 }
 

@@ -45,6 +45,7 @@ struct crl_ppo {
   hipStream_t stream = nullptr;
   int64_t P = 0, Pa = 0, Pc = 0;  // total / actor / critic parameter counts
   int64_t iteration = 0;
+  int64_t exact_reruns = 0;        // iterations whose update phase was re-run exactly under data parallelism (Q4)
   bool env_ready = false;          // crl_env_reset has run (crl_ppo_iterate / crl_rollout_run do it on first use)
   int64_t num_updates = 1;
 
@@ -75,6 +76,8 @@ struct crl_ppo {
   double* vfix = nullptr;      // [8] u, count(u>q), -, flag, sticky flag
   crl_ppo_stats* stats_dev = nullptr;  // [epochs*nmb]
   float* comm_buf = nullptr;   // [P + 8] gradient (+ loss scalars) message for the all-reduce
+  float* snap = nullptr;       // [3P] + betap: parameters / Adam state at the start of an iteration (data-parallel re-run, Q4)
+  double* snap_betap = nullptr;
   // staging for host-pointer calls
   void* stage = nullptr; size_t stage_bytes = 0;
   void* pinned = nullptr; size_t pinned_bytes = 0;
@@ -128,6 +131,7 @@ int launch_shuffle(crl_ppo* h, uint64_t epoch_id, bool with_adv_sums = false);
 int launch_adv_stats_sums(crl_ppo* h);
 int launch_adv_stats_finish(crl_ppo* h);
 int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot);
+int launch_update_exact_dp(crl_ppo* h, int mb, crl_ppo_stats* stats_slot);
 int launch_optim(crl_ppo* h, double eta);
 int comm_allreduce(crl_ppo* h, void* buf, size_t count, bool is_double);
 // wide.hip — layer-wise path for other network shapes

@@ -658,4 +658,40 @@ int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
   return 0;
 }
 
+// Data-parallel step when the value-loss branch u > 0 may be live (ppo.jl:232-237, Q4): the speculative pass, its reduce and
+// all-reduce run as usual; then the GLOBAL flag is read back (the same value on every rank — u is a global mean), and
+// only if it is up do all ranks add: local #{u > q} → all-reduce → exact critic pass → its reduce → all-reduce of the
+// critic slice and the two critic loss sums. Slow path by design (a host read-back per step): crl_ppo_iterate enters it
+// only when re-running an iteration whose sticky flag was raised.
+int launch_update_exact_dp(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
+  if (h->wide) return wide_update(h, mb, stats_slot);   // the layer-wise path is always exact
+  const int P = (int)h->P, Pa = (int)h->Pa, Pc = (int)h->Pc;
+  if (run_update(h, mb, 0)) return 1;
+  int nA, nC;
+  main_pass_blocks(h, &nA, &nC);
+  hipLaunchKernelGGL(reduce_kernel<0>, dim3((P + 63) / 64), dim3(256), 0, h->stream, h->gpart, h->lpart, nA, nC, h->update_blocks,
+                     Pa, Pa, Pc, h->comm_buf, stats_args(h, mb, stats_slot, 0));
+  CRL_HIP_CHECK(hipGetLastError());
+  if (comm_allreduce(h, h->comm_buf, (size_t)P + 4, false)) return 1;
+  hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(64), 0, h->stream, h->comm_buf, P, stats_args(h, mb, stats_slot, 0), 0);
+  CRL_HIP_CHECK(hipGetLastError());
+  if (!h->cfg.clip_value_loss) return 0;
+  double flag = 0.0;
+  CRL_HIP_CHECK(hipMemcpyAsync(&flag, h->vfix + 3, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  if (flag == 0.0) return 0;
+  hipLaunchKernelGGL(vfix_count_kernel, dim3(1), dim3(1024), 0, h->stream, h->dc, h->perm, mb, h->newv, h->value, h->ret, h->vfix);
+  CRL_HIP_CHECK(hipGetLastError());
+  if (comm_allreduce(h, h->vfix + 1, 1, true)) return 1;                       // global #{u > q}
+  if (run_update(h, mb, 1)) return 1;                                          // exact critic gradient of this shard
+  hipLaunchKernelGGL(reduce_kernel<1>, dim3((P + 63) / 64), dim3(256), 0, h->stream, h->gpart, h->lpart, 0, h->update_blocks,
+                     h->update_blocks, Pa, Pa, Pc, h->comm_buf, stats_args(h, mb, stats_slot, 0));
+  CRL_HIP_CHECK(hipGetLastError());
+  if (comm_allreduce(h, h->comm_buf + Pa, (size_t)Pc, false)) return 1;        // critic slice (the actor slice is global already)
+  if (comm_allreduce(h, h->comm_buf + P + 2, 2, false)) return 1;              // Σ(v − R²), Σ max(u, q)
+  hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(64), 0, h->stream, h->comm_buf, P, stats_args(h, mb, stats_slot, 0), 1);
+  CRL_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 }  // namespace crl

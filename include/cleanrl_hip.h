@@ -157,6 +157,10 @@ int32_t crl_ppo_update_minibatch(crl_ppo* h, int32_t mb, double eta, int32_t app
  * update_epochs*num_minibatches records of the LAST iteration. */
 int32_t crl_ppo_iterate(crl_ppo* h, int32_t n_iters, crl_ppo_stats* stats);
 int32_t crl_ppo_iteration(const crl_ppo* h, int64_t* it);
+/* how many iterations had their update phase re-run with the exact value-loss pass under data parallelism: the fused
+ * kernels speculate on u = mean(v - R^2) <= 0 (ppo.jl:232-237); with an RCCL communicator a failed speculation restores the
+ * parameters / Adam state of the iteration's start and repeats its optimiser steps exactly (two more small all-reduces each) */
+int32_t crl_ppo_exact_reruns(const crl_ppo* h, int64_t* n);
 
 /* Data parallelism over num_envs: one RCCL communicator per handle (one process per GPU). The 128-byte id comes
  * from crl_comm_unique_id on rank 0 and is broadcast by the host launcher. Gradients (+ advantage statistics) are

@@ -481,3 +481,35 @@ def test_full_size_update_is_deterministic_and_additive(crl):
     e, t = np.argwhere(term[:, 1:] == 1)[0]
     assert adv[e, t] == np.float32(np.float64(rew[e, t]) - np.float64(val[e, t]))
     agent.close()
+
+
+@pytest.mark.parametrize("forced_comm", [False, True])
+def test_iteration_with_live_unclipped_value_branch(crl, forced_comm, monkeypatch):
+    """γ = 0 makes every return 0 or 1 while a critic head bias of 5 puts u = mean(v − R²) ≈ 4 above every clipped term
+    (Q4): the whole iteration must still match the oracle. Single GPU: the in-line fix-up pass. With an RCCL communicator
+    (forced 1-rank): the speculative pass raises the sticky flag, the iteration's update phase is re-run from the snapshot
+    with the exact data-parallel step (count and critic-slice all-reduces) — same result."""
+    if forced_comm:
+        monkeypatch.setenv("CRL_COMM_FORCE", "1")
+    nt, k = 8, 128
+    cfg = crl.PPOConfig(num_envs=nt, num_steps=k, total_timesteps=nt * k * 10, gamma=0.0)
+    agent = crl.Agent(cfg, shuffle_mode=crl._lib.SHUFFLE_FISHER_YATES)
+    cfgo = O.make_config(num_envs=nt, num_steps=k, gamma=0.0)
+    params = agent.get_params()
+    params[O.param_offsets(cfgo)[11]] = 5.0
+    agent.set_params(params)
+    h = agent.handle
+    if forced_comm:
+        h.comm_init(crl.comm_unique_id(), 1, 0)
+    st = O.State(cfgo); st.params[:] = params; st.env_init()
+    h.env_reset()
+    for it in range(2):
+        gs = h.iterate(1); os_ = st.iterate(10, gen_perm=True)
+        assert max(s["n_unclipped_wins"] for s in os_) > 0, "the test must exercise the u > q branch"
+        for a, b in zip(gs, os_):
+            assert a["n_unclipped_wins"] == b["n_unclipped_wins"]
+            for key in ("loss", "v_loss", "pg_loss"):
+                assert abs(a[key] - b[key]) <= 2e-5 * max(1.0, abs(b[key])), (it, key, a[key], b[key])
+        assert np.max(np.abs(h.read(crl._lib.F_PARAMS) - st.params)) < 2e-5
+    assert h.exact_reruns == (2 if forced_comm else 0)
+    agent.close(); st.close()
