@@ -300,17 +300,41 @@ __global__ void __launch_bounds__(64) dqn_wgrad_kernel(DQNDev a) {
   if (!a.ctl->train_pending) return;
   const int k = (int)a.cfg.batch_size, p = blockIdx.x * 64 + threadIdx.x;
   if (p >= QP) return;
+  // every loop is unrolled 30x: the operands were written by the previous launches, so they come from the Infinity Cache
+  // at ≈2 µs per dependent round trip — 4 rounds of 60 loads in flight instead of 15 of 16. The Float64 adds stay in
+  // sample order. Adding an exact 0.0 for samples of the other action leaves the sum unchanged.
   double g = 0.0;
-  if (p < Qob1) { const int i = p % QH1, kk = p / QH1; for (int b = 0; b < k; ++b) g += a.d1[(size_t)QH1 * b + i] * a.rb_state[(size_t)QD * a.idx[b] + kk]; }
-  else if (p < QoW2) { const int i = p - Qob1; for (int b = 0; b < k; ++b) g += a.d1[(size_t)QH1 * b + i]; }
-  else if (p < Qob2) {
+  if (p < Qob1) {
+    const int i = p % QH1, kk = p / QH1;
+#pragma unroll 30
+    for (int b = 0; b < k; ++b) g += a.d1[(size_t)QH1 * b + i] * a.rb_state[(size_t)QD * a.idx[b] + kk];
+  } else if (p < QoW2) {
+    const int i = p - Qob1;
+#pragma unroll 30
+    for (int b = 0; b < k; ++b) g += a.d1[(size_t)QH1 * b + i];
+  } else if (p < Qob2) {
     const int r = p - QoW2, j = r % QH2, kk = r / QH2;
-#pragma unroll 8
+#pragma unroll 30
     for (int b = 0; b < k; ++b) g += a.d2[(size_t)QH2 * b + j] * a.H1[(size_t)QH1 * b + kk];
+  } else if (p < QoW3) {
+    const int j = p - Qob2;
+#pragma unroll 30
+    for (int b = 0; b < k; ++b) g += a.d2[(size_t)QH2 * b + j];
+  } else if (p < Qob3) {
+    const int r = p - QoW3, aa = r % QA, j = r / QA;
+#pragma unroll 30
+    for (int b = 0; b < k; ++b) {
+      const double t = a.dz[b] * a.H2[(size_t)QH2 * b + j];
+      if (a.rb_action[a.idx[b]] == aa) g += t;
+    }
+  } else {
+    const int aa = p - Qob3;
+#pragma unroll 30
+    for (int b = 0; b < k; ++b) {
+      const double t = a.dz[b];
+      if (a.rb_action[a.idx[b]] == aa) g += t;
+    }
   }
-  else if (p < QoW3) { const int j = p - Qob2; for (int b = 0; b < k; ++b) g += a.d2[(size_t)QH2 * b + j]; }
-  else if (p < Qob3) { const int r = p - QoW3, aa = r % QA, j = r / QA; for (int b = 0; b < k; ++b) if (a.rb_action[a.idx[b]] == aa) g += a.dz[b] * a.H2[(size_t)QH2 * b + j]; }
-  else { const int aa = p - Qob3; for (int b = 0; b < k; ++b) if (a.rb_action[a.idx[b]] == aa) g += a.dz[b]; }
   a.grads[p] = (float)g;
 }
 // Flux Adam(lr) (dqn.jl:41,109) + hard target copy (dqn.jl:111-113) + loss record (dqn.jl:115-117); one block
