@@ -1,3 +1,4 @@
-mkdir -p gpurun_out
-cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_bfy -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --shuffle blocked-fy > /dev/null 2>&1
-echo done
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/bfyprof -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/bfy_bench.json 2>/dev/null
+cd $R/gpurun_out; cp $(find bfyprof -name "*kernel_stats.csv" | head -1) bfy_kernel_stats.csv; rm -rf bfyprof
