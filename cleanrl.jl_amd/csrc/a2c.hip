@@ -141,7 +141,8 @@ __device__ __forceinline__ void head_forward(const float* __restrict__ W3, const
 #pragma clang fp contract(off)
   if (lane < n_out) {
     double acc = 0.0;
-    for (int k = 0; k < AH; ++k) acc += (double)W3[lane + n_out * k] * hs[k];
+#pragma unroll 16
+    for (int k = 0; k < AH; ++k) acc += (double)W3[lane + n_out * k] * hs[k];   // W3 may live in LDS (collect kernel)
     zs[lane] = acc + (double)b3[lane];
   }
   __syncthreads();
@@ -161,8 +162,15 @@ __global__ void __launch_bounds__(64) a2c_collect_kernel(A2CDev a, int64_t max_e
   const float* P = net_base(a.params, 0);
   NetRow r;
   load_row(P, lane, r);
-  const float* W3 = P + AH * AD + AH + AH * AH + AH;
-  const float* b3 = W3 + AA * AH;
+  // the head's rows sit in LDS for the whole launch: its 64-term dot product would otherwise wait for a global load per term
+  __shared__ float w3s[AA * AH + AA];
+  {
+    const float* W3g = P + AH * AD + AH + AH * AH + AH;
+    for (int i = lane; i < AA * AH + AA; i += 64) w3s[i] = W3g[i];
+  }
+  __syncthreads();
+  const float* W3 = w3s;
+  const float* b3 = w3s + AA * AH;
   A2CCtl c = *a.ctl;
   c.n_eps = 0;
   int64_t taken = 0;
