@@ -110,8 +110,13 @@ __global__ void __launch_bounds__(128) dqn_collect_kernel(DQNDev a) {
   __shared__ double obs[QD], h1s[QH1], h2s[QH2], qs[QA];
   __shared__ int go, need_q, action_s;
   __shared__ double eps_s;
+  __shared__ float wq[QP];   // q_net for the greedy steps of this launch (its dot products read one weight per term)
   const int tid = threadIdx.x;
   if (tid == 0) c = *a.ctl;
+  __syncthreads();
+  // nothing to do (budget used up / training still pending): skip the 44 KB weight load
+  if (c.train_pending || c.taken >= c.budget || c.global_step >= a.cfg.total_timesteps) return;
+  for (int p = tid; p < QP; p += 128) wq[p] = a.q[p];
   __syncthreads();
   while (true) {
     if (tid == 0) {
@@ -132,24 +137,24 @@ __global__ void __launch_bounds__(128) dqn_collect_kernel(DQNDev a) {
     if (need_q) {                                                                    // dqn.jl:64 qs = q_net(obs)
       if (tid < QH1) {
         double acc = 0.0;
-        for (int kk = 0; kk < QD; ++kk) acc += (double)a.q[QoW1 + tid + QH1 * kk] * obs[kk];
-        acc += (double)a.q[Qob1 + tid];
+        for (int kk = 0; kk < QD; ++kk) acc += (double)wq[QoW1 + tid + QH1 * kk] * obs[kk];
+        acc += (double)wq[Qob1 + tid];
         h1s[tid] = acc > 0.0 ? acc : 0.0;
       }
       __syncthreads();
       if (tid < QH2) {
         double acc = 0.0;
 #pragma unroll 8
-        for (int kk = 0; kk < QH1; ++kk) acc += (double)a.q[QoW2 + tid + QH2 * kk] * h1s[kk];
-        acc += (double)a.q[Qob2 + tid];
+        for (int kk = 0; kk < QH1; ++kk) acc += (double)wq[QoW2 + tid + QH2 * kk] * h1s[kk];
+        acc += (double)wq[Qob2 + tid];
         h2s[tid] = acc > 0.0 ? acc : 0.0;
       }
       __syncthreads();
       if (tid < QA) {
         double acc = 0.0;
 #pragma unroll 4
-        for (int kk = 0; kk < QH2; ++kk) acc += (double)a.q[QoW3 + tid + QA * kk] * h2s[kk];
-        qs[tid] = acc + (double)a.q[Qob3 + tid];
+        for (int kk = 0; kk < QH2; ++kk) acc += (double)wq[QoW3 + tid + QA * kk] * h2s[kk];
+        qs[tid] = acc + (double)wq[Qob3 + tid];
       }
       __syncthreads();
     }
