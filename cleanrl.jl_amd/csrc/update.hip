@@ -569,7 +569,7 @@ static void main_pass_blocks(crl_ppo* h, int* nA, int* nC) {
     // one role per block; the actor tile is a little longer (softmax + Float64 policy-loss terms), so it gets more blocks
     const int total = 2 * ((h->update_blocks + 1) / 2);
     static int actor_pct = -1;
-    if (actor_pct < 0) actor_pct = env_int("CRL_X3_ACTOR_PCT", 52);
+    if (actor_pct < 0) actor_pct = env_int("CRL_X3_ACTOR_PCT", 53);  // swept 50..55 at nt=65536: 14.92 14.79 14.56 14.41 14.52 14.69 ms of update per iteration
     int a = total * actor_pct / 100;
     if (a < 1) a = 1;
     if (a > total - 1) a = total - 1;
