@@ -178,7 +178,10 @@ def main():
                                 else "v_mfma_f32_32x32x2_f32")},
             "roofline": {"bound": "mfma", "kernel": "update_x3_kernel / update_kernel (fwd+bwd of one minibatch, actor+critic)" if not c3 else
                                    "wide.hip: all forward/backward launches of one minibatch (HIP events around the group)",
-                         "note": f"achieved = algorithmic f32 FLOPs (3 x {fwd_flops:,} per sample) / HIP-event launch time; peak = dense f32 MFMA",
+                         "note": f"achieved = algorithmic f32 FLOPs (3 x {fwd_flops:,} per sample) / HIP-event launch time; peak = dense f32 MFMA. "
+                                 "The 64x64 / 256x256 products actually run as bf16x3 on the bf16 matrix pipe (6 bf16 MFMA products per f32 "
+                                 "product); PMC: that pipe is busy 29 % of SIMD cycles in update_x3_kernel, VALU issue 47 % "
+                                 "(profiles/r01_l_pmc_update_rollout.json) - the kernel is VALU/latency-bound, not matrix-pipe-bound",
                          "achieved": upd_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": upd_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic["update"],
                          "avg_launch_ms": upd_avg_s * 1e3, "launches": upd_n, "flops_per_launch": upd_flops * M},
