@@ -565,6 +565,7 @@ int32_t crl_dqn_run(crl_dqn* h, int64_t max_env_steps, crl_dqn_episode* eps, int
     for (int64_t cy = 0; cy < cycles; ++cy) {
       if (h->cycle_exec) CRL_HIP_CHECK(hipGraphLaunch(h->cycle_exec, st));
       else enqueue_cycle(st, d, k);
+      if ((cy & 4095) == 4095) CRL_HIP_CHECK(hipStreamSynchronize(st));   // bound the queue depth of very long calls
     }
     CRL_HIP_CHECK(hipGetLastError());
   }
