@@ -28,6 +28,7 @@ namespace crl {
 constexpr int WXS = 36;    // LDS stride (floats) of one staged sample row: 32 k + 4 pad → conflict-free ds_read_b128
 constexpr int WLS = 24;    // doubles per loss-kernel block partial: pg, Σ-entropy, Σ(v−R²), Σ value term, db3a[16], db3c
 constexpr int AMAX = 16;
+constexpr int AFUSE = 8;   // most head outputs the fused δ2 paths keep in registers (more ⇒ the separate launch)
 
 enum { EPI_TANH = 0, EPI_BIAS = 1, EPI_DTANH = 2, EPI_STORE = 3 };
 
@@ -446,6 +447,9 @@ struct DenseX3Args {
   float* Y; int M;
   // optional fused head (EPI_TANH, 8-wave variant): Z[a, m] = Σ_n W3[a, n]·Y[n, m] + b3[a] while the tile is at hand
   const float* W3t; const float* b3; float* Z; int A; int ldz;   // W3t: [256 × ·] column-major (ld 256); Z null = no head
+  // optional virtual input (EPI_DTANH): X holds h2 and the operand is formed on the fly as δ2 = (W3ᵀ·δ3) ⊙ (1 − h2²) from
+  // the head cotangent dZ[·, m] (ld ldd, zero-padded) — the [256 × M] δ2 array is never written or read
+  const float* dZ; int ldd; int Ad;      // dZ null = X is the operand itself; Ad = live rows of dZ
 };
 constexpr int X3ROW = 40;                // bf16 per staged sample row per piece: 32 k + 8 pad (80 B: conflict-free b128)
 
@@ -513,10 +517,40 @@ __global__ void __launch_bounds__(64 * NW) wide_dense_x3_kernel(DenseX3Args a) {
   }
   u32x4v wr[WR]; f32x4 xr[XR];
   const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+  // virtual input: this thread's samples are fixed for the whole K walk, so their head cotangents sit in registers
+  const bool virt = a.dZ != nullptr;
+  float dzr[XR][AFUSE];
+  if (virt) {
+#pragma unroll
+    for (int u = 0; u < XR; ++u) {
+      const int i = tid + NT * u, mm = i >> 3, m = m0 + mm;
+#pragma unroll
+      for (int q2 = 0; q2 < AFUSE; ++q2) dzr[u][q2] = (xok[u] && q2 < a.Ad) ? a.dZ[(size_t)a.ldd * m + q2] : 0.0f;
+    }
+  }
+  auto load_x = [&](int sl, int u) -> f32x4 {
+    if (!xok[u]) return zero4;
+    f32x4 v = xsrc[u][sl * 8];
+    if (virt) {
+      const int k = 32 * sl + 4 * ((tid + NT * u) & 7);
+      f32x4 sacc = zero4;
+#pragma unroll
+      for (int q2 = 0; q2 < AFUSE; ++q2) {
+        if (q2 < a.Ad) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(a.W3t + (size_t)256 * q2 + k);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sacc[e] = __builtin_fmaf(w[e], dzr[u][q2], sacc[e]);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = sacc[e] * (1.0f - v[e] * v[e]);
+    }
+    return v;
+  };
 #pragma unroll
   for (int u = 0; u < WR; ++u) wr[u] = wsrc[NT * u];
 #pragma unroll
-  for (int u = 0; u < XR; ++u) xr[u] = xok[u] ? xsrc[u][0] : zero4;
+  for (int u = 0; u < XR; ++u) xr[u] = load_x(0, u);
   const int nslab = a.K >> 5;
   for (int sl = 0; sl < nslab; ++sl) {
     if (sl) __syncthreads();
@@ -538,7 +572,7 @@ __global__ void __launch_bounds__(64 * NW) wide_dense_x3_kernel(DenseX3Args a) {
 #pragma unroll
       for (int u = 0; u < WR; ++u) wr[u] = wsrc[(size_t)(sl + 1) * (X3_SLAB_BF16 / 8) + NT * u];
 #pragma unroll
-      for (int u = 0; u < XR; ++u) xr[u] = xok[u] ? xsrc[u][(sl + 1) * 8] : zero4;
+      for (int u = 0; u < XR; ++u) xr[u] = load_x(sl + 1, u);
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -656,6 +690,7 @@ static int wide_forward(crl_ppo* h, int net, const float* X, int ldx, const int3
     x.Wx3 = pk + w->pk[net].x3f; x.X = w->h1[net]; x.K = H; x.bias = P + o.b2; x.S = nullptr; x.Y = w->h2[net]; x.M = M;
     const bool fuse = wide_x3_fused_head();
     x.W3t = pk + w->pk[net].w3t; x.b3 = P + o.b3; x.Z = fuse ? out : nullptr; x.A = NO; x.ldz = ldo;
+    x.dZ = nullptr; x.ldd = 0; x.Ad = 0;
     if (dense_x3_launch<EPI_TANH>(h->stream, x)) return 1;
     if (fuse) return 0;   // the head came out of the layer-2 epilogue
   } else {
@@ -672,7 +707,11 @@ static int wide_forward(crl_ppo* h, int net, const float* X, int ldx, const int3
 // Block = one (64·TW)² output tile × one chunk; both operands are (feature, sample) arrays, so a 32-sample slab of
 // either is BT contiguous floats per sample and the MFMA operands are read feature-fastest from LDS.
 // ------------------------------------------------------------------------------------------------------
-struct WgradArgs { const float* dY; const float* X; int H; int M; int chunk; float* pW; float* pB; };
+struct WgradArgs {
+  const float* dY; const float* X; int H; int M; int chunk; float* pW; float* pB;
+  // x3 kernel only: dZ != null ⇒ dY holds h2 and the operand is δ2 = (W3ᵀ·δ3) ⊙ (1 − h2²), formed while staging
+  const float* dZ; int ldd; int Ad; const float* W3t;
+};
 
 template <int TW>
 __global__ void __launch_bounds__(256) wide_wgrad_kernel(WgradArgs a) {
@@ -807,12 +846,29 @@ __global__ void __launch_bounds__(128 * WNB) wide_wgrad_x3_kernel(WgradArgs a) {
   const bool do_bias = (tkb == 0) && a.pB;
   const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
   f32x4 yr[4], xr[4], bacc = zero4;
+  // virtual dY: the head's rows for this thread's four hidden units stay in registers for the whole chunk
+  const bool virt = a.dZ != nullptr;
+  f32x4 w3r[AFUSE];
+  if (virt) {
+#pragma unroll
+    for (int q2 = 0; q2 < AFUSE; ++q2)
+      w3r[q2] = q2 < a.Ad ? *reinterpret_cast<const f32x4*>(a.W3t + (size_t)256 * q2 + n0 + rrow) : zero4;
+  }
   auto fetch = [&](int m) {
     const size_t off = (size_t)a.H * (m - c0 + 4 * sg);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const bool ok = m + 4 * sg + e < c1;
-      yr[e] = ok ? *reinterpret_cast<const f32x4*>(ybase + off + (size_t)a.H * e) : zero4;
+      f32x4 y = ok ? *reinterpret_cast<const f32x4*>(ybase + off + (size_t)a.H * e) : zero4;
+      if (virt && ok) {
+        const float* dz = a.dZ + (size_t)a.ldd * (m + 4 * sg + e);
+        f32x4 sacc = zero4;
+#pragma unroll
+        for (int q2 = 0; q2 < AFUSE; ++q2)
+          if (q2 < a.Ad) { const float dv = dz[q2]; sacc += w3r[q2] * dv; }
+        y = sacc * (1.0f - y * y);
+      }
+      yr[e] = y;
       xr[e] = (ok && stage_x) ? *reinterpret_cast<const f32x4*>(xbase + off + (size_t)a.H * e) : zero4;
     }
   };
@@ -1426,11 +1482,18 @@ static int wide_backward(crl_ppo* h, int net, const float* dOut, int ldd, const 
   const NetOff o = net_off(H, w->D, NO);
   (void)o;
   const float* pk = w->pack + w->pk_base[net];
-  // δ2 = (W3ᵀ·δ3) ⊙ (1 − h2²)
+  // δ2 = (W3ᵀ·δ3) ⊙ (1 − h2²) is its own [H × M] pass. CRL_WIDE_FUSE_DELTA2=1 lets both consumers (weight gradient and
+  // backward-data, bf16x3 kernels) form it on the fly from h2 and the head cotangent instead — measured SLOWER at C3
+  // (update 76.4 vs 70.2 ms per iteration: the extra VALU work sits on those kernels' critical path), so it is opt-in.
+  static int fuse_env = -1;
+  if (fuse_env < 0) { const char* e = getenv("CRL_WIDE_FUSE_DELTA2"); fuse_env = (e && atoi(e) != 0) ? 1 : 0; }
+  const bool fuse2 = H == 256 && wide_x3() && fuse_env && NO <= AFUSE;
   DenseArgs d;
   d.idx = nullptr; d.bias = nullptr; d.M = M;
-  d.W = pk + w->pk[net].w3t; d.Kp = ldd; d.X = dOut; d.ldx = ldd; d.Kt = ldd; d.S = w->h2[net]; d.lds = H; d.Y = w->dA; d.ldy = H; d.Nt = H;
-  if (dense_launch<EPI_DTANH>(h->stream, H, d)) return 1;
+  if (!fuse2) {
+    d.W = pk + w->pk[net].w3t; d.Kp = ldd; d.X = dOut; d.ldx = ldd; d.Kt = ldd; d.S = w->h2[net]; d.lds = H; d.Y = w->dA; d.ldy = H; d.Nt = H;
+    if (dense_launch<EPI_DTANH>(h->stream, H, d)) return 1;
+  }
   // dW3[a, k] = Σ δ3[a]·h2[k]
   SkinnyArgs s;
   s.Big = w->h2[net]; s.H = H; s.Small = dOut; s.lds = ldd; s.idx = nullptr; s.M = M; s.chunk = w->chunks;
@@ -1438,7 +1501,8 @@ static int wide_backward(crl_ppo* h, int net, const float* dOut, int ldd, const 
   if (skinny_launch(h->stream, w->Ss, s)) return 1;
   // dW2 = δ2·h1ᵀ, db2 = Σ δ2
   WgradArgs g;
-  g.dY = w->dA; g.X = w->h1[net]; g.H = H; g.M = M; g.chunk = w->chunk2; g.pW = w->pW2[net]; g.pB = w->pB2[net];
+  g.dY = fuse2 ? w->h2[net] : w->dA; g.X = w->h1[net]; g.H = H; g.M = M; g.chunk = w->chunk2; g.pW = w->pW2[net]; g.pB = w->pB2[net];
+  g.dZ = fuse2 ? dOut : nullptr; g.ldd = ldd; g.Ad = NO; g.W3t = pk + w->pk[net].w3t;
   if (H == 256 && wide_x3()) {
     // 256×128 output tiles (dY read twice, X once: 1.5 GB per launch at C3) unless CRL_WIDE_WGRAD_TILE=128 (2 GB)
     static int tile = -1;
@@ -1452,8 +1516,9 @@ static int wide_backward(crl_ppo* h, int net, const float* dOut, int ldd, const 
   // δ1 = (W2ᵀ·δ2) ⊙ (1 − h1²)
   if (H == 256 && wide_x3()) {
     DenseX3Args x;
-    x.Wx3 = pk + w->pk[net].x3b; x.X = w->dA; x.K = H; x.bias = nullptr; x.S = w->h1[net]; x.Y = w->dB; x.M = M;
-    x.W3t = nullptr; x.b3 = nullptr; x.Z = nullptr; x.A = 0; x.ldz = 0;
+    x.Wx3 = pk + w->pk[net].x3b; x.X = fuse2 ? w->h2[net] : w->dA; x.K = H; x.bias = nullptr; x.S = w->h1[net]; x.Y = w->dB; x.M = M;
+    x.W3t = pk + w->pk[net].w3t; x.b3 = nullptr; x.Z = nullptr; x.A = 0; x.ldz = 0;
+    x.dZ = fuse2 ? dOut : nullptr; x.ldd = ldd; x.Ad = NO;
     if (dense_x3_launch<EPI_DTANH>(h->stream, x)) return 1;
   } else {
     d.W = pk + w->pk[net].w2t; d.Kp = H; d.X = w->dA; d.ldx = H; d.Kt = H; d.S = w->h1[net]; d.Y = w->dB;
