@@ -37,6 +37,10 @@ class CrlStats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class CrlEpisodeRecord(C.Structure):
+    _fields_ = [("episode_return", C.c_float), ("episode_length", C.c_int32), ("env", C.c_int32), ("step", C.c_int32)]
+
+
 class CrlEpisodeStats(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("episodes", "return_sum", "length_sum", "return_max")]
 
@@ -48,7 +52,8 @@ EXPORTS = [
     "crl_rollout_store", "crl_env_reset", "crl_rollout_run", "crl_episode_stats_read", "crl_compute_gae",
     "crl_shuffle", "crl_adv_stats", "crl_ppo_update_minibatch", "crl_ppo_iterate", "crl_ppo_iteration",
     "crl_comm_unique_id", "crl_comm_init", "crl_comm_init_external", "crl_adv_stats_local", "crl_adv_stats_finish",
-    "crl_prof_enable", "crl_prof_read", "crl_prof_reset", "crl_ppo_exact_reruns",
+    "crl_prof_enable", "crl_prof_read", "crl_prof_reset", "crl_ppo_exact_reruns", "crl_episode_ring_enable",
+    "crl_episode_ring_read",
     "crl_a2c_create", "crl_a2c_destroy", "crl_a2c_param_count", "crl_a2c_write_params", "crl_a2c_read_params",
     "crl_a2c_read_env", "crl_a2c_read_buffer", "crl_a2c_run_until_update", "crl_a2c_discounted_future_rewards",
     "crl_dqn_create", "crl_dqn_destroy", "crl_dqn_write_params", "crl_dqn_read_params", "crl_dqn_status_read", "crl_dqn_run",
@@ -148,6 +153,8 @@ def load():
     L.crl_prof_reset.argtypes = [vp]
     i64p = C.POINTER(C.c_int64)
     L.crl_ppo_exact_reruns.argtypes = [vp, i64p]
+    L.crl_episode_ring_enable.argtypes = [vp, C.c_int32]
+    L.crl_episode_ring_read.argtypes = [vp, C.POINTER(CrlEpisodeRecord), C.c_int32, ip, i64p]
     L.crl_a2c_create.argtypes = [C.POINTER(CrlA2CConfig), C.c_int32, C.POINTER(vp)]
     L.crl_a2c_destroy.argtypes = [vp]
     L.crl_a2c_param_count.argtypes = [vp, i64p]
@@ -300,6 +307,19 @@ class Handle:
         it = C.c_int64()
         check(load().crl_ppo_iteration(self._h, C.byref(it)))
         return it.value
+
+    def episode_ring_enable(self, capacity):
+        check(load().crl_episode_ring_enable(self._h, int(capacity)))
+        self._ring_cap = int(capacity)
+
+    def episode_records(self):
+        """(records sorted by (step, env) — the reference's logging order —, number of episodes that ended)"""
+        cap = getattr(self, "_ring_cap", 0)
+        buf = (CrlEpisodeRecord * max(cap, 1))(); n = C.c_int32(); tot = C.c_int64()
+        check(load().crl_episode_ring_read(self._h, buf, cap, C.byref(n), C.byref(tot)))
+        recs = [(buf[i].step, buf[i].env, buf[i].episode_return, buf[i].episode_length) for i in range(n.value)]
+        recs.sort()
+        return recs, tot.value
 
     @property
     def exact_reruns(self):

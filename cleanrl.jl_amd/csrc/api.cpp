@@ -202,7 +202,7 @@ int32_t crl_ppo_destroy(crl_ppo* h) {
   comm_destroy(h);
   wide_destroy(h);
   void* ptrs[] = {h->obs, h->action, h->logprob, h->reward, h->terminal, h->value, h->adv, h->ret, h->env_state, h->env_t,
-                  h->cur_obs, h->next_done, h->ep_return, h->ep_length, h->next_value, h->ep_stats, h->params,
+                  h->cur_obs, h->next_done, h->ep_return, h->ep_length, h->next_value, h->ep_stats, h->ep_ring, h->ep_ring_count, h->params,
                   h->adam_m, h->adam_v, h->betap, h->perm, h->perm_tmp, h->bfy_ws, h->bfy_adv_part, h->gpart, h->lpart, h->adv_sums, h->adv_ms, h->newv, h->vfix,
                   h->stats_dev, h->comm_buf, h->snap, h->snap_betap, h->stage};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -366,6 +366,39 @@ int32_t crl_episode_stats_read(crl_ppo* h, crl_episode_stats* out) {
   CRL_HIP_CHECK(hipMemcpyAsync(v, h->ep_stats, sizeof(v), hipMemcpyDeviceToHost, h->stream));
   CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
   out->episodes = v[0]; out->return_sum = v[1]; out->length_sum = v[2]; out->return_max = v[3];
+  return 0;
+}
+
+int32_t crl_episode_ring_enable(crl_ppo* h, int32_t capacity) {
+  CRL_GUARD(h);
+  if (capacity < 0 || capacity > (1 << 26)) { set_error("crl_episode_ring_enable: capacity must be in 0..2^26"); return 1; }
+  CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  if (h->ep_ring) { (void)hipFree(h->ep_ring); h->ep_ring = nullptr; }
+  if (h->ep_ring_count) { (void)hipFree(h->ep_ring_count); h->ep_ring_count = nullptr; }
+  h->ep_ring_cap = 0;
+  if (capacity == 0) return 0;
+  if (dalloc(&h->ep_ring, (size_t)capacity) || dalloc(&h->ep_ring_count, 1)) return 1;
+  h->ep_ring_cap = capacity;
+  return 0;
+}
+
+int32_t crl_episode_ring_read(crl_ppo* h, crl_episode_record* out, int32_t max_records, int32_t* n_stored, int64_t* n_episodes) {
+  CRL_GUARD(h);
+  if (!n_stored || max_records < 0 || (max_records > 0 && !out)) { set_error("crl_episode_ring_read: bad arguments"); return 1; }
+  *n_stored = 0;
+  if (n_episodes) *n_episodes = 0;
+  if (h->ep_ring_cap == 0) { set_error("crl_episode_ring_read: the ring is not enabled (crl_episode_ring_enable)"); return 1; }
+  uint32_t cnt = 0;
+  CRL_HIP_CHECK(hipMemcpyAsync(&cnt, h->ep_ring_count, sizeof(cnt), hipMemcpyDeviceToHost, h->stream));
+  CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  if (n_episodes) *n_episodes = cnt;
+  uint32_t n = cnt < (uint32_t)h->ep_ring_cap ? cnt : (uint32_t)h->ep_ring_cap;
+  if (n > (uint32_t)max_records) n = (uint32_t)max_records;
+  if (n) {
+    CRL_HIP_CHECK(hipMemcpyAsync(out, h->ep_ring, sizeof(crl_episode_record) * n, hipMemcpyDeviceToHost, h->stream));
+    CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  }
+  *n_stored = (int32_t)n;
   return 0;
 }
 

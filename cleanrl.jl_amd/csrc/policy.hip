@@ -134,6 +134,7 @@ struct RolloutArgs {
   float* obs; int32_t* action; float* logprob; float* reward; uint8_t* terminal; float* value;
   float* env_state; int32_t* env_t; float* cur_obs; uint8_t* next_done; float* ep_return; int32_t* ep_length;
   double* ep_stats;
+  crl_episode_record* ring; uint32_t* ring_count; int ring_cap;   // per-episode records (ring_cap = 0: off)
   uint64_t iteration;
   int stagger;  // s_sleep units (64 clocks) by which waves 4-7 of an 8-wave block start late
 };
@@ -217,7 +218,13 @@ __global__ void __launch_bounds__(512, 2) rollout_cartpole_kernel(RolloutArgs a)
     nd = done ? 1 : 0;                                               // ppo.jl:144
     ep_ret += rew;                                                   // ppo.jl:145
     if (done) {                                                      // ppo.jl:147-165
-      if (writer) { st_n += 1.0; st_ret += (double)ep_ret; st_len += (double)ep_len; st_max = fmax(st_max, (double)ep_ret); }
+      if (writer) {
+        st_n += 1.0; st_ret += (double)ep_ret; st_len += (double)ep_len; st_max = fmax(st_max, (double)ep_ret);
+        if (a.ring_cap > 0) {
+          const uint32_t slot = atomicAdd(a.ring_count, 1u);
+          if (slot < (uint32_t)a.ring_cap) a.ring[slot] = crl_episode_record{ep_ret, ep_len, (int32_t)gid, step};
+        }
+      }
       ep_ret = 0.0f; ep_len = 0;
       cartpole_reset(s, c.seed, gid, gstep, 1);                      // ppo.jl:164 reset!(env)
       t_env = 0;
@@ -304,7 +311,13 @@ __global__ void __launch_bounds__(128) rollout_split_kernel(RolloutArgs a) {
       nd = done ? 1 : 0;                                             // ppo.jl:144
       ep_ret += rew;                                                 // ppo.jl:145
       if (done) {                                                    // ppo.jl:147-165
-        if (writer) { st_n += 1.0; st_ret += (double)ep_ret; st_len += (double)ep_len; st_max = fmax(st_max, (double)ep_ret); }
+        if (writer) {
+          st_n += 1.0; st_ret += (double)ep_ret; st_len += (double)ep_len; st_max = fmax(st_max, (double)ep_ret);
+          if (a.ring_cap > 0) {
+            const uint32_t slot = atomicAdd(a.ring_count, 1u);
+            if (slot < (uint32_t)a.ring_cap) a.ring[slot] = crl_episode_record{ep_ret, ep_len, (int32_t)gid, step};
+          }
+        }
         ep_ret = 0.0f; ep_len = 0;
         cartpole_reset(s, c.seed, gid, gstep, 1);                    // ppo.jl:164
         t_env = 0;
@@ -405,6 +418,8 @@ int launch_rollout(crl_ppo* h) {
   a.obs = h->obs; a.action = h->action; a.logprob = h->logprob; a.reward = h->reward; a.terminal = h->terminal; a.value = h->value;
   a.env_state = h->env_state; a.env_t = h->env_t; a.cur_obs = h->cur_obs; a.next_done = h->next_done;
   a.ep_return = h->ep_return; a.ep_length = h->ep_length; a.ep_stats = h->ep_stats; a.iteration = (uint64_t)h->iteration;
+  a.ring = h->ep_ring; a.ring_count = h->ep_ring_count; a.ring_cap = h->ep_ring_cap;
+  if (h->ep_ring_cap > 0) CRL_HIP_CHECK(hipMemsetAsync(h->ep_ring_count, 0, sizeof(uint32_t), h->stream));
   // one wave per 32 envs; spread waves over all 256 CUs before stacking them inside a block
   const int tiles = (h->dc.nt + TILE - 1) / TILE;
   int wpb = tiles >= 2048 ? 8 : (tiles >= 1024 ? 4 : (tiles >= 512 ? 2 : 1));

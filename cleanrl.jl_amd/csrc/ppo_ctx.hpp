@@ -56,6 +56,7 @@ struct crl_ppo {
   float* env_state = nullptr; int32_t* env_t = nullptr; float* cur_obs = nullptr; uint8_t* next_done = nullptr;
   float* ep_return = nullptr; int32_t* ep_length = nullptr; float* next_value = nullptr;
   double* ep_stats = nullptr;  // [4] episodes, return_sum, length_sum, return_max
+  crl_episode_record* ep_ring = nullptr; uint32_t* ep_ring_count = nullptr; int ep_ring_cap = 0;  // opt-in per-episode records
   // optimiser
   float* params = nullptr; float* adam_m = nullptr; float* adam_v = nullptr;  // the gradient lives in comm_buf[0..P)
   double* betap = nullptr;     // [24]

@@ -1127,6 +1127,7 @@ struct WStepArgs {
   DevCfg c; const float* Z; int A8; const float* V;
   float* obs; int32_t* action; float* logprob; float* reward; uint8_t* terminal; float* value;
   float* env_state; int32_t* env_t; float* cur_obs; uint8_t* next_done; float* ep_return; int32_t* ep_length; double* ep_stats;
+  crl_episode_record* ring; uint32_t* ring_count; int ring_cap;
   uint64_t iteration; int step;
 };
 
@@ -1179,6 +1180,10 @@ __global__ void __launch_bounds__(256) wide_step_kernel(WStepArgs a) {
     float ep_ret = a.ep_return[e] + rew;                               // ppo.jl:145
     if (done) {                                                        // ppo.jl:147-165
       st_n = 1.0; st_ret = (double)ep_ret; st_len = (double)ep_len; st_max = fmax(0.0, (double)ep_ret);
+      if (a.ring_cap > 0) {
+        const uint32_t slot = atomicAdd(a.ring_count, 1u);
+        if (slot < (uint32_t)a.ring_cap) a.ring[slot] = crl_episode_record{ep_ret, ep_len, (int32_t)gid, a.step};
+      }
       ep_ret = 0.0f; ep_len = 0;
     }
     a.ep_return[e] = ep_ret; a.ep_length[e] = ep_len;
@@ -1464,6 +1469,8 @@ int wide_rollout(crl_ppo* h) {
   a.obs = h->obs; a.action = h->action; a.logprob = h->logprob; a.reward = h->reward; a.terminal = h->terminal; a.value = h->value;
   a.env_state = h->env_state; a.env_t = h->env_t; a.cur_obs = h->cur_obs; a.next_done = h->next_done;
   a.ep_return = h->ep_return; a.ep_length = h->ep_length; a.ep_stats = h->ep_stats; a.iteration = (uint64_t)h->iteration;
+  a.ring = h->ep_ring; a.ring_count = h->ep_ring_count; a.ring_cap = h->ep_ring_cap;
+  if (h->ep_ring_cap > 0) CRL_HIP_CHECK(hipMemsetAsync(h->ep_ring_count, 0, sizeof(uint32_t), h->stream));
   ProfScope ps(h, CRL_K_ROLLOUT);
   for (int step = 0; step < h->dc.k; ++step) {
     if (wide_forward(h, 0, h->cur_obs, w->D, nullptr, h->dc.nt, w->z, w->A8)) return 1;   // ppo.jl:127

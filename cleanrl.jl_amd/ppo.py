@@ -127,14 +127,19 @@ def _linear_eta(config, update, num_updates):
     return frac * float(np.float32(config.lr))
 
 
-def train(agent: Agent, num_updates=None, log_every=1):
+def train(agent: Agent, num_updates=None, log_every=1, episode_records=0):
     """`train!`-style driver = the `for update in 1:num_updates` loop of ppo.jl:117-253, fully on device.
-    Emits the reference's two records: "Episode Statistics" (aggregated per rollout) and "Training Statistics"."""
+    Emits the reference's two records: "Episode Statistics" and "Training Statistics". By default the episode record is one
+    aggregate per rollout (with 65536 envs the reference's one-record-per-episode is ~10^5 log lines per update);
+    `episode_records=N` turns on the device ring (crl_episode_ring_enable) and logs up to N episodes per rollout one by one,
+    in the reference's order (step, then env; global_step as in ppo.jl:124,148)."""
     cfg = agent.config
     batch_size = cfg.num_steps * cfg.num_envs
     if num_updates is None:
         num_updates = max(1, cfg.total_timesteps // batch_size)  # ppo.jl:91
     h = agent.handle
+    if episode_records:
+        h.episode_ring_enable(int(episode_records))
     if h.iteration == 0:
         h.env_reset()
     start_time = time.time()
@@ -145,7 +150,17 @@ def train(agent: Agent, num_updates=None, log_every=1):
         global_step += batch_size
         ep = h.episode_stats()
         steps_per_sec = int(global_step / max(time.time() - start_time, 1e-9))
-        if ep["episodes"] > 0:
+        if episode_records:
+            recs, _ = h.episode_records()
+            base = global_step - batch_size
+            for step, env, ret, length in recs:
+                gs = base + (step + 1) * cfg.num_envs                              # ppo.jl:124 global_step += num_envs
+                inc = 0 if last_log_step == 0 else gs - last_log_step
+                log.info("Episode Statistics", extra={"crl": dict(
+                    episode_return=ret, episode_length=length, global_step=gs,
+                    steps_per_sec=int(gs / max(time.time() - start_time, 1e-9)), log_step_increment=inc)})
+                last_log_step = gs
+        elif ep["episodes"] > 0:
             inc = 0 if last_log_step == 0 else global_step - last_log_step
             log.info("Episode Statistics", extra={"crl": dict(
                 episode_return=ep["return_sum"] / ep["episodes"], episode_length=ep["length_sum"] / ep["episodes"],

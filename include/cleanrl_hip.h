@@ -139,6 +139,13 @@ int32_t crl_env_reset(crl_ppo* h);
 /* The whole `for step in 1:num_steps` loop — ppo.jl:123-166 — in one launch (on-device env + policy + sampling). */
 int32_t crl_rollout_run(crl_ppo* h);
 int32_t crl_episode_stats_read(crl_ppo* h, crl_episode_stats* out);
+/* Per-episode records of the last rollout (the fields of ppo.jl:157's "Episode Statistics"): off by default; once enabled
+ * every episode end appends {return, length, global env id, step of the rollout} to a device ring of `capacity` records
+ * (episodes beyond that are counted, not stored). Records come back in arrival order — sort by (step, env) for the
+ * reference's logging order (ppo.jl:147-165 walks the done envs of one step in ascending order). */
+typedef struct crl_episode_record { float episode_return; int32_t episode_length; int32_t env; int32_t step; } crl_episode_record;
+int32_t crl_episode_ring_enable(crl_ppo* h, int32_t capacity);
+int32_t crl_episode_ring_read(crl_ppo* h, crl_episode_record* out, int32_t max_records, int32_t* n_stored, int64_t* n_episodes);
 /* bootstrap + advantages + returns — ppo.jl:169-181 — on the resident buffer. */
 int32_t crl_compute_gae(crl_ppo* h);
 /* b_inds = shuffle(b_inds) — ppo.jl:194. epoch_id keys the counter-based stream. */

@@ -513,3 +513,48 @@ def test_iteration_with_live_unclipped_value_branch(crl, forced_comm, monkeypatc
         assert np.max(np.abs(h.read(crl._lib.F_PARAMS) - st.params)) < 2e-5
     assert h.exact_reruns == (2 if forced_comm else 0)
     agent.close(); st.close()
+
+
+def _episodes_from_buffers(reward, terminal, next_done, env_id_offset=0):
+    """Episode records of the FIRST rollout after a reset, rebuilt from the buffer: done at step t is terminal[e, t+1]
+    (next_done for the last step); return / length accumulate like ppo.jl:125,145."""
+    nt, k = reward.shape
+    out = []
+    for e in range(nt):
+        ret = 0.0; length = 0
+        for t in range(k):
+            ret = np.float32(ret + reward[e, t]); length += 1
+            done = terminal[e, t + 1] if t + 1 < k else next_done[e]
+            if done:
+                out.append((t, env_id_offset + e, float(ret), length)); ret = 0.0; length = 0
+    out.sort()
+    return out
+
+
+@pytest.mark.parametrize("kind", ["fused-split", "fused-single", "wide"])
+def test_episode_record_ring(crl, kind, monkeypatch):
+    """ppo.jl:147-165 per-episode records (opt-in ring): every episode end of a rollout with its return, length, env and
+    step — equal to what the stored rewards / terminals imply; overflow is counted, not stored."""
+    L = crl._lib
+    nt, k = 70, 128
+    if kind == "wide":
+        monkeypatch.setenv("CRL_FORCE_WIDE", "1")
+    else:
+        monkeypatch.setenv("CRL_ROLLOUT_SPLIT", "1" if kind == "fused-split" else "0")
+    agent = make_agent(crl, nt=nt, k=k, env_id_offset=1000)
+    h = agent.handle
+    with pytest.raises(crl.CrlError, match="not enabled"):
+        h._ring_cap = 4; h.episode_records()
+    h.episode_ring_enable(4096)
+    h.env_reset(); h.rollout_run()
+    recs, total = h.episode_records()
+    want = _episodes_from_buffers(h.read(L.F_REWARD), h.read(L.F_TERMINAL), h.read(L.F_NEXT_DONE), 1000)
+    assert total == len(want) > 100 and recs == want
+    es = h.episode_stats()
+    assert es["episodes"] == total and es["length_sum"] == sum(r[3] for r in recs)
+    h.episode_ring_enable(16)                      # a ring smaller than the episode count keeps counting
+    h.env_reset(); h.rollout_run()
+    recs2, total2 = h.episode_records()
+    assert total2 == total and len(recs2) == 16 and set(recs2) <= set(want)
+    h.episode_ring_enable(0)
+    agent.close()
