@@ -518,7 +518,7 @@ __global__ void __launch_bounds__(64 * NW) wide_dense_x3_kernel(DenseX3Args a) {
   u32x4v wr[WR]; f32x4 xr[XR];
   const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
   // virtual input: this thread's samples are fixed for the whole K walk, so their head cotangents sit in registers
-  const bool virt = a.dZ != nullptr;
+  const bool virt = (EPI == EPI_DTANH) && a.dZ != nullptr;   // compile-time dead in the forward instantiations
   float dzr[XR][AFUSE];
   if (virt) {
 #pragma unroll
@@ -837,8 +837,11 @@ __global__ void __launch_bounds__(128 * WNB) wide_wgrad_x3_kernel(WgradArgs a) {
       for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.0f;
   const int c0 = blockIdx.x * a.chunk;
   const int c1 = (c0 + a.chunk) < a.M ? (c0 + a.chunk) : a.M;
-  // staging role of this thread: rows 32·wave + 4·ql .. +3, samples 4·sg .. +3 of the slab's 32 (X: the first 4 waves)
-  const int ql = lane & 7, sg = lane >> 3;
+  // staging role of this thread: rows 32·wave + 4·ql .. +3, samples 4·sg .. +3 of the slab's 32 (X: the first 4 waves).
+  // sg on the low lane bits: the 16 lanes one ds_write_b64 group covers are then 8 sample groups (16 consecutive dwords)
+  // of two row quads (80 dwords apart = 16 banks) — conflict-free; with the row quad on the low bits the same store
+  // was 4-way conflicted (SQ_LDS_BANK_CONFLICT 21 % of the kernel's CU cycles)
+  const int sg = lane & 7, ql = lane >> 3;
   const int rrow = 32 * wave + 4 * ql;
   const bool stage_x = wave < BK / 32;
   const float* ybase = a.dY + (size_t)a.H * c0 + n0 + rrow;
@@ -934,13 +937,13 @@ __global__ void __launch_bounds__(128 * WNB) wide_wgrad_x3_kernel(WgradArgs a) {
       }
     }
   if (do_bias) {
-    // fold the 8 sample groups of a wave (lanes ql + 8·sg) in group order; lanes with sg = 0 own rows rrow..rrow+3
+    // fold the 8 sample groups of a row quad (lanes 8·ql + sg) in group order; lanes with sg = 0 own rows rrow..rrow+3
     float* scr = reinterpret_cast<float*>(smw);
     *reinterpret_cast<f32x4*>(scr + 4 * tid) = bacc;
     __syncthreads();
     if (sg == 0) {
       f32x4 sacc = bacc;
-      for (int q = 1; q < 8; ++q) sacc += *reinterpret_cast<const f32x4*>(scr + 4 * (tid + 8 * q));
+      for (int q = 1; q < 8; ++q) sacc += *reinterpret_cast<const f32x4*>(scr + 4 * (tid + q));
       *reinterpret_cast<f32x4*>(a.pB + (size_t)blockIdx.x * a.H + n0 + rrow) = sacc;
     }
   }
