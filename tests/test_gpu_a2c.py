@@ -112,3 +112,19 @@ def test_a2c_entry_point_logs_reference_records(crl, tmp_path):
 def test_a2c_errors(crl):
     with pytest.raises(crl.CrlError, match="min_replay_size"):
         crl.A2CAgent(crl.A2CConfig(min_replay_size=100))
+
+
+def test_a2c_budget_and_total_timesteps_edges(crl):
+    agent = crl.A2CAgent(crl.A2CConfig(total_timesteps=700), params=_params(), seed=2)
+    h = agent.handle
+    taken, ts, eps = h.run_until_update(max_env_steps=0)
+    assert taken == 0 and not ts["trained"] and eps == []
+    total = 0
+    while True:
+        taken, ts, eps = h.run_until_update(max_env_steps=300)
+        total += taken
+        if taken == 0:
+            break
+    assert total == 700 and h.env()[1] == 700          # the loop stops at total_timesteps (a2c.jl:53)
+    assert h.run_until_update()[0] == 0
+    agent.close()

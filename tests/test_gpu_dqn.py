@@ -78,3 +78,17 @@ def test_dqn_errors(crl):
         crl.DQNAgent(crl.DQNConfig(min_buff_size=50))
     with pytest.raises(crl.CrlError, match="batch_size"):
         crl.DQNAgent(crl.DQNConfig(batch_size=5000))
+
+
+def test_dqn_budget_and_total_timesteps_edges(crl):
+    agent = crl.DQNAgent(crl.DQNConfig(total_timesteps=455), params=O.dqn_params(1), seed=4)
+    h = agent.handle
+    assert h.run(0)[0] == 0
+    total = 0
+    for chunk in (3, 207, 1000, 1000):
+        total += h.run(chunk)[0]
+    st = h.status()
+    assert total == 455 and st["global_step"] == 455 and st["n_updates"] == len(range(210, 456, 10))
+    ref = O.DQNState(O.dqn_config(total_timesteps=455, seed=4), O.dqn_params(1)); ref.run(10_000)
+    assert np.array_equal(h.read_params()[0], ref.params()[0])
+    agent.close(); ref.close()

@@ -232,3 +232,24 @@ def test_wide_rccl_path_world1(crl, monkeypatch):
         assert abs(a["loss"] - b["loss"]) <= 2e-5 * max(1.0, abs(b["loss"]))
     assert np.max(np.abs(h.read(crl._lib.F_PARAMS) - st.params)) < 2e-5
     agent.close(); st.close()
+
+
+def test_wide_host_calls_chunk_over_the_workspace(crl):
+    """crl_policy_act / crl_logprob_actions on more observations than the activation workspace holds (it is sized for one
+    minibatch) are processed in chunks; empty inputs are no-ops."""
+    D, A, Hd = 8, 4, 256
+    cfg = ocfg(4, 8, D, A, Hd)                    # workspace: max(M, nt) = 8 samples
+    params = spread_params(cfg, 2)
+    agent = make_wide(crl, 4, 8, D, A, Hd, params=params)
+    rng = np.random.default_rng(1)
+    n = 1000
+    obs = np.asfortranarray(rng.standard_normal((D, n)).astype(np.float32)); u = rng.random(n)
+    a_o, lp_o, v_o, margin = O.get_action(cfg, params, obs, u)
+    a_g, lp_g, v_g = agent.handle.policy_act(obs, u)
+    safe = margin > 1e-6
+    assert np.array_equal(a_g[safe], a_o[safe]) and rel_err(v_g, v_o) < RTOL
+    lp2, ent = crl.logprob_actions(obs, agent.actor, (a_o + 1).astype(np.int32))
+    assert rel_err_s(lp2, lp_o) < RTOL and ent.shape == (A, n)
+    a0, lp0, v0 = agent.handle.policy_act(np.zeros((D, 0), np.float32, order="F"), np.zeros(0))
+    assert a0.shape == (0,) and lp0.shape == (0,)
+    agent.close()
