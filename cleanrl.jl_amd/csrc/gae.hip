@@ -21,7 +21,7 @@ __global__ void __launch_bounds__(512) gae_kernel(const float* __restrict__ valu
                                                    const float* __restrict__ next_value,
                                                    const uint8_t* __restrict__ next_done, int nt, int k, float gamma,
                                                    float gl, int mode, float* __restrict__ adv,
-                                                   float* __restrict__ ret) {
+                                                   float* __restrict__ ret, int nts) {
 #pragma clang fp contract(off)
   extern __shared__ double sm[];
   const int S = blockDim.x / EB;
@@ -92,8 +92,13 @@ __global__ void __launch_bounds__(512) gae_kernel(const float* __restrict__ valu
     if (ev && t < k) {
       const size_t idx = (size_t)e + (size_t)nt * t;
       const float a32 = (float)A;
-      adv[idx] = a32;
-      if (ret) ret[idx] = a32 + v[i];
+      if (nts) {
+        __builtin_nontemporal_store(a32, adv + idx);
+        if (ret) __builtin_nontemporal_store(a32 + v[i], ret + idx);
+      } else {
+        adv[idx] = a32;
+        if (ret) ret[idx] = a32 + v[i];
+      }
     }
   }
 }
@@ -108,6 +113,8 @@ int launch_gae(hipStream_t st, const float* value, const float* reward, const ui
   static int env_L = -1, env_EB = -1;
   if (env_L < 0) { const char* e = getenv("CRL_GAE_L"); env_L = e ? atoi(e) : 0; }
   if (env_EB < 0) { const char* e = getenv("CRL_GAE_EB"); env_EB = e ? atoi(e) : 0; }
+  static int env_nts = -1;   // CRL_GAE_NT=1: nontemporal stores of adv / ret
+  if (env_nts < 0) { const char* e = getenv("CRL_GAE_NT"); env_nts = e ? atoi(e) : 0; }
   // (a 4-envs-per-thread variant with 16-B loads was measured SLOWER: 38.9 vs 32.1 us at nt=65536 — 182 VGPRs leave only
   //  2 waves/SIMD; profiles/r01_g_gae_wide_vs_scalar.txt)
   int L = env_L ? env_L : (k <= 256 ? 8 : 16);
@@ -121,7 +128,7 @@ int launch_gae(hipStream_t st, const float* value, const float* reward, const ui
 #define CRL_GAE_CASE(eb, l)                                                                                          \
   if (EB == eb && L == l) {                                                                                          \
     hipExtLaunchKernelGGL((gae_kernel<eb, l>), grid, block, smem, st, ev_start, ev_stop, 0, value, reward, terminal,   \
-                          next_value, next_done, nt, k, gamma, gl, mode, adv, ret);                                  \
+                          next_value, next_done, nt, k, gamma, gl, mode, adv, ret, env_nts);                         \
   } else
   CRL_GAE_CASE(64, 8) CRL_GAE_CASE(32, 8) CRL_GAE_CASE(16, 8) CRL_GAE_CASE(8, 8)
   CRL_GAE_CASE(64, 16) CRL_GAE_CASE(32, 16) CRL_GAE_CASE(16, 16) CRL_GAE_CASE(8, 16)
