@@ -475,16 +475,18 @@ __global__ void __launch_bounds__(256, 2) update_vfix_kernel(UpdateArgs a) {
 
 // Σ over per-block partials in fixed order → flat gradient (+ the loss sums appended for the all-reduce message)
 // msg layout: [P gradient floats][pg_sum, ent_sum, u_sum, q_sum as floats]
-// Block = 64 consecutive outputs x 4 groups of partials (group g sums blocks b ≡ g mod 4, then g0+g1+g2+g3):
-// 256-B coalesced rows, 4x the loads in flight of a one-thread-per-output loop, still a fixed summation order.
+// Block = 64 consecutive outputs x RG groups of partials (group g sums blocks b ≡ g mod RG in order, then the groups are
+// folded in order): 256-B coalesced rows and every partial of an output in flight at once — at 256 update blocks a
+// thread issues its 8 loads back to back instead of walking 32 of them in 8 dependent rounds — still a fixed summation order.
+constexpr int RG = 16;
 template <int MODE>
-__global__ void __launch_bounds__(256) reduce_kernel(const float* __restrict__ gpart, const double* __restrict__ lpart,
-                                                     int nblkA, int nblkC, int pmax, int gstride, int Pa, int Pc,
-                                                     float* __restrict__ msg, StatsArgs st) {
+__global__ void __launch_bounds__(64 * RG) reduce_kernel(const float* __restrict__ gpart, const double* __restrict__ lpart,
+                                                         int nblkA, int nblkC, int pmax, int gstride, int Pa, int Pc,
+                                                         float* __restrict__ msg, StatsArgs st) {
   const double* vfix = st.vfix;
   if (MODE == 1 && vfix[3] == 0.0) return;
-  __shared__ float sm[4][64];
-  __shared__ double smd[4][4];
+  __shared__ float sm[RG][64];
+  __shared__ double smd[RG][4];
   const int P = Pa + Pc;
   const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + o;
@@ -499,12 +501,12 @@ __global__ void __launch_bounds__(256) reduce_kernel(const float* __restrict__ g
     const float* gp = gpart + (size_t)role * pmax * gstride + (role ? i - Pa : i);
     const int blocks_per_role = role ? nblkC : nblkA;
     int b = g;
-    for (; b + 12 < blocks_per_role; b += 16) {
-      const float v0 = gp[(size_t)b * gstride], v1 = gp[(size_t)(b + 4) * gstride], v2 = gp[(size_t)(b + 8) * gstride],
-                  v3 = gp[(size_t)(b + 12) * gstride];
+    for (; b + 3 * RG < blocks_per_role; b += 4 * RG) {
+      const float v0 = gp[(size_t)b * gstride], v1 = gp[(size_t)(b + RG) * gstride], v2 = gp[(size_t)(b + 2 * RG) * gstride],
+                  v3 = gp[(size_t)(b + 3 * RG) * gstride];
       s += v0; s += v1; s += v2; s += v3;
     }
-    for (; b < blocks_per_role; b += 4) s += gp[(size_t)b * gstride];
+    for (; b < blocks_per_role; b += RG) s += gp[(size_t)b * gstride];
   }
   sm[g][o] = s;
   // the four loss sums ride on the last block: thread (which = o < 4, group g)
@@ -515,14 +517,23 @@ __global__ void __launch_bounds__(256) reduce_kernel(const float* __restrict__ g
     if (!(MODE == 1 && lrole == 0)) {
       const double* l = lpart + (size_t)lrole * pmax * 2 + (which & 1);
       const int nb = lrole ? nblkC : nblkA;
-      for (int b = g; b < nb; b += 4) ds += l[b * 2];
+      for (int b = g; b < nb; b += RG) ds += l[b * 2];
     }
     smd[g][o] = ds;
   }
   __syncthreads();
-  if (g == 0 && live) msg[i] = (sm[0][o] + sm[1][o]) + (sm[2][o] + sm[3][o]);
-  if (last && g == 0 && o < 4 && !(MODE == 1 && (o >> 1) == 0))
-    msg[P + o] = (float)((smd[0][o] + smd[1][o]) + (smd[2][o] + smd[3][o]));
+  if (g == 0 && live) {
+    float t = sm[0][o];
+#pragma unroll
+    for (int q = 1; q < RG; ++q) t += sm[q][o];
+    msg[i] = t;
+  }
+  if (last && g == 0 && o < 4 && !(MODE == 1 && (o >> 1) == 0)) {
+    double t = smd[0][o];
+#pragma unroll
+    for (int q = 1; q < RG; ++q) t += smd[q][o];
+    msg[P + o] = (float)t;
+  }
   if (last && st.fused) {
     __syncthreads();  // the four sums written above are visible to thread 0 of this block
     if (threadIdx.x == 0) compute_stats(msg, P, st.c, st.Mglobal, st.adv_ms, st.mb, st.vfix, st.out, MODE);
@@ -634,7 +645,7 @@ int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
     int nA, nC;
     main_pass_blocks(h, &nA, &nC);
     ProfScope ps(h, CRL_K_REDUCE);
-    hipLaunchKernelGGL(reduce_kernel<0>, dim3((P + 63) / 64), dim3(256), 0, h->stream, h->gpart, h->lpart, nA, nC,
+    hipLaunchKernelGGL(reduce_kernel<0>, dim3((P + 63) / 64), dim3(64 * RG), 0, h->stream, h->gpart, h->lpart, nA, nC,
                        h->update_blocks, (int)h->Pa, (int)h->Pa, (int)h->Pc, h->comm_buf, stats_args(h, mb, stats_slot, dp ? 0 : 1));
     CRL_HIP_CHECK(hipGetLastError());
   }
@@ -651,7 +662,7 @@ int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
     hipLaunchKernelGGL(vfix_count_kernel, dim3(1), dim3(1024), 0, h->stream, h->dc, h->perm, mb, h->newv, h->value, h->ret, h->vfix);
     CRL_HIP_CHECK(hipGetLastError());
     if (run_update(h, mb, 1)) return 1;
-    hipLaunchKernelGGL(reduce_kernel<1>, dim3((P + 63) / 64), dim3(256), 0, h->stream, h->gpart, h->lpart, 0, h->update_blocks,
+    hipLaunchKernelGGL(reduce_kernel<1>, dim3((P + 63) / 64), dim3(64 * RG), 0, h->stream, h->gpart, h->lpart, 0, h->update_blocks,
                        h->update_blocks, (int)h->Pa, (int)h->Pa, (int)h->Pc, h->comm_buf, stats_args(h, mb, stats_slot, 1));
     CRL_HIP_CHECK(hipGetLastError());
   }
@@ -669,7 +680,7 @@ int launch_update_exact_dp(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
   if (run_update(h, mb, 0)) return 1;
   int nA, nC;
   main_pass_blocks(h, &nA, &nC);
-  hipLaunchKernelGGL(reduce_kernel<0>, dim3((P + 63) / 64), dim3(256), 0, h->stream, h->gpart, h->lpart, nA, nC, h->update_blocks,
+  hipLaunchKernelGGL(reduce_kernel<0>, dim3((P + 63) / 64), dim3(64 * RG), 0, h->stream, h->gpart, h->lpart, nA, nC, h->update_blocks,
                      Pa, Pa, Pc, h->comm_buf, stats_args(h, mb, stats_slot, 0));
   CRL_HIP_CHECK(hipGetLastError());
   if (comm_allreduce(h, h->comm_buf, (size_t)P + 4, false)) return 1;
@@ -684,7 +695,7 @@ int launch_update_exact_dp(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
   CRL_HIP_CHECK(hipGetLastError());
   if (comm_allreduce(h, h->vfix + 1, 1, true)) return 1;                       // global #{u > q}
   if (run_update(h, mb, 1)) return 1;                                          // exact critic gradient of this shard
-  hipLaunchKernelGGL(reduce_kernel<1>, dim3((P + 63) / 64), dim3(256), 0, h->stream, h->gpart, h->lpart, 0, h->update_blocks,
+  hipLaunchKernelGGL(reduce_kernel<1>, dim3((P + 63) / 64), dim3(64 * RG), 0, h->stream, h->gpart, h->lpart, 0, h->update_blocks,
                      h->update_blocks, Pa, Pa, Pc, h->comm_buf, stats_args(h, mb, stats_slot, 0));
   CRL_HIP_CHECK(hipGetLastError());
   if (comm_allreduce(h, h->comm_buf + Pa, (size_t)Pc, false)) return 1;        // critic slice (the actor slice is global already)
