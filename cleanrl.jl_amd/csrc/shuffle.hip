@@ -44,10 +44,9 @@ __global__ void bijection_kernel(int32_t* __restrict__ perm, int n, int bits, ui
 // shuffled by the textbook Fisher–Yates loop run by one lane. Sub-buckets are concatenated in (d1,d2) order.
 // Bit-identical to orc_shuffle_blocked_fy.
 // ------------------------------------------------------------------------------------------------------
-constexpr int BFY_T1 = 1024;         // threads per block in the L1 passes
-constexpr int BFY_CHUNK = BFY_T1 * 32;  // elements per block: 32 K — ≈16 per bucket and block at K1 = 2048, so one global
-                                     // reservation per bucket and block serves a 64-B run of stores (8 K-element chunks
-                                     // paid 4x the reservations for 16-B runs)
+// L1 passes: T1 threads x 32 elements per block. Large batches use 1024 threads (32 K elements: ≈16 per bucket and block at
+// K1 = 2048, so one global reservation per bucket and block serves a 64-B run of stores; 8 K-element blocks paid 4x the
+// reservations for 16-B runs); small shards keep 256 threads so that the grid still covers the chip.
 constexpr int BFY_L1 = 4096;        // expected elements per L1 bucket
 constexpr int BFY_CAP = 5632;       // LDS capacity of one L1 bucket (+24 sigma)
 constexpr int BFY_MAXK1 = 16384;    // batches up to 2^26 samples
@@ -58,7 +57,7 @@ __device__ __forceinline__ void bfy_digits(uint32_t i, uint32_t K1, uint64_t see
 }
 
 // pass A (SCATTER=false): tot[d1] += count ; pass C (SCATTER=true): S[cur[d1]++] = i with LDS-aggregated reservations
-template <bool SCATTER>
+template <bool SCATTER, int BFY_T1>
 __global__ void __launch_bounds__(BFY_T1) bfy_l1_kernel(int n, uint32_t K1, uint64_t seed, uint64_t epoch, uint32_t* __restrict__ tot,
                                                      uint32_t* __restrict__ cur, int32_t* __restrict__ S) {
   extern __shared__ uint32_t lds[];   // hist[K1] (+ base[K1] when scattering)
@@ -67,7 +66,7 @@ __global__ void __launch_bounds__(BFY_T1) bfy_l1_kernel(int n, uint32_t K1, uint
   for (uint32_t d = threadIdx.x; d < K1; d += BFY_T1) hist[d] = 0;
   __syncthreads();
   uint32_t dig[32];
-  const int i0 = blockIdx.x * BFY_CHUNK + threadIdx.x;
+  const int i0 = blockIdx.x * (BFY_T1 * 32) + threadIdx.x;
 #pragma unroll 4
   for (int q = 0; q < 32; ++q) {
     const int i = i0 + q * BFY_T1;
@@ -216,10 +215,13 @@ static int launch_blocked_fy(crl_ppo* h, uint64_t epoch_id, bool fused) {
   if (K1 > (uint32_t)BFY_MAXK1) { set_error("blocked Fisher-Yates supports batches up to 2^26 samples"); return 1; }
   uint32_t* tot = h->bfy_ws; uint32_t* off = tot + BFY_MAXK1; uint32_t* cur = off + BFY_MAXK1 + 1; uint32_t* err = cur + BFY_MAXK1;
   CRL_HIP_CHECK(hipMemsetAsync(tot, 0, sizeof(uint32_t) * BFY_MAXK1, h->stream));
-  const int chunks = (n + BFY_CHUNK - 1) / BFY_CHUNK;
-  hipLaunchKernelGGL(bfy_l1_kernel<false>, dim3(chunks), dim3(BFY_T1), sizeof(uint32_t) * K1, h->stream, n, K1, h->cfg.seed, epoch_id, tot, cur, h->perm_tmp);
+  const bool big = n >= (4 << 20);
+  const int t1 = big ? 1024 : 256, chunks = (n + t1 * 32 - 1) / (t1 * 32);
+  if (big) hipLaunchKernelGGL((bfy_l1_kernel<false, 1024>), dim3(chunks), dim3(1024), sizeof(uint32_t) * K1, h->stream, n, K1, h->cfg.seed, epoch_id, tot, cur, h->perm_tmp);
+  else hipLaunchKernelGGL((bfy_l1_kernel<false, 256>), dim3(chunks), dim3(256), sizeof(uint32_t) * K1, h->stream, n, K1, h->cfg.seed, epoch_id, tot, cur, h->perm_tmp);
   hipLaunchKernelGGL(bfy_scan_kernel, dim3(1), dim3(1024), 0, h->stream, K1, tot, off, cur, err);
-  hipLaunchKernelGGL(bfy_l1_kernel<true>, dim3(chunks), dim3(BFY_T1), sizeof(uint32_t) * 2 * K1, h->stream, n, K1, h->cfg.seed, epoch_id, tot, cur, h->perm_tmp);
+  if (big) hipLaunchKernelGGL((bfy_l1_kernel<true, 1024>), dim3(chunks), dim3(1024), sizeof(uint32_t) * 2 * K1, h->stream, n, K1, h->cfg.seed, epoch_id, tot, cur, h->perm_tmp);
+  else hipLaunchKernelGGL((bfy_l1_kernel<true, 256>), dim3(chunks), dim3(256), sizeof(uint32_t) * 2 * K1, h->stream, n, K1, h->cfg.seed, epoch_id, tot, cur, h->perm_tmp);
   const bool fuse = fused && h->bfy_adv_part && h->dc.M >= BFY_CAP && h->dc.nmb <= 256;
   hipLaunchKernelGGL(bfy_leaf_kernel, dim3(K1), dim3(256), 0, h->stream, K1, h->cfg.seed, epoch_id, off, h->perm_tmp, h->perm, err,
                      fuse ? h->adv : nullptr, h->dc.M, h->dc.nmb, h->bfy_adv_part);
