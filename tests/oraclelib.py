@@ -11,6 +11,8 @@ import numpy as np
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _SO = os.path.join(_ROOT, "oracle", "libppo_oracle.so")
+if os.environ.get("CRL_ORACLE_SO"):   # e.g. an ASan/UBSan build (scripts/oracle_sanitize.sh)
+    _SO = os.environ["CRL_ORACLE_SO"]
 
 
 class OrcConfig(C.Structure):
@@ -48,6 +50,8 @@ class OrcState(C.Structure):
 
 def build(force=False):
     srcs = [os.path.join(_ROOT, "oracle", f) for f in ("ppo_oracle.c", "ppo_oracle.h", "a2c_oracle.c", "a2c_oracle.h", "dqn_oracle.c", "dqn_oracle.h")]
+    if os.environ.get("CRL_ORACLE_SO"):
+        return _SO
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle"), "-s"])
     return _SO
