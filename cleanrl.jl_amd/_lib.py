@@ -105,8 +105,8 @@ F_OBS, F_ACTION, F_LOGPROB, F_REWARD, F_TERMINAL, F_VALUE, F_ADVANTAGE, F_RETURN
 GAE_COMPAT, GAE_FIXED = 0, 1
 ENV_CARTPOLE, ENV_SYNTHETIC, ENV_EXTERNAL = 0, 1, 2
 SHUFFLE_FISHER_YATES, SHUFFLE_BIJECTION, SHUFFLE_BLOCKED_FY = 0, 1, 2
-K_ROLLOUT, K_GAE, K_SHUFFLE, K_ADV_STATS, K_UPDATE, K_REDUCE, K_OPTIM, K_ALLREDUCE = range(8)
-KERNEL_NAMES = ["rollout", "gae", "shuffle", "adv_stats", "update", "reduce", "optim", "allreduce"]
+K_ROLLOUT, K_GAE, K_SHUFFLE, K_ADV_STATS, K_UPDATE, K_REDUCE, K_OPTIM, K_ALLREDUCE, K_PACK, K_PERMUTE = range(10)
+KERNEL_NAMES = ["rollout", "gae", "shuffle", "adv_stats", "update", "reduce", "optim", "allreduce", "pack", "permute"]
 
 _lib = None
 

@@ -60,7 +60,7 @@ static bool field_ref(crl_ppo* h, int f, FieldRef* out) {
     case CRL_F_NEXT_DONE: *out = {h->next_done, nt}; return true;
     case CRL_F_ENV_T: *out = {h->env_t, nt * 4}; return true;
     case CRL_F_BETAP: *out = {h->betap, 24 * 8}; return true;
-    case CRL_F_ADV_SUMS: *out = {h->adv_sums, (size_t)h->dc.nmb * 2 * 8}; return true;
+    case CRL_F_ADV_SUMS: *out = {h->adv_sums, (size_t)h->dc.nmb * 2 * 8}; return true;  // current slot
     default: return false;
   }
 }
@@ -79,6 +79,21 @@ static int prof_collect(crl_ppo* h) {
   }
   return 0;
 }
+
+// `perm`, `adv_sums`, `adv_ms` follow the current slot (one slot per update epoch)
+void select_slot(crl_ppo* h, int slot) {
+  h->cur_slot = slot;
+  h->perm = h->perm_base + (size_t)slot * h->dc.B;
+  h->adv_sums = h->adv_sums_base + (size_t)slot * h->dc.nmb * 2;
+  h->adv_ms = h->adv_ms_base + (size_t)slot * h->dc.nmb * 2;
+}
+
+// fused path: the current slot's minibatch-ordered records (and its advantage sums) exist and are current
+int ensure_records(crl_ppo* h) {
+  if (h->wide) return 0;
+  if (!h->recs_dirty && (h->slot_fresh >> h->cur_slot & 1u)) return 0;
+  return launch_permute_records(h, h->cur_slot, 1);
+}
 }  // namespace crl
 
 using namespace crl;
@@ -86,6 +101,9 @@ using namespace crl;
 #define CRL_GUARD(h)                                         \
   if (!(h)) { set_error("null crl_ppo handle"); return 1; } \
   CRL_HIP_CHECK(hipSetDevice((h)->device));
+
+static int settle(crl_ppo* h);
+static int check_bfy(crl_ppo* h);
 
 extern "C" {
 
@@ -133,6 +151,8 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
     set_error("num_envs*num_steps must be divisible by num_minibatches"); return 1;
   }
   if (cfg->num_steps > 1024) { set_error("num_steps > 1024 is not supported"); return 1; }
+  if (cfg->num_minibatches > 1024) { set_error("num_minibatches > 1024 is not supported"); return 1; }
+  if (cfg->update_epochs > 32) { set_error("update_epochs > 32 is not supported"); return 1; }
   int ndev = 0;
   CRL_HIP_CHECK(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) { set_error("crl_ppo_create: no such HIP device (no GPU → no CPU fallback)"); return 1; }
@@ -161,7 +181,17 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
   rc |= dalloc(&h->next_done, nt); rc |= dalloc(&h->ep_return, nt); rc |= dalloc(&h->ep_length, nt);
   rc |= dalloc(&h->next_value, nt); rc |= dalloc(&h->ep_stats, 4);
   rc |= dalloc(&h->params, h->P); rc |= dalloc(&h->adam_m, h->P); rc |= dalloc(&h->adam_v, h->P);
-  rc |= dalloc(&h->betap, 24); rc |= dalloc(&h->perm, B);
+  const size_t E = (size_t)cfg->update_epochs;
+  rc |= dalloc(&h->betap, 24); rc |= dalloc(&h->perm_base, E * B);
+  if (!wide) { rc |= dalloc(&h->recs, B); rc |= dalloc(&h->recs_p, E * B); }
+  {
+    // permute pass: blocks per minibatch (≈1 K samples each, at most 512); the partial-sum scratch also serves the
+    // stand-alone statistics kernels (up to 512 blocks per minibatch of ONE slot)
+    int pb = c.M / 1024; if (pb < 1) pb = 1; if (pb > 512) pb = 512;
+    h->adv_pb = pb;
+    const size_t need = E * (size_t)c.nmb * pb, alone = (size_t)c.nmb * 512;
+    rc |= dalloc(&h->adv_part, 2 * (need > alone ? need : alone));
+  }
   if (cfg->shuffle_mode == CRL_SHUFFLE_BLOCKED_FY) {
     rc |= dalloc(&h->perm_tmp, B); rc |= dalloc(&h->bfy_ws, (size_t)4 * 16384 + 8);
     size_t k1 = 1; while (k1 * 4096 < B) k1 *= 2;
@@ -176,15 +206,17 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
   if (ub * 4 > ntiles) ub = (ntiles + 3) / 4;
   if (ub < 1) ub = 1;
   h->update_blocks = ub;
-  // gpart doubles as the scratch of the advantage-statistics partials (≤ 512 blocks × nmb × 2 doubles)
   if (!wide) { rc |= dalloc(&h->gpart, (size_t)2 * ub * h->Pa + 4096); rc |= dalloc(&h->lpart, (size_t)2 * ub * 2); }
-  else rc |= dalloc(&h->gpart, (size_t)4 * 512 * (c.nmb > 4 ? c.nmb : 4) + 4096);
-  rc |= dalloc(&h->adv_sums, (size_t)c.nmb * 2); rc |= dalloc(&h->adv_ms, (size_t)c.nmb * 2);
+  rc |= dalloc(&h->adv_sums_base, E * c.nmb * 2); rc |= dalloc(&h->adv_ms_base, E * c.nmb * 2);
   rc |= dalloc(&h->newv, (size_t)c.M); rc |= dalloc(&h->vfix, 8);
   rc |= dalloc(&h->stats_dev, (size_t)cfg->update_epochs * c.nmb);
   rc |= dalloc(&h->comm_buf, (size_t)h->P + 8);
   rc |= dalloc(&h->snap, (size_t)3 * h->P); rc |= dalloc(&h->snap_betap, 24);
+  h->snap_env_bytes = nt * d * 8 + nt * 4 * 3 + ((nt + 15) & ~(size_t)15) + 64;
+  { char* p = nullptr; rc |= dalloc(&p, h->snap_env_bytes); h->snap_env = p; }
+  if (const char* e = getenv("CRL_DP_CHECK_EVERY")) { h->window_len = atoi(e); if (h->window_len < 1) h->window_len = 1; }
   if (rc) { crl_ppo_destroy(h); return 1; }
+  select_slot(h, 0);
   if (wide && wide_create(h)) { crl_ppo_destroy(h); return 1; }
   double bp[24];
   for (int i = 0; i < 12; ++i) { bp[2 * i] = 0.9; bp[2 * i + 1] = 0.999; }
@@ -203,8 +235,8 @@ int32_t crl_ppo_destroy(crl_ppo* h) {
   wide_destroy(h);
   void* ptrs[] = {h->obs, h->action, h->logprob, h->reward, h->terminal, h->value, h->adv, h->ret, h->env_state, h->env_t,
                   h->cur_obs, h->next_done, h->ep_return, h->ep_length, h->next_value, h->ep_stats, h->ep_ring, h->ep_ring_count, h->params,
-                  h->adam_m, h->adam_v, h->betap, h->perm, h->perm_tmp, h->bfy_ws, h->bfy_adv_part, h->gpart, h->lpart, h->adv_sums, h->adv_ms, h->newv, h->vfix,
-                  h->stats_dev, h->comm_buf, h->snap, h->snap_betap, h->stage};
+                  h->adam_m, h->adam_v, h->betap, h->perm_base, h->recs, h->recs_p, h->adv_part, h->perm_tmp, h->bfy_ws, h->bfy_adv_part, h->gpart, h->lpart,
+                  h->adv_sums_base, h->adv_ms_base, h->newv, h->vfix, h->stats_dev, h->comm_buf, h->snap, h->snap_betap, h->snap_env, h->stage};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int k = 0; k < CRL_K_COUNT; ++k)
     for (auto& pr : h->prof_slots[k].pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -221,12 +253,15 @@ int32_t crl_ppo_param_count(const crl_ppo* h, int64_t* n) {
 
 int32_t crl_sync(crl_ppo* h) {
   CRL_GUARD(h);
+  if (settle(h)) return 1;
   CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
-  return 0;
+  return check_bfy(h);
 }
+
 
 int32_t crl_ppo_write(crl_ppo* h, int32_t field, const void* host, size_t nbytes) {
   CRL_GUARD(h);
+  if (settle(h)) return 1;
   FieldRef fr;
   if (!field_ref(h, field, &fr)) { set_error("crl_ppo_write: unknown field"); return 1; }
   if (nbytes != fr.bytes) { set_error("crl_ppo_write: size mismatch for field " + std::to_string(field) + ": got " +
@@ -234,14 +269,17 @@ int32_t crl_ppo_write(crl_ppo* h, int32_t field, const void* host, size_t nbytes
   CRL_HIP_CHECK(hipMemcpyAsync(fr.ptr, host, nbytes, hipMemcpyHostToDevice, h->stream));
   CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
   if (field == CRL_F_PARAMS) wide_mark_params_changed(h);
-  if (field == CRL_F_PERM) h->perm_is_bijection = false;
+  if (field == CRL_F_PERM) { h->perm_is_bijection = false; h->slot_fresh &= ~(1u << h->cur_slot); }
   if (field == CRL_F_PERM || field == CRL_F_ADVANTAGE) h->bfy_adv_parts = 0;  // a caller-supplied permutation has no closed-form inverse
+  if (field == CRL_F_OBS || field == CRL_F_ACTION || field == CRL_F_LOGPROB || field == CRL_F_VALUE || field == CRL_F_ADVANTAGE ||
+      field == CRL_F_RETURN) h->recs_dirty = true;
   if (field == CRL_F_ENV_STATE || field == CRL_F_CUR_OBS) h->env_ready = true;  // caller-supplied env state
   return 0;
 }
 
 int32_t crl_ppo_read(crl_ppo* h, int32_t field, void* host, size_t nbytes) {
   CRL_GUARD(h);
+  if (settle(h)) return 1;
   FieldRef fr;
   if (!field_ref(h, field, &fr)) { set_error("crl_ppo_read: unknown field"); return 1; }
   if (nbytes != fr.bytes) { set_error("crl_ppo_read: size mismatch for field " + std::to_string(field) + ": got " +
@@ -336,6 +374,7 @@ int32_t crl_rollout_store(crl_ppo* h, int32_t step, const float* obs, const int3
   CRL_HIP_CHECK(hipMemcpyAsync(h->terminal + off, terminal, nt, hipMemcpyHostToDevice, h->stream));
   CRL_HIP_CHECK(hipMemcpyAsync(h->value + off, value, nt * 4, hipMemcpyHostToDevice, h->stream));
   CRL_HIP_CHECK(hipStreamSynchronize(h->stream));  // host buffers are only borrowed for the call
+  h->recs_dirty = true;
   return 0;
 }
 
@@ -356,12 +395,14 @@ static int ensure_env(crl_ppo* h) {  // ppo.jl:112-115 runs once before the loop
 int32_t crl_rollout_run(crl_ppo* h) {
   CRL_GUARD(h);
   if (ensure_env(h)) return 1;
+  h->recs_dirty = true;
   return launch_rollout(h);
 }
 
 int32_t crl_episode_stats_read(crl_ppo* h, crl_episode_stats* out) {
   CRL_GUARD(h);
   if (!out) { set_error("null argument"); return 1; }
+  if (settle(h)) return 1;
   double v[4];
   CRL_HIP_CHECK(hipMemcpyAsync(v, h->ep_stats, sizeof(v), hipMemcpyDeviceToHost, h->stream));
   CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -388,6 +429,7 @@ int32_t crl_episode_ring_read(crl_ppo* h, crl_episode_record* out, int32_t max_r
   *n_stored = 0;
   if (n_episodes) *n_episodes = 0;
   if (h->ep_ring_cap == 0) { set_error("crl_episode_ring_read: the ring is not enabled (crl_episode_ring_enable)"); return 1; }
+  if (settle(h)) return 1;
   uint32_t cnt = 0;
   CRL_HIP_CHECK(hipMemcpyAsync(&cnt, h->ep_ring_count, sizeof(cnt), hipMemcpyDeviceToHost, h->stream));
   CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -404,6 +446,7 @@ int32_t crl_episode_ring_read(crl_ppo* h, crl_episode_record* out, int32_t max_r
 
 int32_t crl_compute_gae(crl_ppo* h) {
   CRL_GUARD(h);
+  h->recs_dirty = true;
   const bool fixed = h->cfg.gae_mode == CRL_GAE_FIXED;
   if (fixed && launch_next_value(h)) return 1;
   ProfScope ps(h, CRL_K_GAE, /*attach=*/true);
@@ -422,20 +465,28 @@ static int check_bfy(crl_ppo* h) {
 
 int32_t crl_shuffle(crl_ppo* h, uint64_t epoch_id) {
   CRL_GUARD(h);
+  h->slot_fresh &= ~(1u << h->cur_slot);
   if (launch_shuffle(h, epoch_id)) return 1;
   return check_bfy(h);
 }
 
+// local Σadv, Σadv² of the current slot's minibatches → adv_sums: the fused path takes them from the permute pass
+static int adv_sums_local(crl_ppo* h) {
+  if (h->wide) return launch_adv_stats_sums(h);
+  h->slot_fresh &= ~(1u << h->cur_slot);   // recompute: the caller may have overwritten CRL_F_ADV_SUMS
+  return ensure_records(h);
+}
+
 int32_t crl_adv_stats(crl_ppo* h) {
   CRL_GUARD(h);
-  if (launch_adv_stats_sums(h)) return 1;
+  if (adv_sums_local(h)) return 1;
   if (comm_allreduce(h, h->adv_sums, (size_t)h->dc.nmb * 2, true)) return 1;
   return launch_adv_stats_finish(h);
 }
 
 int32_t crl_adv_stats_local(crl_ppo* h) {
   CRL_GUARD(h);
-  return launch_adv_stats_sums(h);
+  return adv_sums_local(h);
 }
 int32_t crl_adv_stats_finish(crl_ppo* h) {
   CRL_GUARD(h);
@@ -451,6 +502,7 @@ static int update_step(crl_ppo* h, int mb, double eta, int apply, int slot) {
 int32_t crl_ppo_update_minibatch(crl_ppo* h, int32_t mb, double eta, int32_t apply_update, crl_ppo_stats* stats) {
   CRL_GUARD(h);
   if (mb < 0 || mb >= h->dc.nmb) { set_error("crl_ppo_update_minibatch: minibatch index out of range"); return 1; }
+  if (ensure_records(h)) return 1;
   if (update_step(h, mb, eta, apply_update, mb)) return 1;
   if (stats) {
     CRL_HIP_CHECK(hipMemcpyAsync(stats, h->stats_dev + mb, sizeof(crl_ppo_stats), hipMemcpyDeviceToHost, h->stream));
@@ -459,66 +511,149 @@ int32_t crl_ppo_update_minibatch(crl_ppo* h, int32_t mb, double eta, int32_t app
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Data-parallel guard (Q4). The fused kernels speculate on u = mean(v − R²) ≤ 0 (ppo.jl:232-237); under RCCL the exact
+// fix-up would cost two more collectives per optimiser step, so the common path stays speculative and a (global, sticky)
+// device flag records a failed speculation. The flag is read back once per WINDOW of iterations (CRL_DP_CHECK_EVERY,
+// default 8) or whenever the host reads results — never per iteration. A window starts with a snapshot of everything an
+// iteration mutates (parameters, Adam state, env state, episode accumulators); if the flag is up at the end, every rank
+// restores the snapshot and repeats the window's iterations with the exact step. The flag derives from all-reduced sums,
+// so all ranks take the same branch as long as they issue the same sequence of library calls.
+// ---------------------------------------------------------------------------------------------------------------
+static bool guard_on(const crl_ppo* h) { return h->comm != nullptr && !h->wide && h->cfg.clip_value_loss; }
+
+struct EnvSnapLayout { size_t state, obs, t, done, ret, len, stats, ring, total; };
+static EnvSnapLayout env_snap_layout(const crl_ppo* h) {
+  const size_t nt = (size_t)h->dc.nt, d = (size_t)h->dc.D;
+  EnvSnapLayout l;
+  l.state = 0; l.obs = l.state + nt * d * 4; l.t = l.obs + nt * d * 4; l.ret = l.t + nt * 4; l.len = l.ret + nt * 4;
+  l.stats = l.len + nt * 4; l.ring = l.stats + 32; l.done = l.ring + 16; l.total = l.done + nt;
+  return l;
+}
+static int guard_copy(crl_ppo* h, bool save) {
+  const size_t P = (size_t)h->P, nt = (size_t)h->dc.nt, d = (size_t)h->dc.D;
+  const EnvSnapLayout l = env_snap_layout(h);
+  if (l.total > h->snap_env_bytes) { set_error("internal: env snapshot buffer too small"); return 1; }
+  char* e = static_cast<char*>(h->snap_env);
+  struct Pair { void* live; void* snap; size_t bytes; };
+  const Pair pairs[] = {
+      {h->params, h->snap, P * 4}, {h->adam_m, h->snap + P, P * 4}, {h->adam_v, h->snap + 2 * P, P * 4}, {h->betap, h->snap_betap, 24 * 8},
+      {h->env_state, e + l.state, nt * d * 4}, {h->cur_obs, e + l.obs, nt * d * 4}, {h->env_t, e + l.t, nt * 4},
+      {h->ep_return, e + l.ret, nt * 4}, {h->ep_length, e + l.len, nt * 4}, {h->ep_stats, e + l.stats, 32},
+      {h->next_done, e + l.done, nt}, {h->ep_ring_count, e + l.ring, 4}};
+  for (const Pair& p : pairs) {
+    if (!p.live) continue;   // the episode ring is optional
+    CRL_HIP_CHECK(hipMemcpyAsync(save ? p.snap : p.live, save ? p.live : p.snap, p.bytes, hipMemcpyDeviceToDevice, h->stream));
+  }
+  return 0;
+}
+
+static double anneal_eta(const crl_ppo* h) {
+  double eta = (double)h->cfg.lr;
+  if (h->cfg.anneal_lr) {  // ppo.jl:118-121 (update is 1-based). The reference loop ends at num_updates; a caller that
+    // keeps iterating past it gets eta = 0 rather than a negative step (gradient ascent)
+    double frac = 1.0 - ((double)(h->iteration + 1) - 1.0) / (double)h->num_updates;
+    if (frac < 0.0) frac = 0.0;
+    eta = frac * (double)h->cfg.lr;
+  }
+  return eta;
+}
+
+// one pass of the ppo.jl:117-253 loop body
+static int iterate_once(crl_ppo* h, bool exact) {
+  const int E = h->cfg.update_epochs, nmb = h->dc.nmb;
+  const double eta = anneal_eta(h);
+  h->recs_dirty = true;
+  if (launch_rollout(h)) return 1;
+  if (crl_compute_gae(h)) return 1;
+  const uint64_t ep0 = (uint64_t)h->iteration * (uint64_t)E;
+  if (h->wide) {
+    // layer-wise path: per-epoch shuffle → statistics (→ all-reduce) → optimiser steps, gathering through the permutation
+    if (h->cfg.shuffle_mode == CRL_SHUFFLE_FISHER_YATES && launch_iota(h)) return 1;  // ppo.jl:191
+    for (int ep = 0; ep < E; ++ep) {
+      if (launch_shuffle(h, ep0 + (uint64_t)ep, /*with_adv_sums=*/true)) return 1;
+      if (launch_adv_stats_sums(h)) return 1;
+      if (comm_allreduce(h, h->adv_sums, (size_t)nmb * 2, true)) return 1;
+      if (launch_adv_stats_finish(h)) return 1;
+      for (int mb = 0; mb < nmb; ++mb)
+        if (update_step(h, mb, eta, 1, ep * nmb + mb)) return 1;
+    }
+    return 0;
+  }
+  // fused path: all update_epochs permutations are drawn up front (they depend on nothing the optimiser changes), one
+  // permute pass lays every epoch's minibatches out contiguously and leaves all E·nmb advantage sums, which cross the
+  // ranks in ONE all-reduce per iteration; after that an optimiser step is update → reduce → (all-reduce) → Adam.
+  if (launch_pack_records(h)) return 1;
+  for (int ep = 0; ep < E; ++ep) {
+    select_slot(h, ep);
+    if (h->cfg.shuffle_mode == CRL_SHUFFLE_FISHER_YATES) {   // b_inds = shuffle(b_inds): each epoch shuffles the previous order
+      if (ep == 0) { if (launch_iota(h)) return 1; }         // ppo.jl:191
+      else CRL_HIP_CHECK(hipMemcpyAsync(h->perm, h->perm - h->dc.B, (size_t)h->dc.B * 4, hipMemcpyDeviceToDevice, h->stream));
+    }
+    if (launch_shuffle(h, ep0 + (uint64_t)ep)) return 1;
+  }
+  if (launch_permute_records(h, 0, E)) return 1;
+  {
+    ProfScope ps(h, CRL_K_ADV_STATS);
+    if (comm_allreduce(h, h->adv_sums_base, (size_t)E * nmb * 2, true)) return 1;
+    if (launch_adv_stats_finish(h, /*all_slots=*/true)) return 1;
+  }
+  for (int ep = 0; ep < E; ++ep) {
+    select_slot(h, ep);
+    for (int mb = 0; mb < nmb; ++mb) {
+      if (exact) {
+        if (launch_update_exact_dp(h, mb, h->stats_dev + ep * nmb + mb)) return 1;
+        if (launch_optim(h, eta)) return 1;
+      } else if (update_step(h, mb, eta, 1, ep * nmb + mb)) return 1;
+    }
+  }
+  return 0;   // the current slot stays at the last epoch: CRL_F_PERM reads back the b_inds the loop ended with
+}
+
+// Ends a guard window: reads the sticky flag (one host sync) and, if the speculation failed anywhere inside the window,
+// restores its start and repeats its iterations exactly. No-op outside data parallelism or with an empty window.
+static int settle(crl_ppo* h) {
+  if (!guard_on(h) || h->window_count == 0) return 0;
+  double sticky = 0.0;
+  CRL_HIP_CHECK(hipMemcpyAsync(&sticky, h->vfix + 4, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  const int n = h->window_count;
+  h->window_count = 0;
+  if (sticky == 0.0) return 0;
+  if (guard_copy(h, /*save=*/false)) return 1;
+  CRL_HIP_CHECK(hipMemsetAsync(h->vfix + 4, 0, sizeof(double), h->stream));
+  h->iteration = h->snap_iteration;
+  for (int i = 0; i < n; ++i) {
+    if (iterate_once(h, /*exact=*/true)) return 1;
+    h->iteration += 1;
+  }
+  CRL_HIP_CHECK(hipMemsetAsync(h->vfix + 4, 0, sizeof(double), h->stream));   // handled: lower the sticky flag
+  h->exact_reruns += n;
+  return 0;
+}
+
 int32_t crl_ppo_iterate(crl_ppo* h, int32_t n_iters, crl_ppo_stats* stats) {
   CRL_GUARD(h);
   if (h->cfg.env_kind == CRL_ENV_EXTERNAL) { set_error("crl_ppo_iterate needs an on-device env (CRL_ENV_CARTPOLE or CRL_ENV_SYNTHETIC)"); return 1; }
   const int E = h->cfg.update_epochs, nmb = h->dc.nmb;
   if (ensure_env(h)) return 1;
+  const bool guard = guard_on(h);
   for (int it = 0; it < n_iters; ++it) {
-    double eta = (double)h->cfg.lr;
-    if (h->cfg.anneal_lr) {  // ppo.jl:118-121 (update is 1-based)
-      const double frac = 1.0 - ((double)(h->iteration + 1) - 1.0) / (double)h->num_updates;
-      eta = frac * (double)h->cfg.lr;
+    if (guard && h->window_count == 0) {
+      if (guard_copy(h, /*save=*/true)) return 1;
+      h->snap_iteration = h->iteration;
     }
-    if (launch_rollout(h)) return 1;
-    if (crl_compute_gae(h)) return 1;
-    // Data parallel + clipped value loss: the fused kernels speculate on u = mean(v − R²) ≤ 0 (Q4). If the (global,
-    // sticky) flag says the speculation failed somewhere in this iteration, the update phase is re-run from a snapshot
-    // with the exact, slower step (launch_update_exact_dp). Every rank sees the same flag, so every rank re-runs.
-    const bool guard = h->comm != nullptr && !h->wide && h->cfg.clip_value_loss;
-    if (guard) {
-      const size_t P = (size_t)h->P;
-      CRL_HIP_CHECK(hipMemcpyAsync(h->snap, h->params, P * 4, hipMemcpyDeviceToDevice, h->stream));
-      CRL_HIP_CHECK(hipMemcpyAsync(h->snap + P, h->adam_m, P * 4, hipMemcpyDeviceToDevice, h->stream));
-      CRL_HIP_CHECK(hipMemcpyAsync(h->snap + 2 * P, h->adam_v, P * 4, hipMemcpyDeviceToDevice, h->stream));
-      CRL_HIP_CHECK(hipMemcpyAsync(h->snap_betap, h->betap, 24 * 8, hipMemcpyDeviceToDevice, h->stream));
-    }
-    for (int pass = 0; pass < 2; ++pass) {
-      const bool exact = pass == 1;
-      if (h->cfg.shuffle_mode == CRL_SHUFFLE_FISHER_YATES && launch_iota(h)) return 1;  // ppo.jl:191
-      for (int ep = 0; ep < E; ++ep) {
-        if (launch_shuffle(h, (uint64_t)h->iteration * (uint64_t)E + (uint64_t)ep, /*with_adv_sums=*/true)) return 1;
-        if (crl_adv_stats(h)) return 1;
-        for (int mb = 0; mb < nmb; ++mb) {
-          if (exact) {
-            if (launch_update_exact_dp(h, mb, h->stats_dev + ep * nmb + mb)) return 1;
-            if (launch_optim(h, eta)) return 1;
-          } else if (update_step(h, mb, eta, 1, ep * nmb + mb)) return 1;
-        }
-      }
-      if (exact) CRL_HIP_CHECK(hipMemsetAsync(h->vfix + 4, 0, sizeof(double), h->stream));   // handled: lower the sticky flag
-      if (!guard || exact) break;
-      double sticky = 0.0;
-      CRL_HIP_CHECK(hipMemcpyAsync(&sticky, h->vfix + 4, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-      CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
-      if (sticky == 0.0) break;
-      const size_t P = (size_t)h->P;
-      CRL_HIP_CHECK(hipMemcpyAsync(h->params, h->snap, P * 4, hipMemcpyDeviceToDevice, h->stream));
-      CRL_HIP_CHECK(hipMemcpyAsync(h->adam_m, h->snap + P, P * 4, hipMemcpyDeviceToDevice, h->stream));
-      CRL_HIP_CHECK(hipMemcpyAsync(h->adam_v, h->snap + 2 * P, P * 4, hipMemcpyDeviceToDevice, h->stream));
-      CRL_HIP_CHECK(hipMemcpyAsync(h->betap, h->snap_betap, 24 * 8, hipMemcpyDeviceToDevice, h->stream));
-      CRL_HIP_CHECK(hipMemsetAsync(h->vfix + 4, 0, sizeof(double), h->stream));
-      wide_mark_params_changed(h);
-      h->exact_reruns += 1;
-    }
+    if (iterate_once(h, /*exact=*/false)) return 1;
     h->iteration += 1;
+    if (guard && ++h->window_count >= h->window_len && settle(h)) return 1;
   }
   if (stats) {
+    if (settle(h)) return 1;   // the host is about to look: make what it sees exact
     CRL_HIP_CHECK(hipMemcpyAsync(stats, h->stats_dev, sizeof(crl_ppo_stats) * (size_t)E * nmb, hipMemcpyDeviceToHost, h->stream));
     CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (check_bfy(h)) return 1;
   }
-  if (check_bfy(h)) return 1;
-  if (h->world > 1 && h->external_comm && !h->wide) {
+  if (h->world > 1 && h->external_comm && !h->wide && stats) {
     // host-side exchange (crl_comm_init_external) cannot run the exact re-pass: fail loudly rather than train on a
     // speculative critic gradient
     double vf[8];

@@ -75,14 +75,20 @@ __global__ void __launch_bounds__(256) adv_sums_fold_kernel(const double* __rest
   if (t == 0) { sums[2 * mb] = sm[0][0]; sums[2 * mb + 1] = sm[1][0]; }
 }
 // mean / corrected std (StatsBase mean/std, ppo.jl:221) from the (all-reduced) sums; n = global minibatch size
-__global__ void adv_finish_kernel(const double* __restrict__ sums, int nmb, double n, double* __restrict__ ms) {
-  const int mb = threadIdx.x;
-  if (mb >= nmb) return;
-  const double mean = sums[2 * mb] / n;
-  double var = (sums[2 * mb + 1] - n * mean * mean) / (n - 1.0);
-  var = var > 0.0 ? var : 0.0;
-  ms[2 * mb] = (double)(float)mean;
-  ms[2 * mb + 1] = (double)(float)sqrt(var);
+__global__ void adv_finish_kernel(const double* __restrict__ sums, int nentries, double n, double* __restrict__ ms) {
+  for (int mb = threadIdx.x; mb < nentries; mb += blockDim.x) {
+    const double mean = sums[2 * mb] / n;
+    double var = (sums[2 * mb + 1] - n * mean * mean) / (n - 1.0);
+    var = var > 0.0 ? var : 0.0;
+    ms[2 * mb] = (double)(float)mean;
+    ms[2 * mb + 1] = (double)(float)sqrt(var);
+  }
+}
+
+int launch_adv_fold(crl_ppo* h, const double* part, int nblk, int nentries, double* sums) {
+  hipLaunchKernelGGL(adv_sums_fold_kernel, dim3(nentries), dim3(256), 0, h->stream, part, nblk, nentries, sums);
+  CRL_HIP_CHECK(hipGetLastError());
+  return 0;
 }
 
 int launch_adv_stats_sums(crl_ppo* h) {
@@ -95,13 +101,13 @@ int launch_adv_stats_sums(crl_ppo* h) {
     return 0;
   }
   const int nblk = 64;
-  double* part = reinterpret_cast<double*>(h->gpart);  // gpart is idle between optimiser steps
+  double* part = h->adv_part;   // sized for num_minibatches x 512 blocks in crl_ppo_create
   ProfScope ps(h, CRL_K_ADV_STATS);
   int nfold = nblk;
   if (h->perm_is_bijection && h->dc.nmb == 4) {
     nfold = 512;
     hipLaunchKernelGGL((adv_sums_inv_kernel<4>), dim3(nfold), dim3(512), 0, h->stream, h->adv, h->dc.B, h->dc.M, bij_bits(h->dc.B),
-                       h->cfg.seed, h->perm_epoch, part);
+                       shuffle_seed(h), h->perm_epoch, part);
   } else {
     hipLaunchKernelGGL(adv_sums_kernel, dim3(nblk, h->dc.nmb), dim3(512), 0, h->stream, h->adv, h->perm, h->dc.M, part);
   }
@@ -109,9 +115,11 @@ int launch_adv_stats_sums(crl_ppo* h) {
   CRL_HIP_CHECK(hipGetLastError());
   return 0;
 }
-int launch_adv_stats_finish(crl_ppo* h) {
-  hipLaunchKernelGGL(adv_finish_kernel, dim3(1), dim3(64), 0, h->stream, h->adv_sums, h->dc.nmb,
-                     (double)h->dc.M * h->world, h->adv_ms);
+// mean/std of the current slot's minibatches; all_slots: of every epoch's slot at once (crl_ppo_iterate)
+int launch_adv_stats_finish(crl_ppo* h, bool all_slots) {
+  const int n = all_slots ? h->cfg.update_epochs * h->dc.nmb : h->dc.nmb;
+  hipLaunchKernelGGL(adv_finish_kernel, dim3(1), dim3(256), 0, h->stream, all_slots ? h->adv_sums_base : h->adv_sums, n,
+                     (double)h->dc.M * h->world, all_slots ? h->adv_ms_base : h->adv_ms);
   CRL_HIP_CHECK(hipGetLastError());
   return 0;
 }

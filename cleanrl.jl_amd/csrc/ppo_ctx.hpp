@@ -30,6 +30,17 @@ struct DevCfg {
   uint64_t seed;
 };
 
+// One sample of the flat batch as the update kernels read it: 64 B = one HBM sector-pair, so a random gather through the
+// permutation costs one fetch per sample (six separate arrays cost six). Quarter 0 = obs, 1 = what only the actor reads,
+// 2 = what only the critic reads (ppo.jl:203-211 gathers the same six fields).
+struct alignas(16) SampleRec {
+  float x[4];
+  int32_t act; float old_lp, adv, pad0;
+  float old_v, ret, pad1, pad2;
+  float pad3[4];
+};
+static_assert(sizeof(SampleRec) == 64, "SampleRec is one 64-byte record");
+
 struct ProfSlot {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
   double total_ms = 0;
@@ -60,7 +71,19 @@ struct crl_ppo {
   // optimiser
   float* params = nullptr; float* adam_m = nullptr; float* adam_v = nullptr;  // the gradient lives in comm_buf[0..P)
   double* betap = nullptr;     // [24]
-  int32_t* perm = nullptr;
+  // One permutation per update epoch (ppo.jl:194): crl_ppo_iterate draws all update_epochs of them right after GAE, so the
+  // advantage statistics of every minibatch of the iteration are known (and all-reduced, once) before the first optimiser
+  // step. `perm` / `adv_ms` point at the CURRENT slot; the host-driven entry points (crl_shuffle, …) use slot 0.
+  int32_t* perm_base = nullptr;    // [update_epochs][B]
+  int32_t* perm = nullptr;         // = perm_base + cur_slot * B
+  int cur_slot = 0;
+  // fused 4/2/64 path: the batch as 64-byte records, in buffer order and in minibatch order per slot (records.hip)
+  crl::SampleRec* recs = nullptr;      // [B]
+  crl::SampleRec* recs_p = nullptr;    // [update_epochs][B]: recs_p[slot][pos] = recs[perm[slot][pos]]
+  bool recs_dirty = true;              // a buffer field changed since the last pack
+  uint32_t slot_fresh = 0;             // bit s: recs_p[s] (and the adv partial sums of slot s) match perm[s] and recs
+  double* adv_part = nullptr;          // per-block partial Σadv, Σadv² (sized in crl_ppo_create; never borrowed scratch)
+  int adv_pb = 1;                      // permute-pass blocks per minibatch
   int32_t* perm_tmp = nullptr;     // blocked Fisher–Yates: elements grouped by L1 bucket
   uint32_t* bfy_ws = nullptr;      // blocked Fisher–Yates: totals | offsets | cursors | error flag
   double* bfy_adv_part = nullptr;  // [nmb][K1][2] Σadv, Σadv² per leaf block, left behind by a fused shuffle (crl_ppo_iterate)
@@ -71,14 +94,23 @@ struct crl_ppo {
   int update_blocks = 0;       // blocks per role
   float* gpart = nullptr;      // [2 roles][update_blocks][Pmax] per-block gradient partials
   double* lpart = nullptr;     // [2 roles][update_blocks][4] per-block loss partial sums
-  double* adv_sums = nullptr;  // [nmb][2] Σadv, Σadv² (+ [nmb] count) — all-reduced under DP
-  double* adv_ms = nullptr;    // [nmb][2] mean, std
+  double* adv_sums_base = nullptr;  // [update_epochs][nmb][2] Σadv, Σadv² — all-reduced under DP (one message per iteration)
+  double* adv_sums = nullptr;       // current slot
+  double* adv_ms_base = nullptr;    // [update_epochs][nmb][2] mean, std
+  double* adv_ms = nullptr;         // current slot
   float* newv = nullptr;       // [M] critic outputs of the current minibatch (value-loss fix-up path)
   double* vfix = nullptr;      // [8] u, count(u>q), -, flag, sticky flag
   crl_ppo_stats* stats_dev = nullptr;  // [epochs*nmb]
   float* comm_buf = nullptr;   // [P + 8] gradient (+ loss scalars) message for the all-reduce
-  float* snap = nullptr;       // [3P] + betap: parameters / Adam state at the start of an iteration (data-parallel re-run, Q4)
+  // Data-parallel guard window (Q4): parameters / Adam state / env state at the start of a window of iterations; the sticky
+  // speculation flag is read back once per window (or when the host reads results), never per iteration.
+  float* snap = nullptr;       // [3P]
   double* snap_betap = nullptr;
+  void* snap_env = nullptr;    // env_state | cur_obs | env_t | next_done | ep_return | ep_length | ep_stats | ring count
+  size_t snap_env_bytes = 0;
+  int64_t snap_iteration = 0;
+  int window_count = 0;        // iterations run speculatively since the snapshot
+  int window_len = 8;          // CRL_DP_CHECK_EVERY
   // staging for host-pointer calls
   void* stage = nullptr; size_t stage_bytes = 0;
   void* pinned = nullptr; size_t pinned_bytes = 0;
@@ -96,6 +128,13 @@ struct crl_ppo {
 };
 
 namespace crl {
+// Key of the minibatch shuffle (ppo.jl:194). Under data parallelism every shard draws its OWN permutation: the key folds in
+// the shard's first global env id, so sample positions are not correlated across ranks (offset 0 = the plain seed).
+inline uint64_t shuffle_seed(const crl_ppo* h) {
+  return h->cfg.seed + 0x9E3779B97F4A7C15ull * (uint64_t)(uint32_t)h->cfg.env_id_offset;
+}
+void select_slot(crl_ppo* h, int slot);
+int ensure_records(crl_ppo* h);
 int ensure_stage(crl_ppo* h, size_t bytes);
 // CRL_GEMM=f32 selects the v_mfma_f32_32x32x2_f32 layers; default is the bf16x3 matrix-pipe path (mlp_x3.hpp)
 bool gemm_x3();
@@ -130,7 +169,9 @@ int launch_rollout(crl_ppo* h);
 int launch_next_value(crl_ppo* h);
 int launch_shuffle(crl_ppo* h, uint64_t epoch_id, bool with_adv_sums = false);
 int launch_adv_stats_sums(crl_ppo* h);
-int launch_adv_stats_finish(crl_ppo* h);
+int launch_adv_stats_finish(crl_ppo* h, bool all_slots = false);
+int launch_pack_records(crl_ppo* h);
+int launch_permute_records(crl_ppo* h, int slot0, int nslots);
 int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot);
 int launch_update_exact_dp(crl_ppo* h, int mb, crl_ppo_stats* stats_slot);
 int launch_optim(crl_ppo* h, double eta);

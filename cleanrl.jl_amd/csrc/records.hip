@@ -1,0 +1,99 @@
+// records.hip — the minibatch gather of ppo.jl:203-211 as two streaming passes instead of six random gathers inside the
+// update kernel.
+//   pack:    once per iteration, after GAE: the six per-sample fields the loss closure reads (state, action, logprob,
+//            advantage, value, return) → one 64-byte SampleRec per sample, buffer order b = e + nt·t (ppo.jl:184-189).
+//   permute: once per update epoch: recs_p[pos] = recs[b_inds[pos]] (ppo.jl:194,203-204) — ONE 64-byte fetch per sample
+//            (six arrays gathered separately drag six sectors), written back as whole 1-KiB rows; the update kernels then
+//            read their minibatch as a contiguous slab. The pass also leaves Σadv, Σadv² per minibatch (Float64, fixed
+//            order) — the statistics of ppo.jl:221 — so nothing else ever walks the permutation.
+// Both passes move bytes only (HBM-bound): pack 36 B in / 64 B out per sample, permute 4 + 64 B in / 64 B out.
+#include "common.hpp"
+#include "ppo_ctx.hpp"
+
+namespace crl {
+
+// four lanes per sample, lane q writes quarter q: every store instruction of a wave covers 1 KiB of consecutive records
+__global__ void __launch_bounds__(256) pack_records_kernel(int B, const float* __restrict__ obs, const int32_t* __restrict__ action,
+                                                           const float* __restrict__ logprob, const float* __restrict__ adv,
+                                                           const float* __restrict__ value, const float* __restrict__ ret,
+                                                           SampleRec* __restrict__ recs) {
+  const int q = threadIdx.x & 3;
+  for (int b = blockIdx.x * 64 + (threadIdx.x >> 2); b < B; b += gridDim.x * 64) {
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (q == 0) v = reinterpret_cast<const f32x4*>(obs)[b];
+    else if (q == 1) { v[0] = __int_as_float(action[b]); v[1] = logprob[b]; v[2] = adv[b]; }
+    else if (q == 2) { v[0] = value[b]; v[1] = ret[b]; }
+    reinterpret_cast<f32x4*>(recs)[(size_t)b * 4 + q] = v;
+  }
+}
+
+// grid (blocks per minibatch, num_minibatches, slots); block (bx, mb, z) moves positions [bx·chunk, (bx+1)·chunk) of
+// minibatch mb of slot slot0+z and leaves its Σadv, Σadv² in part[((z·nmb + mb)·gridDim.x + bx)·2 ..]
+constexpr int PERM_U = 4;
+__global__ void __launch_bounds__(256) permute_records_kernel(int B, int M, int chunk, const int32_t* __restrict__ perm /* [slots][B] */,
+                                                              const SampleRec* __restrict__ recs, SampleRec* __restrict__ recs_p /* [slots][B] */,
+                                                              double* __restrict__ part) {
+  const int q = threadIdx.x & 3, quad = threadIdx.x >> 2;
+  const int mb = blockIdx.y, z = blockIdx.z;
+  const size_t base = (size_t)z * B + (size_t)mb * M;
+  const int32_t* pm = perm + base;
+  const f32x4* src = reinterpret_cast<const f32x4*>(recs);
+  f32x4* dst = reinterpret_cast<f32x4*>(recs_p + base);
+  const int lo = blockIdx.x * chunk, hi = min(M, lo + chunk);
+  double sa = 0.0, sa2 = 0.0;
+  for (int p0 = lo + quad; p0 < hi; p0 += 64 * PERM_U) {
+    int s[PERM_U];
+    f32x4 v[PERM_U];
+#pragma unroll
+    for (int u = 0; u < PERM_U; ++u) { const int p = p0 + 64 * u; s[u] = p < hi ? pm[p] : -1; }
+#pragma unroll
+    for (int u = 0; u < PERM_U; ++u) if (s[u] >= 0) v[u] = src[(size_t)s[u] * 4 + q];
+#pragma unroll
+    for (int u = 0; u < PERM_U; ++u) {
+      if (s[u] < 0) continue;
+      dst[(size_t)(p0 + 64 * u) * 4 + q] = v[u];
+      if (q == 1) { const double a = (double)v[u][2]; sa += a; sa2 += a * a; }
+    }
+  }
+  __shared__ double sm[2][4];
+  sa = wave_sum(sa); sa2 = wave_sum(sa2);
+  if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = sa; sm[1][threadIdx.x >> 6] = sa2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double* o = part + (((size_t)z * gridDim.y + mb) * gridDim.x + blockIdx.x) * 2;
+    o[0] = (sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3]);
+    o[1] = (sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3]);
+  }
+}
+
+int launch_adv_fold(crl_ppo* h, const double* part, int nblk, int nentries, double* sums);  // optim.hip
+
+int launch_pack_records(crl_ppo* h) {
+  if (!h->recs) { set_error("internal: sample records are used by the fused 4/2/64 path only"); return 1; }
+  if (!h->recs_dirty) return 0;
+  const int B = h->dc.B;
+  int blocks = (B + 63) / 64;
+  if (blocks > 8192) blocks = 8192;
+  ProfScope ps(h, CRL_K_PACK);
+  hipLaunchKernelGGL(pack_records_kernel, dim3(blocks), dim3(256), 0, h->stream, B, h->obs, h->action, h->logprob, h->adv, h->value, h->ret, h->recs);
+  CRL_HIP_CHECK(hipGetLastError());
+  h->recs_dirty = false;
+  h->slot_fresh = 0;
+  return 0;
+}
+
+// recs_p[slot] ← recs[perm[slot]] for slots [slot0, slot0 + nslots), plus their per-minibatch advantage sums → adv_sums_base
+int launch_permute_records(crl_ppo* h, int slot0, int nslots) {
+  if (launch_pack_records(h)) return 1;
+  const int B = h->dc.B, M = h->dc.M, nmb = h->dc.nmb, pb = h->adv_pb;
+  const int chunk = (((M + pb - 1) / pb + 63) / 64) * 64;
+  ProfScope ps(h, CRL_K_PERMUTE);
+  hipLaunchKernelGGL(permute_records_kernel, dim3(pb, nmb, nslots), dim3(256), 0, h->stream, B, M, chunk, h->perm_base + (size_t)slot0 * B, h->recs,
+                     h->recs_p + (size_t)slot0 * B, h->adv_part);
+  CRL_HIP_CHECK(hipGetLastError());
+  if (launch_adv_fold(h, h->adv_part, pb, nslots * nmb, h->adv_sums_base + (size_t)slot0 * nmb * 2)) return 1;
+  for (int s = slot0; s < slot0 + nslots; ++s) h->slot_fresh |= 1u << s;
+  return 0;
+}
+
+}  // namespace crl

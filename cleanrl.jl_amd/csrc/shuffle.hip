@@ -217,13 +217,13 @@ static int launch_blocked_fy(crl_ppo* h, uint64_t epoch_id, bool fused) {
   CRL_HIP_CHECK(hipMemsetAsync(tot, 0, sizeof(uint32_t) * BFY_MAXK1, h->stream));
   const bool big = n >= (4 << 20);
   const int t1 = big ? 1024 : 256, chunks = (n + t1 * 32 - 1) / (t1 * 32);
-  if (big) hipLaunchKernelGGL((bfy_l1_kernel<false, 1024>), dim3(chunks), dim3(1024), sizeof(uint32_t) * K1, h->stream, n, K1, h->cfg.seed, epoch_id, tot, cur, h->perm_tmp);
-  else hipLaunchKernelGGL((bfy_l1_kernel<false, 256>), dim3(chunks), dim3(256), sizeof(uint32_t) * K1, h->stream, n, K1, h->cfg.seed, epoch_id, tot, cur, h->perm_tmp);
+  if (big) hipLaunchKernelGGL((bfy_l1_kernel<false, 1024>), dim3(chunks), dim3(1024), sizeof(uint32_t) * K1, h->stream, n, K1, shuffle_seed(h), epoch_id, tot, cur, h->perm_tmp);
+  else hipLaunchKernelGGL((bfy_l1_kernel<false, 256>), dim3(chunks), dim3(256), sizeof(uint32_t) * K1, h->stream, n, K1, shuffle_seed(h), epoch_id, tot, cur, h->perm_tmp);
   hipLaunchKernelGGL(bfy_scan_kernel, dim3(1), dim3(1024), 0, h->stream, K1, tot, off, cur, err);
-  if (big) hipLaunchKernelGGL((bfy_l1_kernel<true, 1024>), dim3(chunks), dim3(1024), sizeof(uint32_t) * 2 * K1, h->stream, n, K1, h->cfg.seed, epoch_id, tot, cur, h->perm_tmp);
-  else hipLaunchKernelGGL((bfy_l1_kernel<true, 256>), dim3(chunks), dim3(256), sizeof(uint32_t) * 2 * K1, h->stream, n, K1, h->cfg.seed, epoch_id, tot, cur, h->perm_tmp);
+  if (big) hipLaunchKernelGGL((bfy_l1_kernel<true, 1024>), dim3(chunks), dim3(1024), sizeof(uint32_t) * 2 * K1, h->stream, n, K1, shuffle_seed(h), epoch_id, tot, cur, h->perm_tmp);
+  else hipLaunchKernelGGL((bfy_l1_kernel<true, 256>), dim3(chunks), dim3(256), sizeof(uint32_t) * 2 * K1, h->stream, n, K1, shuffle_seed(h), epoch_id, tot, cur, h->perm_tmp);
   const bool fuse = fused && h->bfy_adv_part && h->dc.M >= BFY_CAP && h->dc.nmb <= 256;
-  hipLaunchKernelGGL(bfy_leaf_kernel, dim3(K1), dim3(256), 0, h->stream, K1, h->cfg.seed, epoch_id, off, h->perm_tmp, h->perm, err,
+  hipLaunchKernelGGL(bfy_leaf_kernel, dim3(K1), dim3(256), 0, h->stream, K1, shuffle_seed(h), epoch_id, off, h->perm_tmp, h->perm, err,
                      fuse ? h->adv : nullptr, h->dc.M, h->dc.nmb, h->bfy_adv_part);
   CRL_HIP_CHECK(hipGetLastError());
   h->bfy_adv_parts = fuse ? (int)K1 : 0;
@@ -240,11 +240,11 @@ int launch_shuffle(crl_ppo* h, uint64_t epoch_id, bool with_adv_sums) {
   }
   if (h->cfg.shuffle_mode == CRL_SHUFFLE_FISHER_YATES) {
     h->perm_is_bijection = false;
-    hipLaunchKernelGGL(fy_serial_kernel, dim3(1), dim3(64), 0, h->stream, h->perm, n, h->cfg.seed, epoch_id);
+    hipLaunchKernelGGL(fy_serial_kernel, dim3(1), dim3(64), 0, h->stream, h->perm, n, shuffle_seed(h), epoch_id);
   } else {
     const int bits = bij_bits(n);
     h->perm_epoch = epoch_id; h->perm_is_bijection = true;
-    hipLaunchKernelGGL(bijection_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->perm, n, bits, h->cfg.seed, epoch_id);
+    hipLaunchKernelGGL(bijection_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->perm, n, bits, shuffle_seed(h), epoch_id);
   }
   CRL_HIP_CHECK(hipGetLastError());
   return 0;

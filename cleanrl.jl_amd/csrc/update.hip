@@ -2,7 +2,7 @@
 //
 // Work split: actor and critic are independent networks that meet only in the scalar loss, so blocks alternate roles
 // (even = actor, odd = critic); each wave walks 32-sample tiles of the minibatch:
-//   gather by permutation → forward (MFMA, weights in LDS as A-fragments, activations chained in registers)
+//   read the tile's 64-byte sample records (already in minibatch order: records.hip) → forward (MFMA, weights in LDS as A-fragments, activations chained in registers)
 //   → per-sample loss terms and output cotangent → backward:
 //       dh = Wᵀ·δ        MFMA, B operand = δ straight from its C-fragment registers
 //       dW2ᵀ += h1·δ2ᵀ   MFMA with K = samples: both operands transposed through a wave-private LDS tile [64][36]
@@ -30,9 +30,7 @@ constexpr int TSTRIDE = 36;  // floats per row of the transposed tile: 144 B kee
 struct UpdateArgs {
   DevCfg c;
   const float* params;
-  const float* states; const int32_t* actions; const float* logprobs; const float* values;
-  const float* advantages; const float* returns;
-  const int32_t* perm;
+  const SampleRec* recs;  // the minibatch, contiguous: recs_p[slot] + mb·M (ppo.jl:203-211 after the permute pass)
   const double* adv_ms;   // [nmb][2] mean, std of the (global) minibatch advantages
   const double* vfix;     // [8] u, #{u > q}, -, flag, sticky flag
   float* gpart; double* lpart; float* newv;
@@ -40,11 +38,10 @@ struct UpdateArgs {
   int nblk[2];            // blocks working on the actor / the critic
   int pmax;               // capacity (blocks per role) of the partial buffers
   int stagger;            // x3 kernel: start delay of waves 4-7 (units of 1024 clocks)
-  int smp_mask;           // timing experiments only (CRL_DEBUG_GATHER_MASK): AND-mask on gathered sample ids; default all ones
   double Mglobal;         // minibatch size over all ranks (the 1/M of every mean)
 };
 
-// Per-sample inputs of one tile, gathered through the permutation (36 B per sample)
+// Per-sample inputs of one tile: two 16-byte quarters of the sample's record (36 B of it are the fields of SURVEY §8d)
 template <int D>
 struct Gathered {
   float x[D];
@@ -53,16 +50,13 @@ struct Gathered {
 };
 
 template <int D, int ROLE>
-__device__ __forceinline__ void gather(const UpdateArgs& a, int smp, Gathered<D>& g) {
-  if (D == 4) {
-    const float4 xv = reinterpret_cast<const float4*>(a.states)[smp];
-    g.x[0] = xv.x; g.x[1] = xv.y; g.x[2] = xv.z; g.x[3] = xv.w;
-  } else {
-#pragma unroll
-    for (int i = 0; i < D; ++i) g.x[i] = a.states[(size_t)D * smp + i];
-  }
-  if (ROLE == 0) { g.act = a.actions[smp]; g.f0 = a.logprobs[smp]; g.f1 = a.advantages[smp]; }
-  else { g.act = 0; g.f0 = a.values[smp]; g.f1 = a.returns[smp]; }
+__device__ __forceinline__ void gather(const UpdateArgs& a, int pos, Gathered<D>& g) {
+  static_assert(D == 4, "SampleRec carries a 4-float observation");
+  const f32x4* r = reinterpret_cast<const f32x4*>(a.recs + pos);
+  const f32x4 xv = r[0], q = r[ROLE == 0 ? 1 : 2];
+  g.x[0] = xv[0]; g.x[1] = xv[1]; g.x[2] = xv[2]; g.x[3] = xv[3];
+  if (ROLE == 0) { g.act = __float_as_int(q[0]); g.f0 = q[1]; g.f1 = q[2]; }
+  else { g.act = 0; g.f0 = q[0]; g.f1 = q[1]; }
 }
 
 // One role (actor or critic) = RW waves of the block: `smem` is the role's weight image, `scratch` the first of its
@@ -114,17 +108,13 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
   const double nwin = EXACT ? a.vfix[1] : 0.0;
   const double entk = (double)c.ent_coeff / ((double)A * a.Mglobal);
   const double vk = (double)c.v_coef * 0.5 * invM;
-  const int32_t* perm = a.perm + (size_t)a.mb * M;
 
-  // software pipeline of the gather: sample ids two tiles ahead, sample data one tile ahead
+  // the next tile's records are loaded one tile ahead
   int tile = rb * RW + wave;
   Gathered<D> cur, nxt;
-  int smp_n = 0;
   if (tile < ntiles) {
     const int pos = tile * TILE + j;
-    gather<D, ROLE>(a, pos < M ? (perm[pos] & a.smp_mask) : 0, cur);
-    const int pn = (tile + nwaves) * TILE + j;
-    smp_n = pn < M ? (perm[pn] & a.smp_mask) : 0;
+    gather<D, ROLE>(a, pos < M ? pos : 0, cur);
   }
   for (; tile < ntiles; tile += nwaves) {
     const int pos = tile * TILE + j;
@@ -195,10 +185,9 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
     }
 
     // next tile's samples: issued here (after the register-hungry loss section), in flight during the backward pass
-    gather<D, ROLE>(a, smp_n, nxt);
     {
-      const int pn = (tile + 2 * nwaves) * TILE + j;
-      smp_n = pn < M ? (perm[pn] & a.smp_mask) : 0;
+      const int pn = (tile + nwaves) * TILE + j;
+      gather<D, ROLE>(a, pn < M ? pn : 0, nxt);
     }
     // ---- backward ------------------------------------------------------------------------------------
     // (1) h2ᵀ, the output cotangents and x into the wave-private scratch
@@ -548,15 +537,13 @@ __global__ void stats_kernel(const float* __restrict__ msg, int P, StatsArgs st,
 }
 
 // #{b : u > q_b} over the minibatch (only when the speculation flag is up)
-__global__ void vfix_count_kernel(DevCfg c, const int32_t* __restrict__ perm, int mb, const float* __restrict__ newv,
-                                  const float* __restrict__ values, const float* __restrict__ returns, double* vfix) {
+__global__ void vfix_count_kernel(DevCfg c, const SampleRec* __restrict__ recs, const float* __restrict__ newv, double* vfix) {
   if (vfix[3] == 0.0) return;
   __shared__ double sm[4];
   const float u = (float)vfix[0];
   double cnt = 0.0;
   for (int pos = threadIdx.x; pos < c.M; pos += blockDim.x) {
-    const int smp = perm[(size_t)mb * c.M + pos];
-    const float v = newv[pos], ov = values[smp], R = returns[smp];
+    const float v = newv[pos], ov = recs[pos].old_v, R = recs[pos].ret;
     const float cl = fminf(fmaxf(v - ov, -c.clip), c.clip);
     const float vc = ov + cl;
     const float q = (vc - R) * (vc - R);
@@ -594,11 +581,9 @@ static void main_pass_blocks(crl_ppo* h, int* nA, int* nC) {
 static int run_update(crl_ppo* h, int mb, int mode, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
   UpdateArgs a;
   a.c = h->dc; a.params = h->params;
-  a.states = h->obs; a.actions = h->action; a.logprobs = h->logprob; a.values = h->value;
-  a.advantages = h->adv; a.returns = h->ret; a.perm = h->perm; a.adv_ms = h->adv_ms; a.vfix = h->vfix;
+  a.recs = h->recs_p + (size_t)h->cur_slot * h->dc.B + (size_t)mb * h->dc.M; a.adv_ms = h->adv_ms; a.vfix = h->vfix;
   a.gpart = h->gpart; a.lpart = h->lpart; a.newv = h->newv;
   a.mb = mb; a.mode = mode; a.gstride = (int)h->Pa; a.pmax = h->update_blocks; a.stagger = 0;
-  a.smp_mask = env_int("CRL_DEBUG_GATHER_MASK", 0x7fffffff);
   a.Mglobal = (double)h->dc.M * h->world;
   if (mode == 1) {
     a.nblk[0] = 0; a.nblk[1] = h->update_blocks;
@@ -659,7 +644,7 @@ int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
   }
   if (h->cfg.clip_value_loss && h->world == 1) {
     // early-exit launches unless the statistics raised the flag (u > 0)
-    hipLaunchKernelGGL(vfix_count_kernel, dim3(1), dim3(1024), 0, h->stream, h->dc, h->perm, mb, h->newv, h->value, h->ret, h->vfix);
+    hipLaunchKernelGGL(vfix_count_kernel, dim3(1), dim3(1024), 0, h->stream, h->dc, h->recs_p + (size_t)h->cur_slot * h->dc.B + (size_t)mb * h->dc.M, h->newv, h->vfix);
     CRL_HIP_CHECK(hipGetLastError());
     if (run_update(h, mb, 1)) return 1;
     hipLaunchKernelGGL(reduce_kernel<1>, dim3((P + 63) / 64), dim3(64 * RG), 0, h->stream, h->gpart, h->lpart, 0, h->update_blocks,
@@ -691,7 +676,7 @@ int launch_update_exact_dp(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
   CRL_HIP_CHECK(hipMemcpyAsync(&flag, h->vfix + 3, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
   if (flag == 0.0) return 0;
-  hipLaunchKernelGGL(vfix_count_kernel, dim3(1), dim3(1024), 0, h->stream, h->dc, h->perm, mb, h->newv, h->value, h->ret, h->vfix);
+  hipLaunchKernelGGL(vfix_count_kernel, dim3(1), dim3(1024), 0, h->stream, h->dc, h->recs_p + (size_t)h->cur_slot * h->dc.B + (size_t)mb * h->dc.M, h->newv, h->vfix);
   CRL_HIP_CHECK(hipGetLastError());
   if (comm_allreduce(h, h->vfix + 1, 1, true)) return 1;                       // global #{u > q}
   if (run_update(h, mb, 1)) return 1;                                          // exact critic gradient of this shard

@@ -180,7 +180,8 @@ int32_t crl_comm_init_external(crl_ppo* h, int32_t world_size, int32_t rank);
 
 /* Profiling: HIP-event timing of each kernel class on the handle's stream (bench.py roofline). */
 enum crl_kernel_id { CRL_K_ROLLOUT = 0, CRL_K_GAE = 1, CRL_K_SHUFFLE = 2, CRL_K_ADV_STATS = 3, CRL_K_UPDATE = 4,
-                     CRL_K_REDUCE = 5, CRL_K_OPTIM = 6, CRL_K_ALLREDUCE = 7, CRL_K_COUNT = 8 };
+                     CRL_K_REDUCE = 5, CRL_K_OPTIM = 6, CRL_K_ALLREDUCE = 7, CRL_K_PACK = 8, CRL_K_PERMUTE = 9,
+                     CRL_K_COUNT = 10 };
 int32_t crl_prof_enable(crl_ppo* h, int32_t on);
 int32_t crl_prof_read(crl_ppo* h, int32_t kernel_id, double* total_ms, int64_t* launches);
 int32_t crl_prof_reset(crl_ppo* h);
