@@ -96,3 +96,42 @@ def test_shard_envs_contract():
         distmod.shard_envs(10, 4, 0)
     with pytest.raises(ValueError):
         distmod.shard_envs(8, 2, 2)
+
+
+def _bench(*args, timeout=600):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], capture_output=True, text=True, env=env,
+                          timeout=timeout)
+
+
+def test_bench_dry_run_prints_one_fresh_process_per_gpu():
+    """`python bench.py --gpus N` as a bare command: the parent (which never touches the GPU) starts the launcher as a CHILD;
+    --dry-run shows that command and every rank's environment."""
+    import json
+    out = _bench("--gpus", "2", "--steps", "5", "--warmup", "1", "--dry-run")
+    assert out.returncode == 0, out.stderr
+    lines = [json.loads(l) for l in out.stdout.strip().splitlines()]
+    launcher = lines[0]["launcher"]
+    assert launcher[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=2" in launcher and "127.0.0.1" in launcher
+    assert launcher[-6:] == ["--gpus", "2", "--steps", "5", "--warmup", "1"] and "--dry-run" not in launcher
+    ranks = lines[1:]
+    assert [r["rank"] for r in ranks] == [0, 1]
+    for r in ranks:
+        assert r["env"]["WORLD_SIZE"] == "2" and r["env"]["LOCAL_RANK"] == str(r["rank"]) and r["env"]["MASTER_ADDR"] == "127.0.0.1"
+        assert r["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+        assert r["cmd"][-6:] == ["--gpus", "2", "--steps", "5", "--warmup", "1"]
+
+
+def test_bench_bare_command_spawns_ranks_and_exchanges_the_id():
+    """The real spawn path on CPU: bare `bench.py --gpus 2 --rendezvous-only` → child launcher → two ranks meet over gloo,
+    rank 0's 128-byte communicator id reaches rank 1, the env axis is sharded, rank 0 prints ONE JSON line."""
+    import json
+    out = _bench("--gpus", "2", "--rendezvous-only", "--total-envs", "4096")
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec == {"rendezvous": "ok", "world": 2, "envs_per_rank": 2048}

@@ -96,3 +96,59 @@ def test_argparse_struct_mirrors_config_parser():
         argparse_struct(crl.PPOConfig(), ["--no_such_field", "1"])
     with pytest.raises(TypeError):
         argparse_struct({"a": 1}, [])
+
+
+_C_CALLER = r'''
+/* A plain C99 translation unit: includes the public header, checks the layouts the ctypes / ccall mirrors assume and calls
+ * the two entry points that need no GPU. */
+#include <stdio.h>
+#include <string.h>
+#include "cleanrl_hip.h"
+int main(void) {
+  if (crl_version() != CRL_VERSION) { printf("version %d\n", (int)crl_version()); return 2; }
+  const char* e = crl_last_error();
+  if (!e) return 3;
+  crl_ppo* h = (crl_ppo*)0;
+  crl_ppo_config cfg; memset(&cfg, 0, sizeof cfg);
+  if (crl_ppo_create(&cfg, 0, &h) == 0) return 4;         /* an all-zero config must be rejected, with a message */
+  if (strlen(crl_last_error()) == 0) return 5;
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(crl_ppo_config), sizeof(crl_ppo_stats), sizeof(crl_episode_stats),
+         sizeof(crl_episode_record), sizeof(crl_a2c_config), sizeof(crl_dqn_config), sizeof(crl_dqn_status));
+  return 0;
+}
+'''
+
+
+def test_header_is_c99_and_a_c_program_links_the_library(crl, tmp_path):
+    """include/cleanrl_hip.h must be consumable by a C compiler (that is what a Julia `ccall` / cgo / ctypes binding
+    assumes), and a C program linked against libcleanrl_hip.so must be able to call it."""
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    hdr = os.path.join(inc, "cleanrl_hip.h")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    src = tmp_path / "caller.c"
+    src.write_text(_C_CALLER)
+    exe = tmp_path / "caller"
+    libdir = os.path.join(ROOT, "cleanrl.jl_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", inc, str(src), "-o", str(exe),
+                           os.path.join(libdir, "libcleanrl_hip.so"), f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    sizes = [int(x) for x in out.stdout.split()]
+    L = crl._lib
+    assert sizes == [C.sizeof(L.CrlConfig), C.sizeof(L.CrlStats), C.sizeof(L.CrlEpisodeStats), C.sizeof(L.CrlEpisodeRecord),
+                     C.sizeof(L.CrlA2CConfig), C.sizeof(L.CrlDQNConfig), C.sizeof(L.CrlDQNStatus)], sizes
+    assert sizes[:1] == [104] and sizes[4] == 40 and sizes[5] == 112
+
+
+def test_a2c_and_dqn_config_mirrors_follow_the_header(crl):
+    """Field order of crl_a2c_config / crl_dqn_config in the header == the ctypes mirrors (sizes are pinned by the C program
+    of the previous test)."""
+    hdr = open(os.path.join(ROOT, "include", "cleanrl_hip.h")).read()
+    for cname, mirror in (("crl_a2c_config", crl._lib.CrlA2CConfig), ("crl_dqn_config", crl._lib.CrlDQNConfig)):
+        body = hdr[hdr.index("typedef struct %s {" % cname):hdr.index("} %s;" % cname)]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in re.findall(r"(?:int64_t|int32_t|double|uint64_t)\s+([a-z_, ]+);", body):
+            names += [n.strip() for n in decl.split(",")]
+        assert names == [n for n, _ in mirror._fields_], (cname, names)
