@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcleanrl_hip.so")
+LIB_PATH = os.environ.get("CRL_LIB_PATH") or os.path.join(_HERE, "libcleanrl_hip.so")   # CRL_LIB_PATH: build-variant experiments
 
 
 class CrlError(RuntimeError):

@@ -206,9 +206,9 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
   if (ub * 4 > ntiles) ub = (ntiles + 3) / 4;
   if (ub < 1) ub = 1;
   h->update_blocks = ub;
-  if (!wide) { rc |= dalloc(&h->gpart, (size_t)2 * ub * h->Pa + 4096); rc |= dalloc(&h->lpart, (size_t)2 * ub * 2); }
+  if (!wide) { rc |= dalloc(&h->gpart, (size_t)4 * ub * h->Pa + 4096); rc |= dalloc(&h->lpart, (size_t)4 * ub * 2); }
   rc |= dalloc(&h->adv_sums_base, E * c.nmb * 2); rc |= dalloc(&h->adv_ms_base, E * c.nmb * 2);
-  rc |= dalloc(&h->newv, (size_t)c.M); rc |= dalloc(&h->vfix, 8);
+  rc |= dalloc(&h->newv, (size_t)c.M + 64); rc |= dalloc(&h->vfix, 8);
   rc |= dalloc(&h->stats_dev, (size_t)cfg->update_epochs * c.nmb);
   rc |= dalloc(&h->comm_buf, (size_t)h->P + 8);
   rc |= dalloc(&h->snap, (size_t)3 * h->P); rc |= dalloc(&h->snap_betap, 24);

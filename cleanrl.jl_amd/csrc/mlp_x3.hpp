@@ -130,21 +130,27 @@ __device__ __forceinline__ P3 load_wfrag(const float* piece0, int mo, int ks, in
   return a;
 }
 
-// acc[mo] += W(64x64) · X(64 x 32 samples) with X given as C-fragment registers (x[mt][r]); wimg = wf2p or wb2p
+// acc[mo] += W(64x64) · X(64 x 32 samples) with X given as C-fragment registers (x[mt][r]); wimg = wf2p or wb2p.
+// (Tried and dropped, DESIGN.md §3: software-pipelining the k-steps with sched_group_barrier — next step's fragment reads and
+// split under this step's MFMAs — costs 90-150 spilled registers at the 256-register budget and ran 1-6 % slower.)
+__device__ __forceinline__ P3 split_kstep(const f32x16 (&x)[2], int ks) {
+  float xb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) xb[j] = x[ks >> 1][8 * (ks & 1) + j];
+  return split3(xb);
+}
 __device__ __forceinline__ void dense64_x3(const float* wimg, const f32x16 (&x)[2], f32x16& acc0, f32x16& acc1, int lane) {
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    float xb[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) xb[j] = x[ks >> 1][8 * (ks & 1) + j];
-    const P3 b = split3(xb);
+    const P3 b = split_kstep(x, ks);
     acc0 = mfma_x3(load_wfrag(wimg, 0, ks, lane), b, acc0);
     acc1 = mfma_x3(load_wfrag(wimg, 1, ks, lane), b, acc1);
   }
 }
 
 // Forward of one network for a 32-sample tile (same contract as mlp_forward in common.hpp)
-template <int D, int NOUT, bool BWD>
+// DBG (timing experiments only, CRL_ABLATE builds): bit 2 = cheap activation instead of tanh_fast, bit 6 = no layer-2 MFMAs
+template <int D, int NOUT, bool BWD, int DBG = 0>
 __device__ __forceinline__ void mlp_forward_x3(const float* img, const float (&x)[D], f32x16 (&h1)[2], f32x16 (&h2)[2],
                                                float (&out)[NOUT], int lane) {
   using I = NetImageX3<D, NOUT, BWD>;
@@ -159,13 +165,22 @@ __device__ __forceinline__ void mlp_forward_x3(const float* img, const float (&x
     a1 = mfma32(img[I::WF1 + (1 * (D / 2) + ks) * 64 + lane], b, a1);
   }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { h1[0][r] = tanh_fast(a0[r]); h1[1][r] = tanh_fast(a1[r]); }
+  for (int r = 0; r < 16; ++r) {
+    if constexpr (DBG & 4) { h1[0][r] = a0[r] * 0.5f; h1[1][r] = a1[r] * 0.5f; }
+    else { h1[0][r] = tanh_fast(a0[r]); h1[1][r] = tanh_fast(a1[r]); }
+  }
   // layer 2 on the bf16 pipe
   a0 = load16(img + I::B2C + hf * 32);
   a1 = load16(img + I::B2C + hf * 32 + 16);
-  dense64_x3(img + I::WF2P, h1, a0, a1, lane);
+  if constexpr (DBG & 64) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { h2[0][r] = tanh_fast(a0[r]); h2[1][r] = tanh_fast(a1[r]); }
+    for (int r = 0; r < 16; ++r) { a0[r] += h1[0][r]; a1[r] += h1[1][r]; }
+  } else dense64_x3(img + I::WF2P, h1, a0, a1, lane);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if constexpr (DBG & 4) { h2[0][r] = a0[r] * 0.5f; h2[1][r] = a1[r] * 0.5f; }
+    else { h2[0][r] = tanh_fast(a0[r]); h2[1][r] = tanh_fast(a1[r]); }
+  }
   // head on VALU
 #pragma unroll
   for (int a = 0; a < NOUT; ++a) {

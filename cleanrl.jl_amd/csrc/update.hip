@@ -22,24 +22,14 @@
 #include "mlp_x3.hpp"
 #include "ppo_ctx.hpp"
 #include "stats.hpp"
+#include "update_args.hpp"
 
 namespace crl {
 
-constexpr int TSTRIDE = 36;  // floats per row of the transposed tile: 144 B keeps b128 reads aligned and conflict-free
-
-struct UpdateArgs {
-  DevCfg c;
-  const float* params;
-  const SampleRec* recs;  // the minibatch, contiguous: recs_p[slot] + mb·M (ppo.jl:203-211 after the permute pass)
-  const double* adv_ms;   // [nmb][2] mean, std of the (global) minibatch advantages
-  const double* vfix;     // [8] u, #{u > q}, -, flag, sticky flag
-  float* gpart; double* lpart; float* newv;
-  int mb, mode, gstride;
-  int nblk[2];            // blocks working on the actor / the critic
-  int pmax;               // capacity (blocks per role) of the partial buffers
-  int stagger;            // x3 kernel: start delay of waves 4-7 (units of 1024 clocks)
-  double Mglobal;         // minibatch size over all ranks (the 1/M of every mean)
-};
+constexpr int TSTRIDE = 36;
+// phase boundary: orders the wave's LDS traffic AND stops the scheduler from moving register-only work across it (hoisted
+// loads of the next phase were the source of the spills)
+#define CRL_PHASE() do { wave_lds_fence(); __builtin_amdgcn_sched_barrier(0); } while (0)  // floats per row of the transposed tile: 144 B keeps b128 reads aligned and conflict-free
 
 // Per-sample inputs of one tile: two 16-byte quarters of the sample's record (36 B of it are the fields of SURVEY §8d)
 template <int D>
@@ -63,7 +53,9 @@ __device__ __forceinline__ void gather(const UpdateArgs& a, int pos, Gathered<D>
 // RW wave-private tiles. All barriers are block-wide and both roles execute the same number of them.
 constexpr int SCR_FLOATS = 64 * TSTRIDE + TILE * 4 + 2 * TILE;
 
-template <int D, int A, int ROLE, bool EXACT, bool X3, int RW>
+// ABL (CRL_ABLATE builds, scripts/run_ablate.sh): timing experiments that remove one phase each (results are garbage) — the
+// way the per-phase costs in DESIGN.md §3 were measured. 0 in every production instantiation.
+template <int D, int A, int ROLE, bool EXACT, bool X3, int RW, int ABL = 0>
 __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, float* smem, float* scratch) {
   constexpr int NOUT = ROLE == 0 ? A : 1;
   using I = typename std::conditional<X3, NetImageX3<D, NOUT, true>, NetImage<D, NOUT, true>>::type;
@@ -112,13 +104,15 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
   // the next tile's records are loaded one tile ahead
   int tile = rb * RW + wave;
   Gathered<D> cur, nxt;
-  if (tile < ntiles) {
+  constexpr bool PREFETCH = !(ABL & 1);
+  if (PREFETCH && tile < ntiles) {
     const int pos = tile * TILE + j;
     gather<D, ROLE>(a, pos < M ? pos : 0, cur);
   }
   for (; tile < ntiles; tile += nwaves) {
     const int pos = tile * TILE + j;
     const bool ok = pos < M;
+    if constexpr (!PREFETCH) gather<D, ROLE>(a, ok ? pos : 0, cur);
     float x[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) x[i] = cur.x[i];
@@ -128,10 +122,13 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
     int lds_off = 0;
     asm volatile("" : "+v"(lds_off));
     const float* img = img0 + lds_off;
-    if constexpr (X3) mlp_forward_x3<D, NOUT, true>(img, x, h1, h2, out, lane);
+    if constexpr (X3) mlp_forward_x3<D, NOUT, true, ABL>(img, x, h1, h2, out, lane);
     else mlp_forward<D, NOUT, true>(img, x, h1, h2, out, lane);
 
-    if constexpr (ROLE == 0) {
+    if constexpr ((ABL & 32) != 0) {
+#pragma unroll
+      for (int i = 0; i < NOUT; ++i) dout[i] = out[i] * 1e-6f + cur.f0 + cur.f1 + (float)cur.act;
+    } else if constexpr (ROLE == 0) {
       // policy loss + entropy (ppo.jl:213,219-228,242)
       float pr[A], lp[A];
       softmax_logsoftmax<A>(out, pr, lp);
@@ -185,7 +182,7 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
     }
 
     // next tile's samples: issued here (after the register-hungry loss section), in flight during the backward pass
-    {
+    if constexpr (PREFETCH) {
       const int pn = (tile + nwaves) * TILE + j;
       gather<D, ROLE>(a, pn < M ? pn : 0, nxt);
     }
@@ -201,32 +198,36 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
 #pragma unroll
       for (int i = 0; i < D; ++i) xs[j * D + i] = x[i];
     }
-    wave_lds_fence();
-    // (2) lane = row: dW3[a][lane] += Σ_s h2[lane][s]·δ3[a][s];  db3[a] += Σ_s δ3[a][s]
-    // (in chunks of 8 samples with scheduling barriers: un-chunked, the compiler hoists all 8+8·NOUT b128 reads and
-    //  their 96 registers on top of h1, h2 and the dW2 accumulators, and spills)
+    CRL_PHASE();
+    if constexpr (!(ABL & 8))
+    // (2) lane = row: dW3[a][lane] += Σ_s h2[lane][s]·δ3[a][s]. The LDS reads of half a row are issued together and waited
+    // for with counted lgkmcnt (a read → wait → use chain per quad exposed the full LDS latency eight times); two halves
+    // keep the batch at 12 registers-quads so nothing spills. db3 is a per-lane sum, folded over lanes once per kernel.
     {
       const f32x4* tr = reinterpret_cast<const f32x4*>(T + lane * TSTRIDE);
-      float accw[NOUT], accb[NOUT];
+      float accw[NOUT];
 #pragma unroll
-      for (int i = 0; i < NOUT; ++i) { accw[i] = 0.0f; accb[i] = 0.0f; }
+      for (int i = 0; i < NOUT; ++i) { accw[i] = 0.0f; db3acc[i] += hf == 0 ? dout[i] : 0.0f; }
 #pragma unroll
-      for (int q2 = 0; q2 < 4; ++q2) {
+      for (int half = 0; half < 2; ++half) {
+        f32x4 rq[4], dv[NOUT][4];
 #pragma unroll
-        for (int qq = 0; qq < 2; ++qq) {
-          const int q = 2 * q2 + qq;
-          const f32x4 rq = tr[q];
+        for (int q = 0; q < 4; ++q) rq[q] = tr[4 * half + q];
 #pragma unroll
-          for (int i = 0; i < NOUT; ++i) {
-            const f32x4 dv4 = reinterpret_cast<const f32x4*>(d3s + i * TILE)[q];
+        for (int i = 0; i < NOUT; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { accw[i] = __builtin_fmaf(rq[e], dv4[e], accw[i]); accb[i] += dv4[e]; }
-          }
-        }
+          for (int q = 0; q < 4; ++q) dv[i][q] = reinterpret_cast<const f32x4*>(d3s + i * TILE)[4 * half + q];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int i = 0; i < NOUT; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) accw[i] = __builtin_fmaf(rq[q][e], dv[i][q][e], accw[i]);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int i = 0; i < NOUT; ++i) { dW3acc[i] += accw[i]; db3acc[i] += accb[i]; }
+      for (int i = 0; i < NOUT; ++i) dW3acc[i] += accw[i];
     }
     // (3) δ2 = (W3ᵀ·δ3) ⊙ (1 − h2²) in C-fragment registers (h2 dies here)
     f32x16 d2[2];
@@ -259,7 +260,10 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
       f32x16 c0, c1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { c0[r] = 0.0f; c1[r] = 0.0f; }
-      if constexpr (X3) {
+      if constexpr ((ABL & 16) != 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { c0[r] = d2[0][r]; c1[r] = d2[1][r]; }
+      } else if constexpr (X3) {
         dense64_x3(img + I::WB2P, d2, c0, c1, lane);
       } else {
         const f32x4* w0 = reinterpret_cast<const f32x4*>(img + I::WB2) + lane;
@@ -282,13 +286,47 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
         d1[1][r] = c1[r] * (1.0f - h1[1][r] * h1[1][r]);
       }
     }
-    wave_lds_fence();
+    CRL_PHASE();
+    // (7) runs before (5)/(6): δ1 dies here, so the weight-gradient phase below holds 32 fewer live registers (no spills)
+    if constexpr (!(ABL & 8)) {
+    // (7) δ1ᵀ → scratch; lane = row: db1, dW1[lane][c] += Σ_s δ1[lane][s]·x[s][c]
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) T[(32 * mt + rowmap(r, hf)) * TSTRIDE + j] = d1[mt][r];
+    CRL_PHASE();
+    {
+      const f32x4* tr = reinterpret_cast<const f32x4*>(T + lane * TSTRIDE);
+      float sb = 0.0f;
+      f32x4 t4[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t4[q] = tr[q];
+#pragma unroll
+      for (int q2 = 0; q2 < 4; ++q2) {          // the tile's observations, 8 samples (8 broadcast reads) at a time
+        f32x4 xv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e] = *reinterpret_cast<const f32x4*>(xs + (8 * q2 + e) * 4);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float dv = t4[2 * q2 + (e >> 2)][e & 3];
+          sb += dv;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dW1acc[i] = __builtin_fmaf(dv, xv[e][i], dW1acc[i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      db1acc += sb;
+    }
+    CRL_PHASE();
+    } else { db1acc += d1[0][0] + d1[1][5]; }
+    if constexpr (!(ABL & 2)) {
     // (5) δ2ᵀ → scratch; db2; B-fragments (δ2 rows on lanes, samples along k: smp(s,hf) = s + 16hf) (δ2 dies here)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) T[(32 * mt + rowmap(r, hf)) * TSTRIDE + j] = d2[mt][r];
-    wave_lds_fence();
+    CRL_PHASE();
     f32x4 bfr[2][4];
     f32x4 braw[2][2][2];  // x3: raw δ2ᵀ B-fragments [ni][ks][half] (split into bf16 pieces at use: 32 registers, not 48)
     {
@@ -315,13 +353,13 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
         }
       }
     }
-    wave_lds_fence();
+    CRL_PHASE();
     // (6) h1ᵀ → scratch (h1 dies here); A-fragments streamed; dW2ᵀ[mj][ni] += h1[mj-block]·δ2[ni-block]ᵀ over 32 samples
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) T[(32 * mt + rowmap(r, hf)) * TSTRIDE + j] = h1[mt][r];
-    wave_lds_fence();
+    CRL_PHASE();
     if constexpr (X3) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -359,37 +397,9 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
         }
       }
     }
-    wave_lds_fence();
-    // (7) δ1ᵀ → scratch; lane = row: db1, dW1[lane][c] += Σ_s δ1[lane][s]·x[s][c]
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) T[(32 * mt + rowmap(r, hf)) * TSTRIDE + j] = d1[mt][r];
-    wave_lds_fence();
-    {
-      const f32x4* tr = reinterpret_cast<const f32x4*>(T + lane * TSTRIDE);
-      float sb = 0.0f;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const f32x4 t4 = tr[q];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int s = q * 4 + e;
-          sb += t4[e];
-          if (D == 4) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + s * 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) dW1acc[i] = __builtin_fmaf(t4[e], xv[i], dW1acc[i]);
-          } else {
-#pragma unroll
-            for (int i = 0; i < D; ++i) dW1acc[i] = __builtin_fmaf(t4[e], xs[s * D + i], dW1acc[i]);
-          }
-        }
-      }
-      db1acc += sb;
+    CRL_PHASE();
     }
-    wave_lds_fence();
-    cur = nxt;
+    if constexpr (PREFETCH) cur = nxt;
   }
 
   // ---- block reduction: waves add their accumulators into one LDS image in flat Flux order ------------------
@@ -415,9 +425,10 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
       R[P::B2 + lane] += db2acc;
 #pragma unroll
       for (int i = 0; i < NOUT; ++i) R[P::W3 + i + NOUT * lane] += dW3acc[i];
-      if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < NOUT; ++i) R[P::B3 + i] += db3acc[i];
+      for (int i = 0; i < NOUT; ++i) {
+        const float b3 = wave_sum(db3acc[i]);
+        if (lane == 0) R[P::B3 + i] += b3;
       }
     }
     __syncthreads();
@@ -454,6 +465,18 @@ __global__ void __launch_bounds__(512, 2) update_x3_kernel(UpdateArgs a) {
   if ((int)blockIdx.x < a.nblk[0]) update_role<D, A, 0, false, true, 8>(a, blockIdx.x, smem, smem + NetImageX3<D, A, true>::SIZE);
   else update_role<D, A, 1, false, true, 8>(a, blockIdx.x - a.nblk[0], smem, smem + NetImageX3<D, 1, true>::SIZE);
 }
+#ifdef CRL_ABLATE
+// timing experiments only: the same kernel with one phase removed (results are garbage)
+template <int D, int A, int ABL, int RW>
+__global__ void __launch_bounds__(64 * RW, 2) update_x3_dbg_kernel(UpdateArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (RW == 8 && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= 4) {
+    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+  }
+  if ((int)blockIdx.x < a.nblk[0]) update_role<D, A, 0, false, true, RW, ABL>(a, blockIdx.x, smem, smem + NetImageX3<D, A, true>::SIZE);
+  else update_role<D, A, 1, false, true, RW, ABL>(a, blockIdx.x - a.nblk[0], smem, smem + NetImageX3<D, 1, true>::SIZE);
+}
+#endif
 // Exact critic-only pass with the known scalar u and count; runs only when stats_kernel raised the flag
 template <int D, int A>
 __global__ void __launch_bounds__(256, 2) update_vfix_kernel(UpdateArgs a) {
@@ -589,6 +612,19 @@ static int run_update(crl_ppo* h, int mb, int mode, hipEvent_t ev0 = nullptr, hi
     a.nblk[0] = 0; a.nblk[1] = h->update_blocks;
     const size_t smem = sizeof(float) * (NetImage<4, 1, true>::SIZE + 4 * SCR_FLOATS);
     hipLaunchKernelGGL((update_vfix_kernel<4, 2>), dim3(h->update_blocks), dim3(256), smem, h->stream, a);
+#ifdef CRL_ABLATE
+  } else if (getenv("CRL_DEBUG_ABLATE")) {
+    main_pass_blocks(h, &a.nblk[0], &a.nblk[1]);
+    a.stagger = env_int("CRL_X3_STAGGER", 3);
+    const int abl = env_int("CRL_DEBUG_ABLATE", 0), rw = env_int("CRL_DEBUG_RW", 8);
+    const size_t smem = sizeof(float) * (NetImageX3<4, 2, true>::SIZE + 8 * SCR_FLOATS);   // 8 tiles' worth either way: one block per CU at RW = 4 too
+    const dim3 grid(rw == 8 ? a.nblk[0] + a.nblk[1] : 2 * (a.nblk[0] + a.nblk[1]));
+    if (rw == 4) { a.nblk[0] *= 2; a.nblk[1] *= 2; a.pmax *= 2; }
+#define CRL_DBG_CASE(M_, RW_) if (abl == M_ && rw == RW_) hipExtLaunchKernelGGL((update_x3_dbg_kernel<4, 2, M_, RW_>), grid, dim3(64 * RW_), smem, h->stream, ev0, ev1, 0, a);
+    CRL_DBG_CASE(0, 8) CRL_DBG_CASE(0, 4) CRL_DBG_CASE(1, 8) CRL_DBG_CASE(2, 8) CRL_DBG_CASE(4, 8) CRL_DBG_CASE(8, 8) CRL_DBG_CASE(16, 8)
+    CRL_DBG_CASE(32, 8) CRL_DBG_CASE(64, 8) CRL_DBG_CASE(82, 8) CRL_DBG_CASE(86, 8) CRL_DBG_CASE(126, 8)
+#undef CRL_DBG_CASE
+#endif
   } else if (gemm_x3()) {
     main_pass_blocks(h, &a.nblk[0], &a.nblk[1]);
     static int stagger = -1;

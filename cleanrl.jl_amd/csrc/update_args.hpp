@@ -1,0 +1,22 @@
+// update_args.hpp — launch arguments shared by the update kernels (update.hip).
+#pragma once
+#include "ppo_ctx.hpp"
+
+namespace crl {
+
+struct UpdateArgs {
+  DevCfg c;
+  const float* params;
+  const SampleRec* recs;  // the minibatch, contiguous: recs_p[slot] + mb·M (ppo.jl:203-211 after the permute pass)
+  const double* adv_ms;   // [nmb][2] mean, std of the (global) minibatch advantages
+  const double* vfix;     // [8] u, #{u > q}, -, flag, sticky flag
+  float* gpart; double* lpart; float* newv;
+  int mb, mode, gstride;
+  int nblk[2];            // blocks working on the actor / the critic
+  int pmax;               // capacity (blocks per role) of the partial buffers
+  int stagger;            // x3 kernel: start delay of waves 4-7 (units of 1024 clocks)
+  double Mglobal;         // minibatch size over all ranks (the 1/M of every mean)
+};
+
+
+}  // namespace crl
