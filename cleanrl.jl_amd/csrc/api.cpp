@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <utility>
 
 #include "ppo_ctx.hpp"
 
@@ -96,6 +97,17 @@ int ensure_records(crl_ppo* h) {
 }
 }  // namespace crl
 
+static bool env_on(const char* name, bool dflt) { const char* e = getenv(name); return e ? atoi(e) != 0 : dflt; }
+
+namespace crl {
+// compat-mode GAE rides on the tail of the rollout kernels of the fused 4/2/64 path (policy.hip); fixed mode needs the
+// bootstrap critic pass and keeps the separate launches
+bool rollout_can_fuse_gae(const crl_ppo* h) {
+  static const bool on = env_on("CRL_GAE_FUSE", true);
+  return on && !h->wide && h->cfg.gae_mode == CRL_GAE_COMPAT && h->cfg.env_kind == CRL_ENV_CARTPOLE;
+}
+}  // namespace crl
+
 using namespace crl;
 
 #define CRL_GUARD(h)                                         \
@@ -174,6 +186,10 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
   int rc = 0;
   hipError_t se = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (se != hipSuccess) { set_error(std::string("hipStreamCreate: ") + hipGetErrorString(se)); delete h; return 1; }
+  if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+    set_error("hipStreamCreate / hipEventCreate failed"); crl_ppo_destroy(h); return 1;
+  }
   const size_t B = (size_t)c.B, nt = (size_t)c.nt;
   rc |= dalloc(&h->obs, B * d); rc |= dalloc(&h->action, B); rc |= dalloc(&h->logprob, B); rc |= dalloc(&h->reward, B);
   rc |= dalloc(&h->terminal, B); rc |= dalloc(&h->value, B); rc |= dalloc(&h->adv, B); rc |= dalloc(&h->ret, B);
@@ -193,7 +209,7 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
     rc |= dalloc(&h->adv_part, 2 * (need > alone ? need : alone));
   }
   if (cfg->shuffle_mode == CRL_SHUFFLE_BLOCKED_FY) {
-    rc |= dalloc(&h->perm_tmp, B); rc |= dalloc(&h->bfy_ws, (size_t)4 * 16384 + 8);
+    rc |= dalloc(&h->perm_tmp, E * B); rc |= dalloc(&h->bfy_ws, E * ((size_t)4 * 16384 + 8));   // one slice per epoch slot
     size_t k1 = 1; while (k1 * 4096 < B) k1 *= 2;
     rc |= dalloc(&h->bfy_adv_part, (size_t)c.nmb * k1 * 2);
   }
@@ -240,6 +256,9 @@ int32_t crl_ppo_destroy(crl_ppo* h) {
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int k = 0; k < CRL_K_COUNT; ++k)
     for (auto& pr : h->prof_slots[k].pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return 0;
@@ -457,8 +476,10 @@ int32_t crl_compute_gae(crl_ppo* h) {
 static int check_bfy(crl_ppo* h) {
   if (h->cfg.shuffle_mode != CRL_SHUFFLE_BLOCKED_FY) return 0;
   uint32_t err = 0;
-  CRL_HIP_CHECK(hipMemcpyAsync(&err, h->bfy_ws + 3 * 16384 + 1, sizeof(err), hipMemcpyDeviceToHost, h->stream));
-  CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  for (int z = 0; z < h->cfg.update_epochs && !err; ++z) {
+    CRL_HIP_CHECK(hipMemcpyAsync(&err, h->bfy_ws + (size_t)z * (4 * 16384 + 8) + 3 * 16384 + 1, sizeof(err), hipMemcpyDeviceToHost, h->stream));
+    CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  }
   if (err) { set_error("blocked Fisher-Yates: a bucket overflowed its LDS leaf (probability < 1e-200; corrupted state?)"); return 1; }
   return 0;
 }
@@ -559,16 +580,34 @@ static double anneal_eta(const crl_ppo* h) {
   return eta;
 }
 
+// all update_epochs permutations of one iteration (ppo.jl:191-194) into the perm slots, on the handle's CURRENT stream
+static int draw_epoch_permutations(crl_ppo* h, uint64_t ep0) {
+  const int E = h->cfg.update_epochs;
+  if (h->cfg.shuffle_mode == CRL_SHUFFLE_BLOCKED_FY) {   // one launch per pass for all epochs
+    select_slot(h, 0);
+    return launch_shuffle_epochs(h, ep0, E);
+  }
+  for (int ep = 0; ep < E; ++ep) {
+    select_slot(h, ep);
+    if (h->cfg.shuffle_mode == CRL_SHUFFLE_FISHER_YATES) {   // b_inds = shuffle(b_inds): each epoch shuffles the previous order
+      if (ep == 0) { if (launch_iota(h)) return 1; }         // ppo.jl:191
+      else CRL_HIP_CHECK(hipMemcpyAsync(h->perm, h->perm - h->dc.B, (size_t)h->dc.B * 4, hipMemcpyDeviceToDevice, h->stream));
+    }
+    if (launch_shuffle(h, ep0 + (uint64_t)ep)) return 1;
+  }
+  return 0;
+}
+
 // one pass of the ppo.jl:117-253 loop body
 static int iterate_once(crl_ppo* h, bool exact) {
   const int E = h->cfg.update_epochs, nmb = h->dc.nmb;
   const double eta = anneal_eta(h);
-  h->recs_dirty = true;
-  if (launch_rollout(h)) return 1;
-  if (crl_compute_gae(h)) return 1;
   const uint64_t ep0 = (uint64_t)h->iteration * (uint64_t)E;
+  h->recs_dirty = true;
   if (h->wide) {
     // layer-wise path: per-epoch shuffle → statistics (→ all-reduce) → optimiser steps, gathering through the permutation
+    if (launch_rollout(h)) return 1;
+    if (crl_compute_gae(h)) return 1;
     if (h->cfg.shuffle_mode == CRL_SHUFFLE_FISHER_YATES && launch_iota(h)) return 1;  // ppo.jl:191
     for (int ep = 0; ep < E; ++ep) {
       if (launch_shuffle(h, ep0 + (uint64_t)ep, /*with_adv_sums=*/true)) return 1;
@@ -580,18 +619,26 @@ static int iterate_once(crl_ppo* h, bool exact) {
     }
     return 0;
   }
-  // fused path: all update_epochs permutations are drawn up front (they depend on nothing the optimiser changes), one
-  // permute pass lays every epoch's minibatches out contiguously and leaves all E·nmb advantage sums, which cross the
-  // ranks in ONE all-reduce per iteration; after that an optimiser step is update → reduce → (all-reduce) → Adam.
-  if (launch_pack_records(h)) return 1;
-  for (int ep = 0; ep < E; ++ep) {
-    select_slot(h, ep);
-    if (h->cfg.shuffle_mode == CRL_SHUFFLE_FISHER_YATES) {   // b_inds = shuffle(b_inds): each epoch shuffles the previous order
-      if (ep == 0) { if (launch_iota(h)) return 1; }         // ppo.jl:191
-      else CRL_HIP_CHECK(hipMemcpyAsync(h->perm, h->perm - h->dc.B, (size_t)h->dc.B * 4, hipMemcpyDeviceToDevice, h->stream));
-    }
-    if (launch_shuffle(h, ep0 + (uint64_t)ep)) return 1;
+  // fused path. All update_epochs permutations are drawn up front — they depend on nothing the rollout or the optimiser
+  // produces — on the second stream, next to the rollout kernel. One permute pass then lays every epoch's minibatches out
+  // contiguously and leaves all E·nmb advantage sums, which cross the ranks in ONE all-reduce per iteration; after that an
+  // optimiser step is update → reduce → (all-reduce) → Adam.
+  static const bool overlap = env_on("CRL_SHUFFLE_OVERLAP", true);
+  if (overlap) {
+    CRL_HIP_CHECK(hipEventRecord(h->ev_fork, h->stream));          // the previous iteration's permute pass has read the slots
+    CRL_HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+    std::swap(h->stream, h->stream2);
+    const int rc = draw_epoch_permutations(h, ep0);
+    std::swap(h->stream, h->stream2);
+    if (rc) return 1;
+    CRL_HIP_CHECK(hipEventRecord(h->ev_join, h->stream2));
   }
+  const bool fuse = rollout_can_fuse_gae(h);
+  if (launch_rollout(h, fuse)) return 1;
+  if (!fuse && crl_compute_gae(h)) return 1;
+  if (launch_pack_records(h)) return 1;
+  if (overlap) CRL_HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+  else if (draw_epoch_permutations(h, ep0)) return 1;
   if (launch_permute_records(h, 0, E)) return 1;
   {
     ProfScope ps(h, CRL_K_ADV_STATS);

@@ -137,7 +137,47 @@ struct RolloutArgs {
   crl_episode_record* ring; uint32_t* ring_count; int ring_cap;   // per-episode records (ring_cap = 0: off)
   uint64_t iteration;
   int stagger;  // s_sleep units (64 clocks) by which waves 4-7 of an 8-wave block start late
+  // GAE fused into the tail of the rollout (crl_ppo_iterate, compat mode): the wave that stepped 32 envs for num_steps steps
+  // scans their value / reward / terminal columns — which it has just written and which still sit in L2 — backwards and
+  // writes advantages and returns (ppo.jl:48-73,173-181): no separate launch, no HBM read of the scan's inputs.
+  float* adv; float* ret; int fuse_gae; float gamma, gl;
 };
+
+// gae(values, rewards, terminals, γ, λ) for ONE env (this lane), compat mode (ppo.jl:66: the loop starts at k-1, the last slot
+// is defined as 0 — Q1): the reference's serial Float64 recurrence, step by step ⇒ bit-identical to orc_gae.
+__device__ __forceinline__ void gae_tail_compat(const RolloutArgs& a, int e) {
+#pragma clang fp contract(off)
+  const int nt = a.c.nt, k = a.c.k;
+  size_t idx = (size_t)e + (size_t)nt * (k - 1);
+  float vnext = a.value[idx];
+  uint32_t tnext = a.terminal[idx];
+  a.adv[idx] = 0.0f; a.ret[idx] = 0.0f + vnext;
+  double A = 0.0;
+  // eight steps' inputs are loaded together (the loads cannot be hoisted above the stores by the compiler: it must assume
+  // adv / ret alias the inputs), then the serial recurrence runs on registers: one L2 round trip per eight steps
+  constexpr int CH = 8;
+  for (int t0 = k - 2; t0 >= 0; t0 -= CH) {
+    float v[CH], r[CH]; uint32_t tm[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const bool ok = t0 - i >= 0;
+      const size_t ix = ok ? (size_t)e + (size_t)nt * (t0 - i) : (size_t)e;
+      v[i] = a.value[ix]; r[i] = a.reward[ix]; tm[i] = a.terminal[ix];
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      if (t0 - i < 0) break;
+      const size_t ix = (size_t)e + (size_t)nt * (t0 - i);
+      const double nonterm = 1.0 - (double)(tnext ? 1 : 0);
+      const double delta = (double)r[i] + ((double)a.gamma * nonterm) * (double)vnext - (double)v[i];
+      const double cc = (double)a.gl * nonterm;
+      A = delta + (cc * A);
+      const float a32 = (float)A;
+      a.adv[ix] = a32; a.ret[ix] = a32 + v[i];
+      vnext = v[i]; tnext = tm[i];
+    }
+  }
+}
 
 template <int A, bool X3>
 __global__ void __launch_bounds__(512, 2) rollout_cartpole_kernel(RolloutArgs a) {
@@ -235,6 +275,11 @@ __global__ void __launch_bounds__(512, 2) rollout_cartpole_kernel(RolloutArgs a)
     reinterpret_cast<float4*>(a.env_state)[e] = make_float4(s[0], s[1], s[2], s[3]);
     reinterpret_cast<float4*>(a.cur_obs)[e] = make_float4(co[0], co[1], co[2], co[3]);
     a.env_t[e] = t_env; a.next_done[e] = nd; a.ep_return[e] = ep_ret; a.ep_length[e] = ep_len;
+  }
+  if (a.fuse_gae) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's own stores are what the scan reads back
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (writer) gae_tail_compat(a, e);
   }
   // episode statistics of this rollout ("Episode Statistics" record, aggregated): one atomic set per wave
   st_n = wave_sum(st_n); st_ret = wave_sum(st_ret); st_len = wave_sum(st_len);
@@ -338,6 +383,8 @@ __global__ void __launch_bounds__(128) rollout_split_kernel(RolloutArgs a) {
       reinterpret_cast<float4*>(a.env_state)[e] = make_float4(s[0], s[1], s[2], s[3]);
       reinterpret_cast<float4*>(a.cur_obs)[e] = make_float4(co[0], co[1], co[2], co[3]);
       a.env_t[e] = t_env; a.next_done[e] = nd; a.ep_return[e] = ep_ret; a.ep_length[e] = ep_len;
+      // value[] was written by wave 1 of this block; the step loop's closing __syncthreads() made it visible here
+      if (a.fuse_gae) gae_tail_compat(a, e);
     }
     st_n = wave_sum(st_n); st_ret = wave_sum(st_ret); st_len = wave_sum(st_len);
 #pragma unroll
@@ -408,7 +455,7 @@ int launch_env_reset(crl_ppo* h) {
   return 0;
 }
 
-int launch_rollout(crl_ppo* h) {
+int launch_rollout(crl_ppo* h, bool fuse_gae) {
   if (h->cfg.env_kind == CRL_ENV_EXTERNAL) { set_error("crl_rollout_run: envs are stepped by the caller (CRL_ENV_EXTERNAL)"); return 1; }
   if (h->wide) return wide_rollout(h);
   if (check_shape(h)) return 1;
@@ -419,6 +466,7 @@ int launch_rollout(crl_ppo* h) {
   a.env_state = h->env_state; a.env_t = h->env_t; a.cur_obs = h->cur_obs; a.next_done = h->next_done;
   a.ep_return = h->ep_return; a.ep_length = h->ep_length; a.ep_stats = h->ep_stats; a.iteration = (uint64_t)h->iteration;
   a.ring = h->ep_ring; a.ring_count = h->ep_ring_count; a.ring_cap = h->ep_ring_cap;
+  a.adv = h->adv; a.ret = h->ret; a.fuse_gae = fuse_gae ? 1 : 0; a.gamma = h->cfg.gamma; a.gl = h->cfg.gamma * h->cfg.gae_lambda;
   if (h->ep_ring_cap > 0) CRL_HIP_CHECK(hipMemsetAsync(h->ep_ring_count, 0, sizeof(uint32_t), h->stream));
   // one wave per 32 envs; spread waves over all 256 CUs before stacking them inside a block
   const int tiles = (h->dc.nt + TILE - 1) / TILE;

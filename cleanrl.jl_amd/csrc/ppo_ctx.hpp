@@ -54,6 +54,10 @@ struct crl_ppo {
   crl::DevCfg dc;
   int device = 0;
   hipStream_t stream = nullptr;
+  // second stream: crl_ppo_iterate draws the epoch permutations (which depend on nothing the rollout produces) next to the
+  // rollout kernel, whose 128 dependent steps leave most issue slots and all of the memory system idle
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int64_t P = 0, Pa = 0, Pc = 0;  // total / actor / critic parameter counts
   int64_t iteration = 0;
   int64_t exact_reruns = 0;        // iterations whose update phase was re-run exactly under data parallelism (Q4)
@@ -165,9 +169,11 @@ int launch_policy_act(crl_ppo* h, const float* obs_d, const double* u_d, int n, 
                       float* value_d);
 int launch_logprob_actions(crl_ppo* h, const float* obs_d, const int32_t* act_d, int n, float* logprob_d, float* ent_d);
 int launch_env_reset(crl_ppo* h);
-int launch_rollout(crl_ppo* h);
+int launch_rollout(crl_ppo* h, bool fuse_gae = false);
+bool rollout_can_fuse_gae(const crl_ppo* h);
 int launch_next_value(crl_ppo* h);
 int launch_shuffle(crl_ppo* h, uint64_t epoch_id, bool with_adv_sums = false);
+int launch_shuffle_epochs(crl_ppo* h, uint64_t epoch0, int nslots);
 int launch_adv_stats_sums(crl_ppo* h);
 int launch_adv_stats_finish(crl_ppo* h, bool all_slots = false);
 int launch_pack_records(crl_ppo* h);

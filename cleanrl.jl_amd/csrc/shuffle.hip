@@ -57,9 +57,17 @@ __device__ __forceinline__ void bfy_digits(uint32_t i, uint32_t K1, uint64_t see
 }
 
 // pass A (SCATTER=false): tot[d1] += count ; pass C (SCATTER=true): S[cur[d1]++] = i with LDS-aggregated reservations
+// All kernels of the blocked shuffle take the epoch from blockIdx.y: crl_ppo_iterate draws the permutations of all
+// update_epochs in ONE launch per pass (epoch e works in workspace slice e, perm slot e) — 4x fewer, 4x larger launches.
+constexpr int BFY_WS_STRIDE = 4 * 16384 + 8;   // u32 words of workspace per epoch: tot | off | cur | err
+
 template <bool SCATTER, int BFY_T1>
-__global__ void __launch_bounds__(BFY_T1) bfy_l1_kernel(int n, uint32_t K1, uint64_t seed, uint64_t epoch, uint32_t* __restrict__ tot,
-                                                     uint32_t* __restrict__ cur, int32_t* __restrict__ S) {
+__global__ void __launch_bounds__(BFY_T1) bfy_l1_kernel(int n, uint32_t K1, uint64_t seed, uint64_t epoch0, uint32_t* __restrict__ ws,
+                                                     int32_t* __restrict__ S0) {
+  const uint64_t epoch = epoch0 + blockIdx.y;
+  uint32_t* tot = ws + (size_t)blockIdx.y * BFY_WS_STRIDE;
+  uint32_t* cur = tot + 2 * BFY_MAXK1 + 1;
+  int32_t* S = S0 + (size_t)blockIdx.y * n;
   extern __shared__ uint32_t lds[];   // hist[K1] (+ base[K1] when scattering)
   uint32_t* hist = lds;
   uint32_t* base = lds + K1;
@@ -89,8 +97,9 @@ __global__ void __launch_bounds__(BFY_T1) bfy_l1_kernel(int n, uint32_t K1, uint
 }
 
 // exclusive scan of the K1 bucket totals (one block); cur = off; flags buckets that do not fit the LDS leaf kernel
-__global__ void __launch_bounds__(1024) bfy_scan_kernel(uint32_t K1, const uint32_t* __restrict__ tot, uint32_t* __restrict__ off,
-                                                        uint32_t* __restrict__ cur, uint32_t* __restrict__ err) {
+__global__ void __launch_bounds__(1024) bfy_scan_kernel(uint32_t K1, uint32_t* __restrict__ ws) {
+  uint32_t* tot = ws + (size_t)blockIdx.x * BFY_WS_STRIDE;
+  uint32_t* off = tot + BFY_MAXK1; uint32_t* cur = off + BFY_MAXK1 + 1; uint32_t* err = cur + BFY_MAXK1;
   __shared__ uint32_t part[1024];
   const int t = threadIdx.x;
   const int per = (K1 + 1023) / 1024;
@@ -110,10 +119,14 @@ __global__ void __launch_bounds__(1024) bfy_scan_kernel(uint32_t K1, const uint3
 // With adv != nullptr the block also leaves Σadv, Σadv² of its slice per minibatch in part[mb][bucket][2] (Float64, fixed
 // order): the advantage statistics of ppo.jl:221 then need no separate gather pass over the permutation. Requires
 // M >= BFY_CAP so that a bucket touches at most two minibatches.
-__global__ void __launch_bounds__(256, 4) bfy_leaf_kernel(uint32_t K1, uint64_t seed, uint64_t epoch, const uint32_t* __restrict__ off,
-                                                          const int32_t* __restrict__ S, int32_t* __restrict__ perm,
-                                                          const uint32_t* __restrict__ err, const float* __restrict__ adv, int M,
-                                                          int nmb, double* __restrict__ part) {
+__global__ void __launch_bounds__(256, 4) bfy_leaf_kernel(uint32_t K1, uint64_t seed, uint64_t epoch0, int n, const uint32_t* __restrict__ ws,
+                                                          const int32_t* __restrict__ S0, int32_t* __restrict__ perm0,
+                                                          const float* __restrict__ adv, int M, int nmb, double* __restrict__ part) {
+  const uint64_t epoch = epoch0 + blockIdx.y;
+  const uint32_t* off = ws + (size_t)blockIdx.y * BFY_WS_STRIDE + BFY_MAXK1;
+  const uint32_t* err = off + 2 * BFY_MAXK1 + 1;
+  const int32_t* S = S0 + (size_t)blockIdx.y * n;
+  int32_t* perm = perm0 + (size_t)blockIdx.y * n;
   if (*err) return;
   __shared__ int32_t buf[BFY_CAP], buf2[BFY_CAP];
   __shared__ uint8_t dig[BFY_CAP];
@@ -206,28 +219,41 @@ __global__ void __launch_bounds__(256, 4) bfy_leaf_kernel(uint32_t K1, uint64_t 
   }
 }
 
-// fused = also leave the per-minibatch advantage sums in h->bfy_adv_part (crl_ppo_iterate only: there the advantages are
-// final before the shuffle runs)
-static int launch_blocked_fy(crl_ppo* h, uint64_t epoch_id, bool fused) {
+// Permutations of epochs [epoch_id, epoch_id + nslots) into perm slots [cur_slot, cur_slot + nslots), one launch per pass.
+// fused (single slot only) = also leave the per-minibatch advantage sums in h->bfy_adv_part (layer-wise path: there the
+// advantages are final before the shuffle runs)
+static int launch_blocked_fy(crl_ppo* h, uint64_t epoch_id, int nslots, bool fused) {
   const int n = h->dc.B;
   uint32_t K1 = 1;
   while ((uint64_t)K1 * (uint64_t)BFY_L1 < (uint64_t)n) K1 *= 2;
   if (K1 > (uint32_t)BFY_MAXK1) { set_error("blocked Fisher-Yates supports batches up to 2^26 samples"); return 1; }
-  uint32_t* tot = h->bfy_ws; uint32_t* off = tot + BFY_MAXK1; uint32_t* cur = off + BFY_MAXK1 + 1; uint32_t* err = cur + BFY_MAXK1;
-  CRL_HIP_CHECK(hipMemsetAsync(tot, 0, sizeof(uint32_t) * BFY_MAXK1, h->stream));
+  if (h->cur_slot + nslots > h->cfg.update_epochs) { set_error("internal: permutation slots out of range"); return 1; }
+  uint32_t* ws = h->bfy_ws + (size_t)h->cur_slot * BFY_WS_STRIDE;
+  int32_t* S = h->perm_tmp + (size_t)h->cur_slot * n;
+  for (int z = 0; z < nslots; ++z)
+    CRL_HIP_CHECK(hipMemsetAsync(ws + (size_t)z * BFY_WS_STRIDE, 0, sizeof(uint32_t) * BFY_MAXK1, h->stream));
+  const uint64_t seed = shuffle_seed(h);
   const bool big = n >= (4 << 20);
   const int t1 = big ? 1024 : 256, chunks = (n + t1 * 32 - 1) / (t1 * 32);
-  if (big) hipLaunchKernelGGL((bfy_l1_kernel<false, 1024>), dim3(chunks), dim3(1024), sizeof(uint32_t) * K1, h->stream, n, K1, shuffle_seed(h), epoch_id, tot, cur, h->perm_tmp);
-  else hipLaunchKernelGGL((bfy_l1_kernel<false, 256>), dim3(chunks), dim3(256), sizeof(uint32_t) * K1, h->stream, n, K1, shuffle_seed(h), epoch_id, tot, cur, h->perm_tmp);
-  hipLaunchKernelGGL(bfy_scan_kernel, dim3(1), dim3(1024), 0, h->stream, K1, tot, off, cur, err);
-  if (big) hipLaunchKernelGGL((bfy_l1_kernel<true, 1024>), dim3(chunks), dim3(1024), sizeof(uint32_t) * 2 * K1, h->stream, n, K1, shuffle_seed(h), epoch_id, tot, cur, h->perm_tmp);
-  else hipLaunchKernelGGL((bfy_l1_kernel<true, 256>), dim3(chunks), dim3(256), sizeof(uint32_t) * 2 * K1, h->stream, n, K1, shuffle_seed(h), epoch_id, tot, cur, h->perm_tmp);
-  const bool fuse = fused && h->bfy_adv_part && h->dc.M >= BFY_CAP && h->dc.nmb <= 256;
-  hipLaunchKernelGGL(bfy_leaf_kernel, dim3(K1), dim3(256), 0, h->stream, K1, shuffle_seed(h), epoch_id, off, h->perm_tmp, h->perm, err,
-                     fuse ? h->adv : nullptr, h->dc.M, h->dc.nmb, h->bfy_adv_part);
+  const dim3 g1(chunks, nslots);
+  if (big) hipLaunchKernelGGL((bfy_l1_kernel<false, 1024>), g1, dim3(1024), sizeof(uint32_t) * K1, h->stream, n, K1, seed, epoch_id, ws, S);
+  else hipLaunchKernelGGL((bfy_l1_kernel<false, 256>), g1, dim3(256), sizeof(uint32_t) * K1, h->stream, n, K1, seed, epoch_id, ws, S);
+  hipLaunchKernelGGL(bfy_scan_kernel, dim3(nslots), dim3(1024), 0, h->stream, K1, ws);
+  if (big) hipLaunchKernelGGL((bfy_l1_kernel<true, 1024>), g1, dim3(1024), sizeof(uint32_t) * 2 * K1, h->stream, n, K1, seed, epoch_id, ws, S);
+  else hipLaunchKernelGGL((bfy_l1_kernel<true, 256>), g1, dim3(256), sizeof(uint32_t) * 2 * K1, h->stream, n, K1, seed, epoch_id, ws, S);
+  const bool fuse = fused && nslots == 1 && h->bfy_adv_part && h->dc.M >= BFY_CAP && h->dc.nmb <= 256;
+  hipLaunchKernelGGL(bfy_leaf_kernel, dim3(K1, nslots), dim3(256), 0, h->stream, K1, seed, epoch_id, n, ws, S, h->perm, fuse ? h->adv : nullptr,
+                     h->dc.M, h->dc.nmb, h->bfy_adv_part);
   CRL_HIP_CHECK(hipGetLastError());
   h->bfy_adv_parts = fuse ? (int)K1 : 0;
   return 0;
+}
+
+// update_epochs consecutive epochs at once into slots 0 … (crl_ppo_iterate; blocked Fisher–Yates only)
+int launch_shuffle_epochs(crl_ppo* h, uint64_t epoch0, int nslots) {
+  ProfScope ps(h, CRL_K_SHUFFLE);
+  h->bfy_adv_parts = 0; h->perm_is_bijection = false;
+  return launch_blocked_fy(h, epoch0, nslots, false);
 }
 
 int launch_shuffle(crl_ppo* h, uint64_t epoch_id, bool with_adv_sums) {
@@ -236,7 +262,7 @@ int launch_shuffle(crl_ppo* h, uint64_t epoch_id, bool with_adv_sums) {
   h->bfy_adv_parts = 0;
   if (h->cfg.shuffle_mode == CRL_SHUFFLE_BLOCKED_FY) {
     h->perm_is_bijection = false;
-    return launch_blocked_fy(h, epoch_id, with_adv_sums);
+    return launch_blocked_fy(h, epoch_id, 1, with_adv_sums);
   }
   if (h->cfg.shuffle_mode == CRL_SHUFFLE_FISHER_YATES) {
     h->perm_is_bijection = false;
