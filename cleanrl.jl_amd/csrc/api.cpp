@@ -639,11 +639,13 @@ static int iterate_once(crl_ppo* h, bool exact) {
   if (launch_pack_records(h)) return 1;
   if (overlap) CRL_HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
   else if (draw_epoch_permutations(h, ep0)) return 1;
+  // (Measured and dropped: running the permute pass of epochs 1.. on the second stream under epoch 0's update kernels — the
+  //  random 64-byte gathers lengthen the update kernels' own record loads by 25 %, which costs what the overlap saves.)
   if (launch_permute_records(h, 0, E)) return 1;
   {
     ProfScope ps(h, CRL_K_ADV_STATS);
     if (comm_allreduce(h, h->adv_sums_base, (size_t)E * nmb * 2, true)) return 1;
-    if (launch_adv_stats_finish(h, /*all_slots=*/true)) return 1;
+    if (launch_adv_stats_finish(h, 0, E)) return 1;
   }
   for (int ep = 0; ep < E; ++ep) {
     select_slot(h, ep);

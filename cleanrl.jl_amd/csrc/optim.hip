@@ -115,11 +115,12 @@ int launch_adv_stats_sums(crl_ppo* h) {
   CRL_HIP_CHECK(hipGetLastError());
   return 0;
 }
-// mean/std of the current slot's minibatches; all_slots: of every epoch's slot at once (crl_ppo_iterate)
-int launch_adv_stats_finish(crl_ppo* h, bool all_slots) {
-  const int n = all_slots ? h->cfg.update_epochs * h->dc.nmb : h->dc.nmb;
-  hipLaunchKernelGGL(adv_finish_kernel, dim3(1), dim3(256), 0, h->stream, all_slots ? h->adv_sums_base : h->adv_sums, n,
-                     (double)h->dc.M * h->world, all_slots ? h->adv_ms_base : h->adv_ms);
+// mean/std of the minibatches of slots [slot0, slot0 + nslots); slot0 < 0: of the current slot
+int launch_adv_stats_finish(crl_ppo* h, int slot0, int nslots) {
+  if (slot0 < 0) { slot0 = h->cur_slot; nslots = 1; }
+  const size_t o = (size_t)slot0 * h->dc.nmb * 2;
+  hipLaunchKernelGGL(adv_finish_kernel, dim3(1), dim3(256), 0, h->stream, h->adv_sums_base + o, nslots * h->dc.nmb,
+                     (double)h->dc.M * h->world, h->adv_ms_base + o);
   CRL_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -175,7 +175,7 @@ int launch_next_value(crl_ppo* h);
 int launch_shuffle(crl_ppo* h, uint64_t epoch_id, bool with_adv_sums = false);
 int launch_shuffle_epochs(crl_ppo* h, uint64_t epoch0, int nslots);
 int launch_adv_stats_sums(crl_ppo* h);
-int launch_adv_stats_finish(crl_ppo* h, bool all_slots = false);
+int launch_adv_stats_finish(crl_ppo* h, int slot0 = -1, int nslots = 1);
 int launch_pack_records(crl_ppo* h);
 int launch_permute_records(crl_ppo* h, int slot0, int nslots);
 int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot);

@@ -88,10 +88,11 @@ int launch_permute_records(crl_ppo* h, int slot0, int nslots) {
   const int B = h->dc.B, M = h->dc.M, nmb = h->dc.nmb, pb = h->adv_pb;
   const int chunk = (((M + pb - 1) / pb + 63) / 64) * 64;
   ProfScope ps(h, CRL_K_PERMUTE);
+  double* part = h->adv_part + (size_t)slot0 * nmb * pb * 2;   // each slot has its own slice: launches for different slots may overlap
   hipLaunchKernelGGL(permute_records_kernel, dim3(pb, nmb, nslots), dim3(256), 0, h->stream, B, M, chunk, h->perm_base + (size_t)slot0 * B, h->recs,
-                     h->recs_p + (size_t)slot0 * B, h->adv_part);
+                     h->recs_p + (size_t)slot0 * B, part);
   CRL_HIP_CHECK(hipGetLastError());
-  if (launch_adv_fold(h, h->adv_part, pb, nslots * nmb, h->adv_sums_base + (size_t)slot0 * nmb * 2)) return 1;
+  if (launch_adv_fold(h, part, pb, nslots * nmb, h->adv_sums_base + (size_t)slot0 * nmb * 2)) return 1;
   for (int s = slot0; s < slot0 + nslots; ++s) h->slot_fresh |= 1u << s;
   return 0;
 }
