@@ -31,6 +31,14 @@ constexpr int TSTRIDE = 36;
 // loads of the next phase were the source of the spills)
 #define CRL_PHASE() do { wave_lds_fence(); __builtin_amdgcn_sched_barrier(0); } while (0)  // floats per row of the transposed tile: 144 B keeps b128 reads aligned and conflict-free
 
+// a wave-uniform value into scalar registers
+__device__ __forceinline__ float sgpr(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ double sgpr(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // Per-sample inputs of one tile: two 16-byte quarters of the sample's record (36 B of it are the fields of SURVEY §8d)
 template <int D>
 struct Gathered {
@@ -52,6 +60,12 @@ __device__ __forceinline__ void gather(const UpdateArgs& a, int pos, Gathered<D>
 // One role (actor or critic) = RW waves of the block: `smem` is the role's weight image, `scratch` the first of its
 // RW wave-private tiles. All barriers are block-wide and both roles execute the same number of them.
 constexpr int SCR_FLOATS = 64 * TSTRIDE + TILE * 4 + 2 * TILE;
+// bf16x3 kernels: the "skinny" gradient sums (dW1, db1, db2, dW3, db3: 10 floats per lane for the actor) accumulate in a
+// wave-private LDS strip (read at the start of the phase that produces a partial sum, written back at its end) instead of in
+// registers that stay live across the whole loop — those ten registers were what the 256-register budget was short of: the
+// kernel now has no scratch at all (18 spilled registers before)
+constexpr int ACC_SLOTS = 4 + 2 + 2 * 2;
+constexpr int SCR_FLOATS_X3 = SCR_FLOATS + ACC_SLOTS * 64;
 
 // ABL (CRL_ABLATE builds, scripts/run_ablate.sh): timing experiments that remove one phase each (results are garbage) — the
 // way the per-phase costs in DESIGN.md §3 were measured. 0 in every production instantiation.
@@ -60,15 +74,14 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
   constexpr int NOUT = ROLE == 0 ? A : 1;
   using I = typename std::conditional<X3, NetImageX3<D, NOUT, true>, NetImage<D, NOUT, true>>::type;
   using P = NetParams<D, NOUT>;
-  constexpr int SCR = SCR_FLOATS;
+  constexpr int SCR = X3 ? SCR_FLOATS_X3 : SCR_FLOATS;
   static_assert(64 * TSTRIDE + TILE * D + A * TILE <= SCR_FLOATS, "scratch too small");
+  static_assert(D + 2 + 2 * NOUT <= ACC_SLOTS, "accumulator strip too small");
   const DevCfg& c = a.c;
   const int tid = threadIdx.x & (64 * RW - 1), lane = tid & 63, wave = tid >> 6, j = lane & 31, hf = lane >> 5;
   constexpr int NT = 64 * RW;  // threads of this role
   float* img0 = smem;
-  float* T = scratch + wave * SCR;
-  float* xs = T + 64 * TSTRIDE;
-  float* d3s = xs + TILE * D;
+  float* T0 = scratch + wave * SCR;
   const float* p = a.params + (ROLE ? NetParams<D, A>::SIZE : 0);
   if (X3) stage_net_x3<D, NOUT, true>(img0, p, tid, NT);
   else stage_net<D, NOUT, true>(img0, p, tid, NT);
@@ -81,38 +94,46 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
     for (int y = 0; y < 2; ++y)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dW2t[x][y][r] = 0.0f;
-  float dW1acc[D], dW3acc[NOUT], db3acc[NOUT], db1acc = 0.0f, db2acc = 0.0f;
+  // skinny sums: slot k of this lane — dW1[0..D), db1, db2, dW3[0..NOUT), db3[0..NOUT)
+  constexpr int K_B1 = D, K_B2 = D + 1, K_W3 = D + 2, K_B3 = D + 2 + NOUT, NACC = D + 2 + 2 * NOUT;
+  float racc[NACC];
 #pragma unroll
-  for (int i = 0; i < D; ++i) dW1acc[i] = 0.0f;
+  for (int i = 0; i < NACC; ++i) racc[i] = 0.0f;
+  float* ACC = scratch + wave * SCR + SCR_FLOATS + (threadIdx.x & 63);
+  if constexpr (X3) {
 #pragma unroll
-  for (int i = 0; i < NOUT; ++i) { dW3acc[i] = 0.0f; db3acc[i] = 0.0f; }
+    for (int i = 0; i < NACC; ++i) ACC[64 * i] = 0.0f;
+  }
+  constexpr bool LACC = X3;
+  // read at the start of the phase that produces the partial sum, written back at its end (plain LDS read / write: the strip
+  // is private to the lane; ds_add_f32 atomics here cost +24 % on the whole kernel)
+  auto acc_begin = [&](int k) -> float { if constexpr (LACC) return ACC[64 * k]; else return racc[k]; };
+  auto acc_end = [&](int k, float v) { if constexpr (LACC) ACC[64 * k] = v; else racc[k] = v; };
   double ls0 = 0.0, ls1 = 0.0;
 
   const int M = c.M;
-  const double invM = 1.0 / a.Mglobal;
   const int ntiles = (M + TILE - 1) / TILE;
   const int nwaves = a.nblk[ROLE] * RW;
-  // role constants
+  // role constants: wave-uniform, pinned to scalar registers (the values loaded from adv_ms / vfix otherwise sit in vector
+  // registers for the whole loop — eight of the registers that used to be spilled)
+  const double invM = sgpr(1.0 / a.Mglobal);
   float mean_f = 0.0f; double inv_denom = 1.0;
-  if (ROLE == 0) { mean_f = (float)a.adv_ms[2 * a.mb]; inv_denom = 1.0 / ((double)(float)a.adv_ms[2 * a.mb + 1] + 1e-8); }
+  if (ROLE == 0) { mean_f = sgpr((float)a.adv_ms[2 * a.mb]); inv_denom = sgpr(1.0 / ((double)(float)a.adv_ms[2 * a.mb + 1] + 1e-8)); }
   const float eps = c.clip, lo = 1.0f - c.clip, hi = 1.0f + c.clip;
-  const float u_exact = EXACT ? (float)a.vfix[0] : 0.0f;
-  const double nwin = EXACT ? a.vfix[1] : 0.0;
-  const double entk = (double)c.ent_coeff / ((double)A * a.Mglobal);
-  const double vk = (double)c.v_coef * 0.5 * invM;
+  const float u_exact = EXACT ? sgpr((float)a.vfix[0]) : 0.0f;
+  const double nwin = EXACT ? sgpr(a.vfix[1]) : 0.0;
+  const double entk = sgpr((double)c.ent_coeff / ((double)A * a.Mglobal));
+  const double vk = sgpr((double)c.v_coef * 0.5 * invM);
 
-  // the next tile's records are loaded one tile ahead
+  // A tile's records are loaded at the top of the tile: the minibatch is a contiguous slab (records.hip), so the loads are
+  // L2 / HBM streaming reads whose latency the partner wave covers. (Loading one tile ahead kept seven more registers live
+  // through the backward pass — spills — for no measurable gain once the gather through the permutation was gone.)
   int tile = rb * RW + wave;
-  Gathered<D> cur, nxt;
-  constexpr bool PREFETCH = !(ABL & 1);
-  if (PREFETCH && tile < ntiles) {
-    const int pos = tile * TILE + j;
-    gather<D, ROLE>(a, pos < M ? pos : 0, cur);
-  }
+  Gathered<D> cur;
   for (; tile < ntiles; tile += nwaves) {
     const int pos = tile * TILE + j;
     const bool ok = pos < M;
-    if constexpr (!PREFETCH) gather<D, ROLE>(a, ok ? pos : 0, cur);
+    gather<D, ROLE>(a, ok ? pos : 0, cur);
     float x[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) x[i] = cur.x[i];
@@ -122,6 +143,11 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
     int lds_off = 0;
     asm volatile("" : "+v"(lds_off));
     const float* img = img0 + lds_off;
+    // the same opaque offset on the wave's scratch tile: its per-lane row / column addresses are rebuilt every tile (a few VALU
+    // instructions) instead of living in registers across the whole loop, where they were the values that got spilled
+    float* T = T0 + lds_off;
+    float* xs = T + 64 * TSTRIDE;
+    float* d3s = xs + TILE * D;
     if constexpr (X3) mlp_forward_x3<D, NOUT, true, ABL>(img, x, h1, h2, out, lane);
     else mlp_forward<D, NOUT, true>(img, x, h1, h2, out, lane);
 
@@ -181,11 +207,6 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
       for (int i = 0; i < NOUT; ++i) dout[i] = 0.0f;
     }
 
-    // next tile's samples: issued here (after the register-hungry loss section), in flight during the backward pass
-    if constexpr (PREFETCH) {
-      const int pn = (tile + nwaves) * TILE + j;
-      gather<D, ROLE>(a, pn < M ? pn : 0, nxt);
-    }
     // ---- backward ------------------------------------------------------------------------------------
     // (1) h2ᵀ, the output cotangents and x into the wave-private scratch
 #pragma unroll
@@ -205,9 +226,9 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
     // keep the batch at 12 registers-quads so nothing spills. db3 is a per-lane sum, folded over lanes once per kernel.
     {
       const f32x4* tr = reinterpret_cast<const f32x4*>(T + lane * TSTRIDE);
-      float accw[NOUT];
+      float accw[NOUT], ow3[NOUT], ob3[NOUT];
 #pragma unroll
-      for (int i = 0; i < NOUT; ++i) { accw[i] = 0.0f; db3acc[i] += hf == 0 ? dout[i] : 0.0f; }
+      for (int i = 0; i < NOUT; ++i) { accw[i] = 0.0f; ow3[i] = acc_begin(K_W3 + i); ob3[i] = acc_begin(K_B3 + i); }
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         f32x4 rq[4], dv[NOUT][4];
@@ -227,7 +248,7 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int i = 0; i < NOUT; ++i) dW3acc[i] += accw[i];
+      for (int i = 0; i < NOUT; ++i) { acc_end(K_W3 + i, ow3[i] + accw[i]); acc_end(K_B3 + i, ob3[i] + (hf == 0 ? dout[i] : 0.0f)); }
     }
     // (3) δ2 = (W3ᵀ·δ3) ⊙ (1 − h2²) in C-fragment registers (h2 dies here)
     f32x16 d2[2];
@@ -297,7 +318,7 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
     CRL_PHASE();
     {
       const f32x4* tr = reinterpret_cast<const f32x4*>(T + lane * TSTRIDE);
-      float sb = 0.0f;
+      float sb = acc_begin(K_B1), w1[4] = {acc_begin(0), acc_begin(1), acc_begin(2), acc_begin(3)};
       f32x4 t4[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) t4[q] = tr[q];
@@ -312,14 +333,16 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
           const float dv = t4[2 * q2 + (e >> 2)][e & 3];
           sb += dv;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) dW1acc[i] = __builtin_fmaf(dv, xv[e][i], dW1acc[i]);
+          for (int i = 0; i < 4; ++i) w1[i] = __builtin_fmaf(dv, xv[e][i], w1[i]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      db1acc += sb;
+      acc_end(K_B1, sb);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc_end(i, w1[i]);
     }
     CRL_PHASE();
-    } else { db1acc += d1[0][0] + d1[1][5]; }
+    } else { acc_end(K_B1, acc_begin(K_B1) + d1[0][0] + d1[1][5]); }
     if constexpr (!(ABL & 2)) {
     // (5) δ2ᵀ → scratch; db2; B-fragments (δ2 rows on lanes, samples along k: smp(s,hf) = s + 16hf) (δ2 dies here)
 #pragma unroll
@@ -331,10 +354,10 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
     f32x4 braw[2][2][2];  // x3: raw δ2ᵀ B-fragments [ni][ks][half] (split into bf16 pieces at use: 32 registers, not 48)
     {
       const f32x4* tr = reinterpret_cast<const f32x4*>(T + lane * TSTRIDE);
-      float s = 0.0f;
+      float s = acc_begin(K_B2);
 #pragma unroll
       for (int q = 0; q < 8; ++q) { const f32x4 t4 = tr[q]; s += (t4[0] + t4[1]) + (t4[2] + t4[3]); }
-      db2acc += s;
+      acc_end(K_B2, s);
       if constexpr (X3) {
         // k-step ks covers samples 16ks + 8hf + (0..7): two b128 reads per fragment, split into bf16 pieces
 #pragma unroll
@@ -399,10 +422,14 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
     }
     CRL_PHASE();
     }
-    if constexpr (PREFETCH) cur = nxt;
   }
 
   // ---- block reduction: waves add their accumulators into one LDS image in flat Flux order ------------------
+  if constexpr (LACC) {
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) racc[i] = ACC[64 * i];
+  }
   __syncthreads();
   float* R = smem;  // the weight image is dead now
   for (int i = tid; i < P::SIZE; i += NT) R[i] = 0.0f;
@@ -420,14 +447,14 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
           for (int r = 0; r < 16; ++r)
             R[P::W2 + (32 * ni + j) + H * (32 * mj + rowmap(r, hf))] += dW2t[mj][ni][r];
 #pragma unroll
-      for (int i = 0; i < D; ++i) R[P::W1 + lane + H * i] += dW1acc[i];
-      R[P::B1 + lane] += db1acc;
-      R[P::B2 + lane] += db2acc;
+      for (int i = 0; i < D; ++i) R[P::W1 + lane + H * i] += racc[i];
+      R[P::B1 + lane] += racc[K_B1];
+      R[P::B2 + lane] += racc[K_B2];
 #pragma unroll
-      for (int i = 0; i < NOUT; ++i) R[P::W3 + i + NOUT * lane] += dW3acc[i];
+      for (int i = 0; i < NOUT; ++i) R[P::W3 + i + NOUT * lane] += racc[K_W3 + i];
 #pragma unroll
       for (int i = 0; i < NOUT; ++i) {
-        const float b3 = wave_sum(db3acc[i]);
+        const float b3 = wave_sum(racc[K_B3 + i]);
         if (lane == 0) R[P::B3 + i] += b3;
       }
     }
@@ -617,7 +644,7 @@ static int run_update(crl_ppo* h, int mb, int mode, hipEvent_t ev0 = nullptr, hi
     main_pass_blocks(h, &a.nblk[0], &a.nblk[1]);
     a.stagger = env_int("CRL_X3_STAGGER", 3);
     const int abl = env_int("CRL_DEBUG_ABLATE", 0), rw = env_int("CRL_DEBUG_RW", 8);
-    const size_t smem = sizeof(float) * (NetImageX3<4, 2, true>::SIZE + 8 * SCR_FLOATS);   // 8 tiles' worth either way: one block per CU at RW = 4 too
+    const size_t smem = sizeof(float) * (NetImageX3<4, 2, true>::SIZE + 8 * SCR_FLOATS_X3);   // 8 tiles' worth either way: one block per CU at RW = 4 too
     const dim3 grid(rw == 8 ? a.nblk[0] + a.nblk[1] : 2 * (a.nblk[0] + a.nblk[1]));
     if (rw == 4) { a.nblk[0] *= 2; a.nblk[1] *= 2; a.pmax *= 2; }
 #define CRL_DBG_CASE(M_, RW_) if (abl == M_ && rw == RW_) hipExtLaunchKernelGGL((update_x3_dbg_kernel<4, 2, M_, RW_>), grid, dim3(64 * RW_), smem, h->stream, ev0, ev1, 0, a);
@@ -630,7 +657,7 @@ static int run_update(crl_ppo* h, int mb, int mode, hipEvent_t ev0 = nullptr, hi
     static int stagger = -1;
     if (stagger < 0) stagger = env_int("CRL_X3_STAGGER", 3);
     a.stagger = stagger;
-    const size_t smem = sizeof(float) * (NetImageX3<4, 2, true>::SIZE + 8 * SCR_FLOATS);
+    const size_t smem = sizeof(float) * (NetImageX3<4, 2, true>::SIZE + 8 * SCR_FLOATS_X3);
     hipExtLaunchKernelGGL((update_x3_kernel<4, 2>), dim3(a.nblk[0] + a.nblk[1]), dim3(512), smem, h->stream, ev0, ev1, 0, a);
   } else {
     main_pass_blocks(h, &a.nblk[0], &a.nblk[1]);
