@@ -272,7 +272,11 @@ def main():
         gae_avg_s = gae_ms / max(gae_n, 1) * 1e-3
         upd_tflops = upd_flops * M / upd_avg_s / 1e12 if upd_n else 0.0
         gae_gbps = gae_bytes / gae_avg_s / 1e9 if gae_n else 0.0
-        x3 = os.environ.get("CRL_GEMM", "x3") != "f32"
+        gemm = os.environ.get("CRL_GEMM", "x2")
+        x3 = gemm != "f32"
+        # matrix-pipe products issued per f32 product of the three hidden-layer GEMMs (forward, backward-data, weight gradient):
+        # x2 = fp16x2 (3) for forward / backward-data + bf16x3 (6) for the weight gradient; x3 = bf16x3 everywhere; C3 runs bf16x3
+        issue_factor = 1.0 if not x3 else (6.0 if (gemm == "x3" or c3) else (3 + 3 + 6) / 3.0)
         # share of the algorithmic flops that runs as 64x64 (256x256) products = what goes to the matrix pipe
         hh = 2 * 2 * 64 * 64 if not c3 else 2 * 2 * 256 * 256
         mfma_share = hh / fwd_flops
@@ -302,7 +306,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "global_batch": args.total_envs * NUM_STEPS, "parallelism": f"dp{world}",
                        "shuffle": args.shuffle,
-                       "gemm": ("f32 results via bf16x3 split products on the bf16 matrix pipe" if x3 else "v_mfma_f32_32x32x2_f32")},
+                       "gemm": ("v_mfma_f32_32x32x2_f32" if not x3 else
+                                "f32 results via bf16x3 split products on the bf16 matrix pipe" if issue_factor == 6.0 else
+                                "f32 results via fp16x2 (forward, backward-data) and bf16x3 (weight gradient) split products on the f16/bf16 matrix pipe")},
             "roofline": {"bound": "mfma",
                          "kernel": "update kernel (fwd+bwd of one minibatch, actor+critic)" if not c3 else
                                    "wide.hip: all forward/backward launches of one minibatch (HIP events around the group)",
@@ -311,13 +317,13 @@ def main():
                          "traffic": traffic["update"], "traffic_source": traffic_file if traffic["update"] else None,
                          "algorithmic_bytes_per_launch": UPDATE_BYTES_PER_SAMPLE * M if not c3 else None,
                          "avg_launch_ms": upd_avg_s * 1e3, "launches": upd_n, "flops_per_launch": upd_flops * M,
-                         "pipe": {"name": "bf16 mfma" if x3 else "f32 mfma",
-                                  "issued_tflops": upd_tflops * mfma_share * (6 if x3 else 1),
+                         "pipe": {"name": "f16/bf16 mfma" if x3 else "f32 mfma",
+                                  "issued_tflops": upd_tflops * mfma_share * issue_factor,
                                   "peak": PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS,
-                                  "frac": upd_tflops * mfma_share * (6 if x3 else 1) / (PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS)},
+                                  "frac": upd_tflops * mfma_share * issue_factor / (PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS)},
                          "note": f"achieved = ALGORITHMIC f32 flops (3 x {fwd_flops:,} per sample) / HIP-event launch time, against the dense "
                                  "f32-MFMA peak: an f32-equivalent figure. `pipe` prices what is actually issued: the hidden-layer products "
-                                 f"({mfma_share:.0%} of the flops) run as six bf16 partial products each on the bf16 matrix pipe, so "
+                                 f"({mfma_share:.0%} of the flops) run as {issue_factor:g} f16/bf16 partial products per f32 product on the matrix pipe, so "
                                  "pipe.frac is that pipe's utilisation; the rest (tanh, splits, loss, skinny gradients) is VALU work — see "
                                  f"profiles/{PROFILE_TAG}_*pmc* for the measured issue/wait split"},
             "roofline_gae": {"bound": "hbm", "kernel": "gae_kernel (advantages + returns)", "achieved": gae_gbps,

@@ -16,11 +16,13 @@ int comm_unique_id(uint8_t id[128]);
 int comm_init(crl_ppo* h, const uint8_t id[128], int world, int rank);
 int launch_iota(crl_ppo* h);
 
-bool gemm_x3() {
+static int gemm_mode() {
   static int mode = -1;
-  if (mode < 0) { const char* e = std::getenv("CRL_GEMM"); mode = (e && std::string(e) == "f32") ? 0 : 1; }
-  return mode == 1;
+  if (mode < 0) { const char* e = std::getenv("CRL_GEMM"); const std::string v = e ? e : "x2"; mode = v == "f32" ? 0 : v == "x3" ? 1 : 2; }
+  return mode;
 }
+bool gemm_x3() { return gemm_mode() >= 1; }
+bool gemm_x2() { return gemm_mode() == 2; }
 
 int ensure_stage(crl_ppo* h, size_t bytes) {
   if (h->stage_bytes >= bytes) return 0;
@@ -474,6 +476,16 @@ int32_t crl_compute_gae(crl_ppo* h) {
 }
 
 static int check_bfy(crl_ppo* h) {
+  if (!h->wide && gemm_x2()) {
+    double re = 0.0;
+    CRL_HIP_CHECK(hipMemcpyAsync(&re, h->vfix + 5, sizeof(re), hipMemcpyDeviceToHost, h->stream));
+    CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (re != 0.0) {
+      set_error("a hidden-layer weight reached |w| >= 255: outside the fp16x2 window of the update kernel (mlp_x2.hpp); "
+                "results since the last check are invalid — rerun with CRL_GEMM=x3");
+      return 1;
+    }
+  }
   if (h->cfg.shuffle_mode != CRL_SHUFFLE_BLOCKED_FY) return 0;
   uint32_t err = 0;
   for (int z = 0; z < h->cfg.update_epochs && !err; ++z) {

@@ -1,0 +1,211 @@
+// mlp_x2.hpp — the 64x64 dense layers on the f16 matrix pipe at float32 accuracy ("fp16x2").
+//
+// mlp_x3.hpp splits every f32 operand into three bf16 pieces and spends six MFMAs per product; the ablation runs of the
+// update kernel show its GEMM phases bound by exactly that matrix-pipe time. A half-precision float has 11
+// significant bits, so TWO pieces x = hi + lo carry 22 bits and a product needs three MFMAs (hi·hi, hi·lo, lo·hi; the
+// dropped lo·lo term is 2^-22 relative) — half the matrix-pipe time, and the split costs 2 VALU instructions per element
+// instead of 5.5 (the residual x − hi is one mixed-precision subtract). The price is fp16's 5-bit exponent: a piece pair keeps
+// its 22 bits only while |x| stays in [2^-3, 65504); below that the absolute error floor is 2^-25. So every operand is scaled
+// by an exact power of two into that window, and the scale comes back out of the f32 accumulator:
+//   * activations h = tanh(·) ∈ (−1, 1):  h·2^14, produced directly by the activation (tanh_fast with its numerator
+//     coefficients pre-multiplied by 2^14: bit-for-bit 2^14·tanh_fast(x));
+//   * weights:  W·2^8 — full precision for |w| ≥ 2^-11, absolute error 2^-33 below; |w| ≥ 255 does not fit and makes the
+//     kernel raise an error flag instead of computing (CRL_GEMM=x3 is the fallback flavour);
+//   * backward cotangents δ: any magnitude — each SAMPLE (= lane: the N index of the product) is scaled by its own power of
+//     two, taken from the largest |δ| of that sample, and unscaled after the product (a per-column scale commutes with A·B).
+// The weight-gradient product sums over samples (K = samples), where a per-sample scale does not commute: it stays on bf16x3.
+#pragma once
+#include "common.hpp"
+#include "mlp_x3.hpp"
+
+namespace crl {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr float X2_ACT_SCALE = 16384.0f;          // 2^14 on tanh outputs
+constexpr float X2_W_SCALE = 256.0f;              // 2^8 on weights
+constexpr float X2_W_LIMIT = 255.0f;              // |w|·2^8 must stay below the largest half (65504)
+constexpr float X2_FWD_UNSCALE = 1.0f / (16384.0f * 256.0f);
+
+struct P2 { f16x8 hi, lo; };
+
+// x = hi + lo for 8 floats (already scaled into the fp16 window): per pair one v_cvt_pk_f16_f32, two mixed-precision
+// subtracts (x − float(hi), exact) and one more v_cvt_pk_f16_f32
+__device__ __forceinline__ P2 split2(const float (&x)[8]) {
+  P2 p;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x2 v; v[0] = x[2 * q]; v[1] = x[2 * q + 1];
+    const f16x2 h = __builtin_convertvector(v, f16x2);
+    f32x2 r; r[0] = v[0] - (float)h[0]; r[1] = v[1] - (float)h[1];
+    const f16x2 l = __builtin_convertvector(r, f16x2);
+    p.hi[2 * q] = h[0]; p.hi[2 * q + 1] = h[1];
+    p.lo[2 * q] = l[0]; p.lo[2 * q + 1] = l[1];
+  }
+  return p;
+}
+
+__device__ __forceinline__ f32x16 mfma_f16(f16x8 a, f16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+// smallest partial products first
+__device__ __forceinline__ f32x16 mfma_x2(const P2& a, const P2& b, f32x16 c) {
+  c = mfma_f16(a.lo, b.hi, c);
+  c = mfma_f16(a.hi, b.lo, c);
+  c = mfma_f16(a.hi, b.hi, c);
+  return c;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// LDS weight image (offsets in floats; a piece image is 4096 halves = 2048 floats), same fragment order as NetImageX3:
+//   wf2h[piece][mo][ks][lane][8]  forward A-fragments of W2·2^8, wb2h … of W2ᵀ·2^8; k order = kmap (mlp_x3.hpp)
+//   wf1 / b1c / b2c / w3 / b3 as in NetImage (f32)
+// ------------------------------------------------------------------------------------------------------
+template <int D, int NOUT>
+struct NetImageX2 {
+  static constexpr int PIECE = 2048;
+  static constexpr int WF2H = 0;
+  static constexpr int WB2H = WF2H + 2 * PIECE;
+  static constexpr int WF1 = WB2H + 2 * PIECE;
+  static constexpr int B1C = WF1 + 2 * (D / 2) * 64;
+  static constexpr int B2C = B1C + 64;
+  static constexpr int W3 = B2C + 64;
+  static constexpr int B3 = W3 + NOUT * 64;
+  static constexpr int SIZE = ((B3 + NOUT + 3) / 4) * 4;
+};
+
+// returns false (for every thread of the block) when a weight of the hidden layer does not fit the fp16 window
+template <int D, int NOUT>
+__device__ __forceinline__ bool stage_net_x2(float* img, const float* __restrict__ p, int tid, int nthreads, int* lds_flag) {
+  using I = NetImageX2<D, NOUT>;
+  using P = NetParams<D, NOUT>;
+  _Float16* wf = reinterpret_cast<_Float16*>(img + I::WF2H);
+  _Float16* wb = reinterpret_cast<_Float16*>(img + I::WB2H);
+  if (tid == 0) *lds_flag = 0;
+  __syncthreads();
+  bool bad = false;
+  for (int idx = tid; idx < 4096; idx += nthreads) {
+    const int j = idx & 7, lane = (idx >> 3) & 63, ks = (idx >> 9) & 3, mo = idx >> 11;
+    const int i = lane & 31, hf = lane >> 5;
+    const int row = 32 * mo + i, k = kmap(ks, j, hf);
+    {
+      const float w0 = p[P::W2 + row + H * k];
+      bad |= !(__builtin_fabsf(w0) < X2_W_LIMIT);
+      const float w = w0 * X2_W_SCALE;
+      const _Float16 h = (_Float16)w;
+      wf[idx] = h; wf[4096 + idx] = (_Float16)(w - (float)h);
+    }
+    {
+      const float w = p[P::W2 + k + H * row] * X2_W_SCALE;
+      const _Float16 h = (_Float16)w;
+      wb[idx] = h; wb[4096 + idx] = (_Float16)(w - (float)h);
+    }
+  }
+  for (int idx = tid; idx < 2 * (D / 2) * 64; idx += nthreads) {
+    int lane = idx & 63, ks = (idx >> 6) % (D / 2), mo = (idx >> 6) / (D / 2);
+    int i = lane & 31, hf = lane >> 5;
+    img[I::WF1 + idx] = p[P::W1 + (32 * mo + i) + H * (2 * ks + hf)];
+  }
+  for (int idx = tid; idx < 64; idx += nthreads) {
+    int r = idx & 15, mo = (idx >> 4) & 1, hf = idx >> 5;
+    int row = 32 * mo + rowmap(r, hf);
+    img[I::B1C + idx] = p[P::B1 + row];
+    img[I::B2C + idx] = p[P::B2 + row] * (X2_ACT_SCALE * X2_W_SCALE);   // the layer-2 accumulator starts at b2·2^22
+  }
+  for (int idx = tid; idx < NOUT * 64; idx += nthreads) {
+    int q = idx & 31, hf = (idx >> 5) & 1, a = idx >> 6;
+    int mt = q >> 4, r = q & 15;
+    img[I::W3 + idx] = p[P::W3 + a + NOUT * (32 * mt + rowmap(r, hf))];
+  }
+  for (int idx = tid; idx < NOUT; idx += nthreads) img[I::B3 + idx] = p[P::B3 + idx];
+  if (bad) *lds_flag = 1;
+  __syncthreads();
+  return *lds_flag == 0;
+}
+
+__device__ __forceinline__ P2 load_wfrag2(const float* piece0, int mo, int ks, int lane) {
+  const f16x8* q = reinterpret_cast<const f16x8*>(piece0) + ((mo * 4 + ks) * 64 + lane);
+  P2 a;
+  a.hi = q[0]; a.lo = q[512];   // pieces are 4096 halves = 512 fragments apart
+  return a;
+}
+
+// acc[mo] += (W·2^8)(64x64) · Xs(64 x 32 samples), Xs already scaled into the fp16 window, given as C-fragment registers
+__device__ __forceinline__ void dense64_x2(const float* wimg, const f32x16 (&xs)[2], f32x16& acc0, f32x16& acc1, int lane) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    float xb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xb[j] = xs[ks >> 1][8 * (ks & 1) + j];
+    const P2 b = split2(xb);
+    acc0 = mfma_x2(load_wfrag2(wimg, 0, ks, lane), b, acc0);
+    acc1 = mfma_x2(load_wfrag2(wimg, 1, ks, lane), b, acc1);
+  }
+}
+
+// 2^14 · tanh_fast(x), bit for bit (the numerator's coefficients carry the power of two)
+__device__ __forceinline__ float tanh_fast_s14(float x) {
+  x = __builtin_amdgcn_fmed3f(x, -8.1240384f, 8.1240384f);
+  const float x2 = x * x;
+  const float S = X2_ACT_SCALE;
+  const float n = __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, 1.587199e-8f * S, 2.2332108e-5f * S), 0.0035974074f * S), 0.1346604f * S), S);
+  const float d = __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, 8.7767893e-7f, 0.0003453992f), 0.026262015f), 0.4679937f), 1.0f);
+  return x * (n * __builtin_amdgcn_rcpf(d));
+}
+
+// Forward of one network for a 32-sample tile: h1s = 2^14·h1 (what the next product and the backward pass consume), h2 and
+// the head outputs unscaled
+template <int D, int NOUT>
+__device__ __forceinline__ void mlp_forward_x2(const float* img, const float (&x)[D], f32x16 (&h1s)[2], f32x16 (&h2)[2],
+                                               float (&out)[NOUT], int lane) {
+  using I = NetImageX2<D, NOUT>;
+  const int hf = lane >> 5;
+  f32x16 a0 = load16(img + I::B1C + hf * 32);
+  f32x16 a1 = load16(img + I::B1C + hf * 32 + 16);
+#pragma unroll
+  for (int ks = 0; ks < D / 2; ++ks) {
+    const float b = hf ? x[2 * ks + 1] : x[2 * ks];
+    a0 = mfma32(img[I::WF1 + (0 * (D / 2) + ks) * 64 + lane], b, a0);
+    a1 = mfma32(img[I::WF1 + (1 * (D / 2) + ks) * 64 + lane], b, a1);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { h1s[0][r] = tanh_fast_s14(a0[r]); h1s[1][r] = tanh_fast_s14(a1[r]); }
+  a0 = load16(img + I::B2C + hf * 32);
+  a1 = load16(img + I::B2C + hf * 32 + 16);
+  dense64_x2(img + I::WF2H, h1s, a0, a1, lane);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { h2[0][r] = tanh_fast(a0[r] * X2_FWD_UNSCALE); h2[1][r] = tanh_fast(a1[r] * X2_FWD_UNSCALE); }
+#pragma unroll
+  for (int a = 0; a < NOUT; ++a) {
+    const f32x4* w = reinterpret_cast<const f32x4*>(img + I::W3 + a * 64 + hf * 32);
+    float acc = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 wv = w[q];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int idx = q * 4 + e;
+        acc = __builtin_fmaf(wv[e], h2[idx >> 4][idx & 15], acc);
+      }
+    }
+    out[a] = acc + xor32(acc) + img[I::B3 + a];
+  }
+}
+
+// Per-sample power-of-two scale for a cotangent tile in C-fragment registers (lane = sample, both lane halves hold rows of
+// the same sample): s = 2^(14 − ⌈exponent of the sample's largest |δ|⌉), exact; inv = 1 / s.
+__device__ __forceinline__ void sample_scale(const f32x16 (&d)[2], float& s, float& inv) {
+  float m = 0.0f;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(d[mt][r]), __builtin_fabsf(d[mt][r + 1])));
+  m = __builtin_fmaxf(m, xor32(m));
+  int e = (int)((__float_as_uint(m) >> 23) & 0xFFu);   // biased exponent: m in [2^(e-127), 2^(e-126))
+  e = e < 16 ? 16 : e;                                   // zero / tiny columns: any scale will do
+  s = __uint_as_float((unsigned)(268 - e) << 23);        // 2^(141 − e): m·s in [2^14, 2^15)
+  inv = __uint_as_float((unsigned)(e - 14) << 23);       // 2^(e − 141)
+}
+
+}  // namespace crl

@@ -140,8 +140,10 @@ inline uint64_t shuffle_seed(const crl_ppo* h) {
 void select_slot(crl_ppo* h, int slot);
 int ensure_records(crl_ppo* h);
 int ensure_stage(crl_ppo* h, size_t bytes);
-// CRL_GEMM=f32 selects the v_mfma_f32_32x32x2_f32 layers; default is the bf16x3 matrix-pipe path (mlp_x3.hpp)
-bool gemm_x3();
+// CRL_GEMM: x2 (default) = fp16x2 forward / backward-data products in the update kernel + bf16x3 everywhere else
+// (mlp_x2.hpp); x3 = bf16x3 only (mlp_x3.hpp); f32 = the v_mfma_f32_32x32x2_f32 layers
+bool gemm_x3();   // true for x2 and x3
+bool gemm_x2();
 
 // HIP-event timing of one kernel class. attach=true: the events are handed to hipExtLaunchKernelGGL, which stamps the
 // kernel's own begin/end (what rocprofv3 reports); otherwise they are recorded on the stream around the launch(es).

@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "mlp_x2.hpp"
 #include "mlp_x3.hpp"
 #include "ppo_ctx.hpp"
 #include "stats.hpp"
@@ -69,10 +70,14 @@ constexpr int SCR_FLOATS_X3 = SCR_FLOATS + ACC_SLOTS * 64;
 
 // ABL (CRL_ABLATE builds, scripts/run_ablate.sh): timing experiments that remove one phase each (results are garbage) — the
 // way the per-phase costs in DESIGN.md §3 were measured. 0 in every production instantiation.
-template <int D, int A, int ROLE, bool EXACT, bool X3, int RW, int ABL = 0>
+// X2 (with X3): the forward and backward-data products run as fp16x2 (mlp_x2.hpp: three MFMAs per product instead of six, h1
+// carried as 2^14·h1), the weight-gradient product stays on bf16x3.
+template <int D, int A, int ROLE, bool EXACT, bool X3, int RW, int ABL = 0, bool X2 = false>
 __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, float* smem, float* scratch) {
   constexpr int NOUT = ROLE == 0 ? A : 1;
-  using I = typename std::conditional<X3, NetImageX3<D, NOUT, true>, NetImage<D, NOUT, true>>::type;
+  static_assert(!X2 || X3, "the fp16x2 flavour keeps the bf16x3 weight-gradient path");
+  using I = typename std::conditional<X2, NetImageX2<D, NOUT>,
+                                      typename std::conditional<X3, NetImageX3<D, NOUT, true>, NetImage<D, NOUT, true>>::type>::type;
   using P = NetParams<D, NOUT>;
   constexpr int SCR = X3 ? SCR_FLOATS_X3 : SCR_FLOATS;
   static_assert(64 * TSTRIDE + TILE * D + A * TILE <= SCR_FLOATS, "scratch too small");
@@ -83,7 +88,9 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
   float* img0 = smem;
   float* T0 = scratch + wave * SCR;
   const float* p = a.params + (ROLE ? NetParams<D, A>::SIZE : 0);
-  if (X3) stage_net_x3<D, NOUT, true>(img0, p, tid, NT);
+  bool in_range = true;
+  if constexpr (X2) in_range = stage_net_x2<D, NOUT>(img0, p, tid, NT, reinterpret_cast<int*>(scratch + RW * SCR));
+  else if (X3) stage_net_x3<D, NOUT, true>(img0, p, tid, NT);
   else stage_net<D, NOUT, true>(img0, p, tid, NT);
   __syncthreads();
 
@@ -130,6 +137,10 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
   // through the backward pass — spills — for no measurable gain once the gather through the permutation was gone.)
   int tile = rb * RW + wave;
   Gathered<D> cur;
+  if (!in_range) {   // a hidden-layer weight does not fit the fp16x2 window: compute nothing, tell the host (crl_sync / stats)
+    if (tid == 0 && rb == 0) a.range_err[0] = 1.0;
+    tile = ntiles;
+  }
   for (; tile < ntiles; tile += nwaves) {
     const int pos = tile * TILE + j;
     const bool ok = pos < M;
@@ -148,7 +159,8 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
     float* T = T0 + lds_off;
     float* xs = T + 64 * TSTRIDE;
     float* d3s = xs + TILE * D;
-    if constexpr (X3) mlp_forward_x3<D, NOUT, true, ABL>(img, x, h1, h2, out, lane);
+    if constexpr (X2) mlp_forward_x2<D, NOUT>(img, x, h1, h2, out, lane);   // h1 = 2^14·tanh(…) from here on
+    else if constexpr (X3) mlp_forward_x3<D, NOUT, true, ABL>(img, x, h1, h2, out, lane);
     else mlp_forward<D, NOUT, true>(img, x, h1, h2, out, lane);
 
     if constexpr ((ABL & 32) != 0) {
@@ -284,6 +296,19 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
       if constexpr ((ABL & 16) != 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { c0[r] = d2[0][r]; c1[r] = d2[1][r]; }
+      } else if constexpr (X2) {
+        // each sample's cotangent column scaled by its own power of two into the fp16 window, unscaled below
+        float sc, sinv;
+        sample_scale(d2, sc, sinv);
+        f32x16 ds[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ds[mt][r] = d2[mt][r] * sc;
+        dense64_x2(img + I::WB2H, ds, c0, c1, lane);
+        const float f = sinv * (1.0f / X2_W_SCALE);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { c0[r] *= f; c1[r] *= f; }
       } else if constexpr (X3) {
         dense64_x3(img + I::WB2P, d2, c0, c1, lane);
       } else {
@@ -303,8 +328,9 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        d1[0][r] = c0[r] * (1.0f - h1[0][r] * h1[0][r]);
-        d1[1][r] = c1[r] * (1.0f - h1[1][r] * h1[1][r]);
+        constexpr float k = X2 ? 1.0f / (X2_ACT_SCALE * X2_ACT_SCALE) : 1.0f;   // h1 is carried as 2^14·h1 in the fp16x2 flavour
+        d1[0][r] = c0[r] * (1.0f - (h1[0][r] * k) * h1[0][r]);
+        d1[1][r] = c1[r] * (1.0f - (h1[1][r] * k) * h1[1][r]);
       }
     }
     CRL_PHASE();
@@ -445,7 +471,7 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            R[P::W2 + (32 * ni + j) + H * (32 * mj + rowmap(r, hf))] += dW2t[mj][ni][r];
+            R[P::W2 + (32 * ni + j) + H * (32 * mj + rowmap(r, hf))] += dW2t[mj][ni][r] * (X2 ? 1.0f / X2_ACT_SCALE : 1.0f);
 #pragma unroll
       for (int i = 0; i < D; ++i) R[P::W1 + lane + H * i] += racc[i];
       R[P::B1 + lane] += racc[K_B1];
@@ -491,6 +517,16 @@ __global__ void __launch_bounds__(512, 2) update_x3_kernel(UpdateArgs a) {
   }
   if ((int)blockIdx.x < a.nblk[0]) update_role<D, A, 0, false, true, 8>(a, blockIdx.x, smem, smem + NetImageX3<D, A, true>::SIZE);
   else update_role<D, A, 1, false, true, 8>(a, blockIdx.x - a.nblk[0], smem, smem + NetImageX3<D, 1, true>::SIZE);
+}
+// fp16x2 flavour (the default): forward / backward-data products on the f16 matrix pipe, three MFMAs per product
+template <int D, int A>
+__global__ void __launch_bounds__(512, 2) update_x2_kernel(UpdateArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= 4) {
+    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+  }
+  if ((int)blockIdx.x < a.nblk[0]) update_role<D, A, 0, false, true, 8, 0, true>(a, blockIdx.x, smem, smem + NetImageX2<D, A>::SIZE);
+  else update_role<D, A, 1, false, true, 8, 0, true>(a, blockIdx.x - a.nblk[0], smem, smem + NetImageX2<D, 1>::SIZE);
 }
 #ifdef CRL_ABLATE
 // timing experiments only: the same kernel with one phase removed (results are garbage)
@@ -632,7 +668,7 @@ static int run_update(crl_ppo* h, int mb, int mode, hipEvent_t ev0 = nullptr, hi
   UpdateArgs a;
   a.c = h->dc; a.params = h->params;
   a.recs = h->recs_p + (size_t)h->cur_slot * h->dc.B + (size_t)mb * h->dc.M; a.adv_ms = h->adv_ms; a.vfix = h->vfix;
-  a.gpart = h->gpart; a.lpart = h->lpart; a.newv = h->newv;
+  a.gpart = h->gpart; a.lpart = h->lpart; a.newv = h->newv; a.range_err = h->vfix + 5;
   a.mb = mb; a.mode = mode; a.gstride = (int)h->Pa; a.pmax = h->update_blocks; a.stagger = 0;
   a.Mglobal = (double)h->dc.M * h->world;
   if (mode == 1) {
@@ -652,6 +688,11 @@ static int run_update(crl_ppo* h, int mb, int mode, hipEvent_t ev0 = nullptr, hi
     CRL_DBG_CASE(32, 8) CRL_DBG_CASE(64, 8) CRL_DBG_CASE(82, 8) CRL_DBG_CASE(86, 8) CRL_DBG_CASE(126, 8)
 #undef CRL_DBG_CASE
 #endif
+  } else if (gemm_x2()) {
+    main_pass_blocks(h, &a.nblk[0], &a.nblk[1]);
+    a.stagger = env_int("CRL_X3_STAGGER", 3);
+    const size_t smem = sizeof(float) * (NetImageX2<4, 2>::SIZE + 8 * SCR_FLOATS_X3 + 4);
+    hipExtLaunchKernelGGL((update_x2_kernel<4, 2>), dim3(a.nblk[0] + a.nblk[1]), dim3(512), smem, h->stream, ev0, ev1, 0, a);
   } else if (gemm_x3()) {
     main_pass_blocks(h, &a.nblk[0], &a.nblk[1]);
     static int stagger = -1;

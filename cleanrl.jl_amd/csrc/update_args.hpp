@@ -11,6 +11,7 @@ struct UpdateArgs {
   const double* adv_ms;   // [nmb][2] mean, std of the (global) minibatch advantages
   const double* vfix;     // [8] u, #{u > q}, -, flag, sticky flag
   float* gpart; double* lpart; float* newv;
+  double* range_err;      // vfix[5]: set when a hidden-layer weight does not fit the fp16x2 window (mlp_x2.hpp)
   int mb, mode, gstride;
   int nblk[2];            // blocks working on the actor / the critic
   int pmax;               // capacity (blocks per role) of the partial buffers
