@@ -526,8 +526,8 @@ int32_t crl_adv_stats_finish(crl_ppo* h) {
   return launch_adv_stats_finish(h);
 }
 
-static int update_step(crl_ppo* h, int mb, double eta, int apply, int slot) {
-  if (launch_update(h, mb, h->stats_dev + slot)) return 1;
+static int update_step(crl_ppo* h, int mb, double eta, int apply, int slot, bool inline_fix = true) {
+  if (launch_update(h, mb, h->stats_dev + slot, inline_fix)) return 1;
   if (apply && launch_optim(h, eta)) return 1;
   return 0;
 }
@@ -545,15 +545,15 @@ int32_t crl_ppo_update_minibatch(crl_ppo* h, int32_t mb, double eta, int32_t app
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Data-parallel guard (Q4). The fused kernels speculate on u = mean(v − R²) ≤ 0 (ppo.jl:232-237); under RCCL the exact
-// fix-up would cost two more collectives per optimiser step, so the common path stays speculative and a (global, sticky)
-// device flag records a failed speculation. The flag is read back once per WINDOW of iterations (CRL_DP_CHECK_EVERY,
-// default 8) or whenever the host reads results — never per iteration. A window starts with a snapshot of everything an
+// Speculation guard (Q4). The fused kernels speculate on u = mean(v − R²) ≤ 0 (ppo.jl:232-237). Inside crl_ppo_iterate the
+// exact fix-up is NOT enqueued per optimiser step (three early-exit launches on one GPU, two more collectives under RCCL):
+// the common path stays speculative and a (global, sticky) device flag records a failed speculation. The flag is read back
+// once per WINDOW of iterations (CRL_DP_CHECK_EVERY, default 8) or whenever the host reads results — never per iteration. A window starts with a snapshot of everything an
 // iteration mutates (parameters, Adam state, env state, episode accumulators); if the flag is up at the end, every rank
 // restores the snapshot and repeats the window's iterations with the exact step. The flag derives from all-reduced sums,
 // so all ranks take the same branch as long as they issue the same sequence of library calls.
 // ---------------------------------------------------------------------------------------------------------------
-static bool guard_on(const crl_ppo* h) { return h->comm != nullptr && !h->wide && h->cfg.clip_value_loss; }
+static bool guard_on(const crl_ppo* h) { return !h->wide && h->cfg.clip_value_loss && !h->external_comm; }
 
 struct EnvSnapLayout { size_t state, obs, t, done, ret, len, stats, ring, total; };
 static EnvSnapLayout env_snap_layout(const crl_ppo* h) {
@@ -665,7 +665,7 @@ static int iterate_once(crl_ppo* h, bool exact) {
       if (exact) {
         if (launch_update_exact_dp(h, mb, h->stats_dev + ep * nmb + mb)) return 1;
         if (launch_optim(h, eta)) return 1;
-      } else if (update_step(h, mb, eta, 1, ep * nmb + mb)) return 1;
+      } else if (update_step(h, mb, eta, 1, ep * nmb + mb, /*inline_fix=*/!guard_on(h))) return 1;
     }
   }
   return 0;   // the current slot stays at the last epoch: CRL_F_PERM reads back the b_inds the loop ended with

@@ -180,7 +180,7 @@ int launch_adv_stats_sums(crl_ppo* h);
 int launch_adv_stats_finish(crl_ppo* h, int slot0 = -1, int nslots = 1);
 int launch_pack_records(crl_ppo* h);
 int launch_permute_records(crl_ppo* h, int slot0, int nslots);
-int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot);
+int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot, bool inline_fix = true);
 int launch_update_exact_dp(crl_ppo* h, int mb, crl_ppo_stats* stats_slot);
 int launch_optim(crl_ppo* h, double eta);
 int comm_allreduce(crl_ppo* h, void* buf, size_t count, bool is_double);

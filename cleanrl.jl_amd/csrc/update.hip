@@ -718,7 +718,9 @@ static StatsArgs stats_args(crl_ppo* h, int mb, crl_ppo_stats* slot, int fused) 
 
 // One optimiser step's gradient: update pass → fixed-order reduce (+ statistics) → [all-reduce → statistics] →
 // the rare exact value-loss pass (three early-exit launches). The gradient message ends up in comm_buf.
-int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
+// inline_fix: follow the speculative pass with the three early-exit launches of the exact value-loss pass (host-driven single
+// steps). crl_ppo_iterate passes false: there a failed speculation is caught by the guard window (api.cpp) instead.
+int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot, bool inline_fix) {
   if (h->wide) return wide_update(h, mb, stats_slot);
   if (h->cfg.obs_dim != 4 || h->cfg.n_act != 2 || h->cfg.hidden != 64) {
     set_error("this build of libcleanrl_hip supports obs_dim=4, n_act=2, hidden=64 (2x64 MLP) only");
@@ -746,7 +748,7 @@ int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
     hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(64), 0, h->stream, h->comm_buf, P, stats_args(h, mb, stats_slot, 0), 0);
     CRL_HIP_CHECK(hipGetLastError());
   }
-  if (h->cfg.clip_value_loss && h->world == 1) {
+  if (inline_fix && h->cfg.clip_value_loss && h->world == 1) {
     // early-exit launches unless the statistics raised the flag (u > 0)
     hipLaunchKernelGGL(vfix_count_kernel, dim3(1), dim3(1024), 0, h->stream, h->dc, h->recs_p + (size_t)h->cur_slot * h->dc.B + (size_t)mb * h->dc.M, h->newv, h->vfix);
     CRL_HIP_CHECK(hipGetLastError());

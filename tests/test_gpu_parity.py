@@ -554,9 +554,10 @@ def test_full_size_update_is_deterministic_and_additive(crl):
 @pytest.mark.parametrize("forced_comm", [False, True])
 def test_iteration_with_live_unclipped_value_branch(crl, forced_comm, monkeypatch):
     """γ = 0 makes every return 0 or 1 while a critic head bias of 5 puts u = mean(v − R²) ≈ 4 above every clipped term
-    (Q4): the whole iteration must still match the oracle. Single GPU: the in-line fix-up pass. With an RCCL communicator
-    (forced 1-rank): the speculative pass raises the sticky flag, the iteration's update phase is re-run from the snapshot
-    with the exact data-parallel step (count and critic-slice all-reduces) — same result."""
+    (Q4): the whole iteration must still match the oracle. Inside crl_ppo_iterate the speculative pass raises the sticky flag
+    and the guard window repeats the iteration from its snapshot with the exact step — on one GPU and, with an RCCL
+    communicator (forced 1-rank), with the count and critic-slice all-reduces. (Host-driven single steps keep the in-line
+    fix-up: test_update_gradient_matches_oracle[...0.05-True].)"""
     if forced_comm:
         monkeypatch.setenv("CRL_COMM_FORCE", "1")
     nt, k = 8, 128
@@ -579,16 +580,18 @@ def test_iteration_with_live_unclipped_value_branch(crl, forced_comm, monkeypatc
             for key in ("loss", "v_loss", "pg_loss"):
                 assert abs(a[key] - b[key]) <= 2e-5 * max(1.0, abs(b[key])), (it, key, a[key], b[key])
         assert np.max(np.abs(h.read(crl._lib.F_PARAMS) - st.params)) < 2e-5
-    assert h.exact_reruns == (2 if forced_comm else 0)
+    assert h.exact_reruns == 2, "both iterations had to be repeated with the exact value-loss pass (guard window)"
     agent.close(); st.close()
 
 
-def test_guard_window_reruns_all_its_iterations(crl, monkeypatch):
-    """Data-parallel guard window (forced 1-rank RCCL communicator): three iterations are enqueued WITHOUT any read-back; the
+@pytest.mark.parametrize("forced_comm", [False, True])
+def test_guard_window_reruns_all_its_iterations(crl, forced_comm, monkeypatch):
+    """Guard window (single GPU, and with a forced 1-rank RCCL communicator): three iterations are enqueued WITHOUT any read-back; the
     speculation fails in each (γ = 0, critic bias 5). The first host-visible read settles the window: the library restores the
     snapshot (parameters, Adam state, env state, episode accumulators) and repeats all three iterations exactly — parameters
     and episode statistics must equal the oracle's three iterations, and anneal_lr must have followed the rewound counter."""
-    monkeypatch.setenv("CRL_COMM_FORCE", "1")
+    if forced_comm:
+        monkeypatch.setenv("CRL_COMM_FORCE", "1")
     monkeypatch.setenv("CRL_DP_CHECK_EVERY", "8")
     nt, k = 8, 128
     cfg = crl.PPOConfig(num_envs=nt, num_steps=k, total_timesteps=nt * k * 10, gamma=0.0)
@@ -598,7 +601,8 @@ def test_guard_window_reruns_all_its_iterations(crl, monkeypatch):
     params[O.param_offsets(cfgo)[11]] = 5.0
     agent.set_params(params)
     h = agent.handle
-    h.comm_init(crl.comm_unique_id(), 1, 0)
+    if forced_comm:
+        h.comm_init(crl.comm_unique_id(), 1, 0)
     st = O.State(cfgo); st.params[:] = params; st.env_init()
     h.env_reset()
     h.iterate(3, want_stats=False)
