@@ -72,3 +72,39 @@ def test_two_shards_equal_one_handle(crl, path):
         assert abs(sf["adv_std"]) > 0
     for a in [full] + shards:
         a.close()
+
+
+def test_single_minibatch_mode_one_message_per_epoch(crl):
+    """num_minibatches = 1 (north_star's "single all-reduce of gradients per update epoch"): the whole local batch is one
+    minibatch, so an epoch is ONE optimiser step and one gradient message. Two shards with host-side exchange == one handle."""
+    L = crl._lib
+    NT, k, W = 16, 128, 2
+    n = NT // W
+    full = crl.Agent(crl.PPOConfig(num_envs=NT, num_steps=k, num_minibatches=1, total_timesteps=NT * k * 10))
+    params = full.get_params()
+    shards = [crl.Agent(crl.PPOConfig(num_envs=n, num_steps=k, num_minibatches=1, total_timesteps=NT * k * 10), params=params,
+                        env_id_offset=r * n) for r in range(W)]
+    for r, a in enumerate(shards):
+        a.handle.comm_init_external(W, r)
+    for a in [full] + shards:
+        a.handle.env_reset(); a.handle.rollout_run(); a.handle.compute_gae()
+    rng = np.random.default_rng(1)
+    perms = [rng.permutation(n * k).astype(np.int32) for _ in range(W)]
+    union = np.concatenate([(r * n + perms[r] % n) + NT * (perms[r] // n) for r in range(W)]).astype(np.int32)
+    full.handle.write(L.F_PERM, union)
+    for r, a in enumerate(shards):
+        a.handle.write(L.F_PERM, perms[r]); a.handle.adv_stats_local()
+    tot = sum(a.handle.read(L.F_ADV_SUMS) for a in shards)
+    assert tot.shape == (2,)
+    for a in shards:
+        a.handle.write(L.F_ADV_SUMS, tot); a.handle.adv_stats_finish()
+    full.handle.adv_stats()
+    sf = full.handle.update_minibatch(0, 0.0, apply_update=False)
+    gf = full.handle.read(L.F_GRADS).astype(np.float64)
+    gs = np.zeros_like(gf)
+    for a in shards:
+        a.handle.update_minibatch(0, 0.0, apply_update=False, want_stats=False)
+        gs += a.handle.read(L.F_GRADS)
+    assert np.linalg.norm(gs - gf) / np.linalg.norm(gf) < 1e-5 and np.isfinite(sf["loss"])
+    for a in [full] + shards:
+        a.close()

@@ -1,6 +1,10 @@
 """Parity of the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
 Bars (BASELINE.json north_star): bit-exact action indices / permutations / integer fields; float32 results within
-1e-5 relative. GAE is additionally expected bit-exact (Float64 accumulation on both sides)."""
+1e-5 relative. GAE is additionally expected bit-exact (Float64 accumulation on both sides).
+Whole-iteration comparisons use TIGHTER bars than the north_star's: scripts/parity_margins.py (profiles/r02_parity_margins.json)
+measures 1.1e-7 relative on the losses, 3e-8 absolute on the parameters after three iterations and 1.2e-6 relative L2 on the
+gradient arrays, so losses are held to 2e-6 relative and parameters to 1e-6 absolute (IT_LOSS / IT_PARAM below) — wide enough
+for float32 summation-order noise on both sides, an order of magnitude inside "1e-5 relative"."""
 import numpy as np
 import pytest
 
@@ -9,6 +13,7 @@ import oraclelib as O
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-5
+IT_LOSS, IT_PARAM = 2e-6, 1e-6
 
 
 @pytest.fixture(scope="module")
@@ -263,9 +268,9 @@ def test_full_iteration_matches_oracle(crl, n_iters):
         assert rel_err(h.read(crl._lib.F_ADVANTAGE), st.adv) < RTOL
         for a, b in zip(gs, os_):
             for key in ("loss", "pg_loss", "v_loss", "entropy_loss"):
-                assert abs(a[key] - b[key]) <= 2e-5 * max(1.0, abs(b[key])), (it, key, a[key], b[key])
+                assert abs(a[key] - b[key]) <= IT_LOSS * max(1.0, abs(b[key])), (it, key, a[key], b[key])
         pg, po = h.read(crl._lib.F_PARAMS), st.params
-        assert np.max(np.abs(pg - po)) < 2e-5, np.max(np.abs(pg - po))
+        assert np.max(np.abs(pg - po)) < IT_PARAM, np.max(np.abs(pg - po))
     assert h.iteration == n_iters
     agent.close(); st.close()
 
@@ -314,8 +319,8 @@ def test_rccl_path_world1(crl, monkeypatch):
     gs = h.iterate(1); os_ = st.iterate(10, gen_perm=True)
     assert h.prof_read()["allreduce"][1] == 16, "one all-reduce per optimiser step (ppo.jl:250 cadence)"
     for a, b in zip(gs, os_):
-        assert abs(a["loss"] - b["loss"]) <= 2e-5 * max(1.0, abs(b["loss"]))
-    assert np.max(np.abs(h.read(crl._lib.F_PARAMS) - st.params)) < 2e-5
+        assert abs(a["loss"] - b["loss"]) <= IT_LOSS * max(1.0, abs(b["loss"]))
+    assert np.max(np.abs(h.read(crl._lib.F_PARAMS) - st.params)) < IT_PARAM
     agent.close(); st.close()
 
 
@@ -386,7 +391,7 @@ def test_external_env_path_store_then_update(crl):
     h.adv_stats()
     gs = h.update_minibatch(1, 2.5e-4, apply_update=True)
     so = st.update_minibatch(1, 2.5e-4)
-    assert abs(gs["loss"] - so["loss"]) <= 2e-5 * max(1.0, abs(so["loss"]))
+    assert abs(gs["loss"] - so["loss"]) <= IT_LOSS * max(1.0, abs(so["loss"]))
     assert np.max(np.abs(h.read(F.F_PARAMS) - st.params)) < 1e-6
     # critic(obs) through the Policy object, like `value = critic(next_obs)` (ppo.jl:128)
     vv = agent.critic(co)
@@ -427,8 +432,8 @@ def test_iteration_with_blocked_fisher_yates(crl):
         for mb in range(4):
             a = h.update_minibatch(mb, 2.5e-4)
             b = st.update_minibatch(mb, 2.5e-4)
-            assert abs(a["loss"] - b["loss"]) <= 2e-5 * max(1.0, abs(b["loss"]))
-    assert np.max(np.abs(h.read(crl._lib.F_PARAMS) - st.params)) < 2e-5
+            assert abs(a["loss"] - b["loss"]) <= IT_LOSS * max(1.0, abs(b["loss"]))
+    assert np.max(np.abs(h.read(crl._lib.F_PARAMS) - st.params)) < IT_PARAM
     agent.close(); st.close()
 
 
@@ -578,8 +583,8 @@ def test_iteration_with_live_unclipped_value_branch(crl, forced_comm, monkeypatc
         for a, b in zip(gs, os_):
             assert a["n_unclipped_wins"] == b["n_unclipped_wins"]
             for key in ("loss", "v_loss", "pg_loss"):
-                assert abs(a[key] - b[key]) <= 2e-5 * max(1.0, abs(b[key])), (it, key, a[key], b[key])
-        assert np.max(np.abs(h.read(crl._lib.F_PARAMS) - st.params)) < 2e-5
+                assert abs(a[key] - b[key]) <= IT_LOSS * max(1.0, abs(b[key])), (it, key, a[key], b[key])
+        assert np.max(np.abs(h.read(crl._lib.F_PARAMS) - st.params)) < IT_PARAM
     assert h.exact_reruns == 2, "both iterations had to be repeated with the exact value-loss pass (guard window)"
     agent.close(); st.close()
 
@@ -612,7 +617,7 @@ def test_guard_window_reruns_all_its_iterations(crl, forced_comm, monkeypatch):
     assert max(s["n_unclipped_wins"] for s in os_) > 0
     got = h.read(crl._lib.F_PARAMS)            # first host-visible read: settles the window
     assert h.exact_reruns == 3
-    assert np.max(np.abs(got - st.params)) < 2e-5
+    assert np.max(np.abs(got - st.params)) < IT_PARAM
     assert np.array_equal(h.read(crl._lib.F_ACTION), st.action) and np.array_equal(h.read(crl._lib.F_ENV_STATE), st.env_state)
     es = h.episode_stats(); n_ep, ret_sum, len_sum = st.episode_stats
     assert (es["episodes"], es["return_sum"], es["length_sum"]) == (n_ep, ret_sum, len_sum)
