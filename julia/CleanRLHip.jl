@@ -7,7 +7,7 @@
 # tests/test_host_cpu.py::test_config_struct_matches_header_and_reference_defaults pins (104 bytes).
 module CleanRLHip
 
-export PPOConfig, ppo, get_action, logprob_actions, gae
+export PPOConfig, ppo, get_action, logprob_actions, gae, a2c, dqn, q_values, comm_unique_id, comm_init!
 
 const libcrl = get(ENV, "CLEANRL_HIP_LIB", joinpath(@__DIR__, "..", "cleanrl.jl_amd", "libcleanrl_hip.so"))
 
@@ -47,13 +47,18 @@ end
 struct CrlEpisodeStats     # crl_episode_stats
   episodes::Float64; return_sum::Float64; length_sum::Float64; return_max::Float64
 end
+struct CrlEpisodeRecord    # crl_episode_record: one per finished episode (ppo.jl:147-162)
+  episode_return::Float32; episode_length::Int32; env::Int32; step::Int32
+end
 
 check(rc::Int32) = rc == 0 || error(unsafe_string(ccall((:crl_last_error, libcrl), Cstring, ())))
 
 mutable struct Agent
   h::Ptr{Cvoid}
   config::PPOConfig
-  function Agent(config::PPOConfig; device=0, seed=0x5EED, env_id_offset=0, shuffle_mode=1)
+  # shuffle_mode 2 = CRL_SHUFFLE_BLOCKED_FY: an exact uniform shuffle like Random.shuffle (ppo.jl:194); same default as the
+  # ctypes mirror (cleanrl.jl_amd/ppo.py). 0 = serial Fisher–Yates, 1 = keyed bijection (pseudo-random, faster).
+  function Agent(config::PPOConfig; device=0, seed=0x5EED, env_id_offset=0, shuffle_mode=2)
     c = CrlConfig(config.total_timesteps, config.num_steps, config.num_envs, config.num_minibatches, config.update_epochs,
                   config.lr, config.gamma, config.gae_lambda, config.clip_coef, config.ent_coeff, config.v_coef,
                   config.normalize_advantages, config.clip_value_loss, config.anneal_lr,
@@ -102,26 +107,58 @@ function gae(values::AbstractVector{Float32}, rewards::AbstractVector{Float32}, 
   adv
 end
 
-# ppo.jl:75 — same signature; the loop body (ppo.jl:117-253) runs on the GPU, one ccall per update
-function ppo(config::PPOConfig=PPOConfig(); device=0, params::Union{Nothing,Vector{Float32}}=nothing)
-  agent = Agent(config; device)
+# Data parallelism over num_envs, one Julia process per GPU (the reference is single-process): rank 0 draws the 128-byte RCCL
+# id, the launcher (MPI.jl, Distributed, a file) hands it to every rank, each rank attaches its shard handle.
+function comm_unique_id()
+  id = Vector{UInt8}(undef, 128)
+  GC.@preserve id check(ccall((:crl_comm_unique_id, libcrl), Int32, (Ptr{UInt8},), id))
+  id
+end
+comm_init!(a::Agent, id::Vector{UInt8}, world_size::Integer, rank::Integer) =
+  GC.@preserve id check(ccall((:crl_comm_init, libcrl), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Int32, Int32), a.h, id, world_size, rank))
+
+# ppo.jl:75 — same signature; the loop body (ppo.jl:117-253) runs on the GPU, one ccall per update.
+# episode_records > 0 turns on the device ring (crl_episode_ring_enable): every finished episode leaves {return, length, env,
+# step} and `ppo` emits ONE "Episode Statistics" record per episode in the reference's order (ppo.jl:147-165: step by step,
+# done envs ascending; global_step as of that step, ppo.jl:124). With 0 it emits one aggregate record per update (65536 envs
+# finish ~10^5 episodes per rollout). Multi-GPU: pass comm = (id, world_size, rank) and a config whose num_envs is the shard.
+function ppo(config::PPOConfig=PPOConfig(); device=0, params::Union{Nothing,Vector{Float32}}=nothing, episode_records::Integer=4096,
+             comm::Union{Nothing,Tuple{Vector{UInt8},Int,Int}}=nothing)
+  world, rank = comm === nothing ? (1, 0) : (comm[2], comm[3])
+  agent = Agent(config; device, env_id_offset=rank * config.num_envs)
   params === nothing || set_params!(agent, params)
+  comm === nothing || comm_init!(agent, comm[1], world, rank)
+  episode_records > 0 && check(ccall((:crl_episode_ring_enable, libcrl), Int32, (Ptr{Cvoid}, Int32), agent.h, episode_records))
   check(ccall((:crl_env_reset, libcrl), Int32, (Ptr{Cvoid},), agent.h))
-  batch_size = config.num_steps * config.num_envs
-  num_updates = config.total_timesteps ÷ batch_size
+  batch_size = config.num_steps * config.num_envs * world          # ppo.jl:89 over the whole job
+  num_updates = config.total_timesteps ÷ batch_size                # ppo.jl:91
   nstats = config.update_epochs * config.num_minibatches
   stats = Vector{CrlStats}(undef, nstats); ep = Ref{CrlEpisodeStats}()
+  recs = Vector{CrlEpisodeRecord}(undef, max(episode_records, 1)); n_stored = Ref{Int32}(0); n_episodes = Ref{Int64}(0)
   global_step = 0; last_log_step = 0; start_time = time()
   for update in 1:num_updates
     GC.@preserve stats check(ccall((:crl_ppo_iterate, libcrl), Int32, (Ptr{Cvoid}, Int32, Ptr{CrlStats}), agent.h, 1, stats))
-    check(ccall((:crl_episode_stats_read, libcrl), Int32, (Ptr{Cvoid}, Ref{CrlEpisodeStats}), agent.h, ep))
+    base = global_step
     global_step += batch_size
-    steps_per_sec = trunc(global_step / (time() - start_time))
-    if ep[].episodes > 0
-      episode_return = ep[].return_sum / ep[].episodes; episode_length = ep[].length_sum / ep[].episodes
-      log_step_inc = last_log_step == 0 ? 0 : global_step - last_log_step
-      @info "Episode Statistics" episode_return episode_length global_step steps_per_sec log_step_increment = log_step_inc
-      last_log_step = global_step
+    if episode_records > 0
+      GC.@preserve recs check(ccall((:crl_episode_ring_read, libcrl), Int32, (Ptr{Cvoid}, Ptr{CrlEpisodeRecord}, Int32, Ref{Int32}, Ref{Int64}),
+                                    agent.h, recs, episode_records, n_stored, n_episodes))
+      for r in sort!(recs[1:n_stored[]]; by = r -> (r.step, r.env))      # the reference's order
+        gs = base + (r.step + 1) * config.num_envs * world                # ppo.jl:124 global_step += num_envs per step
+        steps_per_sec = trunc(gs / (time() - start_time))
+        log_step_inc = last_log_step == 0 ? 0 : gs - last_log_step
+        @info "Episode Statistics" episode_return = r.episode_return episode_length = r.episode_length global_step = gs steps_per_sec log_step_increment = log_step_inc
+        last_log_step = gs
+      end
+    else
+      check(ccall((:crl_episode_stats_read, libcrl), Int32, (Ptr{Cvoid}, Ref{CrlEpisodeStats}), agent.h, ep))
+      if ep[].episodes > 0
+        steps_per_sec = trunc(global_step / (time() - start_time))
+        episode_return = ep[].return_sum / ep[].episodes; episode_length = ep[].length_sum / ep[].episodes
+        log_step_inc = last_log_step == 0 ? 0 : global_step - last_log_step
+        @info "Episode Statistics" episode_return episode_length global_step steps_per_sec log_step_increment = log_step_inc
+        last_log_step = global_step
+      end
     end
     for s in stats
       log_step_inc = last_log_step == 0 ? 0 : global_step - last_log_step
@@ -170,6 +207,62 @@ function a2c(config; device=0, seed=UInt64(0x5EED), params::Vector{Float32})
     stats[].trained == 1 && @info "Training Statistics" actor_loss = stats[].actor_loss critic_loss = stats[].critic_loss
   end
   check(ccall((:crl_a2c_destroy, libcrl), Int32, (Ptr{Cvoid},), h[]))
+end
+
+# ------------------------------------------------------------------------------------------------------
+# dqn.jl — same names: DQNConfig keeps the reference's fields (dqn.jl:1-19); the loop body runs on the GPU
+# ------------------------------------------------------------------------------------------------------
+struct CrlDQNConfig       # include/cleanrl_hip.h crl_dqn_config
+  log_frequency::Int64; total_timesteps::Int64; buffer_size::Int64; min_buff_size::Int64
+  lr::Float64
+  train_freq::Int64; target_net_freq::Int64; batch_size::Int64
+  gamma::Float64; epsilon_start::Float64; epsilon_end::Float64; epsilon_duration::Float64
+  max_steps::Int32; pad::Int32
+  seed::UInt64
+end
+struct CrlDQNEpisode; episode_return::Float64; episode_length::Int64; global_step::Int64; epsilon::Float64; end   # dqn.jl:88
+struct CrlDQNLossRecord; global_step::Int64; loss::Float64; end                                                    # dqn.jl:116
+
+mutable struct DQNAgent
+  h::Ptr{Cvoid}
+end
+
+# q_net(obs) (dqn.jl:64) for observations (4, n) Float64 → (2, n) Float64
+function q_values(agent::DQNAgent, obs::AbstractMatrix{Float64})
+  o = Array(obs); n = size(o, 2); q = Matrix{Float64}(undef, 2, n)
+  GC.@preserve o q check(ccall((:crl_dqn_q_values, libcrl), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int32, Ptr{Float64}), agent.h, o, n, q))
+  q
+end
+
+# dqn.jl:34 — same signature; `config` is the reference's DQNConfig (note its field `log_frequencey`, sic), `params` =
+# vcat(vec.(Flux.params(q_net))...) of make_nn(env) (dqn.jl:22-26: 4 → 120 → 84 → 2, 10,934 parameters)
+function dqn(config; device=0, seed=UInt64(0x5EED), params::Vector{Float32}, chunk::Integer=10_000)
+  cfg = CrlDQNConfig(config.log_frequencey, config.total_timesteps, config.buffer_size, config.min_buff_size, config.lr,
+                     config.train_freq, config.target_net_freq, config.batch_size, config.gamma, config.epsilon_start,
+                     config.epsilon_end, config.epsilon_duration, 200, 0, seed)
+  h = Ref{Ptr{Cvoid}}(C_NULL)
+  check(ccall((:crl_dqn_create, libcrl), Int32, (Ref{CrlDQNConfig}, Int32, Ref{Ptr{Cvoid}}), cfg, device, h))
+  agent = DQNAgent(h[])
+  finalizer(x -> ccall((:crl_dqn_destroy, libcrl), Int32, (Ptr{Cvoid},), x.h), agent)
+  GC.@preserve params check(ccall((:crl_dqn_write_params, libcrl), Int32, (Ptr{Cvoid}, Ptr{Float32}, Csize_t), agent.h, params, length(params)))
+  eps = Vector{CrlDQNEpisode}(undef, 8192); losses = Vector{CrlDQNLossRecord}(undef, 4096)
+  n_eps = Ref{Int32}(0); n_losses = Ref{Int32}(0); taken = Ref{Int64}(0)
+  start_time = time(); global_step = 0
+  while global_step < config.total_timesteps
+    GC.@preserve eps losses check(ccall((:crl_dqn_run, libcrl), Int32,
+      (Ptr{Cvoid}, Int64, Ptr{CrlDQNEpisode}, Int32, Ref{Int32}, Ptr{CrlDQNLossRecord}, Int32, Ref{Int32}, Ref{Int64}),
+      agent.h, chunk, eps, length(eps), n_eps, losses, length(losses), n_losses, taken))
+    taken[] == 0 && break
+    global_step += taken[]
+    for e in @view eps[1:n_eps[]]
+      steps_per_sec = trunc(e.global_step / (time() - start_time))
+      @info "Episode Statistics" episode_return = e.episode_return episode_length = e.episode_length global_step = e.global_step steps_per_sec ϵ = e.epsilon
+    end
+    for l in @view losses[1:n_losses[]]
+      @info "Training Statistics" loss = l.loss global_step = l.global_step
+    end
+  end
+  agent
 end
 
 end # module
