@@ -152,3 +152,22 @@ def test_a2c_and_dqn_config_mirrors_follow_the_header(crl):
         for decl in re.findall(r"(?:int64_t|int32_t|double|uint64_t)\s+([a-z_, ]+);", body):
             names += [n.strip() for n in decl.split(",")]
         assert names == [n for n, _ in mirror._fields_], (cname, names)
+
+
+def test_julia_shell_structs_and_symbols_follow_the_header(crl):
+    """julia/CleanRLHip.jl cannot be executed here (no Julia in the image): at least its isbits mirrors must list the header's
+    fields in the header's order, and every symbol it `ccall`s must be one the library exports."""
+    jl = open(os.path.join(ROOT, "julia", "CleanRLHip.jl")).read()
+    L = crl._lib
+    for jname, mirror in (("CrlConfig", L.CrlConfig), ("CrlStats", L.CrlStats), ("CrlEpisodeStats", L.CrlEpisodeStats),
+                          ("CrlEpisodeRecord", L.CrlEpisodeRecord), ("CrlA2CConfig", L.CrlA2CConfig), ("CrlDQNConfig", L.CrlDQNConfig)):
+        m = re.search(r"struct %s\b(.*?)\bend" % jname, jl, re.S)
+        assert m, jname
+        body = re.sub(r"#.*", "", m.group(1))
+        names = re.findall(r"([A-Za-z_][A-Za-z_0-9]*)::", body)
+        assert names == [n for n, _ in mirror._fields_], (jname, names)
+    called = set(re.findall(r"ccall\(\(:(crl_[a-z_0-9]+),", jl))
+    assert called and called <= set(L.EXPORTS), called - set(L.EXPORTS)
+    for must in ("crl_comm_init", "crl_comm_unique_id", "crl_episode_ring_enable", "crl_episode_ring_read", "crl_dqn_run", "crl_dqn_q_values"):
+        assert must in called, must
+    assert "shuffle_mode=2" in jl     # exact blocked Fisher-Yates by default, like the ctypes mirror
