@@ -24,6 +24,16 @@ static int gemm_mode() {
 bool gemm_x3() { return gemm_mode() >= 1; }
 bool gemm_x2() { return gemm_mode() == 2; }
 
+// first guess of the fp16x2 weight-gradient scale (mlp_x2.hpp) before any launch has measured |δ2|: δ2 ∝ 1/M, times the
+// typical head weights (actor gain 0.01, critic gain 1) and cotangents; powers of 2^8 like every later value
+int reset_dw_scale(crl_ppo* h) {
+  const double lm = std::log2((double)h->dc.M * (double)h->world);
+  const int ka = 8 * (int)std::lround((lm + 19.0) / 8.0), kc = 8 * (int)std::lround((lm + 3.0) / 8.0);
+  const float init[4] = {std::ldexp(1.0f, ka), std::ldexp(1.0f, kc), 0.0f, 0.0f};
+  CRL_HIP_CHECK(hipMemcpy(h->dscale, init, sizeof(init), hipMemcpyHostToDevice));
+  return 0;
+}
+
 int ensure_stage(crl_ppo* h, size_t bytes) {
   if (h->stage_bytes >= bytes) return 0;
   if (h->stage) CRL_HIP_CHECK(hipFree(h->stage));
@@ -226,7 +236,7 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
   h->update_blocks = ub;
   if (!wide) { rc |= dalloc(&h->gpart, (size_t)4 * ub * h->Pa + 4096); rc |= dalloc(&h->lpart, (size_t)4 * ub * 2); }
   rc |= dalloc(&h->adv_sums_base, E * c.nmb * 2); rc |= dalloc(&h->adv_ms_base, E * c.nmb * 2);
-  rc |= dalloc(&h->newv, (size_t)c.M + 64); rc |= dalloc(&h->vfix, 8);
+  rc |= dalloc(&h->newv, (size_t)c.M + 64); rc |= dalloc(&h->vfix, 8); rc |= dalloc(&h->dscale, 4);
   rc |= dalloc(&h->stats_dev, (size_t)cfg->update_epochs * c.nmb);
   rc |= dalloc(&h->comm_buf, (size_t)h->P + 8);
   rc |= dalloc(&h->snap, (size_t)3 * h->P); rc |= dalloc(&h->snap_betap, 24);
@@ -234,6 +244,7 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
   { char* p = nullptr; rc |= dalloc(&p, h->snap_env_bytes); h->snap_env = p; }
   if (const char* e = getenv("CRL_DP_CHECK_EVERY")) { h->window_len = atoi(e); if (h->window_len < 1) h->window_len = 1; }
   if (rc) { crl_ppo_destroy(h); return 1; }
+  if (reset_dw_scale(h)) { crl_ppo_destroy(h); return 1; }
   select_slot(h, 0);
   if (wide && wide_create(h)) { crl_ppo_destroy(h); return 1; }
   double bp[24];
@@ -254,7 +265,7 @@ int32_t crl_ppo_destroy(crl_ppo* h) {
   void* ptrs[] = {h->obs, h->action, h->logprob, h->reward, h->terminal, h->value, h->adv, h->ret, h->env_state, h->env_t,
                   h->cur_obs, h->next_done, h->ep_return, h->ep_length, h->next_value, h->ep_stats, h->ep_ring, h->ep_ring_count, h->params,
                   h->adam_m, h->adam_v, h->betap, h->perm_base, h->recs, h->recs_p, h->adv_part, h->perm_tmp, h->bfy_ws, h->bfy_adv_part, h->gpart, h->lpart,
-                  h->adv_sums_base, h->adv_ms_base, h->newv, h->vfix, h->stats_dev, h->comm_buf, h->snap, h->snap_betap, h->snap_env, h->stage};
+                  h->adv_sums_base, h->adv_ms_base, h->newv, h->vfix, h->dscale, h->stats_dev, h->comm_buf, h->snap, h->snap_betap, h->snap_env, h->stage};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int k = 0; k < CRL_K_COUNT; ++k)
     for (auto& pr : h->prof_slots[k].pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -745,6 +756,7 @@ int32_t crl_comm_unique_id(uint8_t id[128]) { return comm_unique_id(id); }
 int32_t crl_comm_init(crl_ppo* h, const uint8_t id[128], int32_t world_size, int32_t rank) {
   CRL_GUARD(h);
   if (comm_init(h, id, world_size, rank)) return 1;
+  if (reset_dw_scale(h)) return 1;
   // num_updates = total_timesteps ÷ (global batch) (ppo.jl:89-91)
   const int64_t gb = (int64_t)h->dc.B * h->world;
   h->num_updates = h->cfg.total_timesteps / gb;
@@ -756,6 +768,7 @@ int32_t crl_comm_init_external(crl_ppo* h, int32_t world_size, int32_t rank) {
   CRL_GUARD(h);
   if (world_size < 1 || rank < 0 || rank >= world_size) { set_error("crl_comm_init_external: bad world/rank"); return 1; }
   h->world = world_size; h->rank = rank; h->external_comm = true;
+  if (reset_dw_scale(h)) return 1;
   const int64_t gb = (int64_t)h->dc.B * h->world;
   h->num_updates = h->cfg.total_timesteps / gb;
   if (h->num_updates < 1) h->num_updates = 1;

@@ -13,7 +13,8 @@
 //     kernel raise an error flag instead of computing (CRL_GEMM=x3 is the fallback flavour);
 //   * backward cotangents δ: any magnitude — each SAMPLE (= lane: the N index of the product) is scaled by its own power of
 //     two, taken from the largest |δ| of that sample, and unscaled after the product (a per-column scale commutes with A·B).
-// The weight-gradient product sums over samples (K = samples), where a per-sample scale does not commute: it stays on bf16x3.
+// The weight-gradient product sums over samples (K = samples), where a per-sample scale does not commute: it takes ONE scale
+// per launch, predicted from the previous launch and checked per tile, with bf16x3 as the in-kernel fallback (end of file).
 #pragma once
 #include "common.hpp"
 #include "mlp_x3.hpp"
@@ -194,9 +195,9 @@ __device__ __forceinline__ void mlp_forward_x2(const float* img, const float (&x
 }
 
 // Per-sample power-of-two scale for a cotangent tile in C-fragment registers (lane = sample, both lane halves hold rows of
-// the same sample): s = 2^(14 − ⌈exponent of the sample's largest |δ|⌉), exact; inv = 1 / s.
-__device__ __forceinline__ void sample_scale(const f32x16 (&d)[2], float& s, float& inv) {
-  float m = 0.0f;
+// the same sample): s = 2^(14 − ⌈exponent of the sample's largest |δ|⌉), exact; inv = 1 / s; m = that largest |δ|.
+__device__ __forceinline__ void sample_scale(const f32x16 (&d)[2], float& s, float& inv, float& m) {
+  m = 0.0f;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -206,6 +207,40 @@ __device__ __forceinline__ void sample_scale(const f32x16 (&d)[2], float& s, flo
   e = e < 16 ? 16 : e;                                   // zero / tiny columns: any scale will do
   s = __uint_as_float((unsigned)(268 - e) << 23);        // 2^(141 − e): m·s in [2^14, 2^15)
   inv = __uint_as_float((unsigned)(e - 14) << 23);       // 2^(e − 141)
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Weight-gradient product dW2ᵀ += h1·δ2ᵀ (K = samples) on fp16x2. A per-sample scale does not commute with a sum over
+// samples, and the accumulators live across all tiles of a launch, so δ2 gets ONE power of two G per launch and role. G is
+// carried from launch to launch on the device: every launch records the largest |δ2| it saw, the reduce kernel turns it
+// into the next launch's G (largest·G ≈ 2^8, exponent quantised to multiples of 8 so that it rarely changes). G is a
+// prediction, so every tile checks it: if one of its samples would overflow (|δ2|·G ≥ 2^15.5) or all of them sit below the
+// window (|δ2|·G < 2^-6) the tile takes the bf16x3 path instead — same operands, same scale, no range limits — a
+// wave-uniform branch. Nothing depends on the prediction being right; a wrong one only costs speed.
+// ------------------------------------------------------------------------------------------------------
+constexpr float X2_DW_OVER = 46340.0f;        // ≈ 2^15.5
+constexpr float X2_DW_SMALL = 0.015625f;      // 2^-6
+
+__device__ __forceinline__ bool dw_tile_fits(float m, float G) {
+  const float v = m * G;
+  const bool over = !(v < X2_DW_OVER);        // also catches NaN
+  const bool notsmall = v >= X2_DW_SMALL;
+  return __builtin_amdgcn_ballot_w64(over) == 0 && __builtin_amdgcn_ballot_w64(notsmall) != 0;
+}
+
+// next launch's G from the largest |δ2| of this one (bits of a non-negative float order like unsigned integers). G is
+// sticky: it stays as long as largest·G sits in [2^0, 2^13] and is re-centred (largest·G ≈ 2^8, exponent a multiple of 8)
+// only when the data have moved out of that band — so consecutive launches on similar data use the same G and the same
+// inputs give bit-identical gradients (a different G changes which elements touch fp16's subnormal floor).
+__device__ __forceinline__ float dw_next_scale(unsigned max_bits, float G_old) {
+  if (max_bits == 0) return G_old;
+  const float v = __uint_as_float(max_bits) * G_old;
+  if (v >= 1.0f && v <= 8192.0f) return G_old;
+  const int e = (int)((max_bits >> 23) & 0xFFu) - 127;    // largest in [2^e, 2^(e+1))
+  int k = 8 - e;                                           // largest·2^k in [2^8, 2^9)
+  k = (k >= 0 ? (k + 4) / 8 : -((-k + 4) / 8)) * 8;        // exponent quantised to a multiple of 8
+  k = k < -100 ? -100 : (k > 100 ? 100 : k);
+  return __uint_as_float((unsigned)(k + 127) << 23);
 }
 
 }  // namespace crl

@@ -103,7 +103,8 @@ struct crl_ppo {
   double* adv_ms_base = nullptr;    // [update_epochs][nmb][2] mean, std
   double* adv_ms = nullptr;         // current slot
   float* newv = nullptr;       // [M] critic outputs of the current minibatch (value-loss fix-up path)
-  double* vfix = nullptr;      // [8] u, count(u>q), -, flag, sticky flag
+  double* vfix = nullptr;      // [8] u, count(u>q), -, flag, sticky flag, fp16x2 weight-range error
+  float* dscale = nullptr;     // [4] fp16x2 weight-gradient scale per role + the running largest |δ2| (mlp_x2.hpp)
   crl_ppo_stats* stats_dev = nullptr;  // [epochs*nmb]
   float* comm_buf = nullptr;   // [P + 8] gradient (+ loss scalars) message for the all-reduce
   // Data-parallel guard window (Q4): parameters / Adam state / env state at the start of a window of iterations; the sticky
@@ -140,6 +141,7 @@ inline uint64_t shuffle_seed(const crl_ppo* h) {
 void select_slot(crl_ppo* h, int slot);
 int ensure_records(crl_ppo* h);
 int ensure_stage(crl_ppo* h, size_t bytes);
+int reset_dw_scale(crl_ppo* h);
 // CRL_GEMM: x2 (default) = fp16x2 forward / backward-data products in the update kernel + bf16x3 everywhere else
 // (mlp_x2.hpp); x3 = bf16x3 only (mlp_x3.hpp); f32 = the v_mfma_f32_32x32x2_f32 layers
 bool gemm_x3();   // true for x2 and x3

@@ -28,6 +28,7 @@ __device__ __forceinline__ void compute_stats(const float* msg, int P, const Dev
 struct StatsArgs {
   DevCfg c; double Mglobal; const double* adv_ms; int mb; double* vfix; crl_ppo_stats* out;
   int fused;  // 1: the last block of reduce_kernel also writes the statistics (single-GPU: sums are already global)
+  float* dscale;   // [4]: G actor, G critic, then (as unsigned) the launch's largest |δ2| per role — fp16x2 weight gradient
 };
 
 }  // namespace crl

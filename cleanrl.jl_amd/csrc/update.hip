@@ -137,6 +137,8 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
   // through the backward pass — spills — for no measurable gain once the gather through the permutation was gone.)
   int tile = rb * RW + wave;
   Gathered<D> cur;
+  const float Gdw = X2 ? sgpr(a.dscale[ROLE]) : 1.0f;   // fp16x2 weight-gradient scale of this launch (mlp_x2.hpp)
+  float d2run = 0.0f;
   if (!in_range) {   // a hidden-layer weight does not fit the fp16x2 window: compute nothing, tell the host (crl_sync / stats)
     if (tid == 0 && rb == 0) a.range_err[0] = 1.0;
     tile = ntiles;
@@ -289,6 +291,7 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
     }
     // (4) dh1 = W2ᵀ·δ2 (A-fragments of W2ᵀ from LDS, B = δ2 registers); δ1 = dh1 ⊙ (1 − h1²)
     f32x16 d1[2];
+    float d2max = 0.0f;   // fp16x2: this sample's largest |δ2|
     {
       f32x16 c0, c1;
 #pragma unroll
@@ -299,7 +302,8 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
       } else if constexpr (X2) {
         // each sample's cotangent column scaled by its own power of two into the fp16 window, unscaled below
         float sc, sinv;
-        sample_scale(d2, sc, sinv);
+        sample_scale(d2, sc, sinv, d2max);
+        d2run = __builtin_fmaxf(d2run, d2max);
         f32x16 ds[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -409,7 +413,31 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
 #pragma unroll
       for (int r = 0; r < 16; ++r) T[(32 * mt + rowmap(r, hf)) * TSTRIDE + j] = h1[mt][r];
     CRL_PHASE();
-    if constexpr (X3) {
+    if (X2 && dw_tile_fits(d2max, Gdw)) {
+      if constexpr (X2) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          P2 ap[2], bp[2];
+#pragma unroll
+          for (int mj = 0; mj < 2; ++mj) {
+            const f32x4* fr = reinterpret_cast<const f32x4*>(T + (32 * mj + j) * TSTRIDE + 16 * ks + 8 * hf);
+            const f32x4 f0 = fr[0], f1 = fr[1];
+            const float xa[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+            ap[mj] = split2(xa);
+          }
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            const f32x4 f0 = braw[ni][ks][0], f1 = braw[ni][ks][1];
+            const float xb[8] = {f0[0] * Gdw, f0[1] * Gdw, f0[2] * Gdw, f0[3] * Gdw, f1[0] * Gdw, f1[1] * Gdw, f1[2] * Gdw, f1[3] * Gdw};
+            bp[ni] = split2(xb);
+          }
+          dW2t[0][0] = mfma_x2(ap[0], bp[0], dW2t[0][0]);
+          dW2t[0][1] = mfma_x2(ap[0], bp[1], dW2t[0][1]);
+          dW2t[1][0] = mfma_x2(ap[1], bp[0], dW2t[1][0]);
+          dW2t[1][1] = mfma_x2(ap[1], bp[1], dW2t[1][1]);
+        }
+      }
+    } else if constexpr (X3) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         P3 ap[2];
@@ -424,7 +452,7 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
           const f32x4 f0 = braw[ni][ks][0], f1 = braw[ni][ks][1];
-          const float xb[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+          const float xb[8] = {f0[0] * Gdw, f0[1] * Gdw, f0[2] * Gdw, f0[3] * Gdw, f1[0] * Gdw, f1[1] * Gdw, f1[2] * Gdw, f1[3] * Gdw};
           bp[ni] = split3(xb);
         }
         dW2t[0][0] = mfma_x3(ap[0], bp[0], dW2t[0][0]);
@@ -450,6 +478,14 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
     }
   }
 
+  // fp16x2: the weight-gradient accumulators carry 2^14 (h1) · G (δ2); the launch's largest |δ2| goes to the next launch's G
+  const float dw_unscale = X2 ? (1.0f / X2_ACT_SCALE) / Gdw : 1.0f;
+  if constexpr (X2) {
+    float m = d2run;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0 && m > 0.0f) atomicMax(a.dmax + ROLE, __float_as_uint(m));
+  }
   // ---- block reduction: waves add their accumulators into one LDS image in flat Flux order ------------------
   if constexpr (LACC) {
     wave_lds_fence();
@@ -471,7 +507,7 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            R[P::W2 + (32 * ni + j) + H * (32 * mj + rowmap(r, hf))] += dW2t[mj][ni][r] * (X2 ? 1.0f / X2_ACT_SCALE : 1.0f);
+            R[P::W2 + (32 * ni + j) + H * (32 * mj + rowmap(r, hf))] += dW2t[mj][ni][r] * dw_unscale;
 #pragma unroll
       for (int i = 0; i < D; ++i) R[P::W1 + lane + H * i] += racc[i];
       R[P::B1 + lane] += racc[K_B1];
@@ -609,6 +645,12 @@ __global__ void __launch_bounds__(64 * RG) reduce_kernel(const float* __restrict
     for (int q = 1; q < RG; ++q) t += smd[q][o];
     msg[P + o] = (float)t;
   }
+  if (MODE == 0 && last && st.dscale && threadIdx.x < 2) {
+    // fp16x2 weight gradient: this launch's largest |δ2| becomes the next launch's scale (mlp_x2.hpp), per role
+    unsigned* mx = reinterpret_cast<unsigned*>(st.dscale + 2);
+    st.dscale[threadIdx.x] = dw_next_scale(mx[threadIdx.x], st.dscale[threadIdx.x]);
+    mx[threadIdx.x] = 0u;
+  }
   if (last && st.fused) {
     __syncthreads();  // the four sums written above are visible to thread 0 of this block
     if (threadIdx.x == 0) compute_stats(msg, P, st.c, st.Mglobal, st.adv_ms, st.mb, st.vfix, st.out, MODE);
@@ -669,6 +711,7 @@ static int run_update(crl_ppo* h, int mb, int mode, hipEvent_t ev0 = nullptr, hi
   a.c = h->dc; a.params = h->params;
   a.recs = h->recs_p + (size_t)h->cur_slot * h->dc.B + (size_t)mb * h->dc.M; a.adv_ms = h->adv_ms; a.vfix = h->vfix;
   a.gpart = h->gpart; a.lpart = h->lpart; a.newv = h->newv; a.range_err = h->vfix + 5;
+  a.dscale = h->dscale; a.dmax = reinterpret_cast<unsigned*>(h->dscale + 2);
   a.mb = mb; a.mode = mode; a.gstride = (int)h->Pa; a.pmax = h->update_blocks; a.stagger = 0;
   a.Mglobal = (double)h->dc.M * h->world;
   if (mode == 1) {
@@ -713,6 +756,7 @@ static StatsArgs stats_args(crl_ppo* h, int mb, crl_ppo_stats* slot, int fused) 
   StatsArgs st;
   st.c = h->dc; st.Mglobal = (double)h->dc.M * h->world; st.adv_ms = h->adv_ms; st.mb = mb; st.vfix = h->vfix; st.out = slot;
   st.fused = fused;
+  st.dscale = gemm_x2() ? h->dscale : nullptr;
   return st;
 }
 

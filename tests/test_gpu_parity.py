@@ -544,6 +544,9 @@ def test_full_size_update_is_deterministic_and_additive(crl):
     h = agent.handle; F = crl._lib
     h.env_reset(); h.rollout_run(); h.compute_gae(); h.shuffle(1); h.adv_stats()
     p0 = h.read(F.F_PARAMS)
+    # one launch first: the fp16x2 weight-gradient scale (mlp_x2.hpp) is predicted from the previous launch and settles here;
+    # with the scale settled, the same inputs must give the same bits
+    h.update_minibatch(1, 0.0, apply_update=False, want_stats=False)
     s1 = h.update_minibatch(1, 0.0, apply_update=True); g1 = h.read(F.F_GRADS)
     assert np.array_equal(h.read(F.F_PARAMS), p0)
     s2 = h.update_minibatch(1, 0.0, apply_update=False); g2 = h.read(F.F_GRADS)
