@@ -275,8 +275,9 @@ def main():
         gemm = os.environ.get("CRL_GEMM", "x2")
         x3 = gemm != "f32"
         # matrix-pipe products issued per f32 product of the three hidden-layer GEMMs (forward, backward-data, weight gradient):
-        # x2 = fp16x2 (3) for forward / backward-data + bf16x3 (6) for the weight gradient; x3 = bf16x3 everywhere; C3 runs bf16x3
-        issue_factor = 1.0 if not x3 else (6.0 if (gemm == "x3" or c3) else (3 + 3 + 6) / 3.0)
+        # x2 = fp16x2: 3 (a tile whose cotangents fall outside the launch's scale window takes bf16x3 for its weight gradient: 6);
+        # x3 = bf16x3 everywhere: 6; C3 (wide.hip) runs bf16x3
+        issue_factor = 1.0 if not x3 else (6.0 if (gemm == "x3" or c3) else 3.0)
         # share of the algorithmic flops that runs as 64x64 (256x256) products = what goes to the matrix pipe
         hh = 2 * 2 * 64 * 64 if not c3 else 2 * 2 * 256 * 256
         mfma_share = hh / fwd_flops
@@ -310,7 +311,7 @@ def main():
                        "shuffle": args.shuffle,
                        "gemm": ("v_mfma_f32_32x32x2_f32" if not x3 else
                                 "f32 results via bf16x3 split products on the bf16 matrix pipe" if issue_factor == 6.0 else
-                                "f32 results via fp16x2 (forward, backward-data) and bf16x3 (weight gradient) split products on the f16/bf16 matrix pipe")},
+                                "f32 results via fp16x2 split products (3 per f32 product) on the f16 matrix pipe")},
             "roofline": {"bound": "mfma",
                          "kernel": "update kernel (fwd+bwd of one minibatch, actor+critic)" if not c3 else
                                    "wide.hip: all forward/backward launches of one minibatch (HIP events around the group)",
