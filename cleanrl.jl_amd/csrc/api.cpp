@@ -487,13 +487,13 @@ int32_t crl_compute_gae(crl_ppo* h) {
 }
 
 static int check_bfy(crl_ppo* h) {
-  if (!h->wide && gemm_x2()) {
+  if ((!h->wide && gemm_x2()) || wide_x2_active(h)) {
     double re = 0.0;
-    CRL_HIP_CHECK(hipMemcpyAsync(&re, h->vfix + 5, sizeof(re), hipMemcpyDeviceToHost, h->stream));
+    CRL_HIP_CHECK(hipMemcpyAsync(&re, h->vfix + (h->wide ? 6 : 5), sizeof(re), hipMemcpyDeviceToHost, h->stream));
     CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
     if (re != 0.0) {
       set_error("a hidden-layer weight reached |w| >= 255: outside the fp16x2 window of the update kernel (mlp_x2.hpp); "
-                "results since the last check are invalid — rerun with CRL_GEMM=x3");
+                "results since the last check are invalid — rerun with CRL_GEMM=x3 (CRL_WIDE_GEMM=x3 on the layer-wise path)");
       return 1;
     }
   }

@@ -191,6 +191,7 @@ bool wide_shape_ok(const crl_ppo_config* cfg, std::string* why);
 int wide_create(crl_ppo* h);
 void wide_destroy(crl_ppo* h);
 void wide_mark_params_changed(crl_ppo* h);
+bool wide_x2_active(const crl_ppo* h);
 int wide_policy_act(crl_ppo* h, const float* obs_d, const double* u_d, int n, int32_t* action_d, float* logprob_d, float* value_d);
 int wide_logprob_actions(crl_ppo* h, const float* obs_d, const int32_t* act_d, int n, float* logprob_d, float* ent_d);
 int wide_next_value(crl_ppo* h);

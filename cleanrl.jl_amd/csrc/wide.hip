@@ -19,6 +19,7 @@
 
 #include "common.hpp"
 #include "env.hpp"
+#include "mlp_x2.hpp"
 #include "mlp_x3.hpp"
 #include "ppo_ctx.hpp"
 #include "stats.hpp"
@@ -35,14 +36,17 @@ enum { EPI_TANH = 0, EPI_BIAS = 1, EPI_DTANH = 2, EPI_STORE = 3 };
 // ------------------------------------------------------------------------------------------------------
 // Workspace
 // ------------------------------------------------------------------------------------------------------
-struct WideNetPack { int w1, w3, w2t, w3t, x3f, x3b, size; };  // float offsets of the packed weight copies of one network
+struct WideNetPack { int w1, w3, w2t, w3t, x3f, x3b, x2f, x2b, wmax, size; };  // float offsets of the packed weight copies of one network
 constexpr int X3_SLAB_BF16 = 3 * 2 * 8 * 64 * 8;   // one 32-k slab of a 256-row matrix as bf16x3 A-fragments: [piece][kstep][ntile][lane][8]
+constexpr int X2_SLAB_F16 = 2 * 2 * 8 * 64 * 8;    // the same slab as fp16x2 A-fragments of W·2^8 (mlp_x2.hpp)
 static inline WideNetPack pack_layout(int H, int D8, int O8) {
   WideNetPack p;
   p.w1 = 0; p.w3 = p.w1 + H * D8; p.w2t = p.w3 + 32 * H; p.w3t = p.w2t + H * H;
   p.x3f = p.w3t + H * O8;
   const int x3 = H == 256 ? (H / 32) * X3_SLAB_BF16 / 2 : 0;   // floats
-  p.x3b = p.x3f + x3; p.size = p.x3b + x3;
+  p.x3b = p.x3f + x3;
+  const int x2 = H == 256 ? (H / 32) * X2_SLAB_F16 / 2 : 0;    // floats
+  p.x2f = p.x3b + x3; p.x2b = p.x2f + x2; p.wmax = p.x2b + x2; p.size = p.wmax + AMAX;
   return p;
 }
 
@@ -127,6 +131,7 @@ int wide_create(crl_ppo* h) {
   return 0;
 }
 
+bool wide_x2_active(const crl_ppo* h);
 void wide_mark_params_changed(crl_ppo* h) {
   if (h->wide_ws) static_cast<WideWs*>(h->wide_ws)->pack_dirty = true;
 }
@@ -173,11 +178,53 @@ __global__ void __launch_bounds__(256) wide_pack_x3_kernel(const float* __restri
   reinterpret_cast<bf16x8*>(dst)[2 * 1024 + fr] = p3.lo;
 }
 
-static bool wide_x3() {   // CRL_WIDE_GEMM=f32 keeps every GEMM on v_mfma_f32_32x32x2_f32
-  static int mode = -1;
-  if (mode < 0) { const char* e = getenv("CRL_WIDE_GEMM"); mode = (e && std::string(e) == "f32") ? 0 : 1; }
-  return mode == 1;
+// fp16x2 A-fragments of W2·2^8 / W2ᵀ·2^8 (same fragment order as wide_pack_x3_kernel, two pieces); a weight that does not
+// fit the fp16 window (|w| ≥ 255) raises *range_err (checked by the host at its next synchronisation)
+__global__ void __launch_bounds__(256) wide_pack_x2_kernel(const float* __restrict__ params, float* __restrict__ pack, int pbase,
+                                                          int kbase, WideNetPack pk, double* range_err) {
+  constexpr int H = 256;
+  const int t = blockIdx.x * 256 + threadIdx.x;          // (dir, s, kstep, ntile, lane)
+  if (t >= 2 * 8 * 2 * 8 * 64) return;
+  const int lane = t & 63, ntile = (t >> 6) & 7, kstep = (t >> 9) & 1, sl = (t >> 10) & 7, dir = t >> 13;
+  const int n = 32 * ntile + (lane & 31), k0 = 32 * sl + 16 * kstep + 8 * (lane >> 5);
+  float x[8];
+  const float* W = params + pbase;
+  bool bad = false;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float w = dir ? W[(k0 + e) + H * n] : W[n + H * (k0 + e)];
+    bad |= !(__builtin_fabsf(w) < X2_W_LIMIT);
+    x[e] = w * X2_W_SCALE;
+  }
+  if (bad) *range_err = 1.0;
+  const P2 p2 = split2(x);
+  _Float16* dst = reinterpret_cast<_Float16*>(pack + kbase + (dir ? pk.x2b : pk.x2f)) + (size_t)sl * X2_SLAB_F16;
+  const int fr = (kstep * 8 + ntile) * 64 + lane;
+  reinterpret_cast<f16x8*>(dst)[0 * 1024 + fr] = p2.hi;
+  reinterpret_cast<f16x8*>(dst)[1 * 1024 + fr] = p2.lo;
 }
+// wmax[a] = max_k |W3[a, k]|: with it Σ_a |δ3[a, m]|·wmax[a] bounds every |δ2[k, m]| of a sample — the per-sample (backward-
+// data) and per-chunk (weight-gradient) fp16x2 scales come from this bound, no pass over δ2 needed
+__global__ void __launch_bounds__(64) wide_wmax_kernel(const float* __restrict__ W3, int NO, int H, float* __restrict__ wmax) {
+  for (int a = 0; a < AMAX; ++a) {
+    float m = 0.0f;
+    if (a < NO) for (int k = threadIdx.x; k < H; k += 64) m = __builtin_fmaxf(m, __builtin_fabsf(W3[a + NO * k]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
+    if (threadIdx.x == 0) wmax[a] = m;
+  }
+}
+
+// CRL_WIDE_GEMM: x2 (default) = 256-wide GEMMs as fp16x2 (three f16 MFMAs per product), x3 = bf16x3 (six), f32 = every GEMM
+// on v_mfma_f32_32x32x2_f32
+static int wide_gemm_mode() {
+  static int mode = -1;
+  if (mode < 0) { const char* e = getenv("CRL_WIDE_GEMM"); const std::string v = e ? e : "x2"; mode = v == "f32" ? 0 : v == "x3" ? 1 : 2; }
+  return mode;
+}
+static bool wide_x3() { return wide_gemm_mode() >= 1; }   // a split-product flavour (x2 or x3)
+static bool wide_x2() { return wide_gemm_mode() == 2; }
+bool wide_x2_active(const crl_ppo* h) { return h->wide && h->cfg.hidden == 256 && wide_x2(); }
 
 static bool wide_x3_fused_head() {   // CRL_WIDE_FUSE_HEAD=0 keeps the heads as their own (padded-MFMA) launches
   static int mode = -1;
@@ -195,9 +242,15 @@ static int ensure_pack(crl_ppo* h) {
     const int NO = n ? 1 : w->A, O8 = n ? 8 : w->A8;
     hipLaunchKernelGGL(wide_pack_kernel, dim3((w->pk[n].x3f + 255) / 256), dim3(256), 0, h->stream, h->params, w->pack, w->H, w->D,
                        w->D8, NO, O8, n ? (int)h->Pa : 0, w->pk_base[n], w->pk[n]);
-    if (w->H == 256)
+    if (w->H == 256) {
       hipLaunchKernelGGL(wide_pack_x3_kernel, dim3(2 * 8 * 2 * 8 * 64 / 256), dim3(256), 0, h->stream, h->params, w->pack,
                          (n ? (int)h->Pa : 0) + w->H * w->D + w->H, w->pk_base[n], w->pk[n]);
+      hipLaunchKernelGGL(wide_pack_x2_kernel, dim3(2 * 8 * 2 * 8 * 64 / 256), dim3(256), 0, h->stream, h->params, w->pack,
+                         (n ? (int)h->Pa : 0) + w->H * w->D + w->H, w->pk_base[n], w->pk[n], h->vfix + 6);
+    }
+    hipLaunchKernelGGL(wide_wmax_kernel, dim3(1), dim3(64), 0, h->stream,
+                       h->params + (n ? (int)h->Pa : 0) + w->H * w->D + w->H + w->H * w->H + w->H, NO, w->H,
+                       w->pack + w->pk_base[n] + w->pk[n].wmax);
   }
   CRL_HIP_CHECK(hipGetLastError());
   w->pack_dirty = false;
@@ -450,6 +503,8 @@ struct DenseX3Args {
   // optional virtual input (EPI_DTANH): X holds h2 and the operand is formed on the fly as δ2 = (W3ᵀ·δ3) ⊙ (1 − h2²) from
   // the head cotangent dZ[·, m] (ld ldd, zero-padded) — the [256 × M] δ2 array is never written or read
   const float* dZ; int ldd; int Ad;      // dZ null = X is the operand itself; Ad = live rows of dZ
+  // fp16x2 backward-data (wide_dense_x2_kernel<EPI_DTANH>): the head cotangent and wmax, from which each sample's scale comes
+  const float* bz; int bld; int bA; const float* wmax;
 };
 constexpr int X3ROW = 40;                // bf16 per staged sample row per piece: 32 k + 8 pad (80 B: conflict-free b128)
 
@@ -467,13 +522,13 @@ __device__ __forceinline__ void split3x4(const f32x4 v, uint2& h, uint2& m, uint
 // the C fragment (lane = sample, registers = rows): hp[m_local][a] += Σ_{n in tile} W3[a, n]·tanh(acc + b)[n, m]. One
 // cross-half exchange per output instead of a lane reduction; the tile is then stored line-coalesced by tile_out.
 __device__ __forceinline__ void tile_tanh_head(float* scr, f32x16 acc, int lane, int n0, int mloc0, int mbase, int M,
-                                               const float* bias, float* Y, const float* W3t, int A, float* hp, int hs) {
+                                               const float* bias, float* Y, const float* W3t, int A, float* hp, int hs, float cs = 1.0f) {
   const int j = lane & 31, hf = lane >> 5;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0 + 8 * g + 4 * hf);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[4 * g + e] = tanh_fast(acc[4 * g + e] + bv[e]);
+    for (int e = 0; e < 4; ++e) acc[4 * g + e] = tanh_fast(__builtin_fmaf(acc[4 * g + e], cs, bv[e]));
   }
   for (int aa = 0; aa < A; ++aa) {
     float p = 0.0f;
@@ -648,6 +703,193 @@ static int dense_x3_launch(hipStream_t st, const DenseX3Args& a) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The 256×256 hidden GEMMs as fp16x2 (mlp_x2.hpp): the structure of wide_dense_x3_kernel with two half-precision pieces
+// per operand and three MFMAs per product. Scales are exact powers of two:
+//   forward (EPI_TANH):      X = h1 ∈ (−1, 1) scaled by 2^14 while it is split; the accumulator holds 2^22·(W·h1) and the
+//                            epilogue multiplies by 2^-22 before the bias and the tanh;
+//   backward-data (EPI_DTANH): X = δ2 — each sample (column) scaled by 2^(14 − ⌈log2 bound⌉) with
+//                            bound = Σ_a |δ3[a, m]|·max_k |W3[a, k]| ≥ max_k |δ2[k, m]| (no pass over δ2); the epilogue
+//                            applies the inverse (and the weights' 2^-8) per sample.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split2x4(const f32x4 v, float s, uint2& h, uint2& l) {
+  f32x2 a, b; a[0] = v[0] * s; a[1] = v[1] * s; b[0] = v[2] * s; b[1] = v[3] * s;
+  const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
+  f32x2 ra, rb; ra[0] = a[0] - (float)ha[0]; ra[1] = a[1] - (float)ha[1]; rb[0] = b[0] - (float)hb[0]; rb[1] = b[1] - (float)hb[1];
+  const f16x2 la = __builtin_convertvector(ra, f16x2), lb = __builtin_convertvector(rb, f16x2);
+  h = make_uint2(__builtin_bit_cast(uint32_t, ha), __builtin_bit_cast(uint32_t, hb));
+  l = make_uint2(__builtin_bit_cast(uint32_t, la), __builtin_bit_cast(uint32_t, lb));
+}
+// 2^(14 − e), 2^(e − 14) for bound in [2^e, 2^(e+1)) (bound = 0 or tiny: any scale will do)
+__device__ __forceinline__ void pow2_scale(float bound, float& s, float& inv) {
+  int e = (int)((__float_as_uint(bound) >> 23) & 0xFFu);
+  e = e < 16 ? 16 : (e > 250 ? 250 : e);
+  s = __uint_as_float((unsigned)(268 - e) << 23);
+  inv = __uint_as_float((unsigned)(e - 14) << 23);
+}
+// one accumulator tile through the wave's LDS scratch and out with whole 128-B lines (tile_out) with the fp16x2 unscale:
+// EPI_TANH: tanh(acc·cs + bias); EPI_DTANH: acc·inv[sample]·cs·(1 − S²)
+template <int EPI>
+__device__ __forceinline__ void tile_out_x2(float* scr, const f32x16& acc, int lane, int n0, int mloc0, int mbase, int M, const float* bias,
+                                            const float* S, float* Y, float cs, const float* inv_lds) {
+  const int j = lane & 31, hf = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 o; o[0] = acc[4 * g]; o[1] = acc[4 * g + 1]; o[2] = acc[4 * g + 2]; o[3] = acc[4 * g + 3];
+    *reinterpret_cast<f32x4*>(scr + j * 36 + 8 * g + 4 * hf) = o;
+  }
+  wave_lds_fence();
+  const int c = lane & 7, n = n0 + 4 * c;
+  f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (EPI == EPI_TANH) bv = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int m = (lane >> 3) + 8 * it, gm = mbase + m;
+    f32x4 v = *reinterpret_cast<const f32x4*>(scr + m * 36 + 4 * c);
+    if (gm < M) {
+      if (EPI == EPI_DTANH) {
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(S + (size_t)256 * gm + n);
+        const float f = inv_lds[mloc0 + m] * cs;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (v[e] * f) * (1.0f - sv[e] * sv[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = tanh_fast(__builtin_fmaf(v[e], cs, bv[e]));
+      }
+      *reinterpret_cast<f32x4*>(Y + (size_t)256 * gm + n) = v;
+    }
+  }
+  wave_lds_fence();
+}
+
+template <int EPI, int TM>
+__global__ void __launch_bounds__(512) wide_dense_x2_kernel(DenseX3Args a) {
+  constexpr int NW = 8, NT = 512, MB = 32 * TM;
+  constexpr int WR = X2_SLAB_F16 * 2 / 16 / NT;                // 16-B pieces of the W slab per thread (4)
+  constexpr int XR = (MB * 8 + NT - 1) / NT;                   // float4 pieces of the X slab per thread
+  extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
+  _Float16* Wl = reinterpret_cast<_Float16*>(smx);             // one slab of A-fragments (32 KB)
+  _Float16* Xl = Wl + X2_SLAB_F16;                             // [piece][MB][X3ROW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hf = lane >> 5;
+  const int m0 = blockIdx.x * MB;
+  // [MB] scale | [MB] inverse of the block's samples, behind everything the staging loop and the epilogue use
+  constexpr int SC_OFF = (X2_SLAB_F16 * 2 + 2 * MB * X3ROW * 2 > NW * 32 * 36 * 4 ? X2_SLAB_F16 * 2 + 2 * MB * X3ROW * 2 : NW * 32 * 36 * 4);
+  float* sc = reinterpret_cast<float*>(smx + SC_OFF);
+  if (EPI == EPI_DTANH) {
+    for (int t = tid; t < MB; t += NT) {
+      const int m = m0 + t;
+      float bound = 0.0f;
+      if (m < a.M)
+        for (int q2 = 0; q2 < a.bA; ++q2) bound = __builtin_fmaf(__builtin_fabsf(a.bz[(size_t)a.bld * m + q2]), a.wmax[q2], bound);
+      float s1, i1;
+      pow2_scale(bound, s1, i1);
+      sc[t] = s1; sc[MB + t] = i1;
+    }
+    __syncthreads();
+  }
+  f32x16 acc[TM];
+#pragma unroll
+  for (int y = 0; y < TM; ++y)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[y][r] = 0.0f;
+  const u32x4v* wsrc = reinterpret_cast<const u32x4v*>(a.Wx3) + tid;
+  const f32x4* xsrc[XR]; bool xok[XR]; float xs[XR];
+#pragma unroll
+  for (int u = 0; u < XR; ++u) {
+    const int i = tid + NT * u, mm = i >> 3, q = i & 7, m = m0 + mm;
+    xok[u] = (i < MB * 8) && (m < a.M);
+    xsrc[u] = reinterpret_cast<const f32x4*>(a.X + (size_t)(xok[u] ? m : 0) * a.K) + q;
+    xs[u] = EPI == EPI_DTANH ? sc[i < MB * 8 ? mm : 0] : X2_ACT_SCALE;
+  }
+  u32x4v wr[WR]; f32x4 xr[XR];
+  const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int u = 0; u < WR; ++u) wr[u] = wsrc[NT * u];
+#pragma unroll
+  for (int u = 0; u < XR; ++u) xr[u] = xok[u] ? xsrc[u][0] : zero4;
+  const int nslab = a.K >> 5;
+  for (int sl = 0; sl < nslab; ++sl) {
+    if (sl) __syncthreads();
+#pragma unroll
+    for (int u = 0; u < WR; ++u) reinterpret_cast<u32x4v*>(Wl)[tid + NT * u] = wr[u];
+#pragma unroll
+    for (int u = 0; u < XR; ++u) {
+      const int i = tid + NT * u, mm = i >> 3, q = i & 7;
+      if (i < MB * 8) {
+        uint2 hh, ll;
+        split2x4(xr[u], xs[u], hh, ll);
+        *reinterpret_cast<uint2*>(Xl + (0 * MB + mm) * X3ROW + 4 * q) = hh;
+        *reinterpret_cast<uint2*>(Xl + (1 * MB + mm) * X3ROW + 4 * q) = ll;
+      }
+    }
+    __syncthreads();
+    if (sl + 1 < nslab) {
+#pragma unroll
+      for (int u = 0; u < WR; ++u) wr[u] = wsrc[(size_t)(sl + 1) * (X2_SLAB_F16 / 8) + NT * u];
+#pragma unroll
+      for (int u = 0; u < XR; ++u) xr[u] = xok[u] ? xsrc[u][(sl + 1) * 8] : zero4;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      P2 af, bf[TM];
+      const int fr = (ks * 8 + wave) * 64 + lane;
+      af.hi = reinterpret_cast<const f16x8*>(Wl)[0 * 1024 + fr];
+      af.lo = reinterpret_cast<const f16x8*>(Wl)[1 * 1024 + fr];
+#pragma unroll
+      for (int y = 0; y < TM; ++y) {
+        const int off = (32 * y + j) * X3ROW + 16 * ks + 8 * hf;
+        bf[y].hi = *reinterpret_cast<const f16x8*>(Xl + 0 * MB * X3ROW + off);
+        bf[y].lo = *reinterpret_cast<const f16x8*>(Xl + 1 * MB * X3ROW + off);
+      }
+#pragma unroll
+      for (int y = 0; y < TM; ++y) acc[y] = mfma_x2(af, bf[y], acc[y]);
+    }
+  }
+  __syncthreads();
+  float* scr = reinterpret_cast<float*>(smx) + wave * (32 * 36);
+  if (EPI == EPI_TANH && a.Z) {
+    // fused head: per-wave partials over its 32 rows, then a fixed-order fold over the 8 waves
+    const int hs = a.ldz;
+    float* hp_all = reinterpret_cast<float*>(smx) + NW * (32 * 36);
+    float* hp = hp_all + wave * (MB * hs);
+    for (int i = lane; i < MB * hs; i += 64) hp[i] = 0.0f;
+    wave_lds_fence();
+#pragma unroll
+    for (int y = 0; y < TM; ++y)
+      tile_tanh_head(scr, acc[y], lane, wave * 32, 32 * y, m0 + 32 * y, a.M, a.bias, a.Y, a.W3t, a.A, hp, hs, X2_FWD_UNSCALE);
+    __syncthreads();
+    for (int i = tid; i < MB * a.A; i += NT) {
+      const int m = i / a.A, aa = i - m * a.A;
+      float z = 0.0f;
+#pragma unroll
+      for (int w8 = 0; w8 < NW; ++w8) z += hp_all[w8 * (MB * hs) + m * hs + aa];
+      if (m0 + m < a.M) a.Z[(size_t)a.ldz * (m0 + m) + aa] = z + a.b3[aa];
+    }
+    return;
+  }
+#pragma unroll
+  for (int y = 0; y < TM; ++y)
+    tile_out_x2<EPI>(scr, acc[y], lane, wave * 32, 32 * y, m0 + 32 * y, a.M, a.bias, a.S, a.Y,
+                     EPI == EPI_TANH ? X2_FWD_UNSCALE : 1.0f / X2_W_SCALE, sc + MB);
+}
+
+template <int EPI>
+static int dense_x2_launch(hipStream_t st, const DenseX3Args& a) {
+  if (a.M <= 0) return 0;
+  const bool big = a.M > 32768;
+  const int MB = big ? 64 : 32;
+  size_t region = (size_t)X2_SLAB_F16 * 2 + (size_t)2 * MB * X3ROW * 2;
+  const size_t epi = (size_t)8 * 32 * 36 * 4;
+  if (epi > region) region = epi;
+  size_t smem = region + (size_t)2 * MB * 4;                              // + per-sample scale / inverse
+  const size_t head = a.Z ? epi + (size_t)8 * MB * a.ldz * 4 : 0;         // fused head partials (forward only: no scales needed)
+  if (head > smem) smem = head;
+  if (big) hipLaunchKernelGGL((wide_dense_x2_kernel<EPI, 2>), dim3((a.M + 63) / 64), dim3(512), smem, st, a);
+  else hipLaunchKernelGGL((wide_dense_x2_kernel<EPI, 1>), dim3((a.M + 31) / 32), dim3(512), smem, st, a);
+  CRL_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 template <int EPI>
 static int dense_launch(hipStream_t st, int NP, const DenseArgs& a) {
   if (a.M <= 0) return 0;
@@ -690,8 +932,9 @@ static int wide_forward(crl_ppo* h, int net, const float* X, int ldx, const int3
     x.Wx3 = pk + w->pk[net].x3f; x.X = w->h1[net]; x.K = H; x.bias = P + o.b2; x.S = nullptr; x.Y = w->h2[net]; x.M = M;
     const bool fuse = wide_x3_fused_head();
     x.W3t = pk + w->pk[net].w3t; x.b3 = P + o.b3; x.Z = fuse ? out : nullptr; x.A = NO; x.ldz = ldo;
-    x.dZ = nullptr; x.ldd = 0; x.Ad = 0;
-    if (dense_x3_launch<EPI_TANH>(h->stream, x)) return 1;
+    x.dZ = nullptr; x.ldd = 0; x.Ad = 0; x.bz = nullptr; x.bld = 0; x.bA = 0; x.wmax = nullptr;
+    if (wide_x2()) { x.Wx3 = pk + w->pk[net].x2f; if (dense_x2_launch<EPI_TANH>(h->stream, x)) return 1; }
+    else if (dense_x3_launch<EPI_TANH>(h->stream, x)) return 1;
     if (fuse) return 0;   // the head came out of the layer-2 epilogue
   } else {
     a.W = P + o.W2; a.Kp = H; a.X = w->h1[net]; a.ldx = H; a.Kt = H; a.bias = P + o.b2; a.Y = w->h2[net];
@@ -711,6 +954,8 @@ struct WgradArgs {
   const float* dY; const float* X; int H; int M; int chunk; float* pW; float* pB;
   // x3 kernel only: dZ != null ⇒ dY holds h2 and the operand is δ2 = (W3ᵀ·δ3) ⊙ (1 − h2²), formed while staging
   const float* dZ; int ldd; int Ad; const float* W3t;
+  // x2 kernel: the head cotangent (bz, ld bld, bA live rows) and wmax bound |δ2| per sample — the block's scale comes from them
+  const float* bz; int bld; int bA; const float* wmax;
 };
 
 template <int TW>
@@ -938,6 +1183,138 @@ __global__ void __launch_bounds__(128 * WNB) wide_wgrad_x3_kernel(WgradArgs a) {
     }
   if (do_bias) {
     // fold the 8 sample groups of a row quad (lanes 8·ql + sg) in group order; lanes with sg = 0 own rows rrow..rrow+3
+    float* scr = reinterpret_cast<float*>(smw);
+    *reinterpret_cast<f32x4*>(scr + 4 * tid) = bacc;
+    __syncthreads();
+    if (sg == 0) {
+      f32x4 sacc = bacc;
+      for (int q = 1; q < 8; ++q) sacc += *reinterpret_cast<const f32x4*>(scr + 4 * (tid + q));
+      *reinterpret_cast<f32x4*>(a.pB + (size_t)blockIdx.x * a.H + n0 + rrow) = sacc;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// The same weight gradient as fp16x2 (mlp_x2.hpp). The reduction runs over samples, so dY = δ2 needs ONE power-of-two scale
+// for everything a block accumulates — and a block owns one sample chunk whose partial is unscaled before it is written, so
+// the scale is the block's own: G = 2^(14 − ⌈log2 max_m bound_m⌉) over the chunk's samples, bound_m = Σ_a |δ3[a, m]|·wmax[a]
+// (≥ every |δ2[·, m]|; a few KB of reads, no pass over δ2). X = h1 takes the static 2^14.
+// ------------------------------------------------------------------------------------------------------
+template <int WNB>
+__global__ void __launch_bounds__(128 * WNB) wide_wgrad_x2_kernel(WgradArgs a) {
+  constexpr int BN = 64 * WNB, BK = 128, NT = 128 * WNB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smw[];
+  _Float16* Yp = reinterpret_cast<_Float16*>(smw);             // [2][BN][X3ROW]
+  _Float16* Xp = Yp + 2 * BN * X3ROW;                          // [2][BK][X3ROW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hf = lane >> 5;
+  const int nbn = a.H / BN;
+  const int tnb = blockIdx.y % nbn, tkb = blockIdx.y / nbn;
+  const int n0 = tnb * BN, kk0 = tkb * BK;
+  const int wn = wave % WNB, wk = wave / WNB;
+  const int c0 = blockIdx.x * a.chunk;
+  const int c1 = (c0 + a.chunk) < a.M ? (c0 + a.chunk) : a.M;
+  // the block's scale
+  float G, Ginv;
+  {
+    float bmax = 0.0f;
+    for (int m = c0 + tid; m < c1; m += NT) {
+      float bound = 0.0f;
+      for (int q2 = 0; q2 < a.bA; ++q2) bound = __builtin_fmaf(__builtin_fabsf(a.bz[(size_t)a.bld * m + q2]), a.wmax[q2], bound);
+      bmax = __builtin_fmaxf(bmax, bound);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) bmax = __builtin_fmaxf(bmax, __shfl_xor(bmax, o, 64));
+    float* red = reinterpret_cast<float*>(smw);
+    if (lane == 0) red[wave] = bmax;
+    __syncthreads();
+    bmax = red[0];
+    for (int w8 = 1; w8 < NT / 64; ++w8) bmax = __builtin_fmaxf(bmax, red[w8]);
+    __syncthreads();
+    pow2_scale(bmax, G, Ginv);
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.0f;
+  const int sg = lane & 7, ql = lane >> 3;
+  const int rrow = 32 * wave + 4 * ql;
+  const bool stage_x = wave < BK / 32;
+  const float* ybase = a.dY + (size_t)a.H * c0 + n0 + rrow;
+  const float* xbase = a.X + (size_t)a.H * c0 + kk0 + rrow;
+  const bool do_bias = (tkb == 0) && a.pB;
+  const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 yr[4], xr[4], bacc = zero4;
+  auto fetch = [&](int m) {
+    const size_t off = (size_t)a.H * (m - c0 + 4 * sg);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool ok = m + 4 * sg + e < c1;
+      yr[e] = ok ? *reinterpret_cast<const f32x4*>(ybase + off + (size_t)a.H * e) : zero4;
+      xr[e] = (ok && stage_x) ? *reinterpret_cast<const f32x4*>(xbase + off + (size_t)a.H * e) : zero4;
+    }
+  };
+  if (c0 < c1) fetch(c0);
+  for (int m = c0; m < c1; m += 32) {
+    if (m != c0) __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      f32x4 vy;
+      vy[0] = yr[0][e]; vy[1] = yr[1][e]; vy[2] = yr[2][e]; vy[3] = yr[3][e];
+      uint2 hh, ll;
+      split2x4(vy, G, hh, ll);
+      *reinterpret_cast<uint2*>(Yp + (0 * BN + rrow + e) * X3ROW + 4 * sg) = hh;
+      *reinterpret_cast<uint2*>(Yp + (1 * BN + rrow + e) * X3ROW + 4 * sg) = ll;
+      if (stage_x) {
+        f32x4 vx;
+        vx[0] = xr[0][e]; vx[1] = xr[1][e]; vx[2] = xr[2][e]; vx[3] = xr[3][e];
+        split2x4(vx, X2_ACT_SCALE, hh, ll);
+        *reinterpret_cast<uint2*>(Xp + (0 * BK + rrow + e) * X3ROW + 4 * sg) = hh;
+        *reinterpret_cast<uint2*>(Xp + (1 * BK + rrow + e) * X3ROW + 4 * sg) = ll;
+      }
+    }
+    if (do_bias) bacc += (yr[0] + yr[1]) + (yr[2] + yr[3]);
+    __syncthreads();
+    if (m + 32 < c1) fetch(m + 32);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      P2 af[2], bf[2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        const int off = ((wn * 2 + x) * 32 + j) * X3ROW + 16 * ks + 8 * hf;
+        af[x].hi = *reinterpret_cast<const f16x8*>(Yp + 0 * BN * X3ROW + off);
+        af[x].lo = *reinterpret_cast<const f16x8*>(Yp + 1 * BN * X3ROW + off);
+      }
+#pragma unroll
+      for (int y = 0; y < 2; ++y) {
+        const int off = ((wk * 2 + y) * 32 + j) * X3ROW + 16 * ks + 8 * hf;
+        bf[y].hi = *reinterpret_cast<const f16x8*>(Xp + 0 * BK * X3ROW + off);
+        bf[y].lo = *reinterpret_cast<const f16x8*>(Xp + 1 * BK * X3ROW + off);
+      }
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = mfma_x2(af[x], bf[y], acc[x][y]);
+    }
+  }
+  __syncthreads();
+  const float un = Ginv * (1.0f / X2_ACT_SCALE);
+  float* pw = a.pW + (size_t)blockIdx.x * a.H * a.H;
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const int k = kk0 + (wk * 2 + y) * 32 + j;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + (wn * 2 + x) * 32 + 8 * g + 4 * hf;
+        f32x4 o; o[0] = acc[x][y][4 * g] * un; o[1] = acc[x][y][4 * g + 1] * un; o[2] = acc[x][y][4 * g + 2] * un; o[3] = acc[x][y][4 * g + 3] * un;
+        *reinterpret_cast<f32x4*>(pw + (size_t)a.H * k + n) = o;
+      }
+    }
+  if (do_bias) {
     float* scr = reinterpret_cast<float*>(smw);
     *reinterpret_cast<f32x4*>(scr + 4 * tid) = bacc;
     __syncthreads();
@@ -1513,7 +1890,10 @@ static int wide_backward(crl_ppo* h, int net, const float* dOut, int ldd, const 
   WgradArgs g;
   g.dY = fuse2 ? w->h2[net] : w->dA; g.X = w->h1[net]; g.H = H; g.M = M; g.chunk = w->chunk2; g.pW = w->pW2[net]; g.pB = w->pB2[net];
   g.dZ = fuse2 ? dOut : nullptr; g.ldd = ldd; g.Ad = NO; g.W3t = pk + w->pk[net].w3t;
-  if (H == 256 && wide_x3()) {
+  g.bz = dOut; g.bld = ldd; g.bA = NO; g.wmax = pk + w->pk[net].wmax;
+  const bool x2 = H == 256 && wide_x2() && !fuse2;
+  if (x2) hipLaunchKernelGGL(wide_wgrad_x2_kernel<4>, dim3(w->S2, 2), dim3(512), 2 * (256 + 128) * X3ROW * 2, h->stream, g);
+  else if (H == 256 && wide_x3()) {
     // 256×128 output tiles (dY read twice, X once: 1.5 GB per launch at C3) unless CRL_WIDE_WGRAD_TILE=128 (2 GB)
     static int tile = -1;
     if (tile < 0) { const char* e = getenv("CRL_WIDE_WGRAD_TILE"); tile = e ? atoi(e) : 256; }
@@ -1529,7 +1909,9 @@ static int wide_backward(crl_ppo* h, int net, const float* dOut, int ldd, const 
     x.Wx3 = pk + w->pk[net].x3b; x.X = fuse2 ? w->h2[net] : w->dA; x.K = H; x.bias = nullptr; x.S = w->h1[net]; x.Y = w->dB; x.M = M;
     x.W3t = pk + w->pk[net].w3t; x.b3 = nullptr; x.Z = nullptr; x.A = 0; x.ldz = 0;
     x.dZ = fuse2 ? dOut : nullptr; x.ldd = ldd; x.Ad = NO;
-    if (dense_x3_launch<EPI_DTANH>(h->stream, x)) return 1;
+    x.bz = dOut; x.bld = ldd; x.bA = NO; x.wmax = pk + w->pk[net].wmax;
+    if (x2) { x.Wx3 = pk + w->pk[net].x2b; if (dense_x2_launch<EPI_DTANH>(h->stream, x)) return 1; }
+    else if (dense_x3_launch<EPI_DTANH>(h->stream, x)) return 1;
   } else {
     d.W = pk + w->pk[net].w2t; d.Kp = H; d.X = w->dA; d.ldx = H; d.Kt = H; d.S = w->h1[net]; d.Y = w->dB;
     if (dense_launch<EPI_DTANH>(h->stream, H, d)) return 1;
@@ -1613,6 +1995,7 @@ int wide_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
   }
   StatsArgs st;
   st.c = h->dc; st.Mglobal = Mglobal; st.adv_ms = h->adv_ms; st.mb = mb; st.vfix = h->vfix; st.out = stats_slot; st.fused = 0;
+  st.dscale = nullptr;
   hipLaunchKernelGGL(wide_stats_kernel, dim3(1), dim3(64), 0, h->stream, h->comm_buf, P, st);
   CRL_HIP_CHECK(hipGetLastError());
   return 0;
