@@ -210,7 +210,7 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
   rc |= dalloc(&h->next_value, nt); rc |= dalloc(&h->ep_stats, 4);
   rc |= dalloc(&h->params, h->P); rc |= dalloc(&h->adam_m, h->P); rc |= dalloc(&h->adam_v, h->P);
   const size_t E = (size_t)cfg->update_epochs;
-  rc |= dalloc(&h->betap, 24); rc |= dalloc(&h->perm_base, E * B);
+  rc |= dalloc(&h->betap, 24); rc |= dalloc(&h->perm_base, E * B); rc |= dalloc(&h->optim_part, (size_t)h->P / 4096 + 16);
   if (!wide) { rc |= dalloc(&h->recs, B); rc |= dalloc(&h->recs_p, E * B); }
   {
     // permute pass: blocks per minibatch (≈1 K samples each, at most 512); the partial-sum scratch also serves the
@@ -264,7 +264,7 @@ int32_t crl_ppo_destroy(crl_ppo* h) {
   wide_destroy(h);
   void* ptrs[] = {h->obs, h->action, h->logprob, h->reward, h->terminal, h->value, h->adv, h->ret, h->env_state, h->env_t,
                   h->cur_obs, h->next_done, h->ep_return, h->ep_length, h->next_value, h->ep_stats, h->ep_ring, h->ep_ring_count, h->params,
-                  h->adam_m, h->adam_v, h->betap, h->perm_base, h->recs, h->recs_p, h->adv_part, h->perm_tmp, h->bfy_ws, h->bfy_adv_part, h->gpart, h->lpart,
+                  h->adam_m, h->adam_v, h->betap, h->optim_part, h->perm_base, h->recs, h->recs_p, h->adv_part, h->perm_tmp, h->bfy_ws, h->bfy_adv_part, h->gpart, h->lpart,
                   h->adv_sums_base, h->adv_ms_base, h->newv, h->vfix, h->dscale, h->stats_dev, h->comm_buf, h->snap, h->snap_betap, h->snap_env, h->stage};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int k = 0; k < CRL_K_COUNT; ++k)

@@ -165,6 +165,65 @@ __global__ void __launch_bounds__(1024) clipnorm_adam_kernel(OptimArgs a) {
   if (threadIdx.x == 0) { a.betap[2 * arr] = bp0 * b1; a.betap[2 * arr + 1] = bp1 * b2; }
 }
 
+// The same optimiser for large parameter arrays (2×256: W2 has 65,536 entries), where one block per array makes the step a
+// 100 µs serial walk: slices of 4,096 entries per block. Three launches: per-slice Σg² partials (Float64) → every slice sums its
+// array's partials in slice order (one norm, identical in all slices), clips and applies Adam to its entries → the running β
+// powers advance. Same arithmetic per element as clipnorm_adam_kernel; only the order of the Σg² sum differs (by slices).
+constexpr int OPT_SLICE = 4096, OPT_MAXS = 32;
+struct OptimSliceArgs {
+  int off[13]; int first_blk[13];   // first_blk[a] = index of array a's first slice; first_blk[12] = number of slices
+  float* params; const float* grads; float* m; float* v; double* betap; double* part;
+  double eta, thresh;
+};
+__device__ __forceinline__ void optim_locate(const OptimSliceArgs& a, int blk, int& arr, int& lo, int& hi) {
+  arr = 0;
+  while (arr < 11 && blk >= a.first_blk[arr + 1]) ++arr;
+  const int sl = blk - a.first_blk[arr];
+  lo = a.off[arr] + sl * OPT_SLICE;
+  hi = lo + OPT_SLICE < a.off[arr + 1] ? lo + OPT_SLICE : a.off[arr + 1];
+}
+__global__ void __launch_bounds__(1024) clipnorm_partial_kernel(OptimSliceArgs a) {
+#pragma clang fp contract(off)
+  int arr, lo, hi;
+  optim_locate(a, blockIdx.x, arr, lo, hi);
+  __shared__ double sm[16];
+  double ss = 0.0;
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) { const double g = a.grads[i]; ss += g * g; }
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sm[w];
+    a.part[blockIdx.x] = t;
+  }
+}
+__global__ void __launch_bounds__(1024) adam_slice_kernel(OptimSliceArgs a) {
+#pragma clang fp contract(off)
+  int arr, lo, hi;
+  optim_locate(a, blockIdx.x, arr, lo, hi);
+  double ss = 0.0;
+  for (int b = a.first_blk[arr]; b < a.first_blk[arr + 1]; ++b) ss += a.part[b];
+  const float nrm = (float)sqrt(ss);
+  const bool clip = (double)nrm > a.thresh;
+  const double sc = clip ? a.thresh / (double)nrm : 1.0;
+  const double b1 = 0.9, b2 = 0.999, epsn = 1e-8;
+  const double bp0 = a.betap[2 * arr], bp1 = a.betap[2 * arr + 1];
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    double g = (double)a.grads[i];
+    if (clip) g = (double)(float)(g * sc);
+    const float mi = (float)(b1 * (double)a.m[i] + (1 - b1) * g);
+    const float vi = (float)(b2 * (double)a.v[i] + (1 - b2) * g * g);
+    a.m[i] = mi; a.v[i] = vi;
+    const double delta = (double)mi / (1 - bp0) / (sqrt((double)vi / (1 - bp1)) + epsn) * a.eta;
+    a.params[i] = a.params[i] - (float)delta;
+  }
+}
+__global__ void betap_advance_kernel(double* betap) {
+  const int arr = threadIdx.x;
+  if (arr < 12) { betap[2 * arr] *= 0.9; betap[2 * arr + 1] *= 0.999; }
+}
+
 int launch_optim(crl_ppo* h, double eta) {
   OptimArgs a;
   const int hN = h->cfg.hidden, d = h->cfg.obs_dim, A = h->cfg.n_act;
@@ -174,6 +233,17 @@ int launch_optim(crl_ppo* h, double eta) {
   a.params = h->params; a.grads = h->comm_buf; a.m = h->adam_m; a.v = h->adam_v; a.betap = h->betap;
   a.eta = eta; a.thresh = 0.5; a.arr0 = 0;
   ProfScope ps(h, CRL_K_OPTIM);
+  if (h->P > 32768 && h->optim_part) {
+    OptimSliceArgs b;
+    int nb = 0;
+    for (int i = 0; i < 12; ++i) { b.off[i] = a.off[i]; b.first_blk[i] = nb; nb += (sizes[i] + OPT_SLICE - 1) / OPT_SLICE; }
+    b.off[12] = a.off[12]; b.first_blk[12] = nb;
+    b.params = h->params; b.grads = h->comm_buf; b.m = h->adam_m; b.v = h->adam_v; b.betap = h->betap; b.part = h->optim_part;
+    b.eta = eta; b.thresh = 0.5;
+    hipLaunchKernelGGL(clipnorm_partial_kernel, dim3(nb), dim3(1024), 0, h->stream, b);
+    hipLaunchKernelGGL(adam_slice_kernel, dim3(nb), dim3(1024), 0, h->stream, b);
+    hipLaunchKernelGGL(betap_advance_kernel, dim3(1), dim3(64), 0, h->stream, h->betap);
+  } else
   hipLaunchKernelGGL(clipnorm_adam_kernel, dim3(12), dim3(1024), 0, h->stream, a);
   CRL_HIP_CHECK(hipGetLastError());
   wide_mark_params_changed(h);

@@ -75,6 +75,7 @@ struct crl_ppo {
   // optimiser
   float* params = nullptr; float* adam_m = nullptr; float* adam_v = nullptr;  // the gradient lives in comm_buf[0..P)
   double* betap = nullptr;     // [24]
+  double* optim_part = nullptr;  // per-slice Σg² of the sliced optimiser step (large networks)
   // One permutation per update epoch (ppo.jl:194): crl_ppo_iterate draws all update_epochs of them right after GAE, so the
   // advantage statistics of every minibatch of the iteration are known (and all-reduced, once) before the first optimiser
   // step. `perm` / `adv_ms` point at the CURRENT slot; the host-driven entry points (crl_shuffle, …) use slot 0.

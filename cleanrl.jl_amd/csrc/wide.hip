@@ -113,7 +113,11 @@ int wide_create(crl_ppo* h) {
   rc |= walloc(&w->z, (size_t)w->A8 * Mw); rc |= walloc(&w->v, Mw); rc |= walloc(&w->dv8, 8 * Mw);
   rc |= walloc(&w->dA, H * Mw); rc |= walloc(&w->dB, H * Mw);
   // weight-gradient splits: ≈2048-sample chunks for the MFMA kernel, 512-sample chunks for the VALU kernels
-  int s2 = (M + 2047) / 2048; if (s2 > 512) s2 = 512; if (s2 < 1) s2 = 1;
+  // swept at C3 (M = 524,288; profiles/r02_c3_*): 4096-sample chunks 68.0 ms per iteration, 2048: 69.8, 8192: 75.9 — half the
+  // partials to write and fold against one block per CU instead of two
+  int ck = M >= 262144 ? 4096 : 2048;
+  if (const char* e = getenv("CRL_WIDE_CHUNK2")) { ck = atoi(e); if (ck < 256) ck = 256; }
+  int s2 = (M + ck - 1) / ck; if (s2 > 512) s2 = 512; if (s2 < 1) s2 = 1;
   w->S2 = s2; w->chunk2 = (((M + s2 - 1) / s2) + 31) & ~31;
   int ss = (M + 511) / 512; if (ss > 1024) ss = 1024; if (ss < 1) ss = 1;
   w->Ss = ss; w->chunks = (M + ss - 1) / ss;
