@@ -11,7 +11,9 @@ timeout 300 python $R/bench.py --shuffle bijection --no-cpu-baseline > $O/bench_
 timeout 300 python $R/bench.py --minibatches 1 --no-cpu-baseline > $O/bench_n1_minibatches1.json 2> /dev/null
 CRL_COMM_FORCE=1 timeout 300 python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_n1_rccl_forced.json 2>/dev/null
 for nt in 8192 16384 32768; do timeout 300 python3 $R/bench.py --total-envs $nt --no-cpu-baseline > $O/bench_n1_envs$nt.json 2>/dev/null; done
+timeout 600 python3 $R/bench.py --workload c3 --steps 5 --warmup 2 > $O/bench_c3_n1.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3 -- python3 $R/bench.py --workload c3 --steps 3 --warmup 1 > /dev/null 2> $O/prof_c3.log
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --no-cpu-baseline > $O/prof_bench.json 2> $O/prof.log
 KR="update_x2_kernel|gae_kernel|permute_records|pack_records|rollout_cartpole"
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$KR" --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
@@ -24,7 +26,7 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_AC
   timeout 300 rocprofv3 --pmc $set --kernel-include-regex "update_x2_kernel|rollout_cartpole" --output-format csv -d $O/pmc_sq_$n -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 done
 cd $O
-for d in prof pmc_fetch pmc_write pmc_fetch_gae pmc_write_gae pmc_sq_*; do
+for d in prof prof_c3 pmc_fetch pmc_write pmc_fetch_gae pmc_write_gae pmc_sq_*; do
   for f in $(find $d -name "*kernel_stats.csv" -o -name "*counter_collection.csv" 2>/dev/null); do cp $f ${d}_$(basename $f); done
   rm -rf $d
 done
