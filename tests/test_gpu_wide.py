@@ -213,6 +213,28 @@ def test_c3_full_size_properties(crl):
     agent.close(); st.close()
 
 
+def test_c3_size_minibatch_gradient_matches_oracle(crl):
+    """BASELINE configs[2] at full size, directly: ONE minibatch (num_envs=16384, num_steps=128, obs 8 / act 4 / 2x256: M = 524,288
+    samples, 4.3e11 flop) through the layer-wise HIP path and through orc_loss_grad (OpenMP) on the same buffer — four loss
+    scalars and all twelve gradient arrays."""
+    nt, k, D, A, Hd = 16384, 128, 8, 4, 256
+    cfg = ocfg(nt, k, D, A, Hd)
+    params = spread_params(cfg, 13)
+    agent = make_wide(crl, nt, k, D, A, Hd, params=params, shuffle_mode=1)
+    h = agent.handle; F = crl._lib
+    h.env_reset(); h.rollout_run(); h.compute_gae(); h.shuffle(2); h.adv_stats()
+    gs = h.update_minibatch(2, 0.0, apply_update=False)
+    g = h.read(F.F_GRADS)
+    M = nt * k // 4
+    perm = h.read(F.F_PERM)
+    g_o, so = O.loss_grad(cfg, params, h.read(F.F_OBS).reshape(D, -1, order="F"), h.read(F.F_ACTION), h.read(F.F_LOGPROB),
+                          h.read(F.F_VALUE), h.read(F.F_ADVANTAGE), h.read(F.F_RETURN), perm[2 * M:3 * M])
+    for key in ("loss", "pg_loss", "v_loss", "entropy_loss"):
+        assert abs(gs[key] - so[key]) <= RTOL * max(1.0, abs(so[key])), (key, gs[key], so[key])
+    _grad_close(g, g_o, O.param_offsets(cfg), tol=RTOL)
+    agent.close()
+
+
 def test_wide_rccl_path_world1(crl, monkeypatch):
     """C3 shape with a forced 1-rank RCCL communicator: the gradient message, the advantage statistics AND the two extra
     value-loss scalars (Σ(v − R²), #{u > q}) travel through ncclAllReduce; a sum over one rank is the identity."""
