@@ -151,6 +151,12 @@ def main():
     ap.add_argument("--dry-run", action="store_true")
     ap.add_argument("--rendezvous-only", action="store_true")
     ap.add_argument("--master-port", type=int, default=0)
+    ap.add_argument("--comm", choices=["rccl", "peer"], default="rccl",
+                    help="gradient exchange for --gpus > 1: rccl = ncclAllReduce (default); peer = the one-shot peer-mapped "
+                         "all-reduce of csrc/peer.hip (crl_comm_peer_export/attach)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="functional check on a 1-GPU box: all ranks run on GPU 0 (needs --comm peer; RCCL refuses to put two ranks "
+                         "on one device). The line is labelled shared_gpu and is not a scaling measurement")
     ap.add_argument("--shuffle", choices=["bijection", "fisher-yates", "blocked-fy"], default="blocked-fy",
                     help="blocked-fy = exact parallel Fisher-Yates (uniform over S_B like the reference shuffle; default); "
                          "bijection = keyed pseudo-random permutation (faster, not a uniform draw); fisher-yates = serial exact")
@@ -173,6 +179,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
+    if args.share_gpu:
+        if world > 1 and args.comm != "peer":
+            print("--share-gpu needs --comm peer", file=sys.stderr)
+            return 2
+        local_rank = 0
 
     # stdout carries exactly ONE JSON line (rank 0). Native libraries (RCCL prints a version banner through C stdio,
     # flushed at exit) must not leak into it: fd 1 is pointed at stderr for the whole run and the JSON goes to the saved fd.
@@ -216,7 +227,9 @@ def main():
                                     "blocked-fy": L.SHUFFLE_BLOCKED_FY}[args.shuffle])
     h = agent.handle
     if world > 1:
-        h.comm_init(crl_dist.exchange_unique_id(dist, rank, crl.comm_unique_id), world, rank)
+        crl_dist.attach_comm(dist, h, world, rank, args.comm, crl.comm_unique_id)
+    elif os.environ.get("CRL_COMM_FORCE") and args.comm == "peer":
+        h.comm_peer_attach(h.comm_peer_export(1, 0))   # 1-rank mailbox: the all-reduce kernel still runs (push to self)
     elif os.environ.get("CRL_COMM_FORCE"):
         h.comm_init(crl.comm_unique_id(), 1, 0)  # 1-GPU box: still route the all-reduces through RCCL
     h.env_reset()
@@ -308,6 +321,10 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "global_batch": args.total_envs * NUM_STEPS, "parallelism": f"dp{world}",
+                       "comm": (None if world == 1 and not os.environ.get("CRL_COMM_FORCE") else
+                                "rccl all-reduce" if args.comm == "rccl" else "one-shot peer-mapped all-reduce (csrc/peer.hip)"),
+                       **({"shared_gpu": f"all {world} ranks time-share GPU 0 (functional check of the multi-rank path, NOT a scaling "
+                                         "measurement)"} if args.share_gpu and world > 1 else {}),
                        "shuffle": args.shuffle,
                        "gemm": ("v_mfma_f32_32x32x2_f32" if not x3 else
                                 "f32 results via bf16x3 split products on the bf16 matrix pipe" if issue_factor == 6.0 else

@@ -51,7 +51,7 @@ EXPORTS = [
     "crl_sync", "crl_ppo_write", "crl_ppo_read", "crl_policy_act", "crl_logprob_actions", "crl_gae",
     "crl_rollout_store", "crl_env_reset", "crl_rollout_run", "crl_episode_stats_read", "crl_compute_gae",
     "crl_shuffle", "crl_adv_stats", "crl_ppo_update_minibatch", "crl_ppo_iterate", "crl_ppo_iteration",
-    "crl_comm_unique_id", "crl_comm_init", "crl_comm_init_external", "crl_adv_stats_local", "crl_adv_stats_finish",
+    "crl_comm_unique_id", "crl_comm_init", "crl_comm_init_external", "crl_comm_peer_export", "crl_comm_peer_attach", "crl_adv_stats_local", "crl_adv_stats_finish",
     "crl_prof_enable", "crl_prof_read", "crl_prof_reset", "crl_ppo_exact_reruns", "crl_episode_ring_enable",
     "crl_episode_ring_read",
     "crl_a2c_create", "crl_a2c_destroy", "crl_a2c_param_count", "crl_a2c_write_params", "crl_a2c_read_params",
@@ -146,6 +146,8 @@ def load():
     L.crl_comm_unique_id.argtypes = [u8p]
     L.crl_comm_init.argtypes = [vp, u8p, C.c_int32, C.c_int32]
     L.crl_comm_init_external.argtypes = [vp, C.c_int32, C.c_int32]
+    L.crl_comm_peer_export.argtypes = [vp, C.c_int32, C.c_int32, u8p]
+    L.crl_comm_peer_attach.argtypes = [vp, u8p]
     L.crl_adv_stats_local.argtypes = [vp]
     L.crl_adv_stats_finish.argtypes = [vp]
     L.crl_prof_enable.argtypes = [vp, C.c_int32]
@@ -330,6 +332,17 @@ class Handle:
     def comm_init(self, unique_id: bytes, world_size: int, rank: int):
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         check(load().crl_comm_init(self._h, buf, world_size, rank))
+
+    def comm_peer_export(self, world_size: int, rank: int) -> bytes:
+        """Allocates this rank's mailbox for the one-shot peer all-reduce; returns its 64-byte IPC handle."""
+        buf = (C.c_uint8 * 64)()
+        check(load().crl_comm_peer_export(self._h, world_size, rank, buf))
+        return bytes(buf)
+
+    def comm_peer_attach(self, handles: bytes):
+        """handles: world_size x 64 bytes in rank order (every rank's crl_comm_peer_export result)."""
+        buf = (C.c_uint8 * len(handles)).from_buffer_copy(handles)
+        check(load().crl_comm_peer_attach(self._h, buf))
 
     def comm_init_external(self, world_size: int, rank: int):
         check(load().crl_comm_init_external(self._h, world_size, rank))

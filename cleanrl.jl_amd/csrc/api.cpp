@@ -260,6 +260,7 @@ int32_t crl_ppo_destroy(crl_ppo* h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  peer_destroy(h);
   comm_destroy(h);
   wide_destroy(h);
   void* ptrs[] = {h->obs, h->action, h->logprob, h->reward, h->terminal, h->value, h->adv, h->ret, h->env_state, h->env_t,
@@ -487,6 +488,7 @@ int32_t crl_compute_gae(crl_ppo* h) {
 }
 
 static int check_bfy(crl_ppo* h) {
+  if (peer_check(h)) return 1;
   if ((!h->wide && gemm_x2()) || wide_x2_active(h)) {
     double re = 0.0;
     CRL_HIP_CHECK(hipMemcpyAsync(&re, h->vfix + (h->wide ? 6 : 5), sizeof(re), hipMemcpyDeviceToHost, h->stream));
@@ -758,6 +760,24 @@ int32_t crl_comm_init(crl_ppo* h, const uint8_t id[128], int32_t world_size, int
   if (comm_init(h, id, world_size, rank)) return 1;
   if (reset_dw_scale(h)) return 1;
   // num_updates = total_timesteps ÷ (global batch) (ppo.jl:89-91)
+  const int64_t gb = (int64_t)h->dc.B * h->world;
+  h->num_updates = h->cfg.total_timesteps / gb;
+  if (h->num_updates < 1) h->num_updates = 1;
+  return 0;
+}
+
+int32_t crl_comm_peer_export(crl_ppo* h, int32_t world_size, int32_t rank, uint8_t handle[64]) {
+  CRL_GUARD(h);
+  if (!handle) { set_error("crl_comm_peer_export: null handle"); return 1; }
+  if (settle(h)) return 1;
+  return peer_export(h, world_size, rank, handle);
+}
+
+int32_t crl_comm_peer_attach(crl_ppo* h, const uint8_t* handles) {
+  CRL_GUARD(h);
+  if (!handles) { set_error("crl_comm_peer_attach: null handles"); return 1; }
+  if (peer_attach(h, handles)) return 1;
+  if (reset_dw_scale(h)) return 1;
   const int64_t gb = (int64_t)h->dc.B * h->world;
   h->num_updates = h->cfg.total_timesteps / gb;
   if (h->num_updates < 1) h->num_updates = 1;

@@ -61,6 +61,7 @@ int comm_unique_id(uint8_t id[128]) {
 
 int comm_init(crl_ppo* h, const uint8_t id[128], int world, int rank) {
   if (world < 1 || rank < 0 || rank >= world) { set_error("crl_comm_init: bad world/rank"); return 1; }
+  if (h->peer) { set_error("crl_comm_init: a peer communicator is already attached"); return 1; }
   h->world = world; h->rank = rank;
   // world 1 needs no communicator; CRL_COMM_FORCE=1 creates one anyway so a 1-GPU box can exercise the RCCL path
   if (world == 1 && !std::getenv("CRL_COMM_FORCE")) return 0;
@@ -76,6 +77,7 @@ int comm_init(crl_ppo* h, const uint8_t id[128], int world, int rank) {
 }
 
 int comm_allreduce(crl_ppo* h, void* buf, size_t count, bool is_double) {
+  if (h->peer) return peer_allreduce(h, buf, count, is_double);
   if (!h->comm) {
     if (h->world == 1 || h->external_comm) return 0;
     set_error("all-reduce requested but no communicator attached (crl_comm_init)"); return 1;

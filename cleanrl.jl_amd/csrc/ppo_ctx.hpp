@@ -124,6 +124,7 @@ struct crl_ppo {
   // RCCL (loaded lazily; world_size 1 = no communicator)
   void* comm = nullptr; int world = 1, rank = 0;
   bool external_comm = false;  // shards exchanged by the host (crl_comm_init_external): all-reduce calls are no-ops
+  void* peer = nullptr;        // one-shot peer-mapped all-reduce (peer.hip), the alternative to the RCCL communicator
 
   // generic-shape path (wide.hip): anything but obs 4 / act 2 / hidden 64, or CRL_FORCE_WIDE=1
   bool wide = false;
@@ -200,4 +201,12 @@ int wide_env_reset(crl_ppo* h);
 int wide_rollout(crl_ppo* h);
 int wide_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot);
 void comm_destroy(crl_ppo* h);
+// peer.hip — one-shot all-reduce over hipIpc-shared mailboxes
+int peer_export(crl_ppo* h, int world, int rank, uint8_t handle[64]);
+int peer_attach(crl_ppo* h, const uint8_t* handles);
+bool peer_active(const crl_ppo* h);
+int peer_allreduce(crl_ppo* h, void* buf, size_t count, bool is_double);
+int peer_check(crl_ppo* h);
+void peer_destroy(crl_ppo* h);
+inline bool has_comm(const crl_ppo* h) { return h->comm != nullptr || h->peer != nullptr; }
 }  // namespace crl

@@ -771,7 +771,7 @@ int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot, bool inline_fix
     return 1;
   }
   const int P = (int)h->P;
-  const bool dp = h->comm != nullptr;
+  const bool dp = has_comm(h);
   {
     ProfScope ps(h, CRL_K_UPDATE, /*attach=*/true);
     if (run_update(h, mb, 0, ps.a, ps.b)) return 1;

@@ -1964,7 +1964,7 @@ int wide_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
   const int M = h->dc.M, P = (int)h->P;
   const int32_t* perm = h->perm + (size_t)mb * M;
   const double Mglobal = (double)M * h->world;
-  const bool dp = h->comm != nullptr || h->external_comm;   // a forced 1-rank communicator still goes through RCCL
+  const bool dp = has_comm(h) || h->external_comm;   // a forced 1-rank communicator still goes through RCCL
   if (h->external_comm && h->world > 1 && h->cfg.clip_value_loss) {
     set_error("wide path: clip_value_loss under host-side exchange (crl_comm_init_external) is not supported; use crl_comm_init");
     return 1;

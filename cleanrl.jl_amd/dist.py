@@ -27,3 +27,26 @@ def exchange_unique_id(dist, rank: int, make_id):
     if not isinstance(uid, (bytes, bytearray)) or len(uid) != 128:
         raise ValueError("communicator id must be 128 bytes")
     return bytes(uid)
+
+
+def attach_peer_comm(dist, handle, world_size: int, rank: int):
+    """One-shot peer all-reduce (csrc/peer.hip) instead of RCCL: every rank exports its mailbox, the 64-byte IPC handles are
+    all-gathered over the launcher's rendezvous (which is also the barrier the protocol needs: nobody attaches before
+    everybody has exported) and attached in rank order."""
+    mine = handle.comm_peer_export(world_size, rank)
+    parts = [None] * world_size
+    dist.all_gather_object(parts, mine)
+    if any(not isinstance(b, (bytes, bytearray)) or len(b) != 64 for b in parts):
+        raise ValueError("peer mailbox handles must be 64 bytes each")
+    handle.comm_peer_attach(b"".join(bytes(b) for b in parts))
+    dist.barrier()   # every rank has opened every mailbox before the first message
+
+
+def attach_comm(dist, handle, world_size: int, rank: int, kind: str, make_id):
+    """kind = "rccl" (crl_comm_init) or "peer" (crl_comm_peer_export/attach)."""
+    if kind == "peer":
+        attach_peer_comm(dist, handle, world_size, rank)
+    elif kind == "rccl":
+        handle.comm_init(exchange_unique_id(dist, rank, make_id), world_size, rank)
+    else:
+        raise ValueError(f"unknown communicator kind {kind!r} (rccl | peer)")

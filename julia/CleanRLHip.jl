@@ -7,7 +7,7 @@
 # tests/test_host_cpu.py::test_config_struct_matches_header_and_reference_defaults pins (104 bytes).
 module CleanRLHip
 
-export PPOConfig, ppo, get_action, logprob_actions, gae, a2c, dqn, q_values, comm_unique_id, comm_init!
+export PPOConfig, ppo, get_action, logprob_actions, gae, a2c, dqn, q_values, comm_unique_id, comm_init!, comm_peer_export!, comm_peer_attach!
 
 const libcrl = get(ENV, "CLEANRL_HIP_LIB", joinpath(@__DIR__, "..", "cleanrl.jl_amd", "libcleanrl_hip.so"))
 
@@ -116,6 +116,16 @@ function comm_unique_id()
 end
 comm_init!(a::Agent, id::Vector{UInt8}, world_size::Integer, rank::Integer) =
   GC.@preserve id check(ccall((:crl_comm_init, libcrl), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Int32, Int32), a.h, id, world_size, rank))
+
+# The same exchange without RCCL: a one-shot all-reduce over peer-mapped mailboxes (csrc/peer.hip). Every rank exports its
+# mailbox (64-byte hipIpcMemHandle_t), the launcher all-gathers the handles, every rank attaches all of them in rank order.
+function comm_peer_export!(a::Agent, world_size::Integer, rank::Integer)
+  hnd = Vector{UInt8}(undef, 64)
+  GC.@preserve hnd check(ccall((:crl_comm_peer_export, libcrl), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{UInt8}), a.h, world_size, rank, hnd))
+  hnd
+end
+comm_peer_attach!(a::Agent, handles::Vector{UInt8}) =
+  GC.@preserve handles check(ccall((:crl_comm_peer_attach, libcrl), Int32, (Ptr{Cvoid}, Ptr{UInt8}), a.h, handles))
 
 # ppo.jl:75 — same signature; the loop body (ppo.jl:117-253) runs on the GPU, one ccall per update.
 # episode_records > 0 turns on the device ring (crl_episode_ring_enable): every finished episode leaves {return, length, env,

@@ -1,5 +1,6 @@
-"""Rank body of tests/test_gpu_dp2.py: one process per GPU, launched by torch.distributed.run before anything touches HIP.
-Checks on REAL RCCL (world size = number of ranks):
+"""Rank body of tests/test_gpu_dp2.py: one process per rank, launched by torch.distributed.run before anything touches HIP.
+DP2_COMM = rccl (one GPU per rank) or peer (the one-shot peer-mapped all-reduce; DP2_SHARE_GPU=1 puts every rank on GPU 0 so a
+1-GPU box runs the real multi-process path). Checks with world size = number of ranks:
   1. host-driven optimiser steps on shards (local permutations, global advantage statistics through the library's all-reduce)
      == the same steps of ONE handle that owns the union batch (rank 0 checks, 1e-5 relative per parameter array);
   2. crl_ppo_iterate keeps the replicas bit-identical (all-reduced gradients are the same bytes everywhere);
@@ -28,7 +29,13 @@ def main():
     import cleanrl_jl_amd as crl
     crl_dist = importlib.import_module("cleanrl_jl_amd.dist")
     L = crl._lib
+    kind = os.environ.get("DP2_COMM", "rccl")
+    if os.environ.get("DP2_SHARE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
+
+    def attach(hh):
+        crl_dist.attach_comm(dist, hh, world, rank, kind, crl.comm_unique_id)
     NT, k = 16 * world, 128
     n, off = crl_dist.shard_envs(NT, world, rank)
     out = {}
@@ -42,7 +49,7 @@ def main():
     cfg = crl.PPOConfig(num_envs=n, num_steps=k, total_timesteps=NT * k * 10)
     shard = crl.Agent(cfg, device=local, env_id_offset=off, init_seed=3)
     h = shard.handle
-    h.comm_init(crl_dist.exchange_unique_id(dist, rank, crl.comm_unique_id), world, rank)
+    attach(h)
     h.env_reset(); h.rollout_run(); h.compute_gae()
     perm = np.random.default_rng(100 + rank).permutation(n * k).astype(np.int32)
     h.write(L.F_PERM, perm)
@@ -70,6 +77,7 @@ def main():
         out["max_abs_param_diff_vs_union"] = float(np.max(np.abs(p_full - p_shard)))
         out["rel_l2_vs_union"] = float(np.linalg.norm(p_full.astype(np.float64) - p_shard) / np.linalg.norm(p_full))
         full.close()
+    dist.barrier()
     shard.close()
 
     # ---- 2. + 3. whole iterations; second run forces the u > q branch
@@ -79,13 +87,14 @@ def main():
         if bias is not None:
             p = a.get_params(); p[-1] = bias; a.set_params(p)        # critic head bias is the last parameter
         hh = a.handle
-        hh.comm_init(crl_dist.exchange_unique_id(dist, rank, crl.comm_unique_id), world, rank)
+        attach(hh)
         hh.env_reset()
         hh.iterate(2, want_stats=False)
         stats = hh.iterate(1)
         ps = gather(hh.read(L.F_PARAMS))
         out[name] = {"replicas_equal": all(np.array_equal(ps[0], q) for q in ps), "exact_reruns": hh.exact_reruns,
                      "loss": stats[-1]["loss"], "finite": bool(np.isfinite(ps[0]).all())}
+        dist.barrier()   # nobody frees a mailbox a slower rank could still be pushing into
         a.close()
     if rank == 0:
         print("DP2_RESULT " + json.dumps(out), flush=True)

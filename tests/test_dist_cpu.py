@@ -135,3 +135,41 @@ def test_bench_bare_command_spawns_ranks_and_exchanges_the_id():
     assert len(lines) == 1, out.stdout
     rec = json.loads(lines[0])
     assert rec == {"rendezvous": "ok", "world": 2, "envs_per_rank": 2048}
+
+
+class _FakePeerHandle:
+    """Records what the launcher-side plumbing of the one-shot peer all-reduce hands to the C ABI."""
+    def __init__(self, rank):
+        self.rank = rank; self.attached = None
+
+    def comm_peer_export(self, world, rank):
+        return bytes([rank + 1]) * 64
+
+    def comm_peer_attach(self, handles):
+        self.attached = handles
+
+
+def _peer_worker(rank, world, port, out_dir):
+    import importlib
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    crl_dist = importlib.import_module("cleanrl_jl_amd.dist")
+    h = _FakePeerHandle(rank)
+    crl_dist.attach_comm(dist, h, world, rank, "peer", None)
+    np.save(os.path.join(out_dir, f"peer{rank}.npy"), np.frombuffer(h.attached, dtype=np.uint8))
+    try:
+        crl_dist.attach_comm(dist, h, world, rank, "ring", None)
+        ok = False
+    except ValueError:
+        ok = True
+    assert ok
+    dist.destroy_process_group()
+
+
+def test_peer_mailbox_handles_are_gathered_in_rank_order(tmp_path):
+    """crl_comm_peer_attach wants world_size x 64 bytes in rank order on every rank (include/cleanrl_hip.h)."""
+    world = 3
+    mp.spawn(_peer_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    want = np.concatenate([np.full(64, r + 1, np.uint8) for r in range(world)])
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"peer{r}.npy"), want)

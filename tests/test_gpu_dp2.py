@@ -1,6 +1,10 @@
-"""The data-parallel product path on REAL RCCL with world size > 1: needs at least two GPUs in the box (the 1-GPU boxes of
-this project skip it; tests/test_gpu_dp.py and the forced 1-rank communicator cover the arithmetic there). Fresh processes are
-started by torch.distributed.run before anything touches HIP — never a fork / exec of a GPU-initialised process."""
+"""The data-parallel product path with world size > 1 in real, separate processes.
+  * RCCL: needs one GPU per rank (the 1-GPU boxes of this project skip it);
+  * one-shot peer-mapped all-reduce (csrc/peer.hip): the ranks may share a GPU, so the complete multi-process path — mailbox
+    export / IPC attach, [grad | 4 loss sums] exchange per optimiser step, the f64 advantage sums, the guard window's re-run with
+    its extra all-reduces — runs on a 1-GPU box too.
+Fresh processes are started by torch.distributed.run before anything touches HIP — never a fork / exec of a GPU-initialised
+process."""
 import json
 import os
 import subprocess
@@ -17,14 +21,12 @@ def _gpu_count():
     return torch.cuda.device_count()     # counting devices does not initialise the GPU on this image
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_rccl_ranks_match_union_handle_and_stay_replicated(world):
-    if _gpu_count() < world:
-        pytest.skip(f"needs {world} GPUs")
+def _run_ranks(world, comm, share_gpu, port):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_SOCKET_IFNAME="lo", OMP_NUM_THREADS="4")
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_SOCKET_IFNAME="lo", OMP_NUM_THREADS="4", DP2_COMM=comm,
+               DP2_SHARE_GPU="1" if share_gpu else "0", CRL_PEER_TIMEOUT_S="60")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29500 + world), os.path.join(ROOT, "tests", "dp2_worker.py")]
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dp2_worker.py")]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("DP2_RESULT ")]
@@ -34,3 +36,30 @@ def test_rccl_ranks_match_union_handle_and_stay_replicated(world):
     assert r["rel_l2_vs_union"] < 1e-5, r            # four Adam steps on the union batch vs on shards + all-reduce
     assert r["iterate"]["replicas_equal"] and r["iterate"]["finite"] and r["iterate"]["exact_reruns"] == 0
     assert r["forced_branch"]["replicas_equal"] and r["forced_branch"]["exact_reruns"] == 3, r
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_rccl_ranks_match_union_handle_and_stay_replicated(world):
+    if _gpu_count() < world:
+        pytest.skip(f"needs {world} GPUs")
+    _run_ranks(world, "rccl", False, 29500 + world)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_peer_allreduce_ranks_match_union_handle_and_stay_replicated(world):
+    """One GPU per rank when the box has them, otherwise all ranks on GPU 0."""
+    _run_ranks(world, "peer", _gpu_count() < world, 29600 + world)
+
+
+def test_bench_runs_multi_rank_on_a_shared_gpu():
+    """bench.py's N > 1 path end to end (self-launch, shard, attach, barrier + MAX timing, one JSON line from rank 0)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", "peer", "--share-gpu", "--steps", "3",
+                          "--warmup", "1", "--total-envs", "4096", "--no-cpu-baseline", "--master-port", "29611"],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "shared_gpu" in d["config"]
+    assert d["kernel_ms_per_step"]["allreduce"] > 0
