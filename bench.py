@@ -155,8 +155,8 @@ def main():
                     help="gradient exchange for --gpus > 1: rccl = ncclAllReduce (default); peer = the one-shot peer-mapped "
                          "all-reduce of csrc/peer.hip (crl_comm_peer_export/attach)")
     ap.add_argument("--share-gpu", action="store_true",
-                    help="functional check on a 1-GPU box: all ranks run on GPU 0 (needs --comm peer; RCCL refuses to put two ranks "
-                         "on one device). The line is labelled shared_gpu and is not a scaling measurement")
+                    help="functional check on a 1-GPU box: all ranks run on GPU 0 (use --comm peer; RCCL refuses to put two ranks on "
+                         "one device and the run falls back to the peer all-reduce). The line is labelled shared_gpu and is not a scaling measurement")
     ap.add_argument("--shuffle", choices=["bijection", "fisher-yates", "blocked-fy"], default="blocked-fy",
                     help="blocked-fy = exact parallel Fisher-Yates (uniform over S_B like the reference shuffle; default); "
                          "bijection = keyed pseudo-random permutation (faster, not a uniform draw); fisher-yates = serial exact")
@@ -180,10 +180,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
     if args.share_gpu:
-        if world > 1 and args.comm != "peer":
-            print("--share-gpu needs --comm peer", file=sys.stderr)
-            return 2
-        local_rank = 0
+        local_rank = 0   # with --comm rccl this exercises the fallback: RCCL refuses two ranks on one device
 
     # stdout carries exactly ONE JSON line (rank 0). Native libraries (RCCL prints a version banner through C stdio,
     # flushed at exit) must not leak into it: fd 1 is pointed at stderr for the whole run and the JSON goes to the saved fd.
@@ -226,8 +223,9 @@ def main():
                       shuffle_mode={"bijection": L.SHUFFLE_BIJECTION, "fisher-yates": L.SHUFFLE_FISHER_YATES,
                                     "blocked-fy": L.SHUFFLE_BLOCKED_FY}[args.shuffle])
     h = agent.handle
+    comm_used = args.comm
     if world > 1:
-        crl_dist.attach_comm(dist, h, world, rank, args.comm, crl.comm_unique_id)
+        comm_used = crl_dist.attach_comm(dist, h, world, rank, args.comm, crl.comm_unique_id, fallback=True)
     elif os.environ.get("CRL_COMM_FORCE") and args.comm == "peer":
         h.comm_peer_attach(h.comm_peer_export(1, 0))   # 1-rank mailbox: the all-reduce kernel still runs (push to self)
     elif os.environ.get("CRL_COMM_FORCE"):
@@ -322,7 +320,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "global_batch": args.total_envs * NUM_STEPS, "parallelism": f"dp{world}",
                        "comm": (None if world == 1 and not os.environ.get("CRL_COMM_FORCE") else
-                                "rccl all-reduce" if args.comm == "rccl" else "one-shot peer-mapped all-reduce (csrc/peer.hip)"),
+                                "rccl all-reduce" if comm_used == "rccl" else
+                                "one-shot peer-mapped all-reduce (csrc/peer.hip)" + (" — RCCL initialisation failed" if "failed" in comm_used else "")),
                        **({"shared_gpu": f"all {world} ranks time-share GPU 0 (functional check of the multi-rank path, NOT a scaling "
                                          "measurement)"} if args.share_gpu and world > 1 else {}),
                        "shuffle": args.shuffle,

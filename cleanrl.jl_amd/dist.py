@@ -42,11 +42,26 @@ def attach_peer_comm(dist, handle, world_size: int, rank: int):
     dist.barrier()   # every rank has opened every mailbox before the first message
 
 
-def attach_comm(dist, handle, world_size: int, rank: int, kind: str, make_id):
-    """kind = "rccl" (crl_comm_init) or "peer" (crl_comm_peer_export/attach)."""
+def attach_comm(dist, handle, world_size: int, rank: int, kind: str, make_id, fallback: bool = False):
+    """kind = "rccl" (crl_comm_init) or "peer" (crl_comm_peer_export/attach). Returns the kind attached. With fallback=True a
+    failed RCCL initialisation on ANY rank (agreed over the rendezvous, so all ranks take the same branch) falls back to the
+    peer all-reduce instead of raising."""
     if kind == "peer":
         attach_peer_comm(dist, handle, world_size, rank)
-    elif kind == "rccl":
-        handle.comm_init(exchange_unique_id(dist, rank, make_id), world_size, rank)
-    else:
+        return "peer"
+    if kind != "rccl":
         raise ValueError(f"unknown communicator kind {kind!r} (rccl | peer)")
+    uid = exchange_unique_id(dist, rank, make_id)
+    err = None
+    try:
+        handle.comm_init(uid, world_size, rank)
+    except Exception as e:   # noqa: BLE001 — reported below or re-raised
+        err = e
+    failed = [None] * world_size
+    dist.all_gather_object(failed, err is not None)
+    if not any(failed):
+        return "rccl"
+    if not fallback:
+        raise err if err is not None else RuntimeError("crl_comm_init failed on another rank")
+    attach_peer_comm(dist, handle, world_size, rank)
+    return "peer (RCCL initialisation failed)"

@@ -63,3 +63,16 @@ def test_bench_runs_multi_rank_on_a_shared_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and "shared_gpu" in d["config"]
     assert d["kernel_ms_per_step"]["allreduce"] > 0
+
+
+def test_bench_falls_back_to_the_peer_allreduce_when_rccl_cannot_start():
+    """RCCL refuses two ranks on one device; every rank learns that over the rendezvous and all of them attach mailboxes."""
+    if _gpu_count() >= 2:
+        pytest.skip("needs a box where RCCL cannot place 2 ranks (1 GPU)")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", "rccl", "--share-gpu", "--steps", "2",
+                          "--warmup", "1", "--total-envs", "4096", "--no-cpu-baseline", "--master-port", "29612"],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and "RCCL initialisation failed" in d["config"]["comm"]
