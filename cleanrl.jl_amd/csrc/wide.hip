@@ -1339,9 +1339,12 @@ __global__ void __launch_bounds__(128 * WNB) wide_wgrad_x2_kernel(WgradArgs a) {
 struct SkinnyArgs {
   const float* Big; int H; const float* Small; int lds; const int32_t* idx; int M; int chunk;
   float* pW; int os_row, os_s, St, wsize; float* pB;
+  // D2 variant (dW3 pass only): the same sweep over h2 also emits δ2[k, m] = (Σ_a W3[a, k]·δ3[a, m])·(1 − h2[k, m]²) — the
+  // hidden-layer cotangent both 256-wide backward GEMMs read — so h2 is read once for the two and the K ≤ 8 MFMA pass is gone
+  float* D2out; const float* W3t;
 };
 
-template <int S, bool UNI>
+template <int S, bool UNI, bool D2 = false>
 __global__ void __launch_bounds__(256) wide_skinny_kernel(SkinnyArgs a) {
   // a thread owns 4 consecutive hidden rows (one 16-B load per sample); R4 = H/4 threads cover a sample and the
   // block's 256/R4 groups take samples round-robin. UNI (H = 256): a group is a whole wave, Small goes through SGPRs.
@@ -1354,6 +1357,11 @@ __global__ void __launch_bounds__(256) wide_skinny_kernel(SkinnyArgs a) {
   f32x4 acc[S], bacc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int s = 0; s < S; ++s) acc[s] = bacc;
+  f32x4 w3r[D2 ? S : 1];
+  if (D2) {
+#pragma unroll
+    for (int s = 0; s < S; ++s) w3r[s] = s < a.St ? *reinterpret_cast<const f32x4*>(a.W3t + (size_t)s * a.H + 4 * r4) : bacc;
+  }
   const int c0 = blockIdx.x * a.chunk;
   const int c1 = (c0 + a.chunk) < a.M ? (c0 + a.chunk) : a.M;
   for (int m = c0 + g; m < c1; m += 4 * G) {
@@ -1371,11 +1379,14 @@ __global__ void __launch_bounds__(256) wide_skinny_kernel(SkinnyArgs a) {
         int sr = a.idx ? a.idx[mu] : mu;
         if (UNI) sr = __builtin_amdgcn_readfirstlane(sr);
         const float* sp = a.Small + (size_t)sr * a.lds;
+        f32x4 t = bacc * 0.0f;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
           const float sv = s < a.St ? sp[s] : 0.0f;
           acc[s] += big[u] * sv;
+          if (D2) t += w3r[s] * sv;
         }
+        if (D2) *reinterpret_cast<f32x4*>(a.D2out + (size_t)a.H * mu + 4 * r4) = t * (1.0f - big[u] * big[u]);
         bacc += big[u];
       }
     }
@@ -1408,6 +1419,11 @@ __global__ void __launch_bounds__(256) wide_skinny_kernel(SkinnyArgs a) {
 
 template <int S>
 static void skinny_go(hipStream_t st, int blocks, const SkinnyArgs& a) {
+  if (a.D2out) {
+    if (a.H == 256) hipLaunchKernelGGL((wide_skinny_kernel<S, true, true>), dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wide_skinny_kernel<S, false, true>), dim3(blocks), dim3(256), 0, st, a);
+    return;
+  }
   if (a.H == 256) hipLaunchKernelGGL((wide_skinny_kernel<S, true>), dim3(blocks), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((wide_skinny_kernel<S, false>), dim3(blocks), dim3(256), 0, st, a);
 }
@@ -1879,9 +1895,14 @@ static int wide_backward(crl_ppo* h, int net, const float* dOut, int ldd, const 
   static int fuse_env = -1;
   if (fuse_env < 0) { const char* e = getenv("CRL_WIDE_FUSE_DELTA2"); fuse_env = (e && atoi(e) != 0) ? 1 : 0; }
   const bool fuse2 = H == 256 && wide_x3() && fuse_env && NO <= AFUSE;
+  // default: δ2 comes out of the dW3 sweep over h2 (wide_skinny_kernel<.., D2>); CRL_WIDE_D2_PASS=1 keeps it as its own K ≤ 8
+  // MFMA launch (the round-1 arrangement)
+  static int d2_pass = -1;
+  if (d2_pass < 0) { const char* e = getenv("CRL_WIDE_D2_PASS"); d2_pass = (e && atoi(e) != 0) ? 1 : 0; }
+  const bool d2_sweep = !fuse2 && !d2_pass && NO <= 8;
   DenseArgs d;
   d.idx = nullptr; d.bias = nullptr; d.M = M;
-  if (!fuse2) {
+  if (!fuse2 && !d2_sweep) {
     d.W = pk + w->pk[net].w3t; d.Kp = ldd; d.X = dOut; d.ldx = ldd; d.Kt = ldd; d.S = w->h2[net]; d.lds = H; d.Y = w->dA; d.ldy = H; d.Nt = H;
     if (dense_launch<EPI_DTANH>(h->stream, H, d)) return 1;
   }
@@ -1889,7 +1910,9 @@ static int wide_backward(crl_ppo* h, int net, const float* dOut, int ldd, const 
   SkinnyArgs s;
   s.Big = w->h2[net]; s.H = H; s.Small = dOut; s.lds = ldd; s.idx = nullptr; s.M = M; s.chunk = w->chunks;
   s.pW = w->pW3[net]; s.os_row = NO; s.os_s = 1; s.St = NO; s.wsize = H * NO; s.pB = nullptr;
+  s.D2out = d2_sweep ? w->dA : nullptr; s.W3t = pk + w->pk[net].w3t;
   if (skinny_launch(h->stream, w->Ss, s)) return 1;
+  s.D2out = nullptr;
   // dW2 = δ2·h1ᵀ, db2 = Σ δ2
   WgradArgs g;
   g.dY = fuse2 ? w->h2[net] : w->dA; g.X = w->h1[net]; g.H = H; g.M = M; g.chunk = w->chunk2; g.pW = w->pW2[net]; g.pB = w->pB2[net];
@@ -1917,7 +1940,7 @@ static int wide_backward(crl_ppo* h, int net, const float* dOut, int ldd, const 
     if (x2) { x.Wx3 = pk + w->pk[net].x2b; if (dense_x2_launch<EPI_DTANH>(h->stream, x)) return 1; }
     else if (dense_x3_launch<EPI_DTANH>(h->stream, x)) return 1;
   } else {
-    d.W = pk + w->pk[net].w2t; d.Kp = H; d.X = w->dA; d.ldx = H; d.Kt = H; d.S = w->h1[net]; d.Y = w->dB;
+    d.W = pk + w->pk[net].w2t; d.Kp = H; d.X = w->dA; d.ldx = H; d.Kt = H; d.S = w->h1[net]; d.lds = H; d.Y = w->dB; d.ldy = H; d.Nt = H;
     if (dense_launch<EPI_DTANH>(h->stream, H, d)) return 1;
   }
   // dW1 = δ1·xᵀ, db1 = Σ δ1
