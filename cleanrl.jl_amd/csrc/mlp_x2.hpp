@@ -7,8 +7,8 @@
 // instead of 5.5 (the residual x − hi is one mixed-precision subtract). The price is fp16's 5-bit exponent: a piece pair keeps
 // its 22 bits only while |x| stays in [2^-3, 65504); below that the absolute error floor is 2^-25. So every operand is scaled
 // by an exact power of two into that window, and the scale comes back out of the f32 accumulator:
-//   * activations h = tanh(·) ∈ (−1, 1):  h·2^14, produced directly by the activation (tanh_fast with its numerator
-//     coefficients pre-multiplied by 2^14: bit-for-bit 2^14·tanh_fast(x));
+//   * activations h = tanh(·) ∈ (−1, 1):  h·2^14, produced directly by the activation (tanh_exp2 with S = 2^14: the scale is
+//     the constant of its last fused multiply-add);
 //   * weights:  W·2^8 — full precision for |w| ≥ 2^-11, absolute error 2^-33 below; |w| ≥ 255 does not fit and makes the
 //     kernel raise an error flag instead of computing (CRL_GEMM=x3 is the fallback flavour);
 //   * backward cotangents δ: any magnitude — each SAMPLE (= lane: the N index of the product) is scaled by its own power of
@@ -145,14 +145,19 @@ __device__ __forceinline__ void dense64_x2(const float* wimg, const f32x16 (&xs)
   }
 }
 
-// 2^14 · tanh_fast(x), bit for bit (the numerator's coefficients carry the power of two)
-__device__ __forceinline__ float tanh_fast_s14(float x) {
-  x = __builtin_amdgcn_fmed3f(x, -8.1240384f, 8.1240384f);
-  const float x2 = x * x;
-  const float S = X2_ACT_SCALE;
-  const float n = __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, 1.587199e-8f * S, 2.2332108e-5f * S), 0.0035974074f * S), 0.1346604f * S), S);
-  const float d = __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, 8.7767893e-7f, 0.0003453992f), 0.026262015f), 0.4679937f), 1.0f);
-  return x * (n * __builtin_amdgcn_rcpf(d));
+// The activation of the fp16x2 update kernel: S·tanh(x·c) = S − 2S / (2^(x·pre) + 1) with pre = 2·log2(e)·c — five
+// instructions (v_mul, v_exp_f32, v_add, v_rcp_f32, v_fma) instead of the thirteen of the rational tanh_fast (networks.jl:6),
+// which were 40 % of the kernel's VALU instructions (the kernel is VALU-issue-bound: §3 of DESIGN.md). Both approximate tanh:
+// the rational form to a few ulp relative, this one to ≈1e-7 ABSOLUTE (v_exp_f32 / v_rcp_f32 are 1 ulp; 1 − 2r cancels for
+// small |x|), which is the rounding unit of an activation in (−1, 1) anyway. Measured against the oracle (which evaluates the
+// reference's rational form): gradients 1.16e-6 vs 1.12e-6 relative L2, parameters after three iterations 3e-8 vs 2e-8
+// (profiles/r02_parity_margins.json) — far inside the 1e-5 bar. Saturation needs no clamp: 2^(+big) = inf → S, 2^(−big) = 0 → −S.
+// The rollout keeps tanh_fast: action indices there are bit-compared with the oracle.
+constexpr float TWO_LOG2E = 2.8853900817779268f;
+__device__ __forceinline__ float tanh_exp2(float x, float pre, float S) {
+  const float e = __builtin_amdgcn_exp2f(x * pre);
+  const float r = __builtin_amdgcn_rcpf(e + 1.0f);
+  return __builtin_fmaf(-2.0f * S, r, S);
 }
 
 // Forward of one network for a 32-sample tile: h1s = 2^14·h1 (what the next product and the backward pass consume), h2 and
@@ -171,12 +176,14 @@ __device__ __forceinline__ void mlp_forward_x2(const float* img, const float (&x
     a1 = mfma32(img[I::WF1 + (1 * (D / 2) + ks) * 64 + lane], b, a1);
   }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { h1s[0][r] = tanh_fast_s14(a0[r]); h1s[1][r] = tanh_fast_s14(a1[r]); }
+  for (int r = 0; r < 16; ++r) { h1s[0][r] = tanh_exp2(a0[r], TWO_LOG2E, X2_ACT_SCALE); h1s[1][r] = tanh_exp2(a1[r], TWO_LOG2E, X2_ACT_SCALE); }
   a0 = load16(img + I::B2C + hf * 32);
   a1 = load16(img + I::B2C + hf * 32 + 16);
   dense64_x2(img + I::WF2H, h1s, a0, a1, lane);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { h2[0][r] = tanh_fast(a0[r] * X2_FWD_UNSCALE); h2[1][r] = tanh_fast(a1[r] * X2_FWD_UNSCALE); }
+  for (int r = 0; r < 16; ++r) {   // the fp16x2 unscale rides in the exponent's multiplier
+    h2[0][r] = tanh_exp2(a0[r], TWO_LOG2E * X2_FWD_UNSCALE, 1.0f); h2[1][r] = tanh_exp2(a1[r], TWO_LOG2E * X2_FWD_UNSCALE, 1.0f);
+  }
 #pragma unroll
   for (int a = 0; a < NOUT; ++a) {
     const f32x4* w = reinterpret_cast<const f32x4*>(img + I::W3 + a * 64 + hf * 32);
