@@ -11,6 +11,7 @@
 #include "common.hpp"
 #include "env.hpp"
 #include "mlp_x3.hpp"
+#include "mlp_x2.hpp"
 #include "ppo_ctx.hpp"
 
 namespace crl {
@@ -141,6 +142,7 @@ struct RolloutArgs {
   // scans their value / reward / terminal columns — which it has just written and which still sit in L2 — backwards and
   // writes advantages and returns (ppo.jl:48-73,173-181): no separate launch, no HBM read of the scan's inputs.
   float* adv; float* ret; int fuse_gae; float gamma, gl;
+  double* range_err = nullptr;   // fp16x2 weight-window error word (CX2 kernels)
 };
 
 // gae(values, rewards, terminals, γ, λ) for ONE env (this lane), compat mode (ppo.jl:66: the loop starts at k-1, the last slot
@@ -179,14 +181,23 @@ __device__ __forceinline__ void gae_tail_compat(const RolloutArgs& a, int e) {
   }
 }
 
-template <int A, bool X3>
+// CX2: the critic runs as fp16x2 with the exp2-based activation (mlp_x2.hpp) — its output is a value compared at 1e-5, while
+// the actor keeps bf16x3 + the reference's rational tanh_fast because its output decides action indices that are bit-compared.
+template <int A, bool X3, bool CX2 = false>
 __global__ void __launch_bounds__(512, 2) rollout_cartpole_kernel(RolloutArgs a) {
   constexpr int D = 4;
   constexpr int IASIZE = X3 ? NetImageX3<D, A, false>::SIZE : NetImage<D, A, false>::SIZE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* imgA0 = smem;
   float* imgC0 = smem + IASIZE;
-  if (X3) {
+  if (CX2) {
+    stage_net_x3<D, A, false>(imgA0, a.params, threadIdx.x, blockDim.x);
+    int* flag = reinterpret_cast<int*>(imgC0 + NetImageX2<D, 1>::SIZE);
+    if (!stage_net_x2<D, 1>(imgC0, a.params + NetParams<D, A>::SIZE, threadIdx.x, blockDim.x, flag)) {
+      if (threadIdx.x == 0 && blockIdx.x == 0) a.range_err[0] = 1.0;   // |w| >= 255: reported by the host's next check
+      return;
+    }
+  } else if (X3) {
     stage_net_x3<D, A, false>(imgA0, a.params, threadIdx.x, blockDim.x);
     stage_net_x3<D, 1, false>(imgC0, a.params + NetParams<D, A>::SIZE, threadIdx.x, blockDim.x);
   } else {
@@ -243,7 +254,8 @@ __global__ void __launch_bounds__(512, 2) rollout_cartpole_kernel(RolloutArgs a)
     float lpa = lp[0];
 #pragma unroll
     for (int i = 1; i < A; ++i) lpa = (act == i) ? lp[i] : lpa;
-    if (X3) mlp_forward_x3<D, 1, false>(imgC, co, h1, h2, v, lane);  // ppo.jl:128
+    if (CX2) mlp_forward_x2<D, 1>(imgC, co, h1, h2, v, lane);        // ppo.jl:128
+    else if (X3) mlp_forward_x3<D, 1, false>(imgC, co, h1, h2, v, lane);
     else mlp_forward<D, 1, false>(imgC, co, h1, h2, v, lane);
     const bool done = cartpole_step(s, t_env, act);                  // ppo.jl:130
     const float rew = done ? 0.0f : 1.0f;                            // ppo.jl:132 (RLEnvs: reward 0 on the terminal step)
@@ -481,6 +493,10 @@ int launch_rollout(crl_ppo* h, bool fuse_gae) {
   if (gemm_x3() && split_env && tiles <= 512) {
     const size_t smem = sizeof(float) * (NetImageX3<4, 2, false>::SIZE + NetImageX3<4, 1, false>::SIZE + 2 * TILE * 4);
     hipLaunchKernelGGL((rollout_split_kernel<2>), dim3(tiles), dim3(128), smem, h->stream, a);
+  } else if (gemm_x2() && !getenv("CRL_ROLLOUT_CRITIC_X3")) {
+    a.range_err = h->vfix + 5;
+    const size_t smem = sizeof(float) * (NetImageX3<4, 2, false>::SIZE + NetImageX2<4, 1>::SIZE + 4);
+    hipLaunchKernelGGL((rollout_cartpole_kernel<2, true, true>), dim3(blocks), dim3(64 * wpb), smem, h->stream, a);
   } else if (gemm_x3()) {
     const size_t smem = sizeof(float) * (NetImageX3<4, 2, false>::SIZE + NetImageX3<4, 1, false>::SIZE);
     hipLaunchKernelGGL((rollout_cartpole_kernel<2, true>), dim3(blocks), dim3(64 * wpb), smem, h->stream, a);
