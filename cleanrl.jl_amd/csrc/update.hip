@@ -292,6 +292,7 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
     // (4) dh1 = W2ᵀ·δ2 (A-fragments of W2ᵀ from LDS, B = δ2 registers); δ1 = dh1 ⊙ (1 − h1²)
     f32x16 d1[2];
     float d2max = 0.0f;   // fp16x2: this sample's largest |δ2|
+    float d1f = 1.0f;     // fp16x2: this sample's backward-data unscale
     {
       f32x16 c0, c1;
 #pragma unroll
@@ -310,9 +311,7 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
 #pragma unroll
           for (int r = 0; r < 16; ++r) ds[mt][r] = d2[mt][r] * sc;
         dense64_x2(img + I::WB2H, ds, c0, c1, lane);
-        const float f = sinv * (1.0f / X2_W_SCALE);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { c0[r] *= f; c1[r] *= f; }
+        d1f = sinv * (1.0f / X2_W_SCALE);   // the unscale rides in the (1 − h1²) factor below
       } else if constexpr (X3) {
         dense64_x3(img + I::WB2P, d2, c0, c1, lane);
       } else {
@@ -330,11 +329,21 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
           }
         }
       }
+      if constexpr (X2 && !(ABL & 16)) {
+        // δ1 = (c·f)·(1 − h1²) with h1 carried as 2^14·h1 and f the per-sample unscale: c·(f − (h1s·kf)·h1s), three instructions
+        const float kf = d1f * (1.0f / (X2_ACT_SCALE * X2_ACT_SCALE));
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        constexpr float k = X2 ? 1.0f / (X2_ACT_SCALE * X2_ACT_SCALE) : 1.0f;   // h1 is carried as 2^14·h1 in the fp16x2 flavour
-        d1[0][r] = c0[r] * (1.0f - (h1[0][r] * k) * h1[0][r]);
-        d1[1][r] = c1[r] * (1.0f - (h1[1][r] * k) * h1[1][r]);
+        for (int r = 0; r < 16; ++r) {
+          d1[0][r] = c0[r] * __builtin_fmaf(-(h1[0][r] * kf), h1[0][r], d1f);
+          d1[1][r] = c1[r] * __builtin_fmaf(-(h1[1][r] * kf), h1[1][r], d1f);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          constexpr float k = X2 ? 1.0f / (X2_ACT_SCALE * X2_ACT_SCALE) : 1.0f;   // h1 is carried as 2^14·h1 in the fp16x2 flavour
+          d1[0][r] = c0[r] * (1.0f - (h1[0][r] * k) * h1[0][r]);
+          d1[1][r] = c1[r] * (1.0f - (h1[1][r] * k) * h1[1][r]);
+        }
       }
     }
     CRL_PHASE();
