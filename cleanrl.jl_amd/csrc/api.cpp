@@ -211,7 +211,7 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
   rc |= dalloc(&h->params, h->P); rc |= dalloc(&h->adam_m, h->P); rc |= dalloc(&h->adam_v, h->P);
   const size_t E = (size_t)cfg->update_epochs;
   rc |= dalloc(&h->betap, 24); rc |= dalloc(&h->perm_base, E * B); rc |= dalloc(&h->optim_part, (size_t)h->P / 4096 + 16);
-  if (!wide) { rc |= dalloc(&h->recs, B); rc |= dalloc(&h->recs_p, E * B); }
+  if (!wide) { rc |= dalloc(&h->recs, B); if (!gather_mode()) rc |= dalloc(&h->recs_p, E * B); }   // gather mode never lays minibatches out
   {
     // permute pass: blocks per minibatch (≈1 K samples each, at most 512); the partial-sum scratch also serves the
     // stand-alone statistics kernels (up to 512 blocks per minibatch of ONE slot)

@@ -1,5 +1,6 @@
 // ppo_ctx.hpp — the opaque crl_ppo handle: every buffer of the path resident in HBM, one HIP stream.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
@@ -208,5 +209,13 @@ bool peer_active(const crl_ppo* h);
 int peer_allreduce(crl_ppo* h, void* buf, size_t count, bool is_double);
 int peer_check(crl_ppo* h);
 void peer_destroy(crl_ppo* h);
+// CRL_GATHER (default 1): the update kernels read each sample's 64-byte record THROUGH the epoch's permutation (one random
+// 64-B fetch per sample and role, +2 % on the kernel) and the separate permute pass — a full extra read + write of the batch per
+// epoch — is gone; 0 = lay every epoch's minibatches out contiguously first (records.hip: permute_records_kernel).
+inline bool gather_mode() {
+  static int g = -1;
+  if (g < 0) { const char* e = getenv("CRL_GATHER"); g = (e && atoi(e) == 0) ? 0 : 1; }
+  return g == 1;
+}
 inline bool has_comm(const crl_ppo* h) { return h->comm != nullptr || h->peer != nullptr; }
 }  // namespace crl

@@ -66,6 +66,38 @@ __global__ void __launch_bounds__(256) permute_records_kernel(int B, int M, int 
   }
 }
 
+// Gather mode (CRL_GATHER=1, ppo_ctx.hpp): nothing is moved — the update kernels fetch records through the permutation — and only
+// the advantage statistics of ppo.jl:221 are left to do here: Σadv, Σadv² per minibatch of every slot, the same grid and the same
+// partial layout as the permute pass. adv is the 4-byte-per-sample array the GAE wrote (33.5 MB at the headline size: the random
+// reads hit the Infinity Cache); eight independent gathers per thread are in flight together.
+constexpr int ADVG_U = 8;
+__global__ void __launch_bounds__(256) adv_gather_sums_kernel(int B, int M, int chunk, const int32_t* __restrict__ perm /* [slots][B] */,
+                                                             const float* __restrict__ adv, double* __restrict__ part) {
+  const int mb = blockIdx.y, z = blockIdx.z;
+  const int32_t* pm = perm + (size_t)z * B + (size_t)mb * M;
+  const int lo = blockIdx.x * chunk, hi = min(M, lo + chunk);
+  double sa = 0.0, sa2 = 0.0;
+  for (int p0 = lo + threadIdx.x; p0 < hi; p0 += 256 * ADVG_U) {
+    int s[ADVG_U];
+    float v[ADVG_U];
+#pragma unroll
+    for (int u = 0; u < ADVG_U; ++u) { const int p = p0 + 256 * u; s[u] = p < hi ? pm[p] : -1; }
+#pragma unroll
+    for (int u = 0; u < ADVG_U; ++u) v[u] = s[u] >= 0 ? adv[s[u]] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < ADVG_U; ++u) { const double a = (double)v[u]; sa += a; sa2 += a * a; }
+  }
+  __shared__ double sm[2][4];
+  sa = wave_sum(sa); sa2 = wave_sum(sa2);
+  if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = sa; sm[1][threadIdx.x >> 6] = sa2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double* o = part + (((size_t)z * gridDim.y + mb) * gridDim.x + blockIdx.x) * 2;
+    o[0] = (sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3]);
+    o[1] = (sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3]);
+  }
+}
+
 int launch_adv_fold(crl_ppo* h, const double* part, int nblk, int nentries, double* sums);  // optim.hip
 
 int launch_pack_records(crl_ppo* h) {
@@ -82,13 +114,23 @@ int launch_pack_records(crl_ppo* h) {
   return 0;
 }
 
-// recs_p[slot] ← recs[perm[slot]] for slots [slot0, slot0 + nslots), plus their per-minibatch advantage sums → adv_sums_base
+// recs_p[slot] ← recs[perm[slot]] for slots [slot0, slot0 + nslots) (CRL_GATHER=0 only), plus their per-minibatch advantage sums
+// → adv_sums_base
 int launch_permute_records(crl_ppo* h, int slot0, int nslots) {
   if (launch_pack_records(h)) return 1;
   const int B = h->dc.B, M = h->dc.M, nmb = h->dc.nmb, pb = h->adv_pb;
   const int chunk = (((M + pb - 1) / pb + 63) / 64) * 64;
-  ProfScope ps(h, CRL_K_PERMUTE);
   double* part = h->adv_part + (size_t)slot0 * nmb * pb * 2;   // each slot has its own slice: launches for different slots may overlap
+  if (gather_mode()) {
+    ProfScope ps(h, CRL_K_ADV_STATS);
+    hipLaunchKernelGGL(adv_gather_sums_kernel, dim3(pb, nmb, nslots), dim3(256), 0, h->stream, B, M, chunk, h->perm_base + (size_t)slot0 * B,
+                       h->adv, part);
+    CRL_HIP_CHECK(hipGetLastError());
+    if (launch_adv_fold(h, part, pb, nslots * nmb, h->adv_sums_base + (size_t)slot0 * nmb * 2)) return 1;
+    for (int s = slot0; s < slot0 + nslots; ++s) h->slot_fresh |= 1u << s;
+    return 0;
+  }
+  ProfScope ps(h, CRL_K_PERMUTE);
   hipLaunchKernelGGL(permute_records_kernel, dim3(pb, nmb, nslots), dim3(256), 0, h->stream, B, M, chunk, h->perm_base + (size_t)slot0 * B, h->recs,
                      h->recs_p + (size_t)slot0 * B, part);
   CRL_HIP_CHECK(hipGetLastError());

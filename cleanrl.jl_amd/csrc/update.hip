@@ -51,7 +51,8 @@ struct Gathered {
 template <int D, int ROLE>
 __device__ __forceinline__ void gather(const UpdateArgs& a, int pos, Gathered<D>& g) {
   static_assert(D == 4, "SampleRec carries a 4-float observation");
-  const f32x4* r = reinterpret_cast<const f32x4*>(a.recs + pos);
+  const int idx = a.perm ? a.perm[pos] : pos;
+  const f32x4* r = reinterpret_cast<const f32x4*>(a.recs + idx);
   const f32x4 xv = r[0], q = r[ROLE == 0 ? 1 : 2];
   g.x[0] = xv[0]; g.x[1] = xv[1]; g.x[2] = xv[2]; g.x[3] = xv[3];
   if (ROLE == 0) { g.act = __float_as_int(q[0]); g.f0 = q[1]; g.f1 = q[2]; }
@@ -674,13 +675,15 @@ __global__ void stats_kernel(const float* __restrict__ msg, int P, StatsArgs st,
 }
 
 // #{b : u > q_b} over the minibatch (only when the speculation flag is up)
-__global__ void vfix_count_kernel(DevCfg c, const SampleRec* __restrict__ recs, const float* __restrict__ newv, double* vfix) {
+__global__ void vfix_count_kernel(DevCfg c, const SampleRec* __restrict__ recs, const int32_t* __restrict__ perm, const float* __restrict__ newv,
+                                  double* vfix) {
   if (vfix[3] == 0.0) return;
   __shared__ double sm[4];
   const float u = (float)vfix[0];
   double cnt = 0.0;
   for (int pos = threadIdx.x; pos < c.M; pos += blockDim.x) {
-    const float v = newv[pos], ov = recs[pos].old_v, R = recs[pos].ret;
+    const int idx = perm ? perm[pos] : pos;
+    const float v = newv[pos], ov = recs[idx].old_v, R = recs[idx].ret;
     const float cl = fminf(fmaxf(v - ov, -c.clip), c.clip);
     const float vc = ov + cl;
     const float q = (vc - R) * (vc - R);
@@ -719,6 +722,7 @@ static int run_update(crl_ppo* h, int mb, int mode, hipEvent_t ev0 = nullptr, hi
   UpdateArgs a;
   a.c = h->dc; a.params = h->params;
   a.recs = h->recs_p + (size_t)h->cur_slot * h->dc.B + (size_t)mb * h->dc.M; a.adv_ms = h->adv_ms; a.vfix = h->vfix;
+  if (gather_mode()) { a.recs = h->recs; a.perm = h->perm_base + (size_t)h->cur_slot * h->dc.B + (size_t)mb * h->dc.M; }
   a.gpart = h->gpart; a.lpart = h->lpart; a.newv = h->newv; a.range_err = h->vfix + 5;
   a.dscale = h->dscale; a.dmax = reinterpret_cast<unsigned*>(h->dscale + 2);
   a.mb = mb; a.mode = mode; a.gstride = (int)h->Pa; a.pmax = h->update_blocks; a.stagger = 0;
@@ -759,6 +763,12 @@ static int run_update(crl_ppo* h, int mb, int mode, hipEvent_t ev0 = nullptr, hi
   }
   CRL_HIP_CHECK(hipGetLastError());
   return 0;
+}
+
+static void launch_vfix_count(crl_ppo* h, int mb) {
+  const size_t off = (size_t)h->cur_slot * h->dc.B + (size_t)mb * h->dc.M;
+  if (gather_mode()) hipLaunchKernelGGL(vfix_count_kernel, dim3(1), dim3(1024), 0, h->stream, h->dc, h->recs, h->perm_base + off, h->newv, h->vfix);
+  else hipLaunchKernelGGL(vfix_count_kernel, dim3(1), dim3(1024), 0, h->stream, h->dc, h->recs_p + off, nullptr, h->newv, h->vfix);
 }
 
 static StatsArgs stats_args(crl_ppo* h, int mb, crl_ppo_stats* slot, int fused) {
@@ -803,7 +813,7 @@ int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot, bool inline_fix
   }
   if (inline_fix && h->cfg.clip_value_loss && h->world == 1) {
     // early-exit launches unless the statistics raised the flag (u > 0)
-    hipLaunchKernelGGL(vfix_count_kernel, dim3(1), dim3(1024), 0, h->stream, h->dc, h->recs_p + (size_t)h->cur_slot * h->dc.B + (size_t)mb * h->dc.M, h->newv, h->vfix);
+    launch_vfix_count(h, mb);
     CRL_HIP_CHECK(hipGetLastError());
     if (run_update(h, mb, 1)) return 1;
     hipLaunchKernelGGL(reduce_kernel<1>, dim3((P + 63) / 64), dim3(64 * RG), 0, h->stream, h->gpart, h->lpart, 0, h->update_blocks,
@@ -835,7 +845,7 @@ int launch_update_exact_dp(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
   CRL_HIP_CHECK(hipMemcpyAsync(&flag, h->vfix + 3, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
   if (flag == 0.0) return 0;
-  hipLaunchKernelGGL(vfix_count_kernel, dim3(1), dim3(1024), 0, h->stream, h->dc, h->recs_p + (size_t)h->cur_slot * h->dc.B + (size_t)mb * h->dc.M, h->newv, h->vfix);
+  launch_vfix_count(h, mb);
   CRL_HIP_CHECK(hipGetLastError());
   if (comm_allreduce(h, h->vfix + 1, 1, true)) return 1;                       // global #{u > q}
   if (run_update(h, mb, 1)) return 1;                                          // exact critic gradient of this shard

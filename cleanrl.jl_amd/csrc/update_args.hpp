@@ -8,6 +8,7 @@ struct UpdateArgs {
   DevCfg c;
   const float* params;
   const SampleRec* recs;  // the minibatch, contiguous: recs_p[slot] + mb·M (ppo.jl:203-211 after the permute pass)
+  const int32_t* perm = nullptr;  // gather mode: recs = the unpermuted records, perm = this minibatch's slice of b_inds
   const double* adv_ms;   // [nmb][2] mean, std of the (global) minibatch advantages
   const double* vfix;     // [8] u, #{u > q}, -, flag, sticky flag
   float* gpart; double* lpart; float* newv;
