@@ -224,6 +224,7 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
     rc |= dalloc(&h->perm_tmp, E * B); rc |= dalloc(&h->bfy_ws, E * ((size_t)4 * 16384 + 8));   // one slice per epoch slot
     size_t k1 = 1; while (k1 * 4096 < B) k1 *= 2;
     rc |= dalloc(&h->bfy_adv_part, (size_t)c.nmb * k1 * 2);
+    if (!wide && gather_mode()) { rc |= dalloc(&h->bfy_bucket_mb, E * (size_t)16384); rc |= dalloc(&h->bfy_mbid, E * B); }
   }
   // update grid: two 256-thread blocks per CU, alternating roles; never more waves than tiles
   hipDeviceProp_t prop;
@@ -265,7 +266,7 @@ int32_t crl_ppo_destroy(crl_ppo* h) {
   wide_destroy(h);
   void* ptrs[] = {h->obs, h->action, h->logprob, h->reward, h->terminal, h->value, h->adv, h->ret, h->env_state, h->env_t,
                   h->cur_obs, h->next_done, h->ep_return, h->ep_length, h->next_value, h->ep_stats, h->ep_ring, h->ep_ring_count, h->params,
-                  h->adam_m, h->adam_v, h->betap, h->optim_part, h->perm_base, h->recs, h->recs_p, h->adv_part, h->perm_tmp, h->bfy_ws, h->bfy_adv_part, h->gpart, h->lpart,
+                  h->adam_m, h->adam_v, h->betap, h->optim_part, h->perm_base, h->recs, h->recs_p, h->adv_part, h->perm_tmp, h->bfy_ws, h->bfy_adv_part, h->bfy_bucket_mb, h->bfy_mbid, h->gpart, h->lpart,
                   h->adv_sums_base, h->adv_ms_base, h->newv, h->vfix, h->dscale, h->stats_dev, h->comm_buf, h->snap, h->snap_betap, h->snap_env, h->stage};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int k = 0; k < CRL_K_COUNT; ++k)
@@ -302,7 +303,7 @@ int32_t crl_ppo_write(crl_ppo* h, int32_t field, const void* host, size_t nbytes
   CRL_HIP_CHECK(hipMemcpyAsync(fr.ptr, host, nbytes, hipMemcpyHostToDevice, h->stream));
   CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
   if (field == CRL_F_PARAMS) wide_mark_params_changed(h);
-  if (field == CRL_F_PERM) { h->perm_is_bijection = false; h->slot_fresh &= ~(1u << h->cur_slot); }
+  if (field == CRL_F_PERM) { h->perm_is_bijection = false; h->slot_fresh &= ~(1u << h->cur_slot); h->bfy_tbl_slots &= ~(1u << h->cur_slot); }
   if (field == CRL_F_PERM || field == CRL_F_ADVANTAGE) h->bfy_adv_parts = 0;  // a caller-supplied permutation has no closed-form inverse
   if (field == CRL_F_OBS || field == CRL_F_ACTION || field == CRL_F_LOGPROB || field == CRL_F_VALUE || field == CRL_F_ADVANTAGE ||
       field == CRL_F_RETURN) h->recs_dirty = true;

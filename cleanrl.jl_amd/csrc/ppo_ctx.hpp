@@ -94,6 +94,13 @@ struct crl_ppo {
   uint32_t* bfy_ws = nullptr;      // blocked Fisher–Yates: totals | offsets | cursors | error flag
   double* bfy_adv_part = nullptr;  // [nmb][K1][2] Σadv, Σadv² per leaf block, left behind by a fused shuffle (crl_ppo_iterate)
   int bfy_adv_parts = 0;           // K1 when the partials above belong to the current permutation, else 0
+  // minibatch of every L1 bucket (low 15 bits; bit 15: the bucket straddles a minibatch boundary and its members' minibatches are in
+  // bfy_mbid) — lets the advantage statistics run as ONE sequential pass over adv (records.hip) instead of a gather per epoch
+  uint16_t* bfy_bucket_mb = nullptr;   // [update_epochs][BFY_MAXK1]
+  uint8_t* bfy_mbid = nullptr;         // [update_epochs][B], written for members of straddling buckets only
+  uint32_t bfy_tbl_slots = 0;          // bit s: the two tables of slot s describe perm[s]
+  uint64_t bfy_tbl_epoch0 = 0;         // epoch id of slot 0's permutation (slot s holds epoch0 + s)
+  uint32_t bfy_tbl_K1 = 0;
   bool perm_is_bijection = false;  // perm == π_key(epoch): its inverse is computable (adv-stats fast path)
   uint64_t perm_epoch = 0;
   // update workspace
@@ -182,6 +189,7 @@ int launch_next_value(crl_ppo* h);
 int launch_shuffle(crl_ppo* h, uint64_t epoch_id, bool with_adv_sums = false);
 int launch_shuffle_epochs(crl_ppo* h, uint64_t epoch0, int nslots);
 int launch_adv_stats_sums(crl_ppo* h);
+int launch_adv_bucket_sums(crl_ppo* h, int slot0, int nslots, double* part, int nblk);   // shuffle.hip; 1 = not applicable
 int launch_adv_stats_finish(crl_ppo* h, int slot0 = -1, int nslots = 1);
 int launch_pack_records(crl_ppo* h);
 int launch_permute_records(crl_ppo* h, int slot0, int nslots);

@@ -123,8 +123,11 @@ int launch_permute_records(crl_ppo* h, int slot0, int nslots) {
   double* part = h->adv_part + (size_t)slot0 * nmb * pb * 2;   // each slot has its own slice: launches for different slots may overlap
   if (gather_mode()) {
     ProfScope ps(h, CRL_K_ADV_STATS);
-    hipLaunchKernelGGL(adv_gather_sums_kernel, dim3(pb, nmb, nslots), dim3(256), 0, h->stream, B, M, chunk, h->perm_base + (size_t)slot0 * B,
-                       h->adv, part);
+    static const bool seq = !(getenv("CRL_ADV_SEQ") && atoi(getenv("CRL_ADV_SEQ")) == 0);
+    if (!seq || launch_adv_bucket_sums(h, slot0, nslots, part, pb)) {   // the sequential pass needs the blocked shuffle's tables
+      hipLaunchKernelGGL(adv_gather_sums_kernel, dim3(pb, nmb, nslots), dim3(256), 0, h->stream, B, M, chunk, h->perm_base + (size_t)slot0 * B,
+                         h->adv, part);
+    }
     CRL_HIP_CHECK(hipGetLastError());
     if (launch_adv_fold(h, part, pb, nslots * nmb, h->adv_sums_base + (size_t)slot0 * nmb * 2)) return 1;
     for (int s = slot0; s < slot0 + nslots; ++s) h->slot_fresh |= 1u << s;

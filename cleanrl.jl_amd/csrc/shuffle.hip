@@ -121,7 +121,8 @@ __global__ void __launch_bounds__(1024) bfy_scan_kernel(uint32_t K1, uint32_t* _
 // M >= BFY_CAP so that a bucket touches at most two minibatches.
 __global__ void __launch_bounds__(256, 4) bfy_leaf_kernel(uint32_t K1, uint64_t seed, uint64_t epoch0, int n, const uint32_t* __restrict__ ws,
                                                           const int32_t* __restrict__ S0, int32_t* __restrict__ perm0,
-                                                          const float* __restrict__ adv, int M, int nmb, double* __restrict__ part) {
+                                                          const float* __restrict__ adv, int M, int nmb, double* __restrict__ part,
+                                                          uint16_t* __restrict__ bucket_mb0, uint8_t* __restrict__ mbid0) {
   const uint64_t epoch = epoch0 + blockIdx.y;
   const uint32_t* off = ws + (size_t)blockIdx.y * BFY_WS_STRIDE + BFY_MAXK1;
   const uint32_t* err = off + 2 * BFY_MAXK1 + 1;
@@ -190,6 +191,16 @@ __global__ void __launch_bounds__(256, 4) bfy_leaf_kernel(uint32_t K1, uint64_t 
   __syncthreads();
   if (!adv) {
     for (uint32_t idx = t; idx < c; idx += 256) perm[base + idx] = buf2[idx];
+    if (bucket_mb0) {
+      // which minibatch this bucket's positions [base, base + c) belong to; a bucket across a boundary also says it per member
+      const uint32_t mbf = base / (uint32_t)M, cutp = (mbf + 1u) * (uint32_t)M;
+      const bool straddle = c > 0 && base + c > cutp;
+      if (t == 0) bucket_mb0[(size_t)blockIdx.y * BFY_MAXK1 + d1] = (uint16_t)(mbf | (straddle ? 0x8000u : 0u));
+      if (straddle) {
+        uint8_t* mbid = mbid0 + (size_t)blockIdx.y * n;
+        for (uint32_t idx = t; idx < c; idx += 256) mbid[buf2[idx]] = (uint8_t)((base + idx) / (uint32_t)M);
+      }
+    }
     return;
   }
   const int mb0 = (int)(base / (uint32_t)M);
@@ -242,11 +253,72 @@ static int launch_blocked_fy(crl_ppo* h, uint64_t epoch_id, int nslots, bool fus
   if (big) hipLaunchKernelGGL((bfy_l1_kernel<true, 1024>), g1, dim3(1024), sizeof(uint32_t) * 2 * K1, h->stream, n, K1, seed, epoch_id, ws, S);
   else hipLaunchKernelGGL((bfy_l1_kernel<true, 256>), g1, dim3(256), sizeof(uint32_t) * 2 * K1, h->stream, n, K1, seed, epoch_id, ws, S);
   const bool fuse = fused && nslots == 1 && h->bfy_adv_part && h->dc.M >= BFY_CAP && h->dc.nmb <= 256;
+  // the bucket → minibatch tables (sequential advantage statistics, below) describe slots [0, nslots) of one iterate call
+  const bool tables = !fuse && h->bfy_bucket_mb && h->cur_slot == 0 && h->dc.nmb <= 255;
   hipLaunchKernelGGL(bfy_leaf_kernel, dim3(K1, nslots), dim3(256), 0, h->stream, K1, seed, epoch_id, n, ws, S, h->perm, fuse ? h->adv : nullptr,
-                     h->dc.M, h->dc.nmb, h->bfy_adv_part);
+                     h->dc.M, h->dc.nmb, h->bfy_adv_part, tables ? h->bfy_bucket_mb : nullptr, h->bfy_mbid);
   CRL_HIP_CHECK(hipGetLastError());
   h->bfy_adv_parts = fuse ? (int)K1 : 0;
+  for (int z = 0; z < nslots; ++z) h->bfy_tbl_slots &= ~(1u << (h->cur_slot + z));
+  if (tables) {   // exactly these slots: older tables were drawn for another epoch0
+    h->bfy_tbl_slots = nslots >= 32 ? 0xFFFFFFFFu : ((1u << nslots) - 1u); h->bfy_tbl_epoch0 = epoch_id; h->bfy_tbl_K1 = K1;
+  }
   return 0;
+}
+
+// Σadv, Σadv² per minibatch of the blocked-Fisher–Yates permutations in slots [slot0, slot0 + nslots) WITHOUT walking the
+// permutations: a sample's position is decided by its first Philox digit (its L1 bucket) up to the order inside the bucket, and a
+// bucket (≈4 K consecutive positions) lies inside one minibatch unless it crosses one of the nmb − 1 boundaries. So one coalesced
+// pass over adv recomputes every sample's digit, looks its bucket's minibatch up in the table the leaf pass left, and only for the
+// members of the few straddling buckets reads the per-sample byte. 4 B read per sample and epoch instead of a random cache line.
+template <int NMB>
+__global__ void __launch_bounds__(256) adv_bucket_sums_kernel(int n, uint32_t K1, uint64_t seed, uint64_t epoch0, int slot0,
+                                                             const float* __restrict__ adv, const uint16_t* __restrict__ bucket_mb0,
+                                                             const uint8_t* __restrict__ mbid0, double* __restrict__ part /* [z][mb][gridDim.x][2] */) {
+  const int z = blockIdx.z;
+  const uint64_t epoch = epoch0 + (uint64_t)(slot0 + z);
+  const uint16_t* bmb = bucket_mb0 + (size_t)(slot0 + z) * BFY_MAXK1;
+  const uint8_t* mbid = mbid0 + (size_t)(slot0 + z) * n;
+  double s[NMB], s2[NMB];
+#pragma unroll
+  for (int m = 0; m < NMB; ++m) { s[m] = 0.0; s2[m] = 0.0; }
+  for (int v = blockIdx.x * 256 + threadIdx.x; v < n; v += gridDim.x * 256) {
+    const double a = (double)adv[v];
+    uint32_t d1, d2;
+    bfy_digits((uint32_t)v, K1, seed, epoch, d1, d2);
+    const uint32_t e = bmb[d1];
+    const int mb = (e & 0x8000u) ? (int)mbid[v] : (int)e;
+#pragma unroll
+    for (int m = 0; m < NMB; ++m) { const bool hit = mb == m; s[m] += hit ? a : 0.0; s2[m] += hit ? a * a : 0.0; }
+  }
+  __shared__ double sm[2][NMB][4];
+  const int w = threadIdx.x >> 6;
+#pragma unroll
+  for (int m = 0; m < NMB; ++m) {
+    const double t = wave_sum(s[m]), t2 = wave_sum(s2[m]);
+    if ((threadIdx.x & 63) == 0) { sm[0][m][w] = t; sm[1][m][w] = t2; }
+  }
+  __syncthreads();
+  if (threadIdx.x < NMB) {
+    const int m = threadIdx.x;
+    double* o = part + (((size_t)z * NMB + m) * gridDim.x + blockIdx.x) * 2;
+    o[0] = (sm[0][m][0] + sm[0][m][1]) + (sm[0][m][2] + sm[0][m][3]);
+    o[1] = (sm[1][m][0] + sm[1][m][1]) + (sm[1][m][2] + sm[1][m][3]);
+  }
+}
+
+// returns 1 when the tables do not cover these slots (other shuffle modes, caller-supplied permutations, nmb not 1/2/4/8): the
+// caller then gathers through the permutation instead
+int launch_adv_bucket_sums(crl_ppo* h, int slot0, int nslots, double* part, int nblk) {
+  if (h->cfg.shuffle_mode != CRL_SHUFFLE_BLOCKED_FY || !h->bfy_bucket_mb) return 1;
+  for (int z = slot0; z < slot0 + nslots; ++z) if (!(h->bfy_tbl_slots >> z & 1u)) return 1;
+  const int nmb = h->dc.nmb;
+  const dim3 g(nblk, 1, nslots);
+#define CRL_GO(N) hipLaunchKernelGGL((adv_bucket_sums_kernel<N>), g, dim3(256), 0, h->stream, h->dc.B, h->bfy_tbl_K1, shuffle_seed(h), \
+                                     h->bfy_tbl_epoch0, slot0, h->adv, h->bfy_bucket_mb, h->bfy_mbid, part)
+  if (nmb == 1) CRL_GO(1); else if (nmb == 2) CRL_GO(2); else if (nmb == 4) CRL_GO(4); else if (nmb == 8) CRL_GO(8); else return 1;
+#undef CRL_GO
+  return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 // update_epochs consecutive epochs at once into slots 0 … (crl_ppo_iterate; blocked Fisher–Yates only)

@@ -672,3 +672,25 @@ def test_episode_record_ring(crl, kind, monkeypatch):
     assert total2 == total and len(recs2) == 16 and set(recs2) <= set(want)
     h.episode_ring_enable(0)
     agent.close()
+
+
+@pytest.mark.parametrize("nt,nmb", [(8, 4), (256, 4), (256, 8), (1024, 2), (96, 1), (200, 4)])
+def test_iterate_advantage_sums_match_the_permutation(crl, nt, nmb):
+    """crl_ppo_iterate gets Σadv, Σadv² of every minibatch (ppo.jl:221) from ONE sequential pass over the advantages: a sample's
+    minibatch follows from its blocked-Fisher–Yates bucket, per-sample only inside the few buckets that straddle a boundary
+    (shuffle.hip). Cross-check against the permutation itself: sums over adv[b_inds[minibatch]] of the last epoch, in Float64."""
+    k = 128
+    agent = make_agent(crl, nt=nt, k=k, num_minibatches=nmb)
+    h = agent.handle
+    h.env_reset()
+    h.iterate(1, want_stats=False)
+    L = crl._lib
+    perm = h.read(L.F_PERM); adv = h.read(L.F_ADVANTAGE).reshape(-1, order="F").astype(np.float64)
+    sums = h.read(L.F_ADV_SUMS).reshape(nmb, 2)
+    assert sorted(perm.tolist()) == list(range(nt * k))
+    M = nt * k // nmb
+    for mb in range(nmb):
+        a = adv[perm[mb * M:(mb + 1) * M]]
+        assert abs(sums[mb, 0] - a.sum()) <= 1e-9 * max(1.0, np.abs(a).sum()), (mb, sums[mb, 0], a.sum())
+        assert abs(sums[mb, 1] - (a * a).sum()) <= 1e-9 * max(1.0, (a * a).sum()), mb
+    agent.close()
