@@ -29,7 +29,7 @@ bool gemm_x2() { return gemm_mode() == 2; }
 int reset_dw_scale(crl_ppo* h) {
   const double lm = std::log2((double)h->dc.M * (double)h->world);
   const int ka = 8 * (int)std::lround((lm + 19.0) / 8.0), kc = 8 * (int)std::lround((lm + 3.0) / 8.0);
-  const float init[8] = {std::ldexp(1.0f, ka), std::ldexp(1.0f, kc), 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};   // G x2 | max bits x2 | miss flag
+  const float init[4] = {std::ldexp(1.0f, ka), std::ldexp(1.0f, kc), 0.0f, 0.0f};
   CRL_HIP_CHECK(hipMemcpy(h->dscale, init, sizeof(init), hipMemcpyHostToDevice));
   return 0;
 }
@@ -237,7 +237,7 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
   h->update_blocks = ub;
   if (!wide) { rc |= dalloc(&h->gpart, (size_t)4 * ub * h->Pa + 4096); rc |= dalloc(&h->lpart, (size_t)4 * ub * 2); }
   rc |= dalloc(&h->adv_sums_base, E * c.nmb * 2); rc |= dalloc(&h->adv_ms_base, E * c.nmb * 2);
-  rc |= dalloc(&h->newv, (size_t)c.M + 64); rc |= dalloc(&h->vfix, 8); rc |= dalloc(&h->dscale, 8);
+  rc |= dalloc(&h->newv, (size_t)c.M + 64); rc |= dalloc(&h->vfix, 8); rc |= dalloc(&h->dscale, 4);
   rc |= dalloc(&h->stats_dev, (size_t)cfg->update_epochs * c.nmb);
   rc |= dalloc(&h->comm_buf, (size_t)h->P + 8);
   rc |= dalloc(&h->snap, (size_t)3 * h->P); rc |= dalloc(&h->snap_betap, 24);

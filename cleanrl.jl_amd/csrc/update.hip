@@ -59,10 +59,6 @@ __device__ __forceinline__ void gather(const UpdateArgs& a, int pos, Gathered<D>
   else { g.act = 0; g.f0 = q[0]; g.f1 = q[1]; }
 }
 
-}  // namespace crl
-#include "update16.hpp"   // the 16-sample-tile flavour (needs sgpr / CRL_PHASE above)
-namespace crl {
-
 // One role (actor or critic) = RW waves of the block: `smem` is the role's weight image, `scratch` the first of its
 // RW wave-private tiles. All barriers are block-wide and both roles execute the same number of them.
 constexpr int SCR_FLOATS = 64 * TSTRIDE + TILE * 4 + 2 * TILE;
@@ -578,15 +574,6 @@ __global__ void __launch_bounds__(512, 2) update_x2_kernel(UpdateArgs a) {
   if ((int)blockIdx.x < a.nblk[0]) update_role<D, A, 0, false, true, 8, 0, true>(a, blockIdx.x, smem, smem + NetImageX2<D, A>::SIZE);
   else update_role<D, A, 1, false, true, 8, 0, true>(a, blockIdx.x - a.nblk[0], smem, smem + NetImageX2<D, 1>::SIZE);
 }
-// After update_t16_kernel (update16.hpp): nothing unless a tile of that launch did not fit the carried weight-gradient scale — then
-// the whole minibatch is recomputed on bf16x3 (no range limits) into the same partial buffers, before the reduce reads them.
-template <int D, int A>
-__global__ void __launch_bounds__(512, 2) update_repair_kernel(UpdateArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (*a.dw_miss == 0u) return;
-  if ((int)blockIdx.x < a.nblk[0]) update_role<D, A, 0, false, true, 8>(a, blockIdx.x, smem, smem + NetImageX3<D, A, true>::SIZE);
-  else update_role<D, A, 1, false, true, 8>(a, blockIdx.x - a.nblk[0], smem, smem + NetImageX3<D, 1, true>::SIZE);
-}
 #ifdef CRL_ABLATE
 // timing experiments only: the same kernel with one phase removed (results are garbage)
 template <int D, int A, int ABL, int RW>
@@ -673,7 +660,6 @@ __global__ void __launch_bounds__(64 * RG) reduce_kernel(const float* __restrict
     unsigned* mx = reinterpret_cast<unsigned*>(st.dscale + 2);
     st.dscale[threadIdx.x] = dw_next_scale(mx[threadIdx.x], st.dscale[threadIdx.x]);
     mx[threadIdx.x] = 0u;
-    if (threadIdx.x == 0) mx[2] = 0u;   // the 16-sample kernel's miss flag: update_repair_kernel has run by now
   }
   if (last && st.fused) {
     __syncthreads();  // the four sums written above are visible to thread 0 of this block
@@ -714,8 +700,6 @@ __global__ void vfix_count_kernel(DevCfg c, const SampleRec* __restrict__ recs, 
 }
 
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-// CRL_UPDATE_TILE=16: the 16-sample-tile kernel of update16.hpp (three waves per SIMD) instead of the 32-sample one
-static bool update_tile16() { static int t = -1; if (t < 0) t = env_int("CRL_UPDATE_TILE", 32); return t == 16; }
 
 // block counts of the main pass: {actor, critic}
 static void main_pass_blocks(crl_ppo* h, int* nA, int* nC) {
@@ -740,7 +724,7 @@ static int run_update(crl_ppo* h, int mb, int mode, hipEvent_t ev0 = nullptr, hi
   a.recs = h->recs_p + (size_t)h->cur_slot * h->dc.B + (size_t)mb * h->dc.M; a.adv_ms = h->adv_ms; a.vfix = h->vfix;
   if (gather_mode()) { a.recs = h->recs; a.perm = h->perm_base + (size_t)h->cur_slot * h->dc.B + (size_t)mb * h->dc.M; }
   a.gpart = h->gpart; a.lpart = h->lpart; a.newv = h->newv; a.range_err = h->vfix + 5;
-  a.dscale = h->dscale; a.dmax = reinterpret_cast<unsigned*>(h->dscale + 2); a.dw_miss = reinterpret_cast<unsigned*>(h->dscale + 4);
+  a.dscale = h->dscale; a.dmax = reinterpret_cast<unsigned*>(h->dscale + 2);
   a.mb = mb; a.mode = mode; a.gstride = (int)h->Pa; a.pmax = h->update_blocks; a.stagger = 0;
   a.Mglobal = (double)h->dc.M * h->world;
   if (mode == 1) {
@@ -760,15 +744,6 @@ static int run_update(crl_ppo* h, int mb, int mode, hipEvent_t ev0 = nullptr, hi
     CRL_DBG_CASE(32, 8) CRL_DBG_CASE(64, 8) CRL_DBG_CASE(82, 8) CRL_DBG_CASE(86, 8) CRL_DBG_CASE(126, 8)
 #undef CRL_DBG_CASE
 #endif
-  } else if (gemm_x2() && update_tile16()) {
-    main_pass_blocks(h, &a.nblk[0], &a.nblk[1]);
-    a.stagger = env_int("CRL_T16_STAGGER", 3);
-    const size_t smem = sizeof(float) * update16_smem_floats();
-    if (getenv("CRL_DEBUG_DW_MISS")) a.mode = 2;   // tests: every tile reports a miss, the repair pass produces the result
-    hipExtLaunchKernelGGL((update_t16_kernel<2>), dim3(a.nblk[0] + a.nblk[1]), dim3(64 * RW16), smem, h->stream, ev0, ev1, 0, a);
-    a.mode = 0;
-    const size_t smem3 = sizeof(float) * (NetImageX3<4, 2, true>::SIZE + 8 * SCR_FLOATS_X3);
-    hipLaunchKernelGGL((update_repair_kernel<4, 2>), dim3(a.nblk[0] + a.nblk[1]), dim3(512), smem3, h->stream, a);
   } else if (gemm_x2()) {
     main_pass_blocks(h, &a.nblk[0], &a.nblk[1]);
     a.stagger = env_int("CRL_X3_STAGGER", 3);
