@@ -15,9 +15,12 @@ timeout 600 python3 $R/bench.py --workload c3 --steps 5 --warmup 2 > $O/bench_c3
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3 -- python3 $R/bench.py --workload c3 --steps 3 --warmup 1 > /dev/null 2> $O/prof_c3.log
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --no-cpu-baseline > $O/prof_bench.json 2> $O/prof.log
-KR="update_x2_kernel|gae_kernel|permute_records|pack_records|rollout_cartpole"
+KR="update_x2_kernel|gae_kernel|adv_bucket_sums|pack_records|rollout_cartpole"
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$KR" --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$KR" --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+# calibration of FETCH_SIZE on a gather of whole 64-byte records with a known byte count: the permute pass of CRL_GATHER=0
+CRL_GATHER=0 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "permute_records|update_x2_kernel" --output-format csv -d $O/calib_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+CRL_GATHER=0 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "permute_records|update_x2_kernel" --output-format csv -d $O/calib_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 # the standalone GAE kernel (the loop fuses the scan into the rollout): same counters on CRL_GAE_FUSE=0
 CRL_GAE_FUSE=0 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "gae_kernel" --output-format csv -d $O/pmc_fetch_gae -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 CRL_GAE_FUSE=0 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "gae_kernel" --output-format csv -d $O/pmc_write_gae -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
@@ -26,8 +29,14 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_AC
   timeout 300 rocprofv3 --pmc $set --kernel-include-regex "update_x2_kernel|rollout_cartpole" --output-format csv -d $O/pmc_sq_$n -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 done
 cd $O
-for d in prof prof_c3 pmc_fetch pmc_write pmc_fetch_gae pmc_write_gae pmc_sq_*; do
+for d in prof prof_c3 pmc_fetch pmc_write pmc_fetch_gae pmc_write_gae calib_fetch calib_write pmc_sq_*; do
   for f in $(find $d -name "*kernel_stats.csv" -o -name "*counter_collection.csv" 2>/dev/null); do cp $f ${d}_$(basename $f); done
   rm -rf $d
 done
+# multi-rank functional runs on this one GPU (peer all-reduce) — labelled shared_gpu, not scaling points
+for n in 2 4 8; do
+  timeout 600 python $R/bench.py --gpus $n --comm peer --share-gpu --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | grep '^{' > $O/bench_shared_gpu_n$n.json
+done
+CRL_COMM_FORCE=1 timeout 300 python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --comm peer > $O/bench_n1_peer_forced.json 2>/dev/null
+timeout 900 python $R/scripts/parity_margins.py > $O/parity_margins.json 2>/dev/null
 echo done

@@ -694,3 +694,17 @@ def test_iterate_advantage_sums_match_the_permutation(crl, nt, nmb):
         assert abs(sums[mb, 0] - a.sum()) <= 1e-9 * max(1.0, np.abs(a).sum()), (mb, sums[mb, 0], a.sum())
         assert abs(sums[mb, 1] - (a * a).sum()) <= 1e-9 * max(1.0, (a * a).sum()), mb
     agent.close()
+
+
+def test_permute_pass_flavour_still_matches_the_oracle():
+    """CRL_GATHER=0 (records laid out contiguously per epoch by permute_records_kernel instead of being fetched through the
+    permutation by the update kernels) is a process-wide switch: run the iteration / gradient parity tests under it in a child."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, CRL_GATHER="0")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
+                          "full_iteration_matches_oracle or update_gradient_matches_oracle or guard_window or blocked_fisher_yates", "-p", "no:cacheprovider"],
+                         capture_output=True, text=True, env=env, timeout=1200)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout and "failed" not in out.stdout
