@@ -265,9 +265,13 @@ static int ensure_pack(crl_ppo* h) {
 // register quad but one SAMPLE per lane, so a direct store scatters 16-B pieces over 64 lines per instruction. The tile
 // goes through a wave-private [32][36] LDS scratch instead and comes back row-major: 8 lanes write one sample's 32 rows
 // (128 B), a wave instruction covers 8 whole lines. S (the stored tanh outputs) is read the same way.
+// tanh of the layer-wise path: the reference's rational tanh_fast, or — where nothing is compared bit for bit (the update pass,
+// the critic) — 1 − 2/(2^(2·log2(e)·x) + 1) on v_exp_f32 / v_rcp_f32 (mlp_x2.hpp: 5 instructions instead of 13, ≈1e-7 absolute)
+__device__ __forceinline__ float wide_tanh(float x, bool fast) { return fast ? tanh_exp2(x, TWO_LOG2E, 1.0f) : tanh_fast(x); }
+
 template <int EPI>
 __device__ __forceinline__ void tile_out(float* scr, const f32x16& acc, int lane, int n0, int mbase, int M, const float* bias,
-                                         const float* S, int lds, float* Y, int ldy) {
+                                         const float* S, int lds, float* Y, int ldy, bool fast = false) {
   const int j = lane & 31, hf = lane >> 5;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -289,7 +293,7 @@ __device__ __forceinline__ void tile_out(float* scr, const f32x16& acc, int lane
         for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.0f - sv[e] * sv[e]);
       } else if (EPI == EPI_TANH || EPI == EPI_BIAS) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] += bv[e]; if (EPI == EPI_TANH) v[e] = tanh_fast(v[e]); }
+        for (int e = 0; e < 4; ++e) { v[e] += bv[e]; if (EPI == EPI_TANH) v[e] = wide_tanh(v[e], fast); }
       }
       *reinterpret_cast<f32x4*>(Y + (size_t)ldy * gm + n) = v;
     }
@@ -309,6 +313,7 @@ struct DenseArgs {
   const float* X; int ldx; int Kt; const int32_t* idx;     // sample m's features at X + ldx·(idx ? idx[m] : m), Kt valid
   const float* bias; const float* S; int lds;              // bias[Nt]; S: stored tanh outputs at the Y positions
   float* Y; int ldy; int Nt; int M;
+  int fast_act = 0;   // EPI_TANH: the exp2-based activation of mlp_x2.hpp instead of tanh_fast (update path and critic only)
 };
 
 template <int WN, int TN, int WM, int TM, int EPI>
@@ -464,7 +469,7 @@ __global__ void __launch_bounds__(256) wide_dense_kernel(DenseArgs a) {
     for (int x = 0; x < TN; ++x)
 #pragma unroll
       for (int y = 0; y < TM; ++y)
-        tile_out<EPI>(scr, acc[x][y], lane, (wn * TN + x) * 32, m0 + (wm * TM + y) * 32, a.M, a.bias, a.S, a.lds, a.Y, a.ldy);
+        tile_out<EPI>(scr, acc[x][y], lane, (wn * TN + x) * 32, m0 + (wm * TM + y) * 32, a.M, a.bias, a.S, a.lds, a.Y, a.ldy, a.fast_act != 0);
     return;
   }
 #pragma unroll
@@ -482,7 +487,7 @@ __global__ void __launch_bounds__(256) wide_dense_kernel(DenseArgs a) {
           if (n + e >= a.Nt) continue;
           float o = acc[x][y][4 * g + e];
           if (EPI == EPI_DTANH) { const float sv = a.S[(size_t)a.lds * m + n + e]; o = o * (1.0f - sv * sv); }
-          else { o += a.bias[n + e]; if (EPI == EPI_TANH) o = tanh_fast(o); }
+          else { o += a.bias[n + e]; if (EPI == EPI_TANH) o = wide_tanh(o, a.fast_act != 0); }
           a.Y[(size_t)a.ldy * m + n + e] = o;
         }
       }
@@ -509,6 +514,7 @@ struct DenseX3Args {
   const float* dZ; int ldd; int Ad;      // dZ null = X is the operand itself; Ad = live rows of dZ
   // fp16x2 backward-data (wide_dense_x2_kernel<EPI_DTANH>): the head cotangent and wmax, from which each sample's scale comes
   const float* bz; int bld; int bA; const float* wmax;
+  int fast_act = 0;   // as DenseArgs::fast_act
 };
 constexpr int X3ROW = 40;                // bf16 per staged sample row per piece: 32 k + 8 pad (80 B: conflict-free b128)
 
@@ -526,13 +532,14 @@ __device__ __forceinline__ void split3x4(const f32x4 v, uint2& h, uint2& m, uint
 // the C fragment (lane = sample, registers = rows): hp[m_local][a] += Σ_{n in tile} W3[a, n]·tanh(acc + b)[n, m]. One
 // cross-half exchange per output instead of a lane reduction; the tile is then stored line-coalesced by tile_out.
 __device__ __forceinline__ void tile_tanh_head(float* scr, f32x16 acc, int lane, int n0, int mloc0, int mbase, int M,
-                                               const float* bias, float* Y, const float* W3t, int A, float* hp, int hs, float cs = 1.0f) {
+                                               const float* bias, float* Y, const float* W3t, int A, float* hp, int hs, float cs = 1.0f,
+                                               bool fast = false) {
   const int j = lane & 31, hf = lane >> 5;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0 + 8 * g + 4 * hf);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[4 * g + e] = tanh_fast(__builtin_fmaf(acc[4 * g + e], cs, bv[e]));
+    for (int e = 0; e < 4; ++e) acc[4 * g + e] = wide_tanh(__builtin_fmaf(acc[4 * g + e], cs, bv[e]), fast);
   }
   for (int aa = 0; aa < A; ++aa) {
     float p = 0.0f;
@@ -667,7 +674,7 @@ __global__ void __launch_bounds__(64 * NW) wide_dense_x3_kernel(DenseX3Args a) {
     wave_lds_fence();
 #pragma unroll
     for (int y = 0; y < TM; ++y)
-      tile_tanh_head(scr, acc[0][y], lane, wave * 32, 32 * y, m0 + 32 * y, a.M, a.bias, a.Y, a.W3t, a.A, hp, hs);
+      tile_tanh_head(scr, acc[0][y], lane, wave * 32, 32 * y, m0 + 32 * y, a.M, a.bias, a.Y, a.W3t, a.A, hp, hs, 1.0f, a.fast_act != 0);
     __syncthreads();
     for (int i = tid; i < MB * a.A; i += NT) {
       const int m = i / a.A, aa = i - m * a.A;
@@ -682,7 +689,7 @@ __global__ void __launch_bounds__(64 * NW) wide_dense_x3_kernel(DenseX3Args a) {
   for (int x = 0; x < TN; ++x)
 #pragma unroll
     for (int y = 0; y < TM; ++y)
-      tile_out<EPI>(scr, acc[x][y], lane, (TN * wave + x) * 32, m0 + 32 * y, a.M, a.bias, a.S, 256, a.Y, 256);
+      tile_out<EPI>(scr, acc[x][y], lane, (TN * wave + x) * 32, m0 + 32 * y, a.M, a.bias, a.S, 256, a.Y, 256, a.fast_act != 0);
 }
 
 template <int EPI>
@@ -735,7 +742,7 @@ __device__ __forceinline__ void pow2_scale(float bound, float& s, float& inv) {
 // EPI_TANH: tanh(acc·cs + bias); EPI_DTANH: acc·inv[sample]·cs·(1 − S²)
 template <int EPI>
 __device__ __forceinline__ void tile_out_x2(float* scr, const f32x16& acc, int lane, int n0, int mloc0, int mbase, int M, const float* bias,
-                                            const float* S, float* Y, float cs, const float* inv_lds) {
+                                            const float* S, float* Y, float cs, const float* inv_lds, bool fast = false) {
   const int j = lane & 31, hf = lane >> 5;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -758,7 +765,7 @@ __device__ __forceinline__ void tile_out_x2(float* scr, const f32x16& acc, int l
         for (int e = 0; e < 4; ++e) v[e] = (v[e] * f) * (1.0f - sv[e] * sv[e]);
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = tanh_fast(__builtin_fmaf(v[e], cs, bv[e]));
+        for (int e = 0; e < 4; ++e) v[e] = wide_tanh(__builtin_fmaf(v[e], cs, bv[e]), fast);
       }
       *reinterpret_cast<f32x4*>(Y + (size_t)256 * gm + n) = v;
     }
@@ -860,7 +867,7 @@ __global__ void __launch_bounds__(512) wide_dense_x2_kernel(DenseX3Args a) {
     wave_lds_fence();
 #pragma unroll
     for (int y = 0; y < TM; ++y)
-      tile_tanh_head(scr, acc[y], lane, wave * 32, 32 * y, m0 + 32 * y, a.M, a.bias, a.Y, a.W3t, a.A, hp, hs, X2_FWD_UNSCALE);
+      tile_tanh_head(scr, acc[y], lane, wave * 32, 32 * y, m0 + 32 * y, a.M, a.bias, a.Y, a.W3t, a.A, hp, hs, X2_FWD_UNSCALE, a.fast_act != 0);
     __syncthreads();
     for (int i = tid; i < MB * a.A; i += NT) {
       const int m = i / a.A, aa = i - m * a.A;
@@ -874,7 +881,7 @@ __global__ void __launch_bounds__(512) wide_dense_x2_kernel(DenseX3Args a) {
 #pragma unroll
   for (int y = 0; y < TM; ++y)
     tile_out_x2<EPI>(scr, acc[y], lane, wave * 32, 32 * y, m0 + 32 * y, a.M, a.bias, a.S, a.Y,
-                     EPI == EPI_TANH ? X2_FWD_UNSCALE : 1.0f / X2_W_SCALE, sc + MB);
+                     EPI == EPI_TANH ? X2_FWD_UNSCALE : 1.0f / X2_W_SCALE, sc + MB, a.fast_act != 0);
 }
 
 template <int EPI>
@@ -920,14 +927,18 @@ static NetOff net_off(int H, int D, int NO) {
 }
 
 // forward of one network over M samples: h1, h2 kept in the workspace, head output to out (ld ldo)
-static int wide_forward(crl_ppo* h, int net, const float* X, int ldx, const int32_t* idx, int M, float* out, int ldo) {
+// fast_act: the exp2-based activation (wide_tanh) — the update pass and the critic; the actor of the rollout / get_action keeps
+// tanh_fast because its logits decide action indices that are compared bit for bit
+static int wide_forward(crl_ppo* h, int net, const float* X, int ldx, const int32_t* idx, int M, float* out, int ldo, bool fast_act = false) {
+  static const bool fast_ok = !(getenv("CRL_WIDE_TANH") && std::string(getenv("CRL_WIDE_TANH")) == "rational");
+  fast_act = fast_act && fast_ok;
   WideWs* w = static_cast<WideWs*>(h->wide_ws);
   const int H = w->H, NO = net ? 1 : w->A;
   const NetOff o = net_off(H, w->D, NO);
   const float* P = h->params + (net ? h->Pa : 0);
   const float* pk = w->pack + w->pk_base[net];
   DenseArgs a;
-  a.idx = idx; a.S = nullptr; a.lds = 0; a.M = M;
+  a.idx = idx; a.S = nullptr; a.lds = 0; a.M = M; a.fast_act = fast_act ? 1 : 0;
   a.W = pk + w->pk[net].w1; a.Kp = w->D8; a.X = X; a.ldx = ldx; a.Kt = w->D; a.bias = P + o.b1; a.Y = w->h1[net]; a.ldy = H; a.Nt = H;
   if (dense_launch<EPI_TANH>(h->stream, H, a)) return 1;
   a.idx = nullptr;
@@ -936,7 +947,7 @@ static int wide_forward(crl_ppo* h, int net, const float* X, int ldx, const int3
     x.Wx3 = pk + w->pk[net].x3f; x.X = w->h1[net]; x.K = H; x.bias = P + o.b2; x.S = nullptr; x.Y = w->h2[net]; x.M = M;
     const bool fuse = wide_x3_fused_head();
     x.W3t = pk + w->pk[net].w3t; x.b3 = P + o.b3; x.Z = fuse ? out : nullptr; x.A = NO; x.ldz = ldo;
-    x.dZ = nullptr; x.ldd = 0; x.Ad = 0; x.bz = nullptr; x.bld = 0; x.bA = 0; x.wmax = nullptr;
+    x.dZ = nullptr; x.ldd = 0; x.Ad = 0; x.bz = nullptr; x.bld = 0; x.bA = 0; x.wmax = nullptr; x.fast_act = fast_act ? 1 : 0;
     if (wide_x2()) { x.Wx3 = pk + w->pk[net].x2f; if (dense_x2_launch<EPI_TANH>(h->stream, x)) return 1; }
     else if (dense_x3_launch<EPI_TANH>(h->stream, x)) return 1;
     if (fuse) return 0;   // the head came out of the layer-2 epilogue
@@ -1826,7 +1837,7 @@ int wide_policy_act(crl_ppo* h, const float* obs_d, const double* u_d, int n, in
   for (int o = 0; o < n; o += w->Mw) {
     const int m = (n - o) < w->Mw ? (n - o) : w->Mw;
     if (wide_forward(h, 0, obs_d + (size_t)w->D * o, w->D, nullptr, m, w->z, w->A8)) return 1;
-    if (value_d && wide_forward(h, 1, obs_d + (size_t)w->D * o, w->D, nullptr, m, w->v, 1)) return 1;
+    if (value_d && wide_forward(h, 1, obs_d + (size_t)w->D * o, w->D, nullptr, m, w->v, 1, true)) return 1;
     hipLaunchKernelGGL(wide_sample_kernel, dim3((m + 255) / 256), dim3(256), 0, h->stream, w->z, w->A8, w->A, w->v, u_d + o, m,
                        action_d + o, logprob_d + o, value_d ? value_d + o : nullptr);
     CRL_HIP_CHECK(hipGetLastError());
@@ -1850,7 +1861,7 @@ int wide_logprob_actions(crl_ppo* h, const float* obs_d, const int32_t* act_d, i
 int wide_next_value(crl_ppo* h) {
   if (ensure_pack(h)) return 1;
   WideWs* w = static_cast<WideWs*>(h->wide_ws);
-  return wide_forward(h, 1, h->cur_obs, w->D, nullptr, h->dc.nt, h->next_value, 1);
+  return wide_forward(h, 1, h->cur_obs, w->D, nullptr, h->dc.nt, h->next_value, 1, true);
 }
 
 int wide_env_reset(crl_ppo* h) {
@@ -1874,7 +1885,7 @@ int wide_rollout(crl_ppo* h) {
   ProfScope ps(h, CRL_K_ROLLOUT);
   for (int step = 0; step < h->dc.k; ++step) {
     if (wide_forward(h, 0, h->cur_obs, w->D, nullptr, h->dc.nt, w->z, w->A8)) return 1;   // ppo.jl:127
-    if (wide_forward(h, 1, h->cur_obs, w->D, nullptr, h->dc.nt, w->v, 1)) return 1;       // ppo.jl:128
+    if (wide_forward(h, 1, h->cur_obs, w->D, nullptr, h->dc.nt, w->v, 1, true)) return 1;       // ppo.jl:128
     a.step = step;
     hipLaunchKernelGGL(wide_step_kernel, dim3((h->dc.nt + 255) / 256), dim3(256), 0, h->stream, a);
     CRL_HIP_CHECK(hipGetLastError());
@@ -1953,8 +1964,8 @@ static int wide_backward(crl_ppo* h, int net, const float* dOut, int ldd, const 
 static int wide_grad_passes(crl_ppo* h, int mb, const int32_t* perm, double Mglobal, bool dp) {
   WideWs* w = static_cast<WideWs*>(h->wide_ws);
   const int M = h->dc.M;
-  if (wide_forward(h, 1, h->obs, w->D, perm, M, w->v, 1)) return 1;
-  if (wide_forward(h, 0, h->obs, w->D, perm, M, w->z, w->A8)) return 1;
+  if (wide_forward(h, 1, h->obs, w->D, perm, M, w->v, 1, true)) return 1;
+  if (wide_forward(h, 0, h->obs, w->D, perm, M, w->z, w->A8, true)) return 1;
   if (h->cfg.clip_value_loss) {
     int nb = (M + 255) / 256; if (nb > 1024) nb = 1024;
     hipLaunchKernelGGL(wide_vsum_kernel, dim3(nb), dim3(256), 0, h->stream, w->v, h->ret, perm, M, w->vpart);
