@@ -148,6 +148,9 @@ def main():
     ap.add_argument("--total-envs", type=int, default=TOTAL_ENVS)
     ap.add_argument("--minibatches", type=int, default=4, help="num_minibatches (ppo.jl:5); 1 = one optimiser step and one gradient all-reduce per epoch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-breakdown", action="store_true",
+                    help="time every kernel class with recorded HIP events (kernel_ms_per_step gets all entries; the events cost "
+                         "about 0.3 ms per iteration, so `value` is a little lower than in the default run)")
     ap.add_argument("--dry-run", action="store_true")
     ap.add_argument("--rendezvous-only", action="store_true")
     ap.add_argument("--master-port", type=int, default=0)
@@ -240,7 +243,9 @@ def main():
     for _ in range(args.warmup):
         h.iterate(1, want_stats=False)
     barrier()
-    h.prof_enable(True); h.prof_reset()
+    # level 2 = only the update kernel, whose events ride on the dispatch (no extra packets in the timed stream); --kernel-breakdown
+    # (and the layer-wise workload, whose optimiser pass is a group of launches) records events around every kernel class instead
+    h.prof_enable(1 if (args.kernel_breakdown or c3) else 2); h.prof_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         h.iterate(1, want_stats=False)
@@ -354,7 +359,11 @@ def main():
                                          {"launches": 0, "note": "inside crl_ppo_iterate the compat-mode scan is fused into the tail of the rollout "
                                                                  "kernel (each wave scans the 32 envs it just stepped, inputs still in L2): no launch, no "
                                                                  "HBM read of the scan's inputs; the figures here are the standalone kernel's"})},
-            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if (args.kernel_breakdown or c3 or v[1] > 0)},
+            "kernel_ms_scope": ("every kernel class (events recorded around the launches; they cost about 0.3 ms per iteration)"
+                                if (args.kernel_breakdown or c3) else
+                                "update kernel only (events attached to its dispatch: no extra packets in the timed stream); "
+                                "--kernel-breakdown times every class"),
             "last_iteration": {"loss": stats[-1]["loss"], "episodes": ep["episodes"],
                                "mean_episode_return": ep["return_sum"] / max(ep["episodes"], 1.0), "exact_reruns": reruns},
         }

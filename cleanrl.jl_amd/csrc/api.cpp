@@ -798,7 +798,7 @@ int32_t crl_comm_init_external(crl_ppo* h, int32_t world_size, int32_t rank) {
 
 int32_t crl_prof_enable(crl_ppo* h, int32_t on) {
   CRL_GUARD(h);
-  h->prof = on != 0;
+  h->prof = on < 0 ? 0 : (on > 2 ? 1 : on);
   return 0;
 }
 int32_t crl_prof_read(crl_ppo* h, int32_t kernel_id, double* total_ms, int64_t* launches) {

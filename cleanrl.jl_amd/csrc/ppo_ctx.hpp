@@ -138,7 +138,7 @@ struct crl_ppo {
   bool wide = false;
   void* wide_ws = nullptr;
 
-  bool prof = false;
+  int prof = 0;   // 0 off, 1 every kernel class (events recorded around the launches), 2 only the kernels whose events ride ON the dispatch
   crl::ProfSlot prof_slots[CRL_K_COUNT];
 };
 
@@ -161,14 +161,18 @@ bool gemm_x2();
 // kernel's own begin/end (what rocprofv3 reports); otherwise they are recorded on the stream around the launch(es).
 struct ProfScope {
   crl_ppo* h; int id; bool attach; hipEvent_t a = nullptr, b = nullptr;
+  bool on;
   ProfScope(crl_ppo* h_, int id_, bool attach_ = false) : h(h_), id(id_), attach(attach_) {
-    if (h->prof) {
+    // level 2 times only the attached kind: recorded events are extra packets between dependent kernels (≈0.3 ms per iteration
+    // at the headline size), which a throughput measurement should not carry
+    on = h->prof == 1 || (h->prof == 2 && attach);
+    if (on) {
       (void)hipEventCreate(&a); (void)hipEventCreate(&b);
       if (!attach) (void)hipEventRecord(a, h->stream);
     }
   }
   ~ProfScope() {
-    if (h->prof) {
+    if (on) {
       if (!attach) (void)hipEventRecord(b, h->stream);
       h->prof_slots[id].pending.emplace_back(a, b);
     }
