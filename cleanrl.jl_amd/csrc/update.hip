@@ -503,37 +503,79 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
     for (int i = 0; i < NACC; ++i) racc[i] = ACC[64 * i];
   }
   __syncthreads();
-  float* R = smem;  // the weight image is dead now
-  for (int i = tid; i < P::SIZE; i += NT) R[i] = 0.0f;
-  double* lsum = reinterpret_cast<double*>(smem + 6144);  // inside the dead weight image, past R (all LDS stays dynamic)
-  ls0 = wave_sum(ls0); ls1 = wave_sum(ls1);
-  if (lane == 0) { lsum[wave] = ls0; lsum[8 + wave] = ls1; }
-  __syncthreads();
-  for (int w = 0; w < RW; ++w) {
-    if (wave == w) {
+  // one wave's accumulators into an LDS image in flat Flux order (ADD = false: plain stores — a wave writes every entry)
+  auto deposit = [&](float* R, auto add) {
+    constexpr bool ADD = decltype(add)::value;
 #pragma unroll
-      for (int mj = 0; mj < 2; ++mj)
+    for (int mj = 0; mj < 2; ++mj)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            R[P::W2 + (32 * ni + j) + H * (32 * mj + rowmap(r, hf))] += dW2t[mj][ni][r] * dw_unscale;
+        for (int r = 0; r < 16; ++r) {
+          float* q = R + P::W2 + (32 * ni + j) + H * (32 * mj + rowmap(r, hf));
+          const float v = dW2t[mj][ni][r] * dw_unscale;
+          *q = ADD ? *q + v : v;
+        }
 #pragma unroll
-      for (int i = 0; i < D; ++i) R[P::W1 + lane + H * i] += racc[i];
-      R[P::B1 + lane] += racc[K_B1];
-      R[P::B2 + lane] += racc[K_B2];
+    for (int i = 0; i < D; ++i) { float* q = R + P::W1 + lane + H * i; *q = ADD ? *q + racc[i] : racc[i]; }
+    { float* q = R + P::B1 + lane; *q = ADD ? *q + racc[K_B1] : racc[K_B1]; }
+    { float* q = R + P::B2 + lane; *q = ADD ? *q + racc[K_B2] : racc[K_B2]; }
 #pragma unroll
-      for (int i = 0; i < NOUT; ++i) R[P::W3 + i + NOUT * lane] += racc[K_W3 + i];
+    for (int i = 0; i < NOUT; ++i) { float* q = R + P::W3 + i + NOUT * lane; *q = ADD ? *q + racc[K_W3 + i] : racc[K_W3 + i]; }
 #pragma unroll
-      for (int i = 0; i < NOUT; ++i) {
-        const float b3 = wave_sum(racc[K_B3 + i]);
-        if (lane == 0) R[P::B3 + i] += b3;
-      }
+    for (int i = 0; i < NOUT; ++i) {
+      const float b3 = wave_sum(racc[K_B3 + i]);
+      if (lane == 0) { float* q = R + P::B3 + i; *q = ADD ? *q + b3 : b3; }
     }
-    __syncthreads();
-  }
+  };
   float* gp = a.gpart + ((size_t)ROLE * a.pmax + rb) * a.gstride;
-  for (int i = tid; i < P::SIZE; i += NT) gp[i] = R[i];
+  double* lsum;
+  if constexpr (X2 && RW == 8) {
+    // Four images in the dead weight image + scratch tiles: waves 0-3 STORE theirs, waves 4-7 add on top, then one pass folds the
+    // four into the block's partial — two serial rounds instead of eight (the eight-round version was ≈14 µs of every launch:
+    // 2.5 % at the headline size, 15 % of the 90 µs launch of an 8192-env shard). Fixed order: ((w0+w4) + (w1+w5)) + ((w2+w6) + (w3+w7)).
+    constexpr int IMG = ((P::SIZE + 3) / 4) * 4;
+    static_assert(4 * IMG + 64 <= NetImageX2<D, NOUT>::SIZE + 8 * SCR_FLOATS_X3, "reduction images do not fit the dead LDS");
+    lsum = reinterpret_cast<double*>(smem + 4 * IMG);
+    ls0 = wave_sum(ls0); ls1 = wave_sum(ls1);
+    if (lane == 0) { lsum[wave] = ls0; lsum[8 + wave] = ls1; }
+    if (wave < 4) deposit(smem + wave * IMG, std::false_type{});
+    __syncthreads();
+    if (wave >= 4) deposit(smem + (wave - 4) * IMG, std::true_type{});
+    __syncthreads();
+    for (int i = tid; i < P::SIZE; i += NT) gp[i] = (smem[i] + smem[IMG + i]) + (smem[2 * IMG + i] + smem[3 * IMG + i]);
+  } else {
+    float* R = smem;  // the weight image is dead now
+    for (int i = tid; i < P::SIZE; i += NT) R[i] = 0.0f;
+    lsum = reinterpret_cast<double*>(smem + 6144);  // inside the dead weight image, past R (all LDS stays dynamic)
+    ls0 = wave_sum(ls0); ls1 = wave_sum(ls1);
+    if (lane == 0) { lsum[wave] = ls0; lsum[8 + wave] = ls1; }
+    __syncthreads();
+    for (int w = 0; w < RW; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int mj = 0; mj < 2; ++mj)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              R[P::W2 + (32 * ni + j) + H * (32 * mj + rowmap(r, hf))] += dW2t[mj][ni][r] * dw_unscale;
+#pragma unroll
+        for (int i = 0; i < D; ++i) R[P::W1 + lane + H * i] += racc[i];
+        R[P::B1 + lane] += racc[K_B1];
+        R[P::B2 + lane] += racc[K_B2];
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) R[P::W3 + i + NOUT * lane] += racc[K_W3 + i];
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) {
+          const float b3 = wave_sum(racc[K_B3 + i]);
+          if (lane == 0) R[P::B3 + i] += b3;
+        }
+      }
+      __syncthreads();
+    }
+    for (int i = tid; i < P::SIZE; i += NT) gp[i] = R[i];
+  }
   if (tid == 0) {
     double s0 = 0.0, s1 = 0.0;
     for (int w = 0; w < RW; ++w) { s0 += lsum[w]; s1 += lsum[8 + w]; }
