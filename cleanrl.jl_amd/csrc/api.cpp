@@ -221,8 +221,9 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
     rc |= dalloc(&h->adv_part, 2 * (need > alone ? need : alone));
   }
   if (cfg->shuffle_mode == CRL_SHUFFLE_BLOCKED_FY) {
-    rc |= dalloc(&h->perm_tmp, E * B); rc |= dalloc(&h->bfy_ws, E * ((size_t)4 * 16384 + 8));   // one slice per epoch slot
     size_t k1 = 1; while (k1 * 4096 < B) k1 *= 2;
+    rc |= dalloc(&h->perm_tmp, E * k1 * 5632);   // padded L1 buckets (K1 x BFY_CAP), one slice per epoch slot
+    rc |= dalloc(&h->bfy_ws, E * ((size_t)4 * 16384 + 8));
     rc |= dalloc(&h->bfy_adv_part, (size_t)c.nmb * k1 * 2);
     if (!wide && gather_mode()) { rc |= dalloc(&h->bfy_bucket_mb, E * (size_t)16384); rc |= dalloc(&h->bfy_mbid, E * B); }
   }

@@ -56,19 +56,23 @@ __device__ __forceinline__ void bfy_digits(uint32_t i, uint32_t K1, uint64_t see
   d1 = o.x & (K1 - 1u); d2 = o.y & 255u;
 }
 
-// pass A (SCATTER=false): tot[d1] += count ; pass C (SCATTER=true): S[cur[d1]++] = i with LDS-aggregated reservations
+// Scatter pass: S[d1·CAP + (position inside bucket d1)] = i with LDS-aggregated reservations on the bucket's cursor. Buckets are
+// PADDED to their LDS capacity (BFY_CAP = expected 4096 + 24 sigma), so no counting pass has to run first to find where a bucket
+// starts: the scan after this pass turns the cursors into output offsets for the leaf pass. (The count pass was 0.18 of the 1.0 ms
+// the four epochs' shuffles take; the permutation does not depend on the scatter order — the leaves sort canonically.)
 // All kernels of the blocked shuffle take the epoch from blockIdx.y: crl_ppo_iterate draws the permutations of all
 // update_epochs in ONE launch per pass (epoch e works in workspace slice e, perm slot e) — 4x fewer, 4x larger launches.
-constexpr int BFY_WS_STRIDE = 4 * 16384 + 8;   // u32 words of workspace per epoch: tot | off | cur | err
+constexpr int BFY_WS_STRIDE = 4 * 16384 + 8;   // u32 words of workspace per epoch: (unused) | off | cur | err
 
-template <bool SCATTER, int BFY_T1>
+template <int BFY_T1>
 __global__ void __launch_bounds__(BFY_T1) bfy_l1_kernel(int n, uint32_t K1, uint64_t seed, uint64_t epoch0, uint32_t* __restrict__ ws,
-                                                     int32_t* __restrict__ S0) {
+                                                     int32_t* __restrict__ S0, size_t sstride) {
   const uint64_t epoch = epoch0 + blockIdx.y;
   uint32_t* tot = ws + (size_t)blockIdx.y * BFY_WS_STRIDE;
   uint32_t* cur = tot + 2 * BFY_MAXK1 + 1;
-  int32_t* S = S0 + (size_t)blockIdx.y * n;
-  extern __shared__ uint32_t lds[];   // hist[K1] (+ base[K1] when scattering)
+  uint32_t* err = cur + BFY_MAXK1;
+  int32_t* S = S0 + (size_t)blockIdx.y * sstride;
+  extern __shared__ uint32_t lds[];   // hist[K1] + base[K1]
   uint32_t* hist = lds;
   uint32_t* base = lds + K1;
   for (uint32_t d = threadIdx.x; d < K1; d += BFY_T1) hist[d] = 0;
@@ -83,23 +87,25 @@ __global__ void __launch_bounds__(BFY_T1) bfy_l1_kernel(int n, uint32_t K1, uint
     dig[q] = d1;
   }
   __syncthreads();
-  if (!SCATTER) {
-    for (uint32_t d = threadIdx.x; d < K1; d += BFY_T1) if (hist[d]) atomicAdd(&tot[d], hist[d]);
-    return;
-  }
   for (uint32_t d = threadIdx.x; d < K1; d += BFY_T1) { base[d] = hist[d] ? atomicAdd(&cur[d], hist[d]) : 0u; hist[d] = 0; }
   __syncthreads();
 #pragma unroll 4
   for (int q = 0; q < 32; ++q) {
     const int i = i0 + q * BFY_T1;
-    if (i < n) { const uint32_t d1 = dig[q]; S[base[d1] + atomicAdd(&hist[d1], 1u)] = i; }
+    if (i < n) {
+      const uint32_t d1 = dig[q];
+      const uint32_t at = base[d1] + atomicAdd(&hist[d1], 1u);
+      if (at < (uint32_t)BFY_CAP) S[(size_t)d1 * BFY_CAP + at] = i;
+      else *err = 1u;                       // the bucket does not fit its leaf (the scan flags it too); never written out of bounds
+    }
   }
 }
 
 // exclusive scan of the K1 bucket totals (one block); cur = off; flags buckets that do not fit the LDS leaf kernel
 __global__ void __launch_bounds__(1024) bfy_scan_kernel(uint32_t K1, uint32_t* __restrict__ ws) {
-  uint32_t* tot = ws + (size_t)blockIdx.x * BFY_WS_STRIDE;
-  uint32_t* off = tot + BFY_MAXK1; uint32_t* cur = off + BFY_MAXK1 + 1; uint32_t* err = cur + BFY_MAXK1;
+  uint32_t* off = ws + (size_t)blockIdx.x * BFY_WS_STRIDE + BFY_MAXK1;
+  const uint32_t* tot = off + BFY_MAXK1 + 1;                 // the scatter pass's cursors = bucket sizes
+  uint32_t* err = const_cast<uint32_t*>(tot) + BFY_MAXK1;
   __shared__ uint32_t part[1024];
   const int t = threadIdx.x;
   const int per = (K1 + 1023) / 1024;
@@ -110,7 +116,7 @@ __global__ void __launch_bounds__(1024) bfy_scan_kernel(uint32_t K1, uint32_t* _
   if (t == 0) { uint32_t a = 0; for (int q = 0; q < 1024; ++q) { const uint32_t v = part[q]; part[q] = a; a += v; } }
   __syncthreads();
   uint32_t a = part[t];
-  for (int q = 0; q < per; ++q) { const uint32_t d = t * per + q; if (d < K1) { off[d] = a; cur[d] = a; a += tot[d]; } }
+  for (int q = 0; q < per; ++q) { const uint32_t d = t * per + q; if (d < K1) { off[d] = a; a += tot[d]; } }
   if (t == 1023) off[K1] = a;
 }
 
@@ -120,13 +126,13 @@ __global__ void __launch_bounds__(1024) bfy_scan_kernel(uint32_t K1, uint32_t* _
 // order): the advantage statistics of ppo.jl:221 then need no separate gather pass over the permutation. Requires
 // M >= BFY_CAP so that a bucket touches at most two minibatches.
 __global__ void __launch_bounds__(256, 4) bfy_leaf_kernel(uint32_t K1, uint64_t seed, uint64_t epoch0, int n, const uint32_t* __restrict__ ws,
-                                                          const int32_t* __restrict__ S0, int32_t* __restrict__ perm0,
+                                                          const int32_t* __restrict__ S0, size_t sstride, int32_t* __restrict__ perm0,
                                                           const float* __restrict__ adv, int M, int nmb, double* __restrict__ part,
                                                           uint16_t* __restrict__ bucket_mb0, uint8_t* __restrict__ mbid0) {
   const uint64_t epoch = epoch0 + blockIdx.y;
   const uint32_t* off = ws + (size_t)blockIdx.y * BFY_WS_STRIDE + BFY_MAXK1;
   const uint32_t* err = off + 2 * BFY_MAXK1 + 1;
-  const int32_t* S = S0 + (size_t)blockIdx.y * n;
+  const int32_t* S = S0 + (size_t)blockIdx.y * sstride + (size_t)blockIdx.x * BFY_CAP;   // this bucket's padded slice
   int32_t* perm = perm0 + (size_t)blockIdx.y * n;
   if (*err) return;
   __shared__ int32_t buf[BFY_CAP], buf2[BFY_CAP];
@@ -139,7 +145,7 @@ __global__ void __launch_bounds__(256, 4) bfy_leaf_kernel(uint32_t K1, uint64_t 
   __syncthreads();
 #pragma unroll 1
   for (uint32_t idx = t; idx < c; idx += 256) {
-    const int32_t v = S[base + idx];
+    const int32_t v = S[idx];
     uint32_t a, d2;
     bfy_digits((uint32_t)v, K1, seed, epoch, a, d2);
     buf2[idx] = v; dig[idx] = (uint8_t)d2;
@@ -240,22 +246,21 @@ static int launch_blocked_fy(crl_ppo* h, uint64_t epoch_id, int nslots, bool fus
   if (K1 > (uint32_t)BFY_MAXK1) { set_error("blocked Fisher-Yates supports batches up to 2^26 samples"); return 1; }
   if (h->cur_slot + nslots > h->cfg.update_epochs) { set_error("internal: permutation slots out of range"); return 1; }
   uint32_t* ws = h->bfy_ws + (size_t)h->cur_slot * BFY_WS_STRIDE;
-  int32_t* S = h->perm_tmp + (size_t)h->cur_slot * n;
-  for (int z = 0; z < nslots; ++z)
-    CRL_HIP_CHECK(hipMemsetAsync(ws + (size_t)z * BFY_WS_STRIDE, 0, sizeof(uint32_t) * BFY_MAXK1, h->stream));
+  const size_t sstride = (size_t)K1 * BFY_CAP;
+  int32_t* S = h->perm_tmp + (size_t)h->cur_slot * sstride;
+  for (int z = 0; z < nslots; ++z)   // the buckets' cursors
+    CRL_HIP_CHECK(hipMemsetAsync(ws + (size_t)z * BFY_WS_STRIDE + 2 * BFY_MAXK1 + 1, 0, sizeof(uint32_t) * BFY_MAXK1, h->stream));
   const uint64_t seed = shuffle_seed(h);
   const bool big = n >= (4 << 20);
   const int t1 = big ? 1024 : 256, chunks = (n + t1 * 32 - 1) / (t1 * 32);
   const dim3 g1(chunks, nslots);
-  if (big) hipLaunchKernelGGL((bfy_l1_kernel<false, 1024>), g1, dim3(1024), sizeof(uint32_t) * K1, h->stream, n, K1, seed, epoch_id, ws, S);
-  else hipLaunchKernelGGL((bfy_l1_kernel<false, 256>), g1, dim3(256), sizeof(uint32_t) * K1, h->stream, n, K1, seed, epoch_id, ws, S);
+  if (big) hipLaunchKernelGGL((bfy_l1_kernel<1024>), g1, dim3(1024), sizeof(uint32_t) * 2 * K1, h->stream, n, K1, seed, epoch_id, ws, S, sstride);
+  else hipLaunchKernelGGL((bfy_l1_kernel<256>), g1, dim3(256), sizeof(uint32_t) * 2 * K1, h->stream, n, K1, seed, epoch_id, ws, S, sstride);
   hipLaunchKernelGGL(bfy_scan_kernel, dim3(nslots), dim3(1024), 0, h->stream, K1, ws);
-  if (big) hipLaunchKernelGGL((bfy_l1_kernel<true, 1024>), g1, dim3(1024), sizeof(uint32_t) * 2 * K1, h->stream, n, K1, seed, epoch_id, ws, S);
-  else hipLaunchKernelGGL((bfy_l1_kernel<true, 256>), g1, dim3(256), sizeof(uint32_t) * 2 * K1, h->stream, n, K1, seed, epoch_id, ws, S);
   const bool fuse = fused && nslots == 1 && h->bfy_adv_part && h->dc.M >= BFY_CAP && h->dc.nmb <= 256;
   // the bucket → minibatch tables (sequential advantage statistics, below) describe slots [0, nslots) of one iterate call
   const bool tables = !fuse && h->bfy_bucket_mb && h->cur_slot == 0 && h->dc.nmb <= 255;
-  hipLaunchKernelGGL(bfy_leaf_kernel, dim3(K1, nslots), dim3(256), 0, h->stream, K1, seed, epoch_id, n, ws, S, h->perm, fuse ? h->adv : nullptr,
+  hipLaunchKernelGGL(bfy_leaf_kernel, dim3(K1, nslots), dim3(256), 0, h->stream, K1, seed, epoch_id, n, ws, S, sstride, h->perm, fuse ? h->adv : nullptr,
                      h->dc.M, h->dc.nmb, h->bfy_adv_part, tables ? h->bfy_bucket_mb : nullptr, h->bfy_mbid);
   CRL_HIP_CHECK(hipGetLastError());
   h->bfy_adv_parts = fuse ? (int)K1 : 0;
