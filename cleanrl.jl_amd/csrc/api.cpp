@@ -301,6 +301,17 @@ int32_t crl_ppo_write(crl_ppo* h, int32_t field, const void* host, size_t nbytes
   if (!field_ref(h, field, &fr)) { set_error("crl_ppo_write: unknown field"); return 1; }
   if (nbytes != fr.bytes) { set_error("crl_ppo_write: size mismatch for field " + std::to_string(field) + ": got " +
                                       std::to_string(nbytes) + ", want " + std::to_string(fr.bytes)); return 1; }
+  if (field == CRL_F_PERM) {
+    // b_inds index the batch inside the kernels (records are fetched through them): an entry outside [0, B) would be an
+    // out-of-bounds device read, so it is rejected here
+    const int32_t* pv = static_cast<const int32_t*>(host);
+    const int32_t B = h->dc.B;
+    for (int32_t i = 0; i < B; ++i)
+      if (pv[i] < 0 || pv[i] >= B) {
+        set_error("crl_ppo_write(CRL_F_PERM): entry " + std::to_string(i) + " = " + std::to_string(pv[i]) + " is outside [0, " + std::to_string(B) + ")");
+        return 1;
+      }
+  }
   CRL_HIP_CHECK(hipMemcpyAsync(fr.ptr, host, nbytes, hipMemcpyHostToDevice, h->stream));
   CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
   if (field == CRL_F_PARAMS) wide_mark_params_changed(h);

@@ -285,6 +285,10 @@ def test_errors_are_reported_not_thrown(crl):
     agent = make_agent(crl)
     with pytest.raises(crl.CrlError, match="out of range"):
         agent.handle.update_minibatch(9, 1e-3)
+    bad = np.arange(agent.config.num_envs * agent.config.num_steps, dtype=np.int32)
+    bad[5] = bad.size                      # the kernels index the batch through b_inds: out-of-range entries are refused
+    with pytest.raises(crl.CrlError, match="outside"):
+        agent.handle.write(crl._lib.F_PERM, bad)
     agent.close()
 
 
