@@ -350,9 +350,11 @@ __global__ void __launch_bounds__(128) rollout_split_kernel(RolloutArgs a) {
     if (wave == 0) {
       ep_len += 1;                                                   // ppo.jl:125
       float z[A], p[A], lp[A];
+      // the step's uniform does not depend on the network: drawn first, its ≈80 integer instructions can sit in the shadow of
+      // the forward pass's MFMA chains instead of behind the softmax on the step's critical path
+      const double u = u53(philox_env(c.seed, gid, gstep, 0));
       mlp_forward_x3<D, A, false>(imgA0 + lds_off, co, h1, h2, z, lane);  // ppo.jl:127 get_action
       softmax_logsoftmax<A>(z, p, lp);
-      const double u = u53(philox_env(c.seed, gid, gstep, 0));
       const int act = sample_weights<A>(p, u);
       float lpa = lp[0];
 #pragma unroll
