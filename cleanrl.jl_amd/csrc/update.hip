@@ -139,6 +139,9 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
   int tile = rb * RW + wave;
   Gathered<D> cur;
   const float Gdw = X2 ? sgpr(a.dscale[ROLE]) : 1.0f;   // fp16x2 weight-gradient scale of this launch (mlp_x2.hpp)
+  // fp16x2: G rides on the head cotangent (NOUT multiplies per tile), so δ2 exists only as δ2·G — exactly what the weight-gradient
+  // operand wants (32 multiplies per tile saved); the backward-data product and db2 take the exact power of two back out
+  const float invG = X2 ? sgpr(1.0f / Gdw) : 1.0f;
   float d2run = 0.0f;
   if (!in_range) {   // a hidden-layer weight does not fit the fp16x2 window: compute nothing, tell the host (crl_sync / stats)
     if (tid == 0 && rb == 0) a.range_err[0] = 1.0;
@@ -281,7 +284,7 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int idx = q * 4 + e;
-            d2[idx >> 4][idx & 15] = __builtin_fmaf(wv[e], dout[i], d2[idx >> 4][idx & 15]);
+            d2[idx >> 4][idx & 15] = __builtin_fmaf(wv[e], X2 ? dout[i] * Gdw : dout[i], d2[idx >> 4][idx & 15]);
           }
         }
       }
@@ -312,7 +315,7 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
 #pragma unroll
           for (int r = 0; r < 16; ++r) ds[mt][r] = d2[mt][r] * sc;
         dense64_x2(img + I::WB2H, ds, c0, c1, lane);
-        d1f = sinv * (1.0f / X2_W_SCALE);   // the unscale rides in the (1 − h1²) factor below
+        d1f = sinv * ((1.0f / X2_W_SCALE) * invG);   // the unscale (per-sample scale, 2^8 of the weights, G) rides in the (1 − h1²) factor below
       } else if constexpr (X3) {
         dense64_x3(img + I::WB2P, d2, c0, c1, lane);
       } else {
@@ -423,7 +426,7 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
 #pragma unroll
       for (int r = 0; r < 16; ++r) T[(32 * mt + rowmap(r, hf)) * TSTRIDE + j] = h1[mt][r];
     CRL_PHASE();
-    if (X2 && dw_tile_fits(d2max, Gdw)) {
+    if (X2 && dw_tile_fits(d2max, 1.0f)) {   // d2max is the largest |δ2·G| of the tile
       if constexpr (X2) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -438,7 +441,7 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) {
             const f32x4 f0 = braw[ni][ks][0], f1 = braw[ni][ks][1];
-            const float xb[8] = {f0[0] * Gdw, f0[1] * Gdw, f0[2] * Gdw, f0[3] * Gdw, f1[0] * Gdw, f1[1] * Gdw, f1[2] * Gdw, f1[3] * Gdw};
+            const float xb[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};   // δ2·G already
             bp[ni] = split2(xb);
           }
           dW2t[0][0] = mfma_x2(ap[0], bp[0], dW2t[0][0]);
@@ -462,7 +465,7 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
           const f32x4 f0 = braw[ni][ks][0], f1 = braw[ni][ks][1];
-          const float xb[8] = {f0[0] * Gdw, f0[1] * Gdw, f0[2] * Gdw, f0[3] * Gdw, f1[0] * Gdw, f1[1] * Gdw, f1[2] * Gdw, f1[3] * Gdw};
+          const float xb[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};   // δ2·G already (G = 1 outside the fp16x2 flavour)
           bp[ni] = split3(xb);
         }
         dW2t[0][0] = mfma_x3(ap[0], bp[0], dW2t[0][0]);
@@ -494,7 +497,7 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
     float m = d2run;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
-    if (lane == 0 && m > 0.0f) atomicMax(a.dmax + ROLE, __float_as_uint(m));
+    if (lane == 0 && m > 0.0f) atomicMax(a.dmax + ROLE, __float_as_uint(m * invG));   // d2run tracked |δ2·G|
   }
   // ---- block reduction: waves add their accumulators into one LDS image in flat Flux order ------------------
   if constexpr (LACC) {
@@ -502,6 +505,7 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
 #pragma unroll
     for (int i = 0; i < NACC; ++i) racc[i] = ACC[64 * i];
   }
+  if constexpr (X2) racc[K_B2] *= invG;   // db2 summed δ2·G
   __syncthreads();
   // one wave's accumulators into an LDS image in flat Flux order (ADD = false: plain stores — a wave writes every entry)
   auto deposit = [&](float* R, auto add) {
