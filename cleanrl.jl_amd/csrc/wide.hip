@@ -317,7 +317,7 @@ struct DenseArgs {
 };
 
 template <int WN, int TN, int WM, int TM, int EPI>
-__global__ void __launch_bounds__(256) wide_dense_kernel(DenseArgs a) {
+__device__ __forceinline__ void wide_dense_body(const DenseArgs& a) {
   constexpr int NP = 32 * WN * TN, MB = 32 * WM * TM;
   static_assert(WN * WM == 4, "four waves per block");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -493,6 +493,15 @@ __global__ void __launch_bounds__(256) wide_dense_kernel(DenseArgs a) {
       }
     }
   }
+}
+
+template <int WN, int TN, int WM, int TM, int EPI>
+__global__ void __launch_bounds__(256) wide_dense_kernel(DenseArgs a) { wide_dense_body<WN, TN, WM, TM, EPI>(a); }
+// the same layer of BOTH networks in one launch (blockIdx.y = network): the rollout's per-step forward passes are too small to
+// fill the chip one network at a time
+template <int WN, int TN, int WM, int TM, int EPI>
+__global__ void __launch_bounds__(256) wide_dense_pair_kernel(DenseArgs a0, DenseArgs a1) {
+  if (blockIdx.y == 0) wide_dense_body<WN, TN, WM, TM, EPI>(a0); else wide_dense_body<WN, TN, WM, TM, EPI>(a1);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -774,7 +783,7 @@ __device__ __forceinline__ void tile_out_x2(float* scr, const f32x16& acc, int l
 }
 
 template <int EPI, int TM>
-__global__ void __launch_bounds__(512) wide_dense_x2_kernel(DenseX3Args a) {
+__device__ __forceinline__ void wide_dense_x2_body(const DenseX3Args& a) {
   constexpr int NW = 8, NT = 512, MB = 32 * TM;
   constexpr int WR = X2_SLAB_F16 * 2 / 16 / NT;                // 16-B pieces of the W slab per thread (4)
   constexpr int XR = (MB * 8 + NT - 1) / NT;                   // float4 pieces of the X slab per thread
@@ -884,6 +893,22 @@ __global__ void __launch_bounds__(512) wide_dense_x2_kernel(DenseX3Args a) {
                      EPI == EPI_TANH ? X2_FWD_UNSCALE : 1.0f / X2_W_SCALE, sc + MB, a.fast_act != 0);
 }
 
+template <int EPI, int TM>
+__global__ void __launch_bounds__(512) wide_dense_x2_kernel(DenseX3Args a) { wide_dense_x2_body<EPI, TM>(a); }
+template <int EPI, int TM>
+__global__ void __launch_bounds__(512) wide_dense_x2_pair_kernel(DenseX3Args a0, DenseX3Args a1) {
+  if (blockIdx.y == 0) wide_dense_x2_body<EPI, TM>(a0); else wide_dense_x2_body<EPI, TM>(a1);
+}
+
+static size_t dense_x2_smem(const DenseX3Args& a, int MB) {
+  size_t region = (size_t)X2_SLAB_F16 * 2 + (size_t)2 * MB * X3ROW * 2;
+  const size_t epi = (size_t)8 * 32 * 36 * 4;
+  if (epi > region) region = epi;
+  size_t smem = region + (size_t)2 * MB * 4;                              // + per-sample scale / inverse
+  const size_t head = a.Z ? epi + (size_t)8 * MB * a.ldz * 4 : 0;         // fused head partials (forward only: no scales needed)
+  return head > smem ? head : smem;
+}
+
 template <int EPI>
 static int dense_x2_launch(hipStream_t st, const DenseX3Args& a) {
   if (a.M <= 0) return 0;
@@ -958,6 +983,39 @@ static int wide_forward(crl_ppo* h, int net, const float* X, int ldx, const int3
   a.ldx = H; a.Kt = H;
   a.W = pk + w->pk[net].w3; a.Kp = H; a.X = w->h2[net]; a.bias = P + o.b3; a.Y = out; a.ldy = ldo; a.Nt = NO;
   return dense_launch<EPI_BIAS>(h->stream, 32, a);
+}
+
+// Rollout step: actor and critic forward on the same observations with each layer of the two networks in ONE launch
+// (blockIdx.y = network). Only for the 2×256 fp16x2 configuration with the fused head and M ≤ 32768 (the shapes the pair kernels
+// are instantiated for); anything else runs the two networks one after the other.
+static int wide_forward_pair(crl_ppo* h, const float* X, int ldx, int M, float* outA, int ldoA, float* outC, int ldoC) {
+  WideWs* w = static_cast<WideWs*>(h->wide_ws);
+  static const bool pair_ok = !(getenv("CRL_WIDE_PAIR") && atoi(getenv("CRL_WIDE_PAIR")) == 0);
+  static const bool fast_ok = !(getenv("CRL_WIDE_TANH") && std::string(getenv("CRL_WIDE_TANH")) == "rational");
+  if (!(pair_ok && w->H == 256 && wide_x2() && wide_x3_fused_head() && M > 0 && M <= 32768)) {
+    if (wide_forward(h, 0, X, ldx, nullptr, M, outA, ldoA)) return 1;          // ppo.jl:127
+    return wide_forward(h, 1, X, ldx, nullptr, M, outC, ldoC, true);           // ppo.jl:128
+  }
+  const int H = 256;
+  DenseArgs a[2]; DenseX3Args x[2];
+  for (int net = 0; net < 2; ++net) {
+    const int NO = net ? 1 : w->A;
+    const NetOff o = net_off(H, w->D, NO);
+    const float* P = h->params + (net ? h->Pa : 0);
+    const float* pk = w->pack + w->pk_base[net];
+    const int fast = (net == 1 && fast_ok) ? 1 : 0;      // the actor keeps tanh_fast: its logits decide bit-compared action indices
+    a[net].idx = nullptr; a[net].S = nullptr; a[net].lds = 0; a[net].M = M; a[net].fast_act = fast;
+    a[net].W = pk + w->pk[net].w1; a[net].Kp = w->D8; a[net].X = X; a[net].ldx = ldx; a[net].Kt = w->D; a[net].bias = P + o.b1;
+    a[net].Y = w->h1[net]; a[net].ldy = H; a[net].Nt = H;
+    x[net].Wx3 = pk + w->pk[net].x2f; x[net].X = w->h1[net]; x[net].K = H; x[net].bias = P + o.b2; x[net].S = nullptr; x[net].Y = w->h2[net]; x[net].M = M;
+    x[net].W3t = pk + w->pk[net].w3t; x[net].b3 = P + o.b3; x[net].Z = net ? outC : outA; x[net].A = NO; x[net].ldz = net ? ldoC : ldoA;
+    x[net].dZ = nullptr; x[net].ldd = 0; x[net].Ad = 0; x[net].bz = nullptr; x[net].bld = 0; x[net].bA = 0; x[net].wmax = nullptr; x[net].fast_act = fast;
+  }
+  hipLaunchKernelGGL((wide_dense_pair_kernel<4, 2, 1, 1, EPI_TANH>), dim3((M + 31) / 32, 2), dim3(256), sizeof(float) * (32 * 256 + 32 * WXS), h->stream, a[0], a[1]);
+  const size_t s0 = dense_x2_smem(x[0], 32), s1 = dense_x2_smem(x[1], 32);
+  hipLaunchKernelGGL((wide_dense_x2_pair_kernel<EPI_TANH, 1>), dim3((M + 31) / 32, 2), dim3(512), s0 > s1 ? s0 : s1, h->stream, x[0], x[1]);
+  CRL_HIP_CHECK(hipGetLastError());
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1884,8 +1942,7 @@ int wide_rollout(crl_ppo* h) {
   if (h->ep_ring_cap > 0) CRL_HIP_CHECK(hipMemsetAsync(h->ep_ring_count, 0, sizeof(uint32_t), h->stream));
   ProfScope ps(h, CRL_K_ROLLOUT);
   for (int step = 0; step < h->dc.k; ++step) {
-    if (wide_forward(h, 0, h->cur_obs, w->D, nullptr, h->dc.nt, w->z, w->A8)) return 1;   // ppo.jl:127
-    if (wide_forward(h, 1, h->cur_obs, w->D, nullptr, h->dc.nt, w->v, 1, true)) return 1;       // ppo.jl:128
+    if (wide_forward_pair(h, h->cur_obs, w->D, h->dc.nt, w->z, w->A8, w->v, 1)) return 1;   // ppo.jl:127-128
     a.step = step;
     hipLaunchKernelGGL(wide_step_kernel, dim3((h->dc.nt + 255) / 256), dim3(256), 0, h->stream, a);
     CRL_HIP_CHECK(hipGetLastError());
