@@ -553,7 +553,12 @@ int32_t crl_adv_stats_finish(crl_ppo* h) {
 }
 
 static int update_step(crl_ppo* h, int mb, double eta, int apply, int slot, bool inline_fix = true) {
-  if (launch_update(h, mb, h->stats_dev + slot, inline_fix)) return 1;
+  // with a communicator attached and the optimiser following, the statistics ride in the optimiser launch (optim.hip);
+  // the inline value-loss fix-up reads the flag the statistics raise, so it keeps them as their own launch
+  h->defer_stats = apply && !h->wide && has_comm(h) && !(inline_fix && h->cfg.clip_value_loss && h->world == 1);
+  const int rc = launch_update(h, mb, h->stats_dev + slot, inline_fix);
+  h->defer_stats = false;
+  if (rc) return 1;
   if (apply && launch_optim(h, eta)) return 1;
   return 0;
 }

@@ -2,6 +2,7 @@
 #include "bijection.hpp"
 #include "common.hpp"
 #include "ppo_ctx.hpp"
+#include "stats.hpp"
 
 namespace crl {
 
@@ -133,10 +134,17 @@ struct OptimArgs {
   int off[13]; int arr0;
   float* params; const float* grads; float* m; float* v; double* betap;
   double eta, thresh;
+  // data-parallel step: the "Training Statistics" record of the all-reduced message rides in this launch as one extra block
+  // (it depends on nothing the optimiser writes) instead of being a launch of its own between the all-reduce and the optimiser
+  int stats_block = -1; int P = 0; StatsArgs st{};
 };
 
 __global__ void __launch_bounds__(1024) clipnorm_adam_kernel(OptimArgs a) {
 #pragma clang fp contract(off)
+  if ((int)blockIdx.x == a.stats_block) {
+    if (threadIdx.x == 0) compute_stats(a.grads, a.P, a.st.c, a.st.Mglobal, a.st.adv_ms, a.st.mb, a.st.vfix, a.st.out, 0);
+    return;
+  }
   const int arr = blockIdx.x + a.arr0;
   const int lo = a.off[arr], hi = a.off[arr + 1];
   __shared__ double sm[16];
@@ -243,8 +251,16 @@ int launch_optim(crl_ppo* h, double eta) {
     hipLaunchKernelGGL(clipnorm_partial_kernel, dim3(nb), dim3(1024), 0, h->stream, b);
     hipLaunchKernelGGL(adam_slice_kernel, dim3(nb), dim3(1024), 0, h->stream, b);
     hipLaunchKernelGGL(betap_advance_kernel, dim3(1), dim3(64), 0, h->stream, h->betap);
-  } else
-  hipLaunchKernelGGL(clipnorm_adam_kernel, dim3(12), dim3(1024), 0, h->stream, a);
+  } else {
+    int blocks = 12;
+    if (h->stats_pending) {
+      a.stats_block = 12; a.P = (int)h->P; blocks = 13;
+      a.st.c = h->dc; a.st.Mglobal = (double)h->dc.M * h->world; a.st.adv_ms = h->adv_ms; a.st.mb = h->stats_mb; a.st.vfix = h->vfix;
+      a.st.out = h->stats_slot; a.st.fused = 0; a.st.dscale = nullptr;
+      h->stats_pending = false;
+    }
+    hipLaunchKernelGGL(clipnorm_adam_kernel, dim3(blocks), dim3(1024), 0, h->stream, a);
+  }
   CRL_HIP_CHECK(hipGetLastError());
   wide_mark_params_changed(h);
   return 0;

@@ -133,6 +133,8 @@ struct crl_ppo {
   void* comm = nullptr; int world = 1, rank = 0;
   bool external_comm = false;  // shards exchanged by the host (crl_comm_init_external): all-reduce calls are no-ops
   void* peer = nullptr;        // one-shot peer-mapped all-reduce (peer.hip), the alternative to the RCCL communicator
+  // data-parallel optimiser step: the statistics of the all-reduced message are computed by an extra block of the optimiser launch
+  bool defer_stats = false, stats_pending = false; int stats_mb = 0; crl_ppo_stats* stats_slot = nullptr;
 
   // generic-shape path (wide.hip): anything but obs 4 / act 2 / hidden 64, or CRL_FORCE_WIDE=1
   bool wide = false;

@@ -854,7 +854,8 @@ int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot, bool inline_fix
       ProfScope ps(h, CRL_K_ALLREDUCE);
       if (comm_allreduce(h, h->comm_buf, (size_t)P + 4, false)) return 1;
     }
-    hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(64), 0, h->stream, h->comm_buf, P, stats_args(h, mb, stats_slot, 0), 0);
+    if (h->defer_stats) { h->stats_pending = true; h->stats_mb = mb; h->stats_slot = stats_slot; }   // launch_optim carries them
+    else hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(64), 0, h->stream, h->comm_buf, P, stats_args(h, mb, stats_slot, 0), 0);
     CRL_HIP_CHECK(hipGetLastError());
   }
   if (inline_fix && h->cfg.clip_value_loss && h->world == 1) {
