@@ -410,6 +410,219 @@ __global__ void __launch_bounds__(128) rollout_split_kernel(RolloutArgs a) {
   }
 }
 
+// The same shards on THREE waves per tile (fp16x2 builds): the 128 dependent steps are what a small shard's rollout costs (0.51 ms
+// at any size up to 16384 envs), and a lone wave issues one instruction every ≈5 cycles, so the step time is the actor wave's
+// instruction count. Waves 0 and 1 each compute HALF the actor's hidden rows (rows 32·w … 32·w+31 of both layers): half the
+// tanh_fast evaluations, half the bf16 splits, one 24-MFMA chain instead of two. What the halves owe each other goes through LDS:
+// the split pieces of h1 (each wave's rows are two of the four k-steps of the other's layer-2 product) and the head's dot
+// product, which stays ONE chain over the 64 rows in mlp_forward_x3's order — wave 0 runs its 16 terms per lane half, wave 1
+// continues from that partial, adds the halves and the bias — so every logit is bit-identical to the one-wave forward and the
+// sampled actions do not change. Wave 2 runs the critic as fp16x2 with the exp2 activation (as rollout_cartpole_kernel<…, CX2>),
+// cut in two so that it is never the last wave at a barrier. Wave 1, which ends the head's chain and so has the logits first, also samples and owns the
+// env (the logits never travel). Three block barriers per step.
+template <int A>
+__global__ void __launch_bounds__(192) rollout_split3_kernel(RolloutArgs a) {
+  constexpr int D = 4;
+  using IA = NetImageX3<D, A, false>;
+  using IC = NetImageX2<D, 1>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* imgA0 = smem;
+  float* imgC0 = imgA0 + IA::SIZE;
+  float4* xch = reinterpret_cast<float4*>(imgC0 + IC::SIZE);               // [2][TILE] observations
+  bf16x8* pcs = reinterpret_cast<bf16x8*>(reinterpret_cast<float*>(xch) + 2 * TILE * 4);   // [2 waves][2 k-steps][3 pieces][64 lanes]
+  float* hd = reinterpret_cast<float*>(pcs + 2 * 2 * 3 * 64);              // [A][64] wave 0's partial head sums
+  int* flag = reinterpret_cast<int*>(hd + A * 64);
+  stage_net_x3<D, A, false>(imgA0, a.params, threadIdx.x, blockDim.x);
+  if (!stage_net_x2<D, 1>(imgC0, a.params + NetParams<D, A>::SIZE, threadIdx.x, blockDim.x, flag)) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) a.range_err[0] = 1.0;
+    return;
+  }
+  const DevCfg& c = a.c;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 31, hf = lane >> 5;
+  const int e = blockIdx.x * TILE + j;
+  const bool ok = e < c.nt;
+  const bool writer = ok && hf == 0;
+  const int ee = ok ? e : 0;
+  const uint32_t gid = c.env_id_offset + (uint32_t)ee;
+
+  float s[4] = {0, 0, 0, 0}, co[4] = {0, 0, 0, 0};
+  int t_env = 0, ep_len = 0;
+  uint8_t nd = 0;
+  float ep_ret = 0.0f;
+  double st_n = 0.0, st_ret = 0.0, st_len = 0.0, st_max = 0.0;
+  if (wave == 1) {   // the wave that ends the head's chain has the logits first: it samples and owns the env
+    const float4 sv = reinterpret_cast<const float4*>(a.env_state)[ee];
+    const float4 cv = reinterpret_cast<const float4*>(a.cur_obs)[ee];
+    s[0] = sv.x; s[1] = sv.y; s[2] = sv.z; s[3] = sv.w;
+    co[0] = cv.x; co[1] = cv.y; co[2] = cv.z; co[3] = cv.w;
+    t_env = a.env_t[ee]; nd = a.next_done[ee]; ep_ret = a.ep_return[ee]; ep_len = a.ep_length[ee];
+    if (hf == 0) xch[j] = cv;
+  }
+  __syncthreads();
+
+  for (int step = 0; step < c.k; ++step) {
+    const uint64_t gstep = a.iteration * (uint64_t)c.k + (uint64_t)step;
+    const size_t b = (size_t)ee + (size_t)c.nt * step;
+    int lds_off = 0;
+    asm volatile("" : "+v"(lds_off));  // keep the weight reads in LDS (see rollout_cartpole_kernel)
+    if (wave < 2) {
+      const int mo = wave;
+      const float* img = imgA0 + lds_off;
+      float cx[4];
+      if (wave == 1) { cx[0] = co[0]; cx[1] = co[1]; cx[2] = co[2]; cx[3] = co[3]; }
+      else { const float4 cv = xch[(step & 1) * TILE + j]; cx[0] = cv.x; cx[1] = cv.y; cx[2] = cv.z; cx[3] = cv.w; }
+      double u = 0.0;
+      if (wave == 1) { ep_len += 1; u = u53(philox_env(c.seed, gid, gstep, 0)); }           // ppo.jl:125; drawn early (see split kernel)
+      // layer 1, this wave's 32 rows
+      f32x16 acc = load16(img + IA::B1C + hf * 32 + 16 * mo);
+#pragma unroll
+      for (int ks = 0; ks < D / 2; ++ks) {
+        const float bv = hf ? cx[2 * ks + 1] : cx[2 * ks];
+        acc = mfma32(img[IA::WF1 + (mo * (D / 2) + ks) * 64 + lane], bv, acc);
+      }
+      f32x16 h;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) h[r] = tanh_fast(acc[r]);
+      // my two k-steps of the layer-2 product (k-step 2·mo + q = registers 8q … 8q+7), split once, shared through LDS
+      P3 mine[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float xb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xb[i] = h[8 * q + i];
+        mine[q] = split3(xb);
+        bf16x8* dst = pcs + ((mo * 2 + q) * 3) * 64 + lane;
+        dst[0] = mine[q].hi; dst[64] = mine[q].mid; dst[128] = mine[q].lo;
+      }
+      __syncthreads();                                                                       // (1) both halves of h1 are published
+      P3 other[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const bf16x8* src = pcs + (((1 - mo) * 2 + q) * 3) * 64 + lane;
+        other[q].hi = src[0]; other[q].mid = src[64]; other[q].lo = src[128];
+      }
+      acc = load16(img + IA::B2C + hf * 32 + 16 * mo);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const P3& bq = ((ks >> 1) == mo) ? mine[ks & 1] : other[ks & 1];
+        acc = mfma_x3(load_wfrag(img + IA::WF2P, mo, ks, lane), bq, acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) h[r] = tanh_fast(acc[r]);
+      // head: one chain per lane half over idx = 0 … 31 (mlp_forward_x3): wave 0 owns idx 0-15, wave 1 continues with 16-31
+      if (mo == 0) {
+#pragma unroll
+        for (int o = 0; o < A; ++o) {
+          const f32x4* w = reinterpret_cast<const f32x4*>(img + IA::W3 + o * 64 + hf * 32);
+          float accv = 0.0f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 wv = w[q];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) accv = __builtin_fmaf(wv[i], h[q * 4 + i], accv);
+          }
+          hd[o * 64 + lane] = accv;
+        }
+      }
+      __syncthreads();                                                                       // (2) wave 0's partial sums are there
+      if (mo == 1) {
+        float z[A], p[A], lp[A];
+#pragma unroll
+        for (int o = 0; o < A; ++o) {
+          const f32x4* w = reinterpret_cast<const f32x4*>(img + IA::W3 + o * 64 + hf * 32);
+          float accv = hd[o * 64 + lane];
+#pragma unroll
+          for (int q = 4; q < 8; ++q) {
+            const f32x4 wv = w[q];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) accv = __builtin_fmaf(wv[i], h[(q - 4) * 4 + i], accv);
+          }
+          z[o] = accv + xor32(accv) + img[IA::B3 + o];
+        }
+        softmax_logsoftmax<A>(z, p, lp);                                                     // ppo.jl:127 get_action
+        const int act = sample_weights<A>(p, u);
+        float lpa = lp[0];
+#pragma unroll
+        for (int i = 1; i < A; ++i) lpa = (act == i) ? lp[i] : lpa;
+        const bool done = cartpole_step(s, t_env, act);                                      // ppo.jl:130
+        const float rew = done ? 0.0f : 1.0f;                                                // ppo.jl:132
+        if (writer) {                                                                        // ppo.jl:133-140 Buffer.add! (value: wave 2)
+          store_nt4(reinterpret_cast<f32x4*>(a.obs) + b, co[0], co[1], co[2], co[3]);
+          __builtin_nontemporal_store(act, a.action + b); __builtin_nontemporal_store(lpa, a.logprob + b);
+          a.reward[b] = rew; a.terminal[b] = nd;
+        }
+        co[0] = s[0]; co[1] = s[1]; co[2] = s[2]; co[3] = s[3];                             // ppo.jl:143
+        nd = done ? 1 : 0;                                                                   // ppo.jl:144
+        ep_ret += rew;                                                                       // ppo.jl:145
+        if (done) {                                                                          // ppo.jl:147-165
+          if (writer) {
+            st_n += 1.0; st_ret += (double)ep_ret; st_len += (double)ep_len; st_max = fmax(st_max, (double)ep_ret);
+            if (a.ring_cap > 0) {
+              const uint32_t slot = atomicAdd(a.ring_count, 1u);
+              if (slot < (uint32_t)a.ring_cap) a.ring[slot] = crl_episode_record{ep_ret, ep_len, (int32_t)gid, step};
+            }
+          }
+          ep_ret = 0.0f; ep_len = 0;
+          cartpole_reset(s, c.seed, gid, gstep, 1);                                          // ppo.jl:164
+          t_env = 0;
+          if (!c.stale_obs) { co[0] = s[0]; co[1] = s[1]; co[2] = s[2]; co[3] = s[3]; }
+        }
+        if (hf == 0) xch[((step + 1) & 1) * TILE + j] = make_float4(co[0], co[1], co[2], co[3]);
+      }
+    } else {
+      // critic (ppo.jl:128): mlp_forward_x2 cut at the layer boundary so that each part is shorter than the actor's segment it faces
+      const float* img = imgC0 + lds_off;
+      const float4 cv = xch[(step & 1) * TILE + j];
+      const float cx[4] = {cv.x, cv.y, cv.z, cv.w};
+      f32x16 a0 = load16(img + IC::B1C + hf * 32), a1 = load16(img + IC::B1C + hf * 32 + 16);
+#pragma unroll
+      for (int ks = 0; ks < D / 2; ++ks) {
+        const float bv = hf ? cx[2 * ks + 1] : cx[2 * ks];
+        a0 = mfma32(img[IC::WF1 + (0 * (D / 2) + ks) * 64 + lane], bv, a0);
+        a1 = mfma32(img[IC::WF1 + (1 * (D / 2) + ks) * 64 + lane], bv, a1);
+      }
+      f32x16 h1s[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { h1s[0][r] = tanh_exp2_arg(a0[r], X2_ACT_SCALE); h1s[1][r] = tanh_exp2_arg(a1[r], X2_ACT_SCALE); }
+      __syncthreads();                                                                       // (1)
+      a0 = load16(img + IC::B2C + hf * 32); a1 = load16(img + IC::B2C + hf * 32 + 16);
+      dense64_x2(img + IC::WF2H, h1s, a0, a1, lane);
+      const f32x4* w = reinterpret_cast<const f32x4*>(img + IC::W3 + hf * 32);
+      float accv = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const f32x4 wv = w[q];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int idx = q * 4 + i;
+          const float hv = tanh_exp2((idx >> 4) ? a1[idx & 15] : a0[idx & 15], TWO_LOG2E * X2_FWD_UNSCALE, 1.0f);
+          accv = __builtin_fmaf(wv[i], hv, accv);
+        }
+      }
+      const float v = accv + xor32(accv) + img[IC::B3];
+      __syncthreads();                                                                       // (2)
+      if (writer) a.value[b] = v;
+    }
+    __syncthreads();                                                                         // (3) next observations are published
+  }
+  if (wave == 1) {
+    if (writer) {
+      reinterpret_cast<float4*>(a.env_state)[e] = make_float4(s[0], s[1], s[2], s[3]);
+      reinterpret_cast<float4*>(a.cur_obs)[e] = make_float4(co[0], co[1], co[2], co[3]);
+      a.env_t[e] = t_env; a.next_done[e] = nd; a.ep_return[e] = ep_ret; a.ep_length[e] = ep_len;
+      // value[] was written by wave 2 of this block; the step loop's closing __syncthreads() made it visible here
+      if (a.fuse_gae) gae_tail_compat(a, e);
+    }
+    st_n = wave_sum(st_n); st_ret = wave_sum(st_ret); st_len = wave_sum(st_len);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) st_max = fmax(st_max, __shfl_xor(st_max, o, 64));
+    if (lane == 0 && st_n > 0.0) {
+      atomicAdd(&a.ep_stats[0], st_n); atomicAdd(&a.ep_stats[1], st_ret); atomicAdd(&a.ep_stats[2], st_len);
+      atomicMax(reinterpret_cast<unsigned long long*>(&a.ep_stats[3]), (unsigned long long)__double_as_longlong(st_max));
+    }
+  }
+}
+
 template <int D, int A>
 static size_t act_smem() { return sizeof(float) * (NetImage<D, A, false>::SIZE + NetImage<D, 1, false>::SIZE); }
 
@@ -492,7 +705,12 @@ int launch_rollout(crl_ppo* h, bool fuse_gae) {
   ProfScope ps(h, CRL_K_ROLLOUT);
   const char* split_s = getenv("CRL_ROLLOUT_SPLIT");  // read per launch so tests can exercise both kernels
   const int split_env = split_s ? atoi(split_s) : 1;
-  if (gemm_x3() && split_env && tiles <= 512) {
+  if (gemm_x2() && split_env == 1 && tiles <= 512 && !getenv("CRL_ROLLOUT_CRITIC_X3")) {
+    // three waves per tile: the actor's hidden rows split over two waves, the critic (fp16x2) on the third
+    a.range_err = h->vfix + 5;
+    const size_t smem = sizeof(float) * (NetImageX3<4, 2, false>::SIZE + NetImageX2<4, 1>::SIZE + 2 * TILE * 4 + 2 * 2 * 3 * 64 * 4 + 2 * 64 + 4);
+    hipLaunchKernelGGL((rollout_split3_kernel<2>), dim3(tiles), dim3(192), smem, h->stream, a);
+  } else if (gemm_x3() && split_env && tiles <= 512) {   // CRL_ROLLOUT_SPLIT=2: the two-wave kernel
     const size_t smem = sizeof(float) * (NetImageX3<4, 2, false>::SIZE + NetImageX3<4, 1, false>::SIZE + 2 * TILE * 4);
     hipLaunchKernelGGL((rollout_split_kernel<2>), dim3(tiles), dim3(128), smem, h->stream, a);
   } else if (gemm_x2() && !getenv("CRL_ROLLOUT_CRITIC_X3")) {

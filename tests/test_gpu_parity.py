@@ -119,10 +119,11 @@ def _oracle_state(nt, k, params, **kw):
     return cfg, st
 
 
-@pytest.mark.parametrize("split", ["1", "0"])
+@pytest.mark.parametrize("split", ["1", "2", "0"])
 @pytest.mark.parametrize("nt,stale", [(8, 1), (8, 0), (70, 1)])
 def test_rollout_matches_oracle(crl, nt, stale, split, monkeypatch):
-    """split=1: two waves per tile (actor+env | critic), the small-shard kernel; split=0: one wave per tile."""
+    """split=1: three waves per tile (actor rows 0-31 + sampling + env | actor rows 32-63 | critic), the small-shard kernel;
+    split=2: two waves per tile (actor + env | critic); split=0: one wave per tile."""
     monkeypatch.setenv("CRL_ROLLOUT_SPLIT", split)
     k = 128
     agent = make_agent(crl, nt=nt, k=k, stale_obs=stale)
