@@ -167,7 +167,7 @@ struct ProfScope {
   ProfScope(crl_ppo* h_, int id_, bool attach_ = false) : h(h_), id(id_), attach(attach_) {
     // level 2 times only the attached kind: recorded events are extra packets between dependent kernels (≈0.3 ms per iteration
     // at the headline size), which a throughput measurement should not carry
-    on = h->prof == 1 || (h->prof == 2 && attach);
+    on = h->prof == 1 || (h->prof == 2 && (attach || id == CRL_K_ALLREDUCE));   // + the 16 all-reduces of a data-parallel iteration
     if (on) {
       (void)hipEventCreate(&a); (void)hipEventCreate(&b);
       if (!attach) (void)hipEventRecord(a, h->stream);

@@ -189,7 +189,8 @@ int32_t crl_comm_init_external(crl_ppo* h, int32_t world_size, int32_t rank);
 
 /* Profiling: HIP-event timing of each kernel class on the handle's stream (bench.py roofline). on = 1: every class, events
  * recorded around the launches (extra packets between dependent kernels: a breakdown, not a throughput run); on = 2: only the
- * classes whose events ride on the dispatch itself — the update kernel of the fused path — which costs nothing; 0 = off. */
+ * classes whose events ride on the dispatch itself — the update kernel of the fused path — which costs nothing, plus the gradient
+ * all-reduces of a data-parallel run (recorded events: 32 packets per iteration); 0 = off. */
 enum crl_kernel_id { CRL_K_ROLLOUT = 0, CRL_K_GAE = 1, CRL_K_SHUFFLE = 2, CRL_K_ADV_STATS = 3, CRL_K_UPDATE = 4,
                      CRL_K_REDUCE = 5, CRL_K_OPTIM = 6, CRL_K_ALLREDUCE = 7, CRL_K_PACK = 8, CRL_K_PERMUTE = 9,
                      CRL_K_COUNT = 10 };

@@ -55,7 +55,7 @@ def test_bench_runs_multi_rank_on_a_shared_gpu():
     """bench.py's N > 1 path end to end (self-launch, shard, attach, barrier + MAX timing, one JSON line from rank 0)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", "peer", "--share-gpu", "--steps", "3",
-                          "--warmup", "1", "--total-envs", "4096", "--no-cpu-baseline", "--kernel-breakdown", "--master-port", "29611"],
+                          "--warmup", "1", "--total-envs", "4096", "--no-cpu-baseline", "--master-port", "29611"],
                          capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
