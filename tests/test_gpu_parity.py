@@ -713,3 +713,27 @@ def test_permute_pass_flavour_still_matches_the_oracle():
                          capture_output=True, text=True, env=env, timeout=1200)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout and "failed" not in out.stdout
+
+
+@pytest.mark.parametrize("epochs,nmb", [(1, 2), (3, 8), (6, 1)])
+def test_iterate_equals_host_driven_steps_for_other_epoch_and_minibatch_counts(crl, epochs, nmb):
+    """crl_ppo_iterate draws all update_epochs permutations up front (one slot, one bucket table per epoch) and takes the advantage
+    sums from one sequential pass; the same iteration driven call by call (crl_shuffle / crl_adv_stats / crl_ppo_update_minibatch
+    per epoch) must land on the same parameters — for epoch / minibatch counts other than the default 4 x 4."""
+    nt, k = 64, 128
+    a1 = make_agent(crl, nt=nt, k=k, shuffle_mode=2, update_epochs=epochs, num_minibatches=nmb, anneal_lr=False)
+    a2 = make_agent(crl, nt=nt, k=k, shuffle_mode=2, update_epochs=epochs, num_minibatches=nmb, anneal_lr=False, params=a1.get_params())
+    h1, h2 = a1.handle, a2.handle
+    h1.env_reset(); h2.env_reset()
+    h1.iterate(1, want_stats=False)
+    h2.rollout_run(); h2.compute_gae()
+    assert np.array_equal(h1.read(crl._lib.F_ACTION), h2.read(crl._lib.F_ACTION))
+    assert np.array_equal(h1.read(crl._lib.F_ADVANTAGE), h2.read(crl._lib.F_ADVANTAGE))
+    for ep in range(epochs):
+        h2.shuffle(ep); h2.adv_stats()
+        for mb in range(nmb):
+            h2.update_minibatch(mb, 2.5e-4, apply_update=True, want_stats=False)
+    assert np.array_equal(h1.read(crl._lib.F_PERM), h2.read(crl._lib.F_PERM))          # the last epoch's b_inds
+    p1, p2 = h1.read(crl._lib.F_PARAMS), h2.read(crl._lib.F_PARAMS)
+    assert np.max(np.abs(p1 - p2)) < 1e-7, np.max(np.abs(p1 - p2))
+    a1.close(); a2.close()
