@@ -705,7 +705,9 @@ int launch_rollout(crl_ppo* h, bool fuse_gae) {
   ProfScope ps(h, CRL_K_ROLLOUT);
   const char* split_s = getenv("CRL_ROLLOUT_SPLIT");  // read per launch so tests can exercise both kernels
   const int split_env = split_s ? atoi(split_s) : 1;
-  if (gemm_x2() && split_env == 1 && tiles <= 512 && !getenv("CRL_ROLLOUT_CRITIC_X3")) {
+  static int split_max = -1;
+  if (split_max < 0) { const char* e = getenv("CRL_ROLLOUT_SPLIT_MAX_TILES"); split_max = e ? atoi(e) : 512; }
+  if (gemm_x2() && split_env == 1 && tiles <= split_max && !getenv("CRL_ROLLOUT_CRITIC_X3")) {
     // three waves per tile: the actor's hidden rows split over two waves, the critic (fp16x2) on the third
     a.range_err = h->vfix + 5;
     const size_t smem = sizeof(float) * (NetImageX3<4, 2, false>::SIZE + NetImageX2<4, 1>::SIZE + 2 * TILE * 4 + 2 * 2 * 3 * 64 * 4 + 2 * 64 + 4);
