@@ -40,6 +40,29 @@ def main():
     n, off = crl_dist.shard_envs(NT, world, rank)
     out = {}
 
+    if os.environ.get("DP2_MODE") == "timeout":
+        # a rank that stops answering: rank 0 issues an all-reduce nobody else joins — its kernel must give up after
+        # CRL_PEER_TIMEOUT_S and the next synchronising call must report it (no hang, no garbage passed on silently)
+        cfg = crl.PPOConfig(num_envs=n, num_steps=k, total_timesteps=NT * k * 10)
+        a = crl.Agent(cfg, device=local, env_id_offset=off, init_seed=3)
+        hh = a.handle
+        attach(hh)
+        hh.env_reset(); hh.rollout_run(); hh.compute_gae()
+        msg = ""
+        if rank == 0:
+            hh.write(L.F_PERM, np.arange(n * k, dtype=np.int32))
+            try:
+                hh.adv_stats()        # local sums -> all-reduce (alone) -> mean / std
+                hh.sync()
+            except crl.CrlError as e:
+                msg = str(e)
+            print("DP2_RESULT " + json.dumps({"timeout_error": msg}), flush=True)
+        dist.barrier()               # rank 1 keeps its mailbox mapped until rank 0 is through
+        a.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
     def gather(a):
         parts = [None] * world
         dist.all_gather_object(parts, np.ascontiguousarray(a))

@@ -76,3 +76,17 @@ def test_bench_falls_back_to_the_peer_allreduce_when_rccl_cannot_start():
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 2 and "RCCL initialisation failed" in d["config"]["comm"]
+
+
+def test_peer_allreduce_times_out_instead_of_hanging():
+    """One rank issues an all-reduce its peer never joins: the kernel gives up after CRL_PEER_TIMEOUT_S and the host gets an error."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", DP2_COMM="peer", DP2_SHARE_GPU="1" if _gpu_count() < 2 else "0",
+               DP2_MODE="timeout", CRL_PEER_TIMEOUT_S="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29613", os.path.join(ROOT, "tests", "dp2_worker.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("DP2_RESULT ")]
+    assert line, out.stdout[-2000:]
+    assert "timed out" in json.loads(line[0][len("DP2_RESULT "):])["timeout_error"]
