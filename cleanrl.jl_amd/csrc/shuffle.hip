@@ -249,7 +249,7 @@ static int launch_blocked_fy(crl_ppo* h, uint64_t epoch_id, int nslots, bool fus
   const size_t sstride = (size_t)K1 * BFY_CAP;
   int32_t* S = h->perm_tmp + (size_t)h->cur_slot * sstride;
   for (int z = 0; z < nslots; ++z)   // the buckets' cursors
-    CRL_HIP_CHECK(hipMemsetAsync(ws + (size_t)z * BFY_WS_STRIDE + 2 * BFY_MAXK1 + 1, 0, sizeof(uint32_t) * BFY_MAXK1, h->stream));
+    CRL_HIP_CHECK(hipMemsetAsync(ws + (size_t)z * BFY_WS_STRIDE + 2 * BFY_MAXK1 + 1, 0, sizeof(uint32_t) * K1, h->stream));
   const uint64_t seed = shuffle_seed(h);
   const bool big = n >= (4 << 20);
   const int t1 = big ? 1024 : 256, chunks = (n + t1 * 32 - 1) / (t1 * 32);
