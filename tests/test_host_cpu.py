@@ -171,3 +171,70 @@ def test_julia_shell_structs_and_symbols_follow_the_header(crl):
     for must in ("crl_comm_init", "crl_comm_unique_id", "crl_episode_ring_enable", "crl_episode_ring_read", "crl_dqn_run", "crl_dqn_q_values"):
         assert must in called, must
     assert "shuffle_mode=2" in jl     # exact blocked Fisher-Yates by default, like the ctypes mirror
+
+
+def _pb_fields(buf):
+    """Minimal protobuf reader: yields (field number, wire type, value) — enough for tensorflow.Event / Summary."""
+    import struct
+    i = 0
+    while i < len(buf):
+        key = 0; shift = 0
+        while True:
+            b = buf[i]; i += 1; key |= (b & 0x7F) << shift; shift += 7
+            if not b & 0x80: break
+        num, wt = key >> 3, key & 7
+        if wt == 0:
+            v = 0; shift = 0
+            while True:
+                b = buf[i]; i += 1; v |= (b & 0x7F) << shift; shift += 7
+                if not b & 0x80: break
+        elif wt == 1:
+            v = struct.unpack_from("<d", buf, i)[0]; i += 8
+        elif wt == 5:
+            v = struct.unpack_from("<f", buf, i)[0]; i += 4
+        else:
+            n = 0; shift = 0
+            while True:
+                b = buf[i]; i += 1; n |= (b & 0x7F) << shift; shift += 7
+                if not b & 0x80: break
+            v = bytes(buf[i:i + n]); i += n
+        yield num, wt, v
+
+
+def test_tensorboard_sink_writes_a_valid_event_file(tmp_path):
+    """logger.jl:14-16 — TBLogger("logs/<run_name>"): the pure-Python sink must produce TFRecord-framed tensorflow.Event messages
+    (masked CRC-32C on length and payload), one scalar "<message>/<key>" per numeric key, steps advanced by log_step_increment."""
+    import importlib
+    import struct
+    lg_mod = importlib.import_module("cleanrl_jl_amd.logger")
+    c = 0xFFFFFFFF
+    for b in b"123456789":
+        c = lg_mod._CRC[(c ^ b) & 0xFF] ^ (c >> 8)
+    assert c ^ 0xFFFFFFFF == 0xE3069283                       # CRC-32C (Castagnoli) check value
+    lg = lg_mod.make_logger("run|x", to_terminal=False, to_tensorboard=True, to_json=False, log_dir=str(tmp_path))
+    lg.info("Training Statistics", extra={"crl": dict(loss=1.5, pg_loss=-0.25, log_step_increment=0)})
+    lg.info("Training Statistics", extra={"crl": dict(loss=1.25, pg_loss=-0.5, note="text is skipped", log_step_increment=4096)})
+    lg.info("Episode Statistics", extra={"crl": dict(episode_return=37.0, episode_length=37, log_step_increment=128)})
+    files = os.listdir(tmp_path / "run|x")
+    assert len(files) == 1 and files[0].startswith("events.out.tfevents.")
+    data = (tmp_path / "run|x" / files[0]).read_bytes()
+    off, events = 0, []
+    while off < len(data):
+        (n,) = struct.unpack_from("<Q", data, off)
+        assert struct.unpack_from("<I", data, off + 8)[0] == lg_mod._masked_crc32c(data[off:off + 8])
+        body = data[off + 12:off + 12 + n]
+        assert struct.unpack_from("<I", data, off + 12 + n)[0] == lg_mod._masked_crc32c(body)
+        events.append({num: v for num, _, v in _pb_fields(body)})
+        off += 12 + n + 4
+    assert events[0][3] == b"brain.Event:2" and len(events) == 4
+    steps = [e.get(2, 0) for e in events[1:]]
+    assert steps == [0, 4096, 4224]
+    scal = []
+    for e in events[1:]:
+        vals = [dict((num, v) for num, _, v in _pb_fields(v)) for num, _, v in _pb_fields(e[5]) if num == 1]
+        scal.append({v[1].decode(): v[2] for v in vals})
+    assert scal[0] == {"Training Statistics/loss": 1.5, "Training Statistics/pg_loss": -0.25}
+    assert scal[1] == {"Training Statistics/loss": 1.25, "Training Statistics/pg_loss": -0.5}
+    assert scal[2] == {"Episode Statistics/episode_return": 37.0, "Episode Statistics/episode_length": 37.0}
+    for hd in list(lg.handlers):
+        hd.close(); lg.removeHandler(hd)
