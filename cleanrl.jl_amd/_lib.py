@@ -53,7 +53,7 @@ EXPORTS = [
     "crl_shuffle", "crl_adv_stats", "crl_ppo_update_minibatch", "crl_ppo_iterate", "crl_ppo_iteration",
     "crl_comm_unique_id", "crl_comm_init", "crl_comm_init_external", "crl_comm_peer_export", "crl_comm_peer_attach", "crl_adv_stats_local", "crl_adv_stats_finish",
     "crl_prof_enable", "crl_prof_read", "crl_prof_reset", "crl_ppo_exact_reruns", "crl_episode_ring_enable",
-    "crl_episode_ring_read",
+    "crl_episode_ring_read", "crl_comm_destroy", "crl_ppo_set_option", "crl_ppo_get_option", "crl_ppo_option_name",
     "crl_a2c_create", "crl_a2c_destroy", "crl_a2c_param_count", "crl_a2c_write_params", "crl_a2c_read_params",
     "crl_a2c_read_env", "crl_a2c_read_buffer", "crl_a2c_run_until_update", "crl_a2c_discounted_future_rewards",
     "crl_dqn_create", "crl_dqn_destroy", "crl_dqn_write_params", "crl_dqn_read_params", "crl_dqn_status_read", "crl_dqn_run",
@@ -157,6 +157,10 @@ def load():
     L.crl_ppo_exact_reruns.argtypes = [vp, i64p]
     L.crl_episode_ring_enable.argtypes = [vp, C.c_int32]
     L.crl_episode_ring_read.argtypes = [vp, C.POINTER(CrlEpisodeRecord), C.c_int32, ip, i64p]
+    L.crl_comm_destroy.argtypes = [vp]
+    L.crl_ppo_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.crl_ppo_get_option.argtypes = [vp, C.c_char_p, i64p]
+    L.crl_ppo_option_name.argtypes = [C.c_int32, C.POINTER(C.c_char_p), i64p]
     L.crl_a2c_create.argtypes = [C.POINTER(CrlA2CConfig), C.c_int32, C.POINTER(vp)]
     L.crl_a2c_destroy.argtypes = [vp]
     L.crl_a2c_param_count.argtypes = [vp, i64p]
@@ -353,6 +357,21 @@ class Handle:
     def adv_stats_finish(self):
         check(load().crl_adv_stats_finish(self._h))
 
+    def comm_destroy(self):
+        check(load().crl_comm_destroy(self._h))
+
+    def set_option(self, key: str, value: int):
+        """crl_ppo_set_option: per-handle kernel-flavour / numerics switches (include/cleanrl_hip.h lists them)."""
+        check(load().crl_ppo_set_option(self._h, key.encode(), int(value)))
+
+    def get_option(self, key: str) -> int:
+        v = C.c_int64()
+        check(load().crl_ppo_get_option(self._h, key.encode(), C.byref(v)))
+        return v.value
+
+    def options(self) -> dict:
+        return {k: self.get_option(k) for k in option_names()}
+
     def prof_enable(self, on=True):
         check(load().crl_prof_enable(self._h, int(on)))
 
@@ -366,6 +385,17 @@ class Handle:
             check(load().crl_prof_read(self._h, kid, C.byref(ms), C.byref(n)))
             out[name] = (ms.value, n.value)
         return out
+
+
+def option_names():
+    """Names of every option crl_ppo_set_option accepts, in table order."""
+    out = []
+    i = 0
+    while True:
+        name = C.c_char_p(); d = C.c_int64()
+        if load().crl_ppo_option_name(i, C.byref(name), C.byref(d)) != 0:
+            return out
+        out.append(name.value.decode()); i += 1
 
 
 def comm_unique_id() -> bytes:

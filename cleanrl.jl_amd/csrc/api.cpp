@@ -16,13 +16,68 @@ int comm_unique_id(uint8_t id[128]);
 int comm_init(crl_ppo* h, const uint8_t id[128], int world, int rank);
 int launch_iota(crl_ppo* h);
 
-static int gemm_mode() {
-  static int mode = -1;
-  if (mode < 0) { const char* e = std::getenv("CRL_GEMM"); const std::string v = e ? e : "x2"; mode = v == "f32" ? 0 : v == "x3" ? 1 : 2; }
-  return mode;
+// Option table of crl_ppo_set_option / crl_ppo_get_option (ids: ppo_ctx.hpp). Every switch that selects a kernel flavour or changes
+// numerics is state of one handle; the process environment is read in exactly one place (CRL_OPTIONS, crl_ppo_create).
+struct OptDesc { const char* name; int64_t dflt, lo, hi; };
+static const OptDesc kOpts[OPT_COUNT] = {
+    {"gemm", 2, 1, 2},
+    {"rollout_split", 1, 0, 2},
+    {"rollout_split_max_tiles", 512, 0, 1 << 20},
+    {"rollout_stagger", 6, 0, 64},
+    {"gae_fuse", 1, 0, 1},
+    {"shuffle_overlap", 1, 0, 1},
+    {"guard_window", 8, 1, 1 << 20},
+    {"update_stagger", 3, 0, 64},
+    {"actor_block_pct", 53, 1, 99},
+    {"adv_seq", 1, 0, 1},
+    {"comm_force", 0, 0, 1},
+    {"peer_timeout_ms", 20000, 1, 3600000},
+    {"wide_gemm", 2, 0, 2},
+    {"wide_tanh_rational", 0, 0, 1},
+    {"gae_seg", 0, 0, 16},
+    {"gae_tile", 0, 0, 64},
+};
+static int opt_find(const char* key) {
+  if (!key) return -1;
+  for (int i = 0; i < OPT_COUNT; ++i) if (std::strcmp(kOpts[i].name, key) == 0) return i;
+  return -1;
 }
-bool gemm_x3() { return gemm_mode() >= 1; }
-bool gemm_x2() { return gemm_mode() == 2; }
+static int opt_set(crl_ppo* h, const char* key, int64_t value) {
+  const int id = opt_find(key);
+  if (id < 0) { set_error(std::string("crl_ppo_set_option: unknown option '") + (key ? key : "(null)") + "'"); return 1; }
+  if (value < kOpts[id].lo || value > kOpts[id].hi) {
+    set_error(std::string("crl_ppo_set_option: ") + key + " = " + std::to_string(value) + " is outside [" + std::to_string(kOpts[id].lo) + ", " +
+              std::to_string(kOpts[id].hi) + "]");
+    return 1;
+  }
+  if (id == OPT_GAE_SEG && value != 0 && value != 8 && value != 16) { set_error("crl_ppo_set_option: gae_seg is 0 (automatic), 8 or 16"); return 1; }
+  if (id == OPT_GAE_TILE && value != 0 && value != 8 && value != 16 && value != 32 && value != 64) { set_error("crl_ppo_set_option: gae_tile is 0 (automatic), 8, 16, 32 or 64"); return 1; }
+  h->opt[id] = value;
+  if (id == OPT_GUARD_WINDOW) h->window_len = (int)value;
+  return 0;
+}
+// CRL_OPTIONS="key=value,key=value": the one environment hook left, for shell-driven experiments (scripts/, bench.py --opt goes
+// through crl_ppo_set_option instead). Unknown keys and out-of-range values fail crl_ppo_create loudly.
+static int opt_apply_env(crl_ppo* h) {
+  const char* e = std::getenv("CRL_OPTIONS");
+  if (!e || !*e) return 0;
+  std::string s(e);
+  size_t pos = 0;
+  while (pos < s.size()) {
+    size_t end = s.find(',', pos);
+    if (end == std::string::npos) end = s.size();
+    const std::string item = s.substr(pos, end - pos);
+    pos = end + 1;
+    if (item.empty()) continue;
+    const size_t eq = item.find('=');
+    if (eq == std::string::npos) { set_error("CRL_OPTIONS: expected key=value, got '" + item + "'"); return 1; }
+    char* endp = nullptr;
+    const long long v = std::strtoll(item.c_str() + eq + 1, &endp, 10);
+    if (!endp || *endp) { set_error("CRL_OPTIONS: value of '" + item + "' is not an integer"); return 1; }
+    if (opt_set(h, item.substr(0, eq).c_str(), (int64_t)v)) return 1;
+  }
+  return 0;
+}
 
 // first guess of the fp16x2 weight-gradient scale (mlp_x2.hpp) before any launch has measured |δ2|: δ2 ∝ 1/M, times the
 // typical head weights (actor gain 0.01, critic gain 1) and cotangents; powers of 2^8 like every later value
@@ -101,22 +156,19 @@ void select_slot(crl_ppo* h, int slot) {
   h->adv_ms = h->adv_ms_base + (size_t)slot * h->dc.nmb * 2;
 }
 
-// fused path: the current slot's minibatch-ordered records (and its advantage sums) exist and are current
+// fused path: the records are packed and the current slot's advantage sums are current
 int ensure_records(crl_ppo* h) {
   if (h->wide) return 0;
   if (!h->recs_dirty && (h->slot_fresh >> h->cur_slot & 1u)) return 0;
-  return launch_permute_records(h, h->cur_slot, 1);
+  return launch_slot_adv_sums(h, h->cur_slot, 1);
 }
 }  // namespace crl
-
-static bool env_on(const char* name, bool dflt) { const char* e = getenv(name); return e ? atoi(e) != 0 : dflt; }
 
 namespace crl {
 // compat-mode GAE rides on the tail of the rollout kernels of the fused 4/2/64 path (policy.hip); fixed mode needs the
 // bootstrap critic pass and keeps the separate launches
 bool rollout_can_fuse_gae(const crl_ppo* h) {
-  static const bool on = env_on("CRL_GAE_FUSE", true);
-  return on && !h->wide && h->cfg.gae_mode == CRL_GAE_COMPAT && h->cfg.env_kind == CRL_ENV_CARTPOLE;
+  return opt(h, OPT_GAE_FUSE) != 0 && !h->wide && h->cfg.gae_mode == CRL_GAE_COMPAT && h->cfg.env_kind == CRL_ENV_CARTPOLE;
 }
 }  // namespace crl
 
@@ -128,6 +180,12 @@ using namespace crl;
 
 static int settle(crl_ppo* h);
 static int check_bfy(crl_ppo* h);
+// Every entry point that reads or mutates handle state first closes an open speculation guard window (see settle below): a
+// host-driven step, an env reset or a field write issued inside a window would otherwise be undone by a later restore + replay.
+// crl_ppo_iterate itself and the pure getters are the only entry points that do not.
+#define CRL_GUARD_SETTLED(h) \
+  CRL_GUARD(h);              \
+  if (settle(h)) return 1;
 
 extern "C" {
 
@@ -184,6 +242,9 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
   crl_ppo* h = new (std::nothrow) crl_ppo();
   if (!h) { set_error("out of host memory"); return 1; }
   h->cfg = *cfg; h->device = device; h->wide = wide;
+  for (int i = 0; i < OPT_COUNT; ++i) h->opt[i] = kOpts[i].dflt;
+  h->window_len = (int)kOpts[OPT_GUARD_WINDOW].dflt;
+  if (opt_apply_env(h)) { delete h; return 1; }
   DevCfg& c = h->dc;
   c.nt = cfg->num_envs; c.k = cfg->num_steps; c.B = (int)B64; c.nmb = cfg->num_minibatches; c.M = c.B / c.nmb;
   c.D = cfg->obs_dim; c.A = cfg->n_act; c.gamma = cfg->gamma; c.lambda = cfg->gae_lambda; c.clip = cfg->clip_coef;
@@ -211,9 +272,9 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
   rc |= dalloc(&h->params, h->P); rc |= dalloc(&h->adam_m, h->P); rc |= dalloc(&h->adam_v, h->P);
   const size_t E = (size_t)cfg->update_epochs;
   rc |= dalloc(&h->betap, 24); rc |= dalloc(&h->perm_base, E * B); rc |= dalloc(&h->optim_part, (size_t)h->P / 4096 + 16);
-  if (!wide) { rc |= dalloc(&h->recs, B); if (!gather_mode()) rc |= dalloc(&h->recs_p, E * B); }   // gather mode never lays minibatches out
+  if (!wide) rc |= dalloc(&h->recs, B);   // the update kernels fetch records through the epoch's permutation: no permuted copies
   {
-    // permute pass: blocks per minibatch (≈1 K samples each, at most 512); the partial-sum scratch also serves the
+    // advantage-sum pass: blocks per minibatch (≈1 K samples each, at most 512); the partial-sum scratch also serves the
     // stand-alone statistics kernels (up to 512 blocks per minibatch of ONE slot)
     int pb = c.M / 1024; if (pb < 1) pb = 1; if (pb > 512) pb = 512;
     h->adv_pb = pb;
@@ -225,7 +286,7 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
     rc |= dalloc(&h->perm_tmp, E * k1 * 5632);   // padded L1 buckets (K1 x BFY_CAP), one slice per epoch slot
     rc |= dalloc(&h->bfy_ws, E * ((size_t)4 * 16384 + 8));
     rc |= dalloc(&h->bfy_adv_part, (size_t)c.nmb * k1 * 2);
-    if (!wide && gather_mode()) { rc |= dalloc(&h->bfy_bucket_mb, E * (size_t)16384); rc |= dalloc(&h->bfy_mbid, E * B); }
+    if (!wide) { rc |= dalloc(&h->bfy_bucket_mb, E * (size_t)16384); rc |= dalloc(&h->bfy_mbid, E * B); }
   }
   // update grid: two 256-thread blocks per CU, alternating roles; never more waves than tiles
   hipDeviceProp_t prop;
@@ -242,9 +303,8 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
   rc |= dalloc(&h->stats_dev, (size_t)cfg->update_epochs * c.nmb);
   rc |= dalloc(&h->comm_buf, (size_t)h->P + 8);
   rc |= dalloc(&h->snap, (size_t)3 * h->P); rc |= dalloc(&h->snap_betap, 24);
-  h->snap_env_bytes = nt * d * 8 + nt * 4 * 3 + ((nt + 15) & ~(size_t)15) + 64;
+  h->snap_env_bytes = nt * d * 8 + nt * 4 * 3 + ((nt + 15) & ~(size_t)15) + 96;
   { char* p = nullptr; rc |= dalloc(&p, h->snap_env_bytes); h->snap_env = p; }
-  if (const char* e = getenv("CRL_DP_CHECK_EVERY")) { h->window_len = atoi(e); if (h->window_len < 1) h->window_len = 1; }
   if (rc) { crl_ppo_destroy(h); return 1; }
   if (reset_dw_scale(h)) { crl_ppo_destroy(h); return 1; }
   select_slot(h, 0);
@@ -267,7 +327,7 @@ int32_t crl_ppo_destroy(crl_ppo* h) {
   wide_destroy(h);
   void* ptrs[] = {h->obs, h->action, h->logprob, h->reward, h->terminal, h->value, h->adv, h->ret, h->env_state, h->env_t,
                   h->cur_obs, h->next_done, h->ep_return, h->ep_length, h->next_value, h->ep_stats, h->ep_ring, h->ep_ring_count, h->params,
-                  h->adam_m, h->adam_v, h->betap, h->optim_part, h->perm_base, h->recs, h->recs_p, h->adv_part, h->perm_tmp, h->bfy_ws, h->bfy_adv_part, h->bfy_bucket_mb, h->bfy_mbid, h->gpart, h->lpart,
+                  h->adam_m, h->adam_v, h->betap, h->optim_part, h->perm_base, h->recs, h->adv_part, h->perm_tmp, h->bfy_ws, h->bfy_adv_part, h->bfy_bucket_mb, h->bfy_mbid, h->gpart, h->lpart,
                   h->adv_sums_base, h->adv_ms_base, h->newv, h->vfix, h->dscale, h->stats_dev, h->comm_buf, h->snap, h->snap_betap, h->snap_env, h->stage};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int k = 0; k < CRL_K_COUNT; ++k)
@@ -337,7 +397,7 @@ int32_t crl_ppo_read(crl_ppo* h, int32_t field, void* host, size_t nbytes) {
 
 int32_t crl_policy_act(crl_ppo* h, const float* obs, const double* u, int32_t n, int32_t* action, float* logprob,
                        float* value) {
-  CRL_GUARD(h);
+  CRL_GUARD_SETTLED(h);
   if (n < 0 || (n > 0 && (!obs || !u || !action || !logprob))) { set_error("crl_policy_act: bad arguments"); return 1; }
   if (n == 0) return 0;
   const size_t d = (size_t)h->dc.D, N = (size_t)n;
@@ -358,7 +418,7 @@ int32_t crl_policy_act(crl_ppo* h, const float* obs, const double* u, int32_t n,
 
 int32_t crl_logprob_actions(crl_ppo* h, const float* obs, const int32_t* actions, int32_t n, float* logprob,
                             float* entropy) {
-  CRL_GUARD(h);
+  CRL_GUARD_SETTLED(h);
   if (n < 0 || (n > 0 && (!obs || !actions || !logprob || !entropy))) { set_error("crl_logprob_actions: bad arguments"); return 1; }
   if (n == 0) return 0;
   const size_t d = (size_t)h->dc.D, A = (size_t)h->dc.A, N = (size_t)n;
@@ -409,7 +469,7 @@ int32_t crl_gae(int32_t device, const float* value, const float* reward, const u
 
 int32_t crl_rollout_store(crl_ppo* h, int32_t step, const float* obs, const int32_t* action, const float* logprob,
                           const float* reward, const uint8_t* terminal, const float* value) {
-  CRL_GUARD(h);
+  CRL_GUARD_SETTLED(h);
   if (step < 0 || step >= h->dc.k) { set_error("crl_rollout_store: step out of range"); return 1; }
   if (!obs || !action || !logprob || !reward || !terminal || !value) { set_error("crl_rollout_store: null argument"); return 1; }
   const size_t nt = (size_t)h->dc.nt, d = (size_t)h->dc.D, off = nt * (size_t)step;
@@ -425,7 +485,7 @@ int32_t crl_rollout_store(crl_ppo* h, int32_t step, const float* obs, const int3
 }
 
 int32_t crl_env_reset(crl_ppo* h) {
-  CRL_GUARD(h);
+  CRL_GUARD_SETTLED(h);
   if (launch_env_reset(h)) return 1;
   h->env_ready = true;
   return 0;
@@ -439,7 +499,7 @@ static int ensure_env(crl_ppo* h) {  // ppo.jl:112-115 runs once before the loop
 }
 
 int32_t crl_rollout_run(crl_ppo* h) {
-  CRL_GUARD(h);
+  CRL_GUARD_SETTLED(h);
   if (ensure_env(h)) return 1;
   h->recs_dirty = true;
   return launch_rollout(h);
@@ -457,7 +517,7 @@ int32_t crl_episode_stats_read(crl_ppo* h, crl_episode_stats* out) {
 }
 
 int32_t crl_episode_ring_enable(crl_ppo* h, int32_t capacity) {
-  CRL_GUARD(h);
+  CRL_GUARD_SETTLED(h);
   if (capacity < 0 || capacity > (1 << 26)) { set_error("crl_episode_ring_enable: capacity must be in 0..2^26"); return 1; }
   CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
   if (h->ep_ring) { (void)hipFree(h->ep_ring); h->ep_ring = nullptr; }
@@ -490,25 +550,29 @@ int32_t crl_episode_ring_read(crl_ppo* h, crl_episode_record* out, int32_t max_r
   return 0;
 }
 
-int32_t crl_compute_gae(crl_ppo* h) {
-  CRL_GUARD(h);
+static int compute_gae(crl_ppo* h) {
   h->recs_dirty = true;
   const bool fixed = h->cfg.gae_mode == CRL_GAE_FIXED;
   if (fixed && launch_next_value(h)) return 1;
   ProfScope ps(h, CRL_K_GAE, /*attach=*/true);
   return launch_gae(h->stream, h->value, h->reward, h->terminal, fixed ? h->next_value : nullptr, h->next_done, h->dc.nt,
-                    h->dc.k, h->cfg.gamma, h->cfg.gae_lambda, h->cfg.gae_mode, h->adv, h->ret, ps.a, ps.b);
+                    h->dc.k, h->cfg.gamma, h->cfg.gae_lambda, h->cfg.gae_mode, h->adv, h->ret, ps.a, ps.b, (int)opt(h, OPT_GAE_SEG),
+                    (int)opt(h, OPT_GAE_TILE));
+}
+int32_t crl_compute_gae(crl_ppo* h) {
+  CRL_GUARD_SETTLED(h);
+  return compute_gae(h);
 }
 
 static int check_bfy(crl_ppo* h) {
   if (peer_check(h)) return 1;
-  if ((!h->wide && gemm_x2()) || wide_x2_active(h)) {
+  if (wide_x2_active(h)) {
     double re = 0.0;
-    CRL_HIP_CHECK(hipMemcpyAsync(&re, h->vfix + (h->wide ? 6 : 5), sizeof(re), hipMemcpyDeviceToHost, h->stream));
+    CRL_HIP_CHECK(hipMemcpyAsync(&re, h->vfix + 6, sizeof(re), hipMemcpyDeviceToHost, h->stream));
     CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
     if (re != 0.0) {
-      set_error("a hidden-layer weight reached |w| >= 255: outside the fp16x2 window of the update kernel (mlp_x2.hpp); "
-                "results since the last check are invalid — rerun with CRL_GEMM=x3 (CRL_WIDE_GEMM=x3 on the layer-wise path)");
+      set_error("a 256-wide hidden-layer weight reached |w| >= 255: outside the fp16x2 window of the layer-wise path (wide.hip); "
+                "results since the last check are invalid — set option wide_gemm = 1 (bf16x3) and rerun");
       return 1;
     }
   }
@@ -523,13 +587,13 @@ static int check_bfy(crl_ppo* h) {
 }
 
 int32_t crl_shuffle(crl_ppo* h, uint64_t epoch_id) {
-  CRL_GUARD(h);
+  CRL_GUARD_SETTLED(h);
   h->slot_fresh &= ~(1u << h->cur_slot);
   if (launch_shuffle(h, epoch_id)) return 1;
   return check_bfy(h);
 }
 
-// local Σadv, Σadv² of the current slot's minibatches → adv_sums: the fused path takes them from the permute pass
+// local Σadv, Σadv² of the current slot's minibatches → adv_sums
 static int adv_sums_local(crl_ppo* h) {
   if (h->wide) return launch_adv_stats_sums(h);
   h->slot_fresh &= ~(1u << h->cur_slot);   // recompute: the caller may have overwritten CRL_F_ADV_SUMS
@@ -537,18 +601,18 @@ static int adv_sums_local(crl_ppo* h) {
 }
 
 int32_t crl_adv_stats(crl_ppo* h) {
-  CRL_GUARD(h);
+  CRL_GUARD_SETTLED(h);
   if (adv_sums_local(h)) return 1;
   if (comm_allreduce(h, h->adv_sums, (size_t)h->dc.nmb * 2, true)) return 1;
   return launch_adv_stats_finish(h);
 }
 
 int32_t crl_adv_stats_local(crl_ppo* h) {
-  CRL_GUARD(h);
+  CRL_GUARD_SETTLED(h);
   return adv_sums_local(h);
 }
 int32_t crl_adv_stats_finish(crl_ppo* h) {
-  CRL_GUARD(h);
+  CRL_GUARD_SETTLED(h);
   return launch_adv_stats_finish(h);
 }
 
@@ -564,7 +628,7 @@ static int update_step(crl_ppo* h, int mb, double eta, int apply, int slot, bool
 }
 
 int32_t crl_ppo_update_minibatch(crl_ppo* h, int32_t mb, double eta, int32_t apply_update, crl_ppo_stats* stats) {
-  CRL_GUARD(h);
+  CRL_GUARD_SETTLED(h);
   if (mb < 0 || mb >= h->dc.nmb) { set_error("crl_ppo_update_minibatch: minibatch index out of range"); return 1; }
   if (ensure_records(h)) return 1;
   if (update_step(h, mb, eta, apply_update, mb)) return 1;
@@ -586,12 +650,12 @@ int32_t crl_ppo_update_minibatch(crl_ppo* h, int32_t mb, double eta, int32_t app
 // ---------------------------------------------------------------------------------------------------------------
 static bool guard_on(const crl_ppo* h) { return !h->wide && h->cfg.clip_value_loss && !h->external_comm; }
 
-struct EnvSnapLayout { size_t state, obs, t, done, ret, len, stats, ring, total; };
+struct EnvSnapLayout { size_t state, obs, t, done, ret, len, stats, ring, dscale, total; };
 static EnvSnapLayout env_snap_layout(const crl_ppo* h) {
   const size_t nt = (size_t)h->dc.nt, d = (size_t)h->dc.D;
   EnvSnapLayout l;
   l.state = 0; l.obs = l.state + nt * d * 4; l.t = l.obs + nt * d * 4; l.ret = l.t + nt * 4; l.len = l.ret + nt * 4;
-  l.stats = l.len + nt * 4; l.ring = l.stats + 32; l.done = l.ring + 16; l.total = l.done + nt;
+  l.stats = l.len + nt * 4; l.ring = l.stats + 32; l.dscale = l.ring + 16; l.done = l.dscale + 16; l.total = l.done + nt;
   return l;
 }
 static int guard_copy(crl_ppo* h, bool save) {
@@ -604,7 +668,10 @@ static int guard_copy(crl_ppo* h, bool save) {
       {h->params, h->snap, P * 4}, {h->adam_m, h->snap + P, P * 4}, {h->adam_v, h->snap + 2 * P, P * 4}, {h->betap, h->snap_betap, 24 * 8},
       {h->env_state, e + l.state, nt * d * 4}, {h->cur_obs, e + l.obs, nt * d * 4}, {h->env_t, e + l.t, nt * 4},
       {h->ep_return, e + l.ret, nt * 4}, {h->ep_length, e + l.len, nt * 4}, {h->ep_stats, e + l.stats, 32},
-      {h->next_done, e + l.done, nt}, {h->ep_ring_count, e + l.ring, 4}};
+      {h->next_done, e + l.done, nt}, {h->ep_ring_count, e + l.ring, 4},
+      // the sticky fp16x2 weight-gradient scale and the running largest |δ2| (mlp_x2.hpp): a replay starts from the scales the window
+      // started with, so it is bit-identical to a run that never speculated
+      {h->dscale, e + l.dscale, 16}};
   for (const Pair& p : pairs) {
     if (!p.live) continue;   // the episode ring is optional
     CRL_HIP_CHECK(hipMemcpyAsync(save ? p.snap : p.live, save ? p.live : p.snap, p.bytes, hipMemcpyDeviceToDevice, h->stream));
@@ -650,7 +717,7 @@ static int iterate_once(crl_ppo* h, bool exact) {
   if (h->wide) {
     // layer-wise path: per-epoch shuffle → statistics (→ all-reduce) → optimiser steps, gathering through the permutation
     if (launch_rollout(h)) return 1;
-    if (crl_compute_gae(h)) return 1;
+    if (compute_gae(h)) return 1;
     if (h->cfg.shuffle_mode == CRL_SHUFFLE_FISHER_YATES && launch_iota(h)) return 1;  // ppo.jl:191
     for (int ep = 0; ep < E; ++ep) {
       if (launch_shuffle(h, ep0 + (uint64_t)ep, /*with_adv_sums=*/true)) return 1;
@@ -663,12 +730,12 @@ static int iterate_once(crl_ppo* h, bool exact) {
     return 0;
   }
   // fused path. All update_epochs permutations are drawn up front — they depend on nothing the rollout or the optimiser
-  // produces — on the second stream, next to the rollout kernel. One permute pass then lays every epoch's minibatches out
-  // contiguously and leaves all E·nmb advantage sums, which cross the ranks in ONE all-reduce per iteration; after that an
-  // optimiser step is update → reduce → (all-reduce) → Adam.
-  static const bool overlap = env_on("CRL_SHUFFLE_OVERLAP", true);
+  // produces — on the second stream, next to the rollout kernel. One sequential pass over the advantages then leaves all E·nmb
+  // advantage sums, which cross the ranks in ONE all-reduce per iteration; after that an optimiser step is
+  // update (records fetched through the permutation) → reduce → (all-reduce) → Adam.
+  const bool overlap = opt(h, OPT_SHUFFLE_OVERLAP) != 0;
   if (overlap) {
-    CRL_HIP_CHECK(hipEventRecord(h->ev_fork, h->stream));          // the previous iteration's permute pass has read the slots
+    CRL_HIP_CHECK(hipEventRecord(h->ev_fork, h->stream));          // the previous iteration's update kernels have read the slots
     CRL_HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
     std::swap(h->stream, h->stream2);
     const int rc = draw_epoch_permutations(h, ep0);
@@ -678,13 +745,11 @@ static int iterate_once(crl_ppo* h, bool exact) {
   }
   const bool fuse = rollout_can_fuse_gae(h);
   if (launch_rollout(h, fuse)) return 1;
-  if (!fuse && crl_compute_gae(h)) return 1;
+  if (!fuse && compute_gae(h)) return 1;
   if (launch_pack_records(h)) return 1;
   if (overlap) CRL_HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
   else if (draw_epoch_permutations(h, ep0)) return 1;
-  // (Measured and dropped: running the permute pass of epochs 1.. on the second stream under epoch 0's update kernels — the
-  //  random 64-byte gathers lengthen the update kernels' own record loads by 25 %, which costs what the overlap saves.)
-  if (launch_permute_records(h, 0, E)) return 1;
+  if (launch_slot_adv_sums(h, 0, E)) return 1;
   {
     ProfScope ps(h, CRL_K_ADV_STATS);
     if (comm_allreduce(h, h->adv_sums_base, (size_t)E * nmb * 2, true)) return 1;
@@ -706,6 +771,8 @@ static int iterate_once(crl_ppo* h, bool exact) {
 // restores its start and repeats its iterations exactly. No-op outside data parallelism or with an empty window.
 static int settle(crl_ppo* h) {
   if (!guard_on(h) || h->window_count == 0) return 0;
+  // a timed-out peer exchange leaves garbage in the all-reduced sums the sticky flag derives from: report it instead of replaying
+  if (peer_check(h)) { h->window_count = 0; return 1; }
   double sticky = 0.0;
   CRL_HIP_CHECK(hipMemcpyAsync(&sticky, h->vfix + 4, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -745,7 +812,7 @@ int32_t crl_ppo_iterate(crl_ppo* h, int32_t n_iters, crl_ppo_stats* stats) {
     CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
     if (check_bfy(h)) return 1;
   }
-  if (h->world > 1 && h->external_comm && !h->wide && stats) {
+  if (h->world > 1 && h->external_comm && !h->wide && h->cfg.clip_value_loss) {
     // host-side exchange (crl_comm_init_external) cannot run the exact re-pass: fail loudly rather than train on a
     // speculative critic gradient
     double vf[8];
@@ -774,7 +841,7 @@ int32_t crl_ppo_iteration(const crl_ppo* h, int64_t* it) {
 int32_t crl_comm_unique_id(uint8_t id[128]) { return comm_unique_id(id); }
 
 int32_t crl_comm_init(crl_ppo* h, const uint8_t id[128], int32_t world_size, int32_t rank) {
-  CRL_GUARD(h);
+  CRL_GUARD_SETTLED(h);
   if (comm_init(h, id, world_size, rank)) return 1;
   if (reset_dw_scale(h)) return 1;
   // num_updates = total_timesteps ÷ (global batch) (ppo.jl:89-91)
@@ -792,7 +859,7 @@ int32_t crl_comm_peer_export(crl_ppo* h, int32_t world_size, int32_t rank, uint8
 }
 
 int32_t crl_comm_peer_attach(crl_ppo* h, const uint8_t* handles) {
-  CRL_GUARD(h);
+  CRL_GUARD_SETTLED(h);
   if (!handles) { set_error("crl_comm_peer_attach: null handles"); return 1; }
   if (peer_attach(h, handles)) return 1;
   if (reset_dw_scale(h)) return 1;
@@ -803,13 +870,54 @@ int32_t crl_comm_peer_attach(crl_ppo* h, const uint8_t* handles) {
 }
 
 int32_t crl_comm_init_external(crl_ppo* h, int32_t world_size, int32_t rank) {
-  CRL_GUARD(h);
+  CRL_GUARD_SETTLED(h);
   if (world_size < 1 || rank < 0 || rank >= world_size) { set_error("crl_comm_init_external: bad world/rank"); return 1; }
   h->world = world_size; h->rank = rank; h->external_comm = true;
   if (reset_dw_scale(h)) return 1;
   const int64_t gb = (int64_t)h->dc.B * h->world;
   h->num_updates = h->cfg.total_timesteps / gb;
   if (h->num_updates < 1) h->num_updates = 1;
+  return 0;
+}
+
+int32_t crl_comm_destroy(crl_ppo* h) {
+  CRL_GUARD_SETTLED(h);
+  CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  peer_destroy(h);
+  comm_destroy(h);
+  h->external_comm = false; h->world = 1; h->rank = 0;
+  if (reset_dw_scale(h)) return 1;
+  h->num_updates = h->cfg.total_timesteps / (int64_t)h->dc.B;
+  if (h->num_updates < 1) h->num_updates = 1;
+  return 0;
+}
+
+int32_t crl_ppo_set_option(crl_ppo* h, const char* key, int64_t value) {
+  CRL_GUARD_SETTLED(h);   // an option may select a different kernel flavour: never inside an open guard window
+  return opt_set(h, key, value);
+}
+
+int32_t crl_ppo_get_option(crl_ppo* h, const char* key, int64_t* value) {
+  CRL_GUARD(h);
+  if (!value) { set_error("crl_ppo_get_option: null argument"); return 1; }
+  if (key && std::strcmp(key, "gemm_fallback_seen") == 0) {
+    // read-only: 1 once a launch has run a role as bf16x3 because a hidden-layer weight left the fp16x2 window (|w| >= 255)
+    double re = 0.0;
+    CRL_HIP_CHECK(hipMemcpyAsync(&re, h->vfix + 5, sizeof(re), hipMemcpyDeviceToHost, h->stream));
+    CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+    *value = re != 0.0 ? 1 : 0;
+    return 0;
+  }
+  const int id = opt_find(key);
+  if (id < 0) { set_error(std::string("crl_ppo_get_option: unknown option '") + (key ? key : "(null)") + "'"); return 1; }
+  *value = h->opt[id];
+  return 0;
+}
+
+int32_t crl_ppo_option_name(int32_t index, const char** name, int64_t* dflt) {
+  if (index < 0 || index >= OPT_COUNT || !name) { set_error("crl_ppo_option_name: index out of range"); return 1; }
+  *name = kOpts[index].name;
+  if (dflt) *dflt = kOpts[index].dflt;
   return 0;
 }
 

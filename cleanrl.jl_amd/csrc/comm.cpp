@@ -63,8 +63,8 @@ int comm_init(crl_ppo* h, const uint8_t id[128], int world, int rank) {
   if (world < 1 || rank < 0 || rank >= world) { set_error("crl_comm_init: bad world/rank"); return 1; }
   if (h->peer) { set_error("crl_comm_init: a peer communicator is already attached"); return 1; }
   h->world = world; h->rank = rank;
-  // world 1 needs no communicator; CRL_COMM_FORCE=1 creates one anyway so a 1-GPU box can exercise the RCCL path
-  if (world == 1 && !std::getenv("CRL_COMM_FORCE")) return 0;
+  // world 1 needs no communicator; option comm_force = 1 creates one anyway so a 1-GPU box can exercise the RCCL path
+  if (world == 1 && !opt(h, OPT_COMM_FORCE)) return 0;
   if (load_rccl()) return 1;
   CRL_HIP_CHECK(hipSetDevice(h->device));
   ncclUniqueId u;

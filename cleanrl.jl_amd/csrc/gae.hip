@@ -105,16 +105,12 @@ __global__ void __launch_bounds__(512) gae_kernel(const float* __restrict__ valu
 
 int launch_gae(hipStream_t st, const float* value, const float* reward, const uint8_t* terminal,
                const float* next_value, const uint8_t* next_done, int nt, int k, float gamma, float lambda, int mode,
-               float* adv, float* ret, hipEvent_t ev_start, hipEvent_t ev_stop) {
+               float* adv, float* ret, hipEvent_t ev_start, hipEvent_t ev_stop, int seg, int tile) {
   if (nt <= 0 || k <= 0) { set_error("gae: empty input"); return 1; }
   const float gl = gamma * lambda;  // Float32 product, as `γ * λ` with both T=Float32 (ppo.jl:68)
   // segment length L and env tile EB: S = ceil(k/L) segments, block = S*EB <= 512 threads.
   // Short segments + narrow tiles give the most loads in flight; long rollouts fall back to longer segments.
-  static int env_L = -1, env_EB = -1;
-  if (env_L < 0) { const char* e = getenv("CRL_GAE_L"); env_L = e ? atoi(e) : 0; }
-  if (env_EB < 0) { const char* e = getenv("CRL_GAE_EB"); env_EB = e ? atoi(e) : 0; }
-  static int env_nts = -1;   // CRL_GAE_NT=1: nontemporal stores of adv / ret
-  if (env_nts < 0) { const char* e = getenv("CRL_GAE_NT"); env_nts = e ? atoi(e) : 0; }
+  const int env_L = seg, env_EB = tile, env_nts = 0;   // options gae_seg / gae_tile (0 = automatic)
   // (a 4-envs-per-thread variant with 16-B loads was measured SLOWER: 38.9 vs 32.1 us at nt=65536 — 182 VGPRs leave only
   //  2 waves/SIMD; profiles/r01_g_gae_wide_vs_scalar.txt)
   int L = env_L ? env_L : (k <= 256 ? 8 : 16);

@@ -19,6 +19,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "ppo_ctx.hpp"
 
@@ -78,8 +79,17 @@ __global__ __launch_bounds__(PEER_CHUNK) void peer_allreduce_kernel(PeerArgs a, 
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   if (!live) return;
   const char* mine = a.box[a.rank] + a.data_off + (size_t)par * W * a.slot_bytes;
+  // The slots were written by OTHER devices over xGMI while this kernel was already running, and this rank read the same parity's
+  // slots two messages ago: every slot word is read with a system-scope atomic load, which is served at the memory side and can
+  // never be a stale line of this device's L2 or of this CU's vector L1 (the mailbox is fine-grained / uncached memory on top).
+  using U = typename std::conditional<sizeof(T) == 8, unsigned long long, unsigned int>::type;
   T s = T(0);
-  for (int r = 0; r < W; ++r) s += __builtin_nontemporal_load(reinterpret_cast<const T*>(mine + (size_t)r * a.slot_bytes) + i);
+  for (int r = 0; r < W; ++r) {
+    const U bits = __hip_atomic_load(reinterpret_cast<const U*>(mine + (size_t)r * a.slot_bytes) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    T v;
+    __builtin_memcpy(&v, &bits, sizeof(T));
+    s += v;
+  }
   buf[i] = s;
 }
 
@@ -92,7 +102,7 @@ int peer_export(crl_ppo* h, int world, int rank, uint8_t handle[64]) {
   if (world < 1 || world > PEER_MAX || rank < 0 || rank >= world) {
     set_error("crl_comm_peer_export: need 1 <= world_size <= 16 and 0 <= rank < world_size"); return 1;
   }
-  if (h->peer || h->comm || h->external_comm) { set_error("crl_comm_peer_export: a communicator is already attached"); return 1; }
+  if (h->peer || h->comm || h->external_comm) { set_error("crl_comm_peer_export: a communicator is already attached (crl_comm_destroy detaches it)"); return 1; }
   CRL_HIP_CHECK(hipSetDevice(h->device));
   PeerState* s = new PeerState;
   s->world = world; s->rank = rank;
@@ -103,10 +113,19 @@ int peer_export(crl_ppo* h, int world, int rank, uint8_t handle[64]) {
   s->slot_bytes = (size_t)s->nblk * PEER_CHUNK * sizeof(double);     // a chunk is 256 ELEMENTS of either type
   s->data_off = (((size_t)2 * world * s->nblk * sizeof(uint32_t)) + 255) & ~(size_t)255;
   s->box_bytes = s->data_off + (size_t)2 * world * s->slot_bytes;
+  // The protocol needs a peer's stores over xGMI to become visible inside an already-running kernel of the home GPU: the mailbox
+  // must be uncached or fine-grained device memory. Ordinary (coarse-grained) hipMalloc memory is NOT a fallback — the home L2
+  // could serve stale slot lines and the sums would be silently wrong — so a failed allocation is an error.
   void* box = nullptr;
   hipError_t e = hipExtMallocWithFlags(&box, s->box_bytes, hipDeviceMallocUncached);
-  if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&box, s->box_bytes); }
-  if (e != hipSuccess) { delete s; set_error(std::string("peer mailbox allocation: ") + hipGetErrorString(e)); return 1; }
+  if (e != hipSuccess) { (void)hipGetLastError(); box = nullptr; e = hipExtMallocWithFlags(&box, s->box_bytes, hipDeviceMallocFinegrained); }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    delete s;
+    set_error(std::string("peer mailbox: neither uncached nor fine-grained device memory could be allocated (") + hipGetErrorString(e) +
+              "); the peer all-reduce is refused rather than run on cached memory — use crl_comm_init (RCCL)");
+    return 1;
+  }
   s->box[rank] = static_cast<char*>(box);
   hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&s->err), sizeof(uint32_t));
   if (e2 != hipSuccess) { (void)hipFree(box); delete s; set_error("peer error word allocation failed"); return 1; }
@@ -142,6 +161,16 @@ int peer_attach(crl_ppo* h, const uint8_t* handles) {
       set_error(std::string("hipIpcOpenMemHandle (rank ") + std::to_string(p) + "): " + hipGetErrorString(e)); return 1;
     }
     s->box[p] = static_cast<char*>(ptr); s->opened[p] = true;
+    // a mailbox that lives on another device must be reachable from this one over xGMI / PCIe peer access
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, ptr) == hipSuccess && at.device >= 0 && at.device != h->device) {
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, h->device, at.device) == hipSuccess && !can) {
+        set_error("crl_comm_peer_attach: device " + std::to_string(h->device) + " cannot access the mailbox of rank " + std::to_string(p) +
+                  " on device " + std::to_string(at.device) + " (hipDeviceCanAccessPeer = 0); use crl_comm_init (RCCL)");
+        return 1;
+      }
+    } else (void)hipGetLastError();
   }
   s->attached = true;
   return 0;
@@ -156,8 +185,7 @@ int peer_allreduce(crl_ppo* h, void* buf, size_t count, bool is_double) {
   const int nblk = (int)((count + PEER_CHUNK - 1) / PEER_CHUNK);
   if (nblk > s->nblk || bytes > s->slot_bytes) { set_error("peer all-reduce: message larger than the mailbox slot"); return 1; }
   if (count == 0) return 0;
-  static double timeout_s = -1.0;
-  if (timeout_s < 0) { const char* e = getenv("CRL_PEER_TIMEOUT_S"); timeout_s = e ? atof(e) : 20.0; if (timeout_s <= 0) timeout_s = 20.0; }
+  const double timeout_s = (double)opt(h, OPT_PEER_TIMEOUT_MS) * 1e-3;
   PeerArgs a;
   for (int p = 0; p < PEER_MAX; ++p) a.box[p] = s->box[p];
   a.world = s->world; a.rank = s->rank; a.seq = ++s->seq; a.nblk = s->nblk; a.slot_bytes = s->slot_bytes; a.data_off = s->data_off;

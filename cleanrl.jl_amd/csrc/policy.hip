@@ -183,27 +183,25 @@ __device__ __forceinline__ void gae_tail_compat(const RolloutArgs& a, int e) {
 
 // CX2: the critic runs as fp16x2 with the exp2-based activation (mlp_x2.hpp) — its output is a value compared at 1e-5, while
 // the actor keeps bf16x3 + the reference's rational tanh_fast because its output decides action indices that are bit-compared.
-template <int A, bool X3, bool CX2 = false>
+// A critic whose hidden-layer weights leave the fp16 window (|w| >= 255) is restaged and run as bf16x3 by the same launch.
+template <int A, bool CX2>
 __global__ void __launch_bounds__(512, 2) rollout_cartpole_kernel(RolloutArgs a) {
   constexpr int D = 4;
-  constexpr int IASIZE = X3 ? NetImageX3<D, A, false>::SIZE : NetImage<D, A, false>::SIZE;
+  constexpr int IASIZE = NetImageX3<D, A, false>::SIZE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* imgA0 = smem;
   float* imgC0 = smem + IASIZE;
+  bool cx2 = CX2;   // block-uniform
+  stage_net_x3<D, A, false>(imgA0, a.params, threadIdx.x, blockDim.x);
   if (CX2) {
-    stage_net_x3<D, A, false>(imgA0, a.params, threadIdx.x, blockDim.x);
+    static_assert(NetImageX2<D, 1>::SIZE >= NetImageX3<D, 1, false>::SIZE, "the fp16x2 critic image (forward + backward pieces) is the larger one");
     int* flag = reinterpret_cast<int*>(imgC0 + NetImageX2<D, 1>::SIZE);
     if (!stage_net_x2<D, 1>(imgC0, a.params + NetParams<D, A>::SIZE, threadIdx.x, blockDim.x, flag)) {
-      if (threadIdx.x == 0 && blockIdx.x == 0) a.range_err[0] = 1.0;   // |w| >= 255: reported by the host's next check
-      return;
+      if (threadIdx.x == 0 && blockIdx.x == 0) a.range_err[0] = 1.0;   // informational: the fallback ran
+      cx2 = false;
     }
-  } else if (X3) {
-    stage_net_x3<D, A, false>(imgA0, a.params, threadIdx.x, blockDim.x);
-    stage_net_x3<D, 1, false>(imgC0, a.params + NetParams<D, A>::SIZE, threadIdx.x, blockDim.x);
-  } else {
-    stage_net<D, A, false>(imgA0, a.params, threadIdx.x, blockDim.x);
-    stage_net<D, 1, false>(imgC0, a.params + NetParams<D, A>::SIZE, threadIdx.x, blockDim.x);
   }
+  if (!cx2) stage_net_x3<D, 1, false>(imgC0, a.params + NetParams<D, A>::SIZE, threadIdx.x, blockDim.x);
   __syncthreads();
   const DevCfg& c = a.c;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, hf = lane >> 5;
@@ -246,17 +244,15 @@ __global__ void __launch_bounds__(512, 2) rollout_cartpole_kernel(RolloutArgs a)
     asm volatile("" : "+v"(lds_off));
     const float* imgA = imgA0 + lds_off;
     const float* imgC = imgC0 + lds_off;
-    if (X3) mlp_forward_x3<D, A, false>(imgA, co, h1, h2, z, lane);  // ppo.jl:127 get_action
-    else mlp_forward<D, A, false>(imgA, co, h1, h2, z, lane);
+    mlp_forward_x3<D, A, false>(imgA, co, h1, h2, z, lane);          // ppo.jl:127 get_action
     softmax_logsoftmax<A>(z, p, lp);
     const double u = u53(philox_env(c.seed, gid, gstep, 0));
     const int act = sample_weights<A>(p, u);
     float lpa = lp[0];
 #pragma unroll
     for (int i = 1; i < A; ++i) lpa = (act == i) ? lp[i] : lpa;
-    if (CX2) mlp_forward_x2<D, 1>(imgC, co, h1, h2, v, lane);        // ppo.jl:128
-    else if (X3) mlp_forward_x3<D, 1, false>(imgC, co, h1, h2, v, lane);
-    else mlp_forward<D, 1, false>(imgC, co, h1, h2, v, lane);
+    if (CX2 && cx2) mlp_forward_x2<D, 1>(imgC, co, h1, h2, v, lane);  // ppo.jl:128
+    else mlp_forward_x3<D, 1, false>(imgC, co, h1, h2, v, lane);
     const bool done = cartpole_step(s, t_env, act);                  // ppo.jl:130
     const float rew = done ? 0.0f : 1.0f;                            // ppo.jl:132 (RLEnvs: reward 0 on the terminal step)
     if (writer) {                                                    // ppo.jl:133-140 Buffer.add!
@@ -433,9 +429,11 @@ __global__ void __launch_bounds__(192) rollout_split3_kernel(RolloutArgs a) {
   float* hd = reinterpret_cast<float*>(pcs + 2 * 2 * 3 * 64);              // [A][64] wave 0's partial head sums
   int* flag = reinterpret_cast<int*>(hd + A * 64);
   stage_net_x3<D, A, false>(imgA0, a.params, threadIdx.x, blockDim.x);
+  bool cx2 = true;   // block-uniform: false = the critic's weights left the fp16 window (|w| >= 255) and it runs as bf16x3
   if (!stage_net_x2<D, 1>(imgC0, a.params + NetParams<D, A>::SIZE, threadIdx.x, blockDim.x, flag)) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) a.range_err[0] = 1.0;
-    return;
+    if (threadIdx.x == 0 && blockIdx.x == 0) a.range_err[0] = 1.0;   // informational: the fallback ran
+    cx2 = false;
+    stage_net_x3<D, 1, false>(imgC0, a.params + NetParams<D, A>::SIZE, threadIdx.x, blockDim.x);
   }
   const DevCfg& c = a.c;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 31, hf = lane >> 5;
@@ -569,6 +567,16 @@ __global__ void __launch_bounds__(192) rollout_split3_kernel(RolloutArgs a) {
         }
         if (hf == 0) xch[((step + 1) & 1) * TILE + j] = make_float4(co[0], co[1], co[2], co[3]);
       }
+    } else if (!cx2) {
+      // critic as bf16x3 (the fallback flavour): same three barriers per step
+      const float4 cv = xch[(step & 1) * TILE + j];
+      const float cx[4] = {cv.x, cv.y, cv.z, cv.w};
+      f32x16 h1[2], h2[2];
+      float v[1];
+      mlp_forward_x3<D, 1, false>(imgC0 + lds_off, cx, h1, h2, v, lane);                     // ppo.jl:128
+      __syncthreads();                                                                       // (1)
+      __syncthreads();                                                                       // (2)
+      if (writer) a.value[b] = v[0];
     } else {
       // critic (ppo.jl:128): mlp_forward_x2 cut at the layer boundary so that each part is shorter than the actor's segment it faces
       const float* img = imgC0 + lds_off;
@@ -698,33 +706,23 @@ int launch_rollout(crl_ppo* h, bool fuse_gae) {
   // one wave per 32 envs; spread waves over all 256 CUs before stacking them inside a block
   const int tiles = (h->dc.nt + TILE - 1) / TILE;
   int wpb = tiles >= 2048 ? 8 : (tiles >= 1024 ? 4 : (tiles >= 512 ? 2 : 1));
-  static int stagger_env = -1;
-  if (stagger_env < 0) { const char* e = getenv("CRL_ROLLOUT_STAGGER"); stagger_env = e ? atoi(e) : 6; }
-  a.stagger = wpb == 8 ? stagger_env : 0;
+  a.stagger = wpb == 8 ? (int)opt(h, OPT_ROLLOUT_STAGGER) : 0;
   const int blocks = (tiles + wpb - 1) / wpb;
   ProfScope ps(h, CRL_K_ROLLOUT);
-  const char* split_s = getenv("CRL_ROLLOUT_SPLIT");  // read per launch so tests can exercise both kernels
-  const int split_env = split_s ? atoi(split_s) : 1;
-  static int split_max = -1;
-  if (split_max < 0) { const char* e = getenv("CRL_ROLLOUT_SPLIT_MAX_TILES"); split_max = e ? atoi(e) : 512; }
-  if (gemm_x2() && split_env == 1 && tiles <= split_max && !getenv("CRL_ROLLOUT_CRITIC_X3")) {
+  const int split = (int)opt(h, OPT_ROLLOUT_SPLIT);
+  const bool small = tiles <= (int)opt(h, OPT_ROLLOUT_SPLIT_MAX_TILES);
+  a.range_err = h->vfix + 5;
+  if (gemm_x2(h) && split == 1 && small) {
     // three waves per tile: the actor's hidden rows split over two waves, the critic (fp16x2) on the third
-    a.range_err = h->vfix + 5;
     const size_t smem = sizeof(float) * (NetImageX3<4, 2, false>::SIZE + NetImageX2<4, 1>::SIZE + 2 * TILE * 4 + 2 * 2 * 3 * 64 * 4 + 2 * 64 + 4);
     hipLaunchKernelGGL((rollout_split3_kernel<2>), dim3(tiles), dim3(192), smem, h->stream, a);
-  } else if (gemm_x3() && split_env && tiles <= 512) {   // CRL_ROLLOUT_SPLIT=2: the two-wave kernel
+  } else if (split != 0 && small) {   // two waves per tile (actor + env | critic), all bf16x3: rollout_split = 2, or gemm = 1
     const size_t smem = sizeof(float) * (NetImageX3<4, 2, false>::SIZE + NetImageX3<4, 1, false>::SIZE + 2 * TILE * 4);
     hipLaunchKernelGGL((rollout_split_kernel<2>), dim3(tiles), dim3(128), smem, h->stream, a);
-  } else if (gemm_x2() && !getenv("CRL_ROLLOUT_CRITIC_X3")) {
-    a.range_err = h->vfix + 5;
-    const size_t smem = sizeof(float) * (NetImageX3<4, 2, false>::SIZE + NetImageX2<4, 1>::SIZE + 4);
-    hipLaunchKernelGGL((rollout_cartpole_kernel<2, true, true>), dim3(blocks), dim3(64 * wpb), smem, h->stream, a);
-  } else if (gemm_x3()) {
-    const size_t smem = sizeof(float) * (NetImageX3<4, 2, false>::SIZE + NetImageX3<4, 1, false>::SIZE);
-    hipLaunchKernelGGL((rollout_cartpole_kernel<2, true>), dim3(blocks), dim3(64 * wpb), smem, h->stream, a);
   } else {
-    const size_t smem = act_smem<4, 2>();
-    hipLaunchKernelGGL((rollout_cartpole_kernel<2, false>), dim3(blocks), dim3(64 * wpb), smem, h->stream, a);
+    const size_t smem = sizeof(float) * (NetImageX3<4, 2, false>::SIZE + NetImageX2<4, 1>::SIZE + 4);
+    if (gemm_x2(h)) hipLaunchKernelGGL((rollout_cartpole_kernel<2, true>), dim3(blocks), dim3(64 * wpb), smem, h->stream, a);
+    else hipLaunchKernelGGL((rollout_cartpole_kernel<2, false>), dim3(blocks), dim3(64 * wpb), smem, h->stream, a);
   }
   CRL_HIP_CHECK(hipGetLastError());
   return 0;

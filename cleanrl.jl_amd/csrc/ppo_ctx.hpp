@@ -42,6 +42,29 @@ struct alignas(16) SampleRec {
 };
 static_assert(sizeof(SampleRec) == 64, "SampleRec is one 64-byte record");
 
+// Per-handle options (crl_ppo_set_option / crl_ppo_get_option, include/cleanrl_hip.h). They replace the process-wide CRL_*
+// environment switches of rounds 1-2: a selector that changes numerics or picks a kernel is state of ONE handle, can be changed
+// between calls, is testable in-process and is reported by bench.py. The table (name, default, range) lives in api.cpp.
+enum OptId {
+  OPT_GEMM = 0,               // 2 = fp16x2 split products (default), 1 = bf16x3 (the documented fallback flavour)
+  OPT_ROLLOUT_SPLIT,          // small-shard rollout: 1 = three waves per tile (default), 2 = two waves, 0 = one wave per tile
+  OPT_ROLLOUT_SPLIT_MAX_TILES,// largest shard (in 32-env tiles) the split kernels take
+  OPT_ROLLOUT_STAGGER,        // start delay of waves 4-7 of an 8-wave rollout block (units of 1024 clocks)
+  OPT_GAE_FUSE,               // 1 = compat-mode GAE rides on the rollout kernel's tail inside crl_ppo_iterate
+  OPT_SHUFFLE_OVERLAP,        // 1 = epoch permutations drawn on the second stream next to the rollout
+  OPT_GUARD_WINDOW,           // iterations per speculation guard window (api.cpp)
+  OPT_UPDATE_STAGGER,         // start delay of waves 4-7 of an update block
+  OPT_ACTOR_BLOCK_PCT,        // share of update blocks given to the actor role
+  OPT_ADV_SEQ,                // 1 = advantage sums from one sequential pass over adv (blocked shuffle tables)
+  OPT_COMM_FORCE,             // 1 = crl_comm_init with world_size 1 still creates an RCCL communicator (1-GPU test of the path)
+  OPT_PEER_TIMEOUT_MS,        // in-kernel time-out of the peer all-reduce
+  OPT_WIDE_GEMM,              // layer-wise path, 256-wide layers: 2 = fp16x2 (default), 1 = bf16x3, 0 = f32 MFMA
+  OPT_WIDE_TANH_RATIONAL,     // 1 = the layer-wise path evaluates tanh_fast everywhere (default 0: exp2 form outside the actor's rollout forward)
+  OPT_GAE_SEG,                // standalone GAE kernel: steps per segment (0 = automatic)
+  OPT_GAE_TILE,               // standalone GAE kernel: envs per block (0 = automatic)
+  OPT_COUNT
+};
+
 struct ProfSlot {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
   double total_ms = 0;
@@ -83,13 +106,12 @@ struct crl_ppo {
   int32_t* perm_base = nullptr;    // [update_epochs][B]
   int32_t* perm = nullptr;         // = perm_base + cur_slot * B
   int cur_slot = 0;
-  // fused 4/2/64 path: the batch as 64-byte records, in buffer order and in minibatch order per slot (records.hip)
+  // fused 4/2/64 path: the batch as 64-byte records in buffer order (records.hip); the update kernels fetch them through perm
   crl::SampleRec* recs = nullptr;      // [B]
-  crl::SampleRec* recs_p = nullptr;    // [update_epochs][B]: recs_p[slot][pos] = recs[perm[slot][pos]]
   bool recs_dirty = true;              // a buffer field changed since the last pack
-  uint32_t slot_fresh = 0;             // bit s: recs_p[s] (and the adv partial sums of slot s) match perm[s] and recs
+  uint32_t slot_fresh = 0;             // bit s: the advantage sums of slot s match perm[s] and recs
   double* adv_part = nullptr;          // per-block partial Σadv, Σadv² (sized in crl_ppo_create; never borrowed scratch)
-  int adv_pb = 1;                      // permute-pass blocks per minibatch
+  int adv_pb = 1;                      // advantage-sum blocks per minibatch
   int32_t* perm_tmp = nullptr;     // blocked Fisher–Yates: elements grouped by L1 bucket
   uint32_t* bfy_ws = nullptr;      // blocked Fisher–Yates: totals | offsets | cursors | error flag
   double* bfy_adv_part = nullptr;  // [nmb][K1][2] Σadv, Σadv² per leaf block, left behind by a fused shuffle (crl_ppo_iterate)
@@ -140,6 +162,8 @@ struct crl_ppo {
   bool wide = false;
   void* wide_ws = nullptr;
 
+  int64_t opt[crl::OPT_COUNT] = {};   // crl_ppo_set_option
+
   int prof = 0;   // 0 off, 1 every kernel class (events recorded around the launches), 2 only the kernels whose events ride ON the dispatch
   crl::ProfSlot prof_slots[CRL_K_COUNT];
 };
@@ -154,10 +178,11 @@ void select_slot(crl_ppo* h, int slot);
 int ensure_records(crl_ppo* h);
 int ensure_stage(crl_ppo* h, size_t bytes);
 int reset_dw_scale(crl_ppo* h);
-// CRL_GEMM: x2 (default) = fp16x2 forward / backward-data products in the update kernel + bf16x3 everywhere else
-// (mlp_x2.hpp); x3 = bf16x3 only (mlp_x3.hpp); f32 = the v_mfma_f32_32x32x2_f32 layers
-bool gemm_x3();   // true for x2 and x3
-bool gemm_x2();
+// option "gemm": 2 (default) = fp16x2 products in the update kernel and the rollout's critic, bf16x3 for the rollout's actor
+// (mlp_x2.hpp); 1 = bf16x3 everywhere (mlp_x3.hpp) — the fallback flavour, also taken per block when a hidden-layer weight
+// leaves the fp16x2 window
+inline bool gemm_x2(const crl_ppo* h) { return h->opt[OPT_GEMM] == 2; }
+inline int64_t opt(const crl_ppo* h, int id) { return h->opt[id]; }
 
 // HIP-event timing of one kernel class. attach=true: the events are handed to hipExtLaunchKernelGGL, which stamps the
 // kernel's own begin/end (what rocprofv3 reports); otherwise they are recorded on the stream around the launch(es).
@@ -184,7 +209,7 @@ struct ProfScope {
 // kernel launchers (each in its own translation unit)
 int launch_gae(hipStream_t st, const float* value, const float* reward, const uint8_t* terminal,
                const float* next_value, const uint8_t* next_done, int nt, int k, float gamma, float lambda, int mode,
-               float* adv, float* ret, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+               float* adv, float* ret, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int seg = 0, int tile = 0);
 int launch_policy_act(crl_ppo* h, const float* obs_d, const double* u_d, int n, int32_t* action_d, float* logprob_d,
                       float* value_d);
 int launch_logprob_actions(crl_ppo* h, const float* obs_d, const int32_t* act_d, int n, float* logprob_d, float* ent_d);
@@ -198,7 +223,7 @@ int launch_adv_stats_sums(crl_ppo* h);
 int launch_adv_bucket_sums(crl_ppo* h, int slot0, int nslots, double* part, int nblk);   // shuffle.hip; 1 = not applicable
 int launch_adv_stats_finish(crl_ppo* h, int slot0 = -1, int nslots = 1);
 int launch_pack_records(crl_ppo* h);
-int launch_permute_records(crl_ppo* h, int slot0, int nslots);
+int launch_slot_adv_sums(crl_ppo* h, int slot0, int nslots);   // records.hip: Σadv, Σadv² of every minibatch of the slots
 int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot, bool inline_fix = true);
 int launch_update_exact_dp(crl_ppo* h, int mb, crl_ppo_stats* stats_slot);
 int launch_optim(crl_ppo* h, double eta);
@@ -223,13 +248,5 @@ bool peer_active(const crl_ppo* h);
 int peer_allreduce(crl_ppo* h, void* buf, size_t count, bool is_double);
 int peer_check(crl_ppo* h);
 void peer_destroy(crl_ppo* h);
-// CRL_GATHER (default 1): the update kernels read each sample's 64-byte record THROUGH the epoch's permutation (one random
-// 64-B fetch per sample and role, +2 % on the kernel) and the separate permute pass — a full extra read + write of the batch per
-// epoch — is gone; 0 = lay every epoch's minibatches out contiguously first (records.hip: permute_records_kernel).
-inline bool gather_mode() {
-  static int g = -1;
-  if (g < 0) { const char* e = getenv("CRL_GATHER"); g = (e && atoi(e) == 0) ? 0 : 1; }
-  return g == 1;
-}
 inline bool has_comm(const crl_ppo* h) { return h->comm != nullptr || h->peer != nullptr; }
 }  // namespace crl

@@ -1,12 +1,10 @@
-// records.hip — the minibatch gather of ppo.jl:203-211 as two streaming passes instead of six random gathers inside the
-// update kernel.
-//   pack:    once per iteration, after GAE: the six per-sample fields the loss closure reads (state, action, logprob,
-//            advantage, value, return) → one 64-byte SampleRec per sample, buffer order b = e + nt·t (ppo.jl:184-189).
-//   permute: once per update epoch: recs_p[pos] = recs[b_inds[pos]] (ppo.jl:194,203-204) — ONE 64-byte fetch per sample
-//            (six arrays gathered separately drag six sectors), written back as whole 1-KiB rows; the update kernels then
-//            read their minibatch as a contiguous slab. The pass also leaves Σadv, Σadv² per minibatch (Float64, fixed
-//            order) — the statistics of ppo.jl:221 — so nothing else ever walks the permutation.
-// Both passes move bytes only (HBM-bound): pack 36 B in / 64 B out per sample, permute 4 + 64 B in / 64 B out.
+// records.hip — the minibatch gather of ppo.jl:203-211 without six random gathers inside the update kernel.
+//   pack:  once per iteration, after GAE: the six per-sample fields the loss closure reads (state, action, logprob, advantage,
+//          value, return) → one 64-byte SampleRec per sample, buffer order b = e + nt·t (ppo.jl:184-189). The update kernels
+//          fetch recs[b_inds[pos]] themselves: ONE 64-byte line per sample and role (six separate arrays drag six sectors).
+//   sums:  Σadv, Σadv² per minibatch of every epoch's permutation (the statistics of ppo.jl:221), Float64, fixed order.
+// (Rounds 1-2 also had a permute pass that laid every epoch's minibatches out contiguously — 1.16 ms per iteration and 2.1 GB of
+// copies against +2 % on the update kernel for fetching through the permutation; it lost every measurement and is gone.)
 #include "common.hpp"
 #include "ppo_ctx.hpp"
 
@@ -27,49 +25,11 @@ __global__ void __launch_bounds__(256) pack_records_kernel(int B, const float* _
   }
 }
 
-// grid (blocks per minibatch, num_minibatches, slots); block (bx, mb, z) moves positions [bx·chunk, (bx+1)·chunk) of
-// minibatch mb of slot slot0+z and leaves its Σadv, Σadv² in part[((z·nmb + mb)·gridDim.x + bx)·2 ..]
-constexpr int PERM_U = 4;
-__global__ void __launch_bounds__(256) permute_records_kernel(int B, int M, int chunk, const int32_t* __restrict__ perm /* [slots][B] */,
-                                                              const SampleRec* __restrict__ recs, SampleRec* __restrict__ recs_p /* [slots][B] */,
-                                                              double* __restrict__ part) {
-  const int q = threadIdx.x & 3, quad = threadIdx.x >> 2;
-  const int mb = blockIdx.y, z = blockIdx.z;
-  const size_t base = (size_t)z * B + (size_t)mb * M;
-  const int32_t* pm = perm + base;
-  const f32x4* src = reinterpret_cast<const f32x4*>(recs);
-  f32x4* dst = reinterpret_cast<f32x4*>(recs_p + base);
-  const int lo = blockIdx.x * chunk, hi = min(M, lo + chunk);
-  double sa = 0.0, sa2 = 0.0;
-  for (int p0 = lo + quad; p0 < hi; p0 += 64 * PERM_U) {
-    int s[PERM_U];
-    f32x4 v[PERM_U];
-#pragma unroll
-    for (int u = 0; u < PERM_U; ++u) { const int p = p0 + 64 * u; s[u] = p < hi ? pm[p] : -1; }
-#pragma unroll
-    for (int u = 0; u < PERM_U; ++u) if (s[u] >= 0) v[u] = src[(size_t)s[u] * 4 + q];
-#pragma unroll
-    for (int u = 0; u < PERM_U; ++u) {
-      if (s[u] < 0) continue;
-      dst[(size_t)(p0 + 64 * u) * 4 + q] = v[u];
-      if (q == 1) { const double a = (double)v[u][2]; sa += a; sa2 += a * a; }
-    }
-  }
-  __shared__ double sm[2][4];
-  sa = wave_sum(sa); sa2 = wave_sum(sa2);
-  if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = sa; sm[1][threadIdx.x >> 6] = sa2; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double* o = part + (((size_t)z * gridDim.y + mb) * gridDim.x + blockIdx.x) * 2;
-    o[0] = (sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3]);
-    o[1] = (sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3]);
-  }
-}
-
-// Gather mode (CRL_GATHER=1, ppo_ctx.hpp): nothing is moved — the update kernels fetch records through the permutation — and only
-// the advantage statistics of ppo.jl:221 are left to do here: Σadv, Σadv² per minibatch of every slot, the same grid and the same
-// partial layout as the permute pass. adv is the 4-byte-per-sample array the GAE wrote (33.5 MB at the headline size: the random
-// reads hit the Infinity Cache); eight independent gathers per thread are in flight together.
+// The advantage statistics of ppo.jl:221 by a gather through the permutation: Σadv, Σadv² per minibatch of every slot; grid (blocks
+// per minibatch, num_minibatches, slots), block (bx, mb, z) leaves its sums in part[((z·nmb + mb)·gridDim.x + bx)·2 ..]. adv is the
+// 4-byte-per-sample array the GAE wrote (33.5 MB at the headline size: the random reads hit the Infinity Cache); eight independent
+// gathers per thread are in flight together. The fallback of the sequential pass (shuffle.hip: adv_bucket_sums_kernel), which needs
+// the blocked shuffle's bucket tables.
 constexpr int ADVG_U = 8;
 __global__ void __launch_bounds__(256) adv_gather_sums_kernel(int B, int M, int chunk, const int32_t* __restrict__ perm /* [slots][B] */,
                                                              const float* __restrict__ adv, double* __restrict__ part) {
@@ -114,28 +74,17 @@ int launch_pack_records(crl_ppo* h) {
   return 0;
 }
 
-// recs_p[slot] ← recs[perm[slot]] for slots [slot0, slot0 + nslots) (CRL_GATHER=0 only), plus their per-minibatch advantage sums
-// → adv_sums_base
-int launch_permute_records(crl_ppo* h, int slot0, int nslots) {
+// Σadv, Σadv² of every minibatch of slots [slot0, slot0 + nslots) → adv_sums_base (packs the records first if a field changed)
+int launch_slot_adv_sums(crl_ppo* h, int slot0, int nslots) {
   if (launch_pack_records(h)) return 1;
   const int B = h->dc.B, M = h->dc.M, nmb = h->dc.nmb, pb = h->adv_pb;
   const int chunk = (((M + pb - 1) / pb + 63) / 64) * 64;
-  double* part = h->adv_part + (size_t)slot0 * nmb * pb * 2;   // each slot has its own slice: launches for different slots may overlap
-  if (gather_mode()) {
-    ProfScope ps(h, CRL_K_ADV_STATS);
-    static const bool seq = !(getenv("CRL_ADV_SEQ") && atoi(getenv("CRL_ADV_SEQ")) == 0);
-    if (!seq || launch_adv_bucket_sums(h, slot0, nslots, part, pb)) {   // the sequential pass needs the blocked shuffle's tables
-      hipLaunchKernelGGL(adv_gather_sums_kernel, dim3(pb, nmb, nslots), dim3(256), 0, h->stream, B, M, chunk, h->perm_base + (size_t)slot0 * B,
-                         h->adv, part);
-    }
-    CRL_HIP_CHECK(hipGetLastError());
-    if (launch_adv_fold(h, part, pb, nslots * nmb, h->adv_sums_base + (size_t)slot0 * nmb * 2)) return 1;
-    for (int s = slot0; s < slot0 + nslots; ++s) h->slot_fresh |= 1u << s;
-    return 0;
+  double* part = h->adv_part + (size_t)slot0 * nmb * pb * 2;   // each slot has its own slice
+  ProfScope ps(h, CRL_K_ADV_STATS);
+  if (!opt(h, OPT_ADV_SEQ) || launch_adv_bucket_sums(h, slot0, nslots, part, pb)) {   // the sequential pass needs the blocked shuffle's tables
+    hipLaunchKernelGGL(adv_gather_sums_kernel, dim3(pb, nmb, nslots), dim3(256), 0, h->stream, B, M, chunk, h->perm_base + (size_t)slot0 * B,
+                       h->adv, part);
   }
-  ProfScope ps(h, CRL_K_PERMUTE);
-  hipLaunchKernelGGL(permute_records_kernel, dim3(pb, nmb, nslots), dim3(256), 0, h->stream, B, M, chunk, h->perm_base + (size_t)slot0 * B, h->recs,
-                     h->recs_p + (size_t)slot0 * B, part);
   CRL_HIP_CHECK(hipGetLastError());
   if (launch_adv_fold(h, part, pb, nslots * nmb, h->adv_sums_base + (size_t)slot0 * nmb * 2)) return 1;
   for (int s = slot0; s < slot0 + nslots; ++s) h->slot_fresh |= 1u << s;

@@ -73,8 +73,10 @@ constexpr int SCR_FLOATS_X3 = SCR_FLOATS + ACC_SLOTS * 64;
 // way the per-phase costs in DESIGN.md §3 were measured. 0 in every production instantiation.
 // X2 (with X3): the forward and backward-data products run as fp16x2 (mlp_x2.hpp: three MFMAs per product instead of six, h1
 // carried as 2^14·h1), the weight-gradient product stays on bf16x3.
+// Returns false — before any work, uniformly for the block — only in the fp16x2 flavour when a hidden-layer weight of this role does
+// not fit the fp16 window (|w| >= 255, mlp_x2.hpp): the caller then runs the bf16x3 flavour of the same role on the same LDS.
 template <int D, int A, int ROLE, bool EXACT, bool X3, int RW, int ABL = 0, bool X2 = false>
-__device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, float* smem, float* scratch) {
+__device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, float* smem, float* scratch) {
   constexpr int NOUT = ROLE == 0 ? A : 1;
   static_assert(!X2 || X3, "the fp16x2 flavour keeps the bf16x3 weight-gradient path");
   using I = typename std::conditional<X2, NetImageX2<D, NOUT>,
@@ -89,8 +91,13 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
   float* img0 = smem;
   float* T0 = scratch + wave * SCR;
   const float* p = a.params + (ROLE ? NetParams<D, A>::SIZE : 0);
-  bool in_range = true;
-  if constexpr (X2) in_range = stage_net_x2<D, NOUT>(img0, p, tid, NT, reinterpret_cast<int*>(scratch + RW * SCR));
+  if constexpr (X2) {
+    if (!stage_net_x2<D, NOUT>(img0, p, tid, NT, reinterpret_cast<int*>(scratch + RW * SCR))) {
+      if (tid == 0 && rb == 0) a.range_err[0] = 1.0;   // informational: the bf16x3 fallback ran (crl_ppo_get_option "gemm_fallback_seen")
+      __syncthreads();                                  // every thread has read the flag before the image is restaged
+      return false;
+    }
+  }
   else if (X3) stage_net_x3<D, NOUT, true>(img0, p, tid, NT);
   else stage_net<D, NOUT, true>(img0, p, tid, NT);
   __syncthreads();
@@ -143,10 +150,6 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
   // operand wants (32 multiplies per tile saved); the backward-data product and db2 take the exact power of two back out
   const float invG = X2 ? sgpr(1.0f / Gdw) : 1.0f;
   float d2run = 0.0f;
-  if (!in_range) {   // a hidden-layer weight does not fit the fp16x2 window: compute nothing, tell the host (crl_sync / stats)
-    if (tid == 0 && rb == 0) a.range_err[0] = 1.0;
-    tile = ntiles;
-  }
   for (; tile < ntiles; tile += nwaves) {
     const int pos = tile * TILE + j;
     const bool ok = pos < M;
@@ -586,19 +589,10 @@ __device__ __forceinline__ void update_role(const UpdateArgs& a, const int rb, f
     double* lp = a.lpart + ((size_t)ROLE * a.pmax + rb) * 2;
     lp[0] = s0; lp[1] = s1;
   }
+  return true;
 }
 
-// Speculative pass (assumes u <= 0, see header), f32-MFMA flavour. One 512-thread block per CU: waves 0-3 run the actor,
-// waves 4-7 the critic. Waves w and w+4 of a block share a SIMD, so every SIMD hosts one actor and one critic wave:
-// their tiles have different lengths, which keeps the two co-resident waves out of lockstep.
-template <int D, int A>
-__global__ void __launch_bounds__(512, 2) update_kernel(UpdateArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int IA = NetImage<D, A, true>::SIZE, IC = NetImage<D, 1, true>::SIZE;
-  float* scratch = smem + IA + IC;
-  if (threadIdx.x < 256) update_role<D, A, 0, false, false, 4>(a, blockIdx.x, smem, scratch);
-  else update_role<D, A, 1, false, false, 4>(a, blockIdx.x, smem + IA, scratch + 4 * SCR_FLOATS);
-}
+// Speculative pass (assumes u <= 0, see header). Waves w and w+4 of a block share a SIMD.
 // bf16x3 flavour (mlp_x3.hpp): the split weight images are 51 KB per network, so a 512-thread block carries ONE role
 // (blocks [0, nblk[0]) = actor, the rest = critic) and its 8 waves share that image.
 template <int D, int A>
@@ -617,8 +611,14 @@ __global__ void __launch_bounds__(512, 2) update_x2_kernel(UpdateArgs a) {
   if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= 4) {
     for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
   }
-  if ((int)blockIdx.x < a.nblk[0]) update_role<D, A, 0, false, true, 8, 0, true>(a, blockIdx.x, smem, smem + NetImageX2<D, A>::SIZE);
-  else update_role<D, A, 1, false, true, 8, 0, true>(a, blockIdx.x - a.nblk[0], smem, smem + NetImageX2<D, 1>::SIZE);
+  // a role whose hidden-layer weights left the fp16 window (|w| >= 255) runs as bf16x3 for this launch: same operands, no range limit
+  if ((int)blockIdx.x < a.nblk[0]) {
+    if (!update_role<D, A, 0, false, true, 8, 0, true>(a, blockIdx.x, smem, smem + NetImageX2<D, A>::SIZE))
+      update_role<D, A, 0, false, true, 8>(a, blockIdx.x, smem, smem + NetImageX3<D, A, true>::SIZE);
+  } else {
+    if (!update_role<D, A, 1, false, true, 8, 0, true>(a, blockIdx.x - a.nblk[0], smem, smem + NetImageX2<D, 1>::SIZE))
+      update_role<D, A, 1, false, true, 8>(a, blockIdx.x - a.nblk[0], smem, smem + NetImageX3<D, 1, true>::SIZE);
+  }
 }
 #ifdef CRL_ABLATE
 // timing experiments only: the same kernel with one phase removed (results are garbage)
@@ -745,30 +745,26 @@ __global__ void vfix_count_kernel(DevCfg c, const SampleRec* __restrict__ recs, 
   }
 }
 
+#ifdef CRL_ABLATE
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#endif
 
 // block counts of the main pass: {actor, critic}
 static void main_pass_blocks(crl_ppo* h, int* nA, int* nC) {
-  if (gemm_x3()) {
-    // one role per block; the actor tile is a little longer (softmax + Float64 policy-loss terms), so it gets more blocks
-    const int total = 2 * ((h->update_blocks + 1) / 2);
-    static int actor_pct = -1;
-    if (actor_pct < 0) actor_pct = env_int("CRL_X3_ACTOR_PCT", 53);  // swept 50..55 at nt=65536: 14.92 14.79 14.56 14.41 14.52 14.69 ms of update per iteration
-    int a = total * actor_pct / 100;
-    if (a < 1) a = 1;
-    if (a > total - 1) a = total - 1;
-    if (total < 2) { *nA = 1; *nC = 1; return; }
-    *nA = a; *nC = total - a;
-  } else {
-    *nA = h->update_blocks; *nC = h->update_blocks;
-  }
+  // one role per block; the actor tile is a little longer (softmax + Float64 policy-loss terms), so it gets more blocks
+  const int total = 2 * ((h->update_blocks + 1) / 2);
+  const int actor_pct = (int)opt(h, OPT_ACTOR_BLOCK_PCT);  // swept 50..55 at nt=65536: 14.92 14.79 14.56 14.41 14.52 14.69 ms of update per iteration
+  int a = total * actor_pct / 100;
+  if (a < 1) a = 1;
+  if (a > total - 1) a = total - 1;
+  if (total < 2) { *nA = 1; *nC = 1; return; }
+  *nA = a; *nC = total - a;
 }
 
 static int run_update(crl_ppo* h, int mb, int mode, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
   UpdateArgs a;
   a.c = h->dc; a.params = h->params;
-  a.recs = h->recs_p + (size_t)h->cur_slot * h->dc.B + (size_t)mb * h->dc.M; a.adv_ms = h->adv_ms; a.vfix = h->vfix;
-  if (gather_mode()) { a.recs = h->recs; a.perm = h->perm_base + (size_t)h->cur_slot * h->dc.B + (size_t)mb * h->dc.M; }
+  a.recs = h->recs; a.perm = h->perm_base + (size_t)h->cur_slot * h->dc.B + (size_t)mb * h->dc.M; a.adv_ms = h->adv_ms; a.vfix = h->vfix;
   a.gpart = h->gpart; a.lpart = h->lpart; a.newv = h->newv; a.range_err = h->vfix + 5;
   a.dscale = h->dscale; a.dmax = reinterpret_cast<unsigned*>(h->dscale + 2);
   a.mb = mb; a.mode = mode; a.gstride = (int)h->Pa; a.pmax = h->update_blocks; a.stagger = 0;
@@ -790,22 +786,14 @@ static int run_update(crl_ppo* h, int mb, int mode, hipEvent_t ev0 = nullptr, hi
     CRL_DBG_CASE(32, 8) CRL_DBG_CASE(64, 8) CRL_DBG_CASE(82, 8) CRL_DBG_CASE(86, 8) CRL_DBG_CASE(126, 8)
 #undef CRL_DBG_CASE
 #endif
-  } else if (gemm_x2()) {
-    main_pass_blocks(h, &a.nblk[0], &a.nblk[1]);
-    a.stagger = env_int("CRL_X3_STAGGER", 3);
-    const size_t smem = sizeof(float) * (NetImageX2<4, 2>::SIZE + 8 * SCR_FLOATS_X3 + 4);
-    hipExtLaunchKernelGGL((update_x2_kernel<4, 2>), dim3(a.nblk[0] + a.nblk[1]), dim3(512), smem, h->stream, ev0, ev1, 0, a);
-  } else if (gemm_x3()) {
-    main_pass_blocks(h, &a.nblk[0], &a.nblk[1]);
-    static int stagger = -1;
-    if (stagger < 0) stagger = env_int("CRL_X3_STAGGER", 3);
-    a.stagger = stagger;
-    const size_t smem = sizeof(float) * (NetImageX3<4, 2, true>::SIZE + 8 * SCR_FLOATS_X3);
-    hipExtLaunchKernelGGL((update_x3_kernel<4, 2>), dim3(a.nblk[0] + a.nblk[1]), dim3(512), smem, h->stream, ev0, ev1, 0, a);
   } else {
     main_pass_blocks(h, &a.nblk[0], &a.nblk[1]);
-    const size_t smem = sizeof(float) * (NetImage<4, 2, true>::SIZE + NetImage<4, 1, true>::SIZE + 8 * SCR_FLOATS);
-    hipExtLaunchKernelGGL((update_kernel<4, 2>), dim3(h->update_blocks), dim3(512), smem, h->stream, ev0, ev1, 0, a);
+    a.stagger = (int)opt(h, OPT_UPDATE_STAGGER);
+    // LDS for the larger of the two layouts: the fp16x2 kernel runs a role as bf16x3 when its weights leave the fp16 window
+    const size_t smem = sizeof(float) * (NetImageX3<4, 2, true>::SIZE + 8 * SCR_FLOATS_X3 + 4);
+    static_assert(NetImageX3<4, 2, true>::SIZE >= NetImageX2<4, 2>::SIZE, "the bf16x3 image is the larger one");
+    if (gemm_x2(h)) hipExtLaunchKernelGGL((update_x2_kernel<4, 2>), dim3(a.nblk[0] + a.nblk[1]), dim3(512), smem, h->stream, ev0, ev1, 0, a);
+    else hipExtLaunchKernelGGL((update_x3_kernel<4, 2>), dim3(a.nblk[0] + a.nblk[1]), dim3(512), smem, h->stream, ev0, ev1, 0, a);
   }
   CRL_HIP_CHECK(hipGetLastError());
   return 0;
@@ -813,15 +801,14 @@ static int run_update(crl_ppo* h, int mb, int mode, hipEvent_t ev0 = nullptr, hi
 
 static void launch_vfix_count(crl_ppo* h, int mb) {
   const size_t off = (size_t)h->cur_slot * h->dc.B + (size_t)mb * h->dc.M;
-  if (gather_mode()) hipLaunchKernelGGL(vfix_count_kernel, dim3(1), dim3(1024), 0, h->stream, h->dc, h->recs, h->perm_base + off, h->newv, h->vfix);
-  else hipLaunchKernelGGL(vfix_count_kernel, dim3(1), dim3(1024), 0, h->stream, h->dc, h->recs_p + off, nullptr, h->newv, h->vfix);
+  hipLaunchKernelGGL(vfix_count_kernel, dim3(1), dim3(1024), 0, h->stream, h->dc, h->recs, h->perm_base + off, h->newv, h->vfix);
 }
 
 static StatsArgs stats_args(crl_ppo* h, int mb, crl_ppo_stats* slot, int fused) {
   StatsArgs st;
   st.c = h->dc; st.Mglobal = (double)h->dc.M * h->world; st.adv_ms = h->adv_ms; st.mb = mb; st.vfix = h->vfix; st.out = slot;
   st.fused = fused;
-  st.dscale = gemm_x2() ? h->dscale : nullptr;
+  st.dscale = gemm_x2(h) ? h->dscale : nullptr;
   return st;
 }
 

@@ -7,8 +7,8 @@ namespace crl {
 struct UpdateArgs {
   DevCfg c;
   const float* params;
-  const SampleRec* recs;  // the minibatch, contiguous: recs_p[slot] + mb·M (ppo.jl:203-211 after the permute pass)
-  const int32_t* perm = nullptr;  // gather mode: recs = the unpermuted records, perm = this minibatch's slice of b_inds
+  const SampleRec* recs;  // the batch as 64-byte records, buffer order (records.hip)
+  const int32_t* perm = nullptr;  // this minibatch's slice of b_inds (ppo.jl:203-204): sample pos reads recs[perm[pos]]
   const double* adv_ms;   // [nmb][2] mean, std of the (global) minibatch advantages
   const double* vfix;     // [8] u, #{u > q}, -, flag, sticky flag
   float* gpart; double* lpart; float* newv;

@@ -116,7 +116,6 @@ int wide_create(crl_ppo* h) {
   // swept at C3 (M = 524,288; profiles/r02_c3_*): 4096-sample chunks 68.0 ms per iteration, 2048: 69.8, 8192: 75.9 — half the
   // partials to write and fold against one block per CU instead of two
   int ck = M >= 262144 ? 4096 : 2048;
-  if (const char* e = getenv("CRL_WIDE_CHUNK2")) { ck = atoi(e); if (ck < 256) ck = 256; }
   int s2 = (M + ck - 1) / ck; if (s2 > 512) s2 = 512; if (s2 < 1) s2 = 1;
   w->S2 = s2; w->chunk2 = (((M + s2 - 1) / s2) + 31) & ~31;
   int ss = (M + 511) / 512; if (ss > 1024) ss = 1024; if (ss < 1) ss = 1;
@@ -219,25 +218,11 @@ __global__ void __launch_bounds__(64) wide_wmax_kernel(const float* __restrict__
   }
 }
 
-// CRL_WIDE_GEMM: x2 (default) = 256-wide GEMMs as fp16x2 (three f16 MFMAs per product), x3 = bf16x3 (six), f32 = every GEMM
-// on v_mfma_f32_32x32x2_f32
-static int wide_gemm_mode() {
-  static int mode = -1;
-  if (mode < 0) { const char* e = getenv("CRL_WIDE_GEMM"); const std::string v = e ? e : "x2"; mode = v == "f32" ? 0 : v == "x3" ? 1 : 2; }
-  return mode;
-}
-static bool wide_x3() { return wide_gemm_mode() >= 1; }   // a split-product flavour (x2 or x3)
-static bool wide_x2() { return wide_gemm_mode() == 2; }
-bool wide_x2_active(const crl_ppo* h) { return h->wide && h->cfg.hidden == 256 && wide_x2(); }
-
-static bool wide_x3_fused_head() {   // CRL_WIDE_FUSE_HEAD=0 keeps the heads as their own (padded-MFMA) launches
-  static int mode = -1;
-  if (mode < 0) {
-    const char* e = getenv("CRL_WIDE_FUSE_HEAD"); const char* nw = getenv("CRL_WIDE_X3_WAVES");
-    mode = (!(e && atoi(e) == 0) && !(nw && atoi(nw) != 8)) ? 1 : 0;
-  }
-  return mode == 1;
-}
+// option "wide_gemm": 2 (default) = 256-wide GEMMs as fp16x2 (three f16 MFMAs per product), 1 = bf16x3 (six; the fallback
+// flavour without range limits), 0 = every GEMM on v_mfma_f32_32x32x2_f32
+static bool wide_x3(const crl_ppo* h) { return opt(h, OPT_WIDE_GEMM) >= 1; }   // a split-product flavour (x2 or x3)
+static bool wide_x2(const crl_ppo* h) { return opt(h, OPT_WIDE_GEMM) == 2; }
+bool wide_x2_active(const crl_ppo* h) { return h->wide && h->cfg.hidden == 256 && wide_x2(h); }
 
 static int ensure_pack(crl_ppo* h) {
   WideWs* w = static_cast<WideWs*>(h->wide_ws);
@@ -704,20 +689,16 @@ __global__ void __launch_bounds__(64 * NW) wide_dense_x3_kernel(DenseX3Args a) {
 template <int EPI>
 static int dense_x3_launch(hipStream_t st, const DenseX3Args& a) {
   if (a.M <= 0) return 0;
-  static int nw = -1;
-  if (nw < 0) { const char* e = getenv("CRL_WIDE_X3_WAVES"); nw = e ? atoi(e) : 8; }
   const size_t head32 = a.Z ? (size_t)8 * 32 * 36 * 4 + (size_t)8 * 32 * a.ldz * 4 : 0;
   const size_t head64 = a.Z ? (size_t)8 * 32 * 36 * 4 + (size_t)8 * 64 * a.ldz * 4 : 0;
   if (a.M <= 32768) {
     size_t smem = X3_SLAB_BF16 * 2 + 3 * 32 * X3ROW * 2;
     if (head32 > smem) smem = head32;
-    if (nw == 8) hipLaunchKernelGGL((wide_dense_x3_kernel<EPI, 1, 8>), dim3((a.M + 31) / 32), dim3(512), smem, st, a);
-    else hipLaunchKernelGGL((wide_dense_x3_kernel<EPI, 1, 4>), dim3((a.M + 31) / 32), dim3(256), smem, st, a);
+    hipLaunchKernelGGL((wide_dense_x3_kernel<EPI, 1, 8>), dim3((a.M + 31) / 32), dim3(512), smem, st, a);
   } else {
     size_t smem = X3_SLAB_BF16 * 2 + 3 * 64 * X3ROW * 2;
     if (head64 > smem) smem = head64;
-    if (nw == 8) hipLaunchKernelGGL((wide_dense_x3_kernel<EPI, 2, 8>), dim3((a.M + 63) / 64), dim3(512), smem, st, a);
-    else hipLaunchKernelGGL((wide_dense_x3_kernel<EPI, 2, 4>), dim3((a.M + 63) / 64), dim3(256), smem, st, a);
+    hipLaunchKernelGGL((wide_dense_x3_kernel<EPI, 2, 8>), dim3((a.M + 63) / 64), dim3(512), smem, st, a);
   }
   CRL_HIP_CHECK(hipGetLastError());
   return 0;
@@ -955,8 +936,7 @@ static NetOff net_off(int H, int D, int NO) {
 // fast_act: the exp2-based activation (wide_tanh) — the update pass and the critic; the actor of the rollout / get_action keeps
 // tanh_fast because its logits decide action indices that are compared bit for bit
 static int wide_forward(crl_ppo* h, int net, const float* X, int ldx, const int32_t* idx, int M, float* out, int ldo, bool fast_act = false) {
-  static const bool fast_ok = !(getenv("CRL_WIDE_TANH") && std::string(getenv("CRL_WIDE_TANH")) == "rational");
-  fast_act = fast_act && fast_ok;
+  fast_act = fast_act && !opt(h, OPT_WIDE_TANH_RATIONAL);
   WideWs* w = static_cast<WideWs*>(h->wide_ws);
   const int H = w->H, NO = net ? 1 : w->A;
   const NetOff o = net_off(H, w->D, NO);
@@ -967,13 +947,13 @@ static int wide_forward(crl_ppo* h, int net, const float* X, int ldx, const int3
   a.W = pk + w->pk[net].w1; a.Kp = w->D8; a.X = X; a.ldx = ldx; a.Kt = w->D; a.bias = P + o.b1; a.Y = w->h1[net]; a.ldy = H; a.Nt = H;
   if (dense_launch<EPI_TANH>(h->stream, H, a)) return 1;
   a.idx = nullptr;
-  if (H == 256 && wide_x3()) {
+  if (H == 256 && wide_x3(h)) {
     DenseX3Args x;
     x.Wx3 = pk + w->pk[net].x3f; x.X = w->h1[net]; x.K = H; x.bias = P + o.b2; x.S = nullptr; x.Y = w->h2[net]; x.M = M;
-    const bool fuse = wide_x3_fused_head();
+    const bool fuse = true;   // the head comes out of the layer-2 epilogue (tile_tanh_head)
     x.W3t = pk + w->pk[net].w3t; x.b3 = P + o.b3; x.Z = fuse ? out : nullptr; x.A = NO; x.ldz = ldo;
     x.dZ = nullptr; x.ldd = 0; x.Ad = 0; x.bz = nullptr; x.bld = 0; x.bA = 0; x.wmax = nullptr; x.fast_act = fast_act ? 1 : 0;
-    if (wide_x2()) { x.Wx3 = pk + w->pk[net].x2f; if (dense_x2_launch<EPI_TANH>(h->stream, x)) return 1; }
+    if (wide_x2(h)) { x.Wx3 = pk + w->pk[net].x2f; if (dense_x2_launch<EPI_TANH>(h->stream, x)) return 1; }
     else if (dense_x3_launch<EPI_TANH>(h->stream, x)) return 1;
     if (fuse) return 0;   // the head came out of the layer-2 epilogue
   } else {
@@ -990,9 +970,8 @@ static int wide_forward(crl_ppo* h, int net, const float* X, int ldx, const int3
 // are instantiated for); anything else runs the two networks one after the other.
 static int wide_forward_pair(crl_ppo* h, const float* X, int ldx, int M, float* outA, int ldoA, float* outC, int ldoC) {
   WideWs* w = static_cast<WideWs*>(h->wide_ws);
-  static const bool pair_ok = !(getenv("CRL_WIDE_PAIR") && atoi(getenv("CRL_WIDE_PAIR")) == 0);
-  static const bool fast_ok = !(getenv("CRL_WIDE_TANH") && std::string(getenv("CRL_WIDE_TANH")) == "rational");
-  if (!(pair_ok && w->H == 256 && wide_x2() && wide_x3_fused_head() && M > 0 && M <= 32768)) {
+  const bool fast_ok = !opt(h, OPT_WIDE_TANH_RATIONAL);
+  if (!(w->H == 256 && wide_x2(h) && M > 0 && M <= 32768)) {
     if (wide_forward(h, 0, X, ldx, nullptr, M, outA, ldoA)) return 1;          // ppo.jl:127
     return wide_forward(h, 1, X, ldx, nullptr, M, outC, ldoC, true);           // ppo.jl:128
   }
@@ -1957,17 +1936,11 @@ static int wide_backward(crl_ppo* h, int net, const float* dOut, int ldd, const 
   const NetOff o = net_off(H, w->D, NO);
   (void)o;
   const float* pk = w->pack + w->pk_base[net];
-  // δ2 = (W3ᵀ·δ3) ⊙ (1 − h2²) is its own [H × M] pass. CRL_WIDE_FUSE_DELTA2=1 lets both consumers (weight gradient and
-  // backward-data, bf16x3 kernels) form it on the fly from h2 and the head cotangent instead — measured SLOWER at C3
-  // (update 76.4 vs 70.2 ms per iteration: the extra VALU work sits on those kernels' critical path), so it is opt-in.
-  static int fuse_env = -1;
-  if (fuse_env < 0) { const char* e = getenv("CRL_WIDE_FUSE_DELTA2"); fuse_env = (e && atoi(e) != 0) ? 1 : 0; }
-  const bool fuse2 = H == 256 && wide_x3() && fuse_env && NO <= AFUSE;
-  // default: δ2 comes out of the dW3 sweep over h2 (wide_skinny_kernel<.., D2>); CRL_WIDE_D2_PASS=1 keeps it as its own K ≤ 8
-  // MFMA launch (the round-1 arrangement)
-  static int d2_pass = -1;
-  if (d2_pass < 0) { const char* e = getenv("CRL_WIDE_D2_PASS"); d2_pass = (e && atoi(e) != 0) ? 1 : 0; }
-  const bool d2_sweep = !fuse2 && !d2_pass && NO <= 8;
+  // δ2 = (W3ᵀ·δ3) ⊙ (1 − h2²) comes out of the dW3 sweep over h2 (wide_skinny_kernel<.., D2>) when the head has ≤ 8 outputs,
+  // else it is its own K ≤ 16 MFMA launch. (Measured and dropped: forming δ2 on the fly inside its two consumers — update 76.4 vs
+  // 70.2 ms per iteration at C3, the extra VALU work sits on those kernels' critical path.)
+  constexpr bool fuse2 = false;
+  const bool d2_sweep = NO <= 8;
   DenseArgs d;
   d.idx = nullptr; d.bias = nullptr; d.M = M;
   if (!fuse2 && !d2_sweep) {
@@ -1986,20 +1959,15 @@ static int wide_backward(crl_ppo* h, int net, const float* dOut, int ldd, const 
   g.dY = fuse2 ? w->h2[net] : w->dA; g.X = w->h1[net]; g.H = H; g.M = M; g.chunk = w->chunk2; g.pW = w->pW2[net]; g.pB = w->pB2[net];
   g.dZ = fuse2 ? dOut : nullptr; g.ldd = ldd; g.Ad = NO; g.W3t = pk + w->pk[net].w3t;
   g.bz = dOut; g.bld = ldd; g.bA = NO; g.wmax = pk + w->pk[net].wmax;
-  const bool x2 = H == 256 && wide_x2() && !fuse2;
+  const bool x2 = H == 256 && wide_x2(h);
   if (x2) hipLaunchKernelGGL(wide_wgrad_x2_kernel<4>, dim3(w->S2, 2), dim3(512), 2 * (256 + 128) * X3ROW * 2, h->stream, g);
-  else if (H == 256 && wide_x3()) {
-    // 256×128 output tiles (dY read twice, X once: 1.5 GB per launch at C3) unless CRL_WIDE_WGRAD_TILE=128 (2 GB)
-    static int tile = -1;
-    if (tile < 0) { const char* e = getenv("CRL_WIDE_WGRAD_TILE"); tile = e ? atoi(e) : 256; }
-    if (tile == 256) hipLaunchKernelGGL(wide_wgrad_x3_kernel<4>, dim3(w->S2, 2), dim3(512), 3 * (256 + 128) * X3ROW * 2, h->stream, g);
-    else hipLaunchKernelGGL(wide_wgrad_x3_kernel<2>, dim3(w->S2, 4), dim3(256), 3 * (128 + 128) * X3ROW * 2, h->stream, g);
-  }
+  else if (H == 256 && wide_x3(h))   // 256×128 output tiles (dY read twice, X once: 1.5 GB per launch at C3; 128×128 tiles read 2 GB)
+    hipLaunchKernelGGL(wide_wgrad_x3_kernel<4>, dim3(w->S2, 2), dim3(512), 3 * (256 + 128) * X3ROW * 2, h->stream, g);
   else if (H >= 128) { const int nb = H / 128; hipLaunchKernelGGL(wide_wgrad_kernel<2>, dim3(w->S2, nb * nb), dim3(256), 0, h->stream, g); }
   else hipLaunchKernelGGL(wide_wgrad_kernel<1>, dim3(w->S2, 1), dim3(256), 0, h->stream, g);
   CRL_HIP_CHECK(hipGetLastError());
   // δ1 = (W2ᵀ·δ2) ⊙ (1 − h1²)
-  if (H == 256 && wide_x3()) {
+  if (H == 256 && wide_x3(h)) {
     DenseX3Args x;
     x.Wx3 = pk + w->pk[net].x3b; x.X = fuse2 ? w->h2[net] : w->dA; x.K = H; x.bias = nullptr; x.S = w->h1[net]; x.Y = w->dB; x.M = M;
     x.W3t = pk + w->pk[net].w3t; x.b3 = nullptr; x.Z = nullptr; x.A = 0; x.ldz = 0;

@@ -18,15 +18,28 @@ def global_minibatch(local_minibatch: int, world_size: int) -> int:
     return local_minibatch * world_size
 
 
-def exchange_unique_id(dist, rank: int, make_id):
+def exchange_unique_id(dist, rank: int, make_id, allow_failure: bool = False):
     """Rank 0 creates the 128-byte communicator id (crl_comm_unique_id); everyone receives it over the launcher's
-    rendezvous (`dist` = torch.distributed with any backend)."""
-    box = [make_id() if rank == 0 else None]
+    rendezvous (`dist` = torch.distributed with any backend). If rank 0 cannot create it (librccl missing, …) it still takes
+    part in the broadcast — with an error marker — so no rank is left waiting: with allow_failure every rank gets None, otherwise
+    every rank raises."""
+    uid, err = None, None
+    if rank == 0:
+        try:
+            uid = make_id()
+            if not isinstance(uid, (bytes, bytearray)) or len(uid) != 128:
+                raise ValueError("communicator id must be 128 bytes")
+        except Exception as e:   # noqa: BLE001 — broadcast as a marker below, then re-raised or reported
+            uid, err = None, e
+    box = [bytes(uid) if uid is not None else None]
     dist.broadcast_object_list(box, src=0)
-    uid = box[0]
-    if not isinstance(uid, (bytes, bytearray)) or len(uid) != 128:
+    if box[0] is None:
+        if allow_failure:
+            return None
+        raise err if err is not None else RuntimeError("rank 0 could not create the communicator id")
+    if not isinstance(box[0], (bytes, bytearray)) or len(box[0]) != 128:
         raise ValueError("communicator id must be 128 bytes")
-    return bytes(uid)
+    return bytes(box[0])
 
 
 def attach_peer_comm(dist, handle, world_size: int, rank: int):
@@ -44,24 +57,30 @@ def attach_peer_comm(dist, handle, world_size: int, rank: int):
 
 def attach_comm(dist, handle, world_size: int, rank: int, kind: str, make_id, fallback: bool = False):
     """kind = "rccl" (crl_comm_init) or "peer" (crl_comm_peer_export/attach). Returns the kind attached. With fallback=True a
-    failed RCCL initialisation on ANY rank (agreed over the rendezvous, so all ranks take the same branch) falls back to the
-    peer all-reduce instead of raising."""
+    failed RCCL start on ANY rank — rank 0 cannot create the id, or crl_comm_init fails somewhere — is agreed over the rendezvous
+    (so all ranks take the same branch): ranks whose communicator did come up drop it again (crl_comm_destroy) and everybody
+    attaches the peer all-reduce instead of raising."""
     if kind == "peer":
         attach_peer_comm(dist, handle, world_size, rank)
         return "peer"
     if kind != "rccl":
         raise ValueError(f"unknown communicator kind {kind!r} (rccl | peer)")
-    uid = exchange_unique_id(dist, rank, make_id)
+    uid = exchange_unique_id(dist, rank, make_id, allow_failure=fallback)
     err = None
-    try:
-        handle.comm_init(uid, world_size, rank)
-    except Exception as e:   # noqa: BLE001 — reported below or re-raised
-        err = e
+    if uid is None:
+        err = RuntimeError("rank 0 could not create the RCCL communicator id")
+    else:
+        try:
+            handle.comm_init(uid, world_size, rank)
+        except Exception as e:   # noqa: BLE001 — reported below or re-raised
+            err = e
     failed = [None] * world_size
     dist.all_gather_object(failed, err is not None)
     if not any(failed):
         return "rccl"
     if not fallback:
         raise err if err is not None else RuntimeError("crl_comm_init failed on another rank")
+    if err is None:
+        handle.comm_destroy()   # this rank's communicator came up, another rank's did not: peer_export refuses a second exchange
     attach_peer_comm(dist, handle, world_size, rank)
     return "peer (RCCL initialisation failed)"

@@ -65,10 +65,12 @@ class Policy:
 class Agent:
     """Actor + critic + optimiser state + rollout buffer + vectorised env of one PPO run, all resident on one GPU."""
 
-    def __init__(self, config: PPOConfig, *, device=0, params=None, seed=0x5EED, init_seed=0, **shape):
+    def __init__(self, config: PPOConfig, *, device=0, params=None, seed=0x5EED, init_seed=0, options=None, **shape):
         self.config = config
         self.crl_cfg = _crl_config(config, seed=seed, **shape)
         self.handle = L.Handle(self.crl_cfg, device)
+        for key, value in (options or {}).items():      # crl_ppo_set_option: kernel-flavour switches of this handle
+            self.handle.set_option(key, value)
         if params is None:
             params = networks.make_actor_critic(self.crl_cfg.n_act, self.crl_cfg.obs_dim, [self.crl_cfg.hidden] * 2, seed=init_seed)
         self.set_params(params)

@@ -187,6 +187,34 @@ int32_t crl_comm_peer_attach(crl_ppo* h, const uint8_t* handles);
  * minibatch size and the host sums the per-shard gradient messages (CRL_F_GRADS) itself. */
 int32_t crl_comm_init_external(crl_ppo* h, int32_t world_size, int32_t rank);
 
+/* Detaches whatever exchange is attached (RCCL communicator, peer mailboxes, or the external-exchange declaration) and returns the
+ * handle to a single-shard configuration; a launcher uses it to fall back from a partially failed RCCL initialisation to the peer
+ * all-reduce (cleanrl.jl_amd/dist.py: attach_comm). No reference counterpart (the reference is single-process). */
+int32_t crl_comm_destroy(crl_ppo* h);
+
+/* Per-handle options: every switch that selects a kernel flavour or changes numerics (earlier rounds: process-wide CRL_*
+ * environment variables). Integer-valued, by name; unknown names and out-of-range values are errors. The defaults are what
+ * bench.py measures. crl_ppo_option_name enumerates them (index 0 … until it fails).
+ *   gemm                    2 = 64x64 products as fp16x2 split operands (default); 1 = bf16x3 everywhere — the fallback flavour, which
+ *                           a launch also takes by itself, per role, when a hidden-layer weight leaves the fp16 window (|w| >= 255)
+ *   rollout_split           small-shard rollout kernel: 1 = three waves per 32-env tile (default), 2 = two, 0 = one
+ *   rollout_split_max_tiles largest shard, in 32-env tiles, the split kernels take (512)
+ *   rollout_stagger         start delay of waves 4-7 of an 8-wave rollout block, units of 1024 clocks (6)
+ *   gae_fuse                1 = inside crl_ppo_iterate the compat-mode GAE is the tail of the rollout kernel (default), 0 = own launch
+ *   shuffle_overlap         1 = epoch permutations are drawn on a second stream next to the rollout (default)
+ *   guard_window            iterations crl_ppo_iterate enqueues between two read-backs of the value-loss speculation flag (8)
+ *   update_stagger, actor_block_pct, adv_seq   launch-shape knobs of the update pass (3, 53, 1)
+ *   comm_force              1 = crl_comm_init with world_size 1 still creates an RCCL communicator (1-GPU test of that path)
+ *   peer_timeout_ms         in-kernel time-out of the peer all-reduce (20000)
+ *   wide_gemm               layer-wise path, 256-wide layers: 2 = fp16x2 (default), 1 = bf16x3, 0 = f32 MFMA
+ *   wide_tanh_rational      1 = the layer-wise path evaluates NNlib's rational tanh_fast everywhere (default 0)
+ *   gae_seg, gae_tile       standalone GAE kernel: steps per segment / envs per block, 0 = automatic
+ * Read-only through crl_ppo_get_option: gemm_fallback_seen (1 once any launch took the bf16x3 fallback).
+ * The environment variable CRL_OPTIONS="key=value,key=value" applies options at crl_ppo_create (shell-driven experiments). */
+int32_t crl_ppo_set_option(crl_ppo* h, const char* key, int64_t value);
+int32_t crl_ppo_get_option(crl_ppo* h, const char* key, int64_t* value);
+int32_t crl_ppo_option_name(int32_t index, const char** name, int64_t* dflt);
+
 /* Profiling: HIP-event timing of each kernel class on the handle's stream (bench.py roofline). on = 1: every class, events
  * recorded around the launches (extra packets between dependent kernels: a breakdown, not a throughput run); on = 2: only the
  * classes whose events ride on the dispatch itself — the update kernel of the fused path — which costs nothing, plus the gradient

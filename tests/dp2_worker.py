@@ -35,6 +35,7 @@ def main():
     torch.cuda.set_device(local)
 
     def attach(hh):
+        hh.set_option("peer_timeout_ms", int(os.environ.get("DP2_PEER_TIMEOUT_MS", "60000")))
         crl_dist.attach_comm(dist, hh, world, rank, kind, crl.comm_unique_id)
     NT, k = 16 * world, 128
     n, off = crl_dist.shard_envs(NT, world, rank)
@@ -42,7 +43,7 @@ def main():
 
     if os.environ.get("DP2_MODE") == "timeout":
         # a rank that stops answering: rank 0 issues an all-reduce nobody else joins — its kernel must give up after
-        # CRL_PEER_TIMEOUT_S and the next synchronising call must report it (no hang, no garbage passed on silently)
+        # option peer_timeout_ms and the next synchronising call must report it (no hang, no garbage passed on silently)
         cfg = crl.PPOConfig(num_envs=n, num_steps=k, total_timesteps=NT * k * 10)
         a = crl.Agent(cfg, device=local, env_id_offset=off, init_seed=3)
         hh = a.handle

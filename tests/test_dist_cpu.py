@@ -173,3 +173,64 @@ def test_peer_mailbox_handles_are_gathered_in_rank_order(tmp_path):
     want = np.concatenate([np.full(64, r + 1, np.uint8) for r in range(world)])
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"peer{r}.npy"), want)
+
+
+class _FakeCommHandle(_FakePeerHandle):
+    """A handle whose RCCL start can be made to fail per rank; like the real one, peer_export refuses while a communicator is up."""
+    def __init__(self, rank, rccl_fails):
+        super().__init__(rank)
+        self.rccl_fails = rccl_fails; self.comm_up = False; self.destroyed = 0
+
+    def comm_init(self, uid, world, rank):
+        if self.rccl_fails:
+            raise RuntimeError("ncclCommInitRank failed")
+        self.comm_up = True
+
+    def comm_destroy(self):
+        self.comm_up = False; self.destroyed += 1
+
+    def comm_peer_export(self, world, rank):
+        if self.comm_up:
+            raise RuntimeError("a communicator is already attached")
+        return super().comm_peer_export(world, rank)
+
+
+def _fallback_worker(rank, world, port, out_dir, case):
+    import importlib
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    crl_dist = importlib.import_module("cleanrl_jl_amd.dist")
+    if case == "no_id":          # librccl cannot even be loaded on rank 0: make_id raises there, nobody else may hang
+        def make_id():
+            raise RuntimeError("cannot load librccl")
+        h = _FakeCommHandle(rank, rccl_fails=False)
+    else:                        # partial failure: rank 1's communicator does not come up, rank 0's does
+        def make_id():
+            return bytes(range(128))
+        h = _FakeCommHandle(rank, rccl_fails=(rank == 1))
+    kind = crl_dist.attach_comm(dist, h, world, rank, "rccl", make_id, fallback=True)
+    assert kind.startswith("peer") and "failed" in kind, kind
+    assert h.attached is not None and len(h.attached) == 64 * world and not h.comm_up
+    if case == "partial":
+        assert h.destroyed == (1 if rank == 0 else 0)
+    # without fallback every rank raises (and none hangs)
+    h2 = _FakeCommHandle(rank, rccl_fails=(rank == 1) if case == "partial" else False)
+    try:
+        crl_dist.attach_comm(dist, h2, world, rank, "rccl", make_id, fallback=False)
+        raised = False
+    except RuntimeError:
+        raised = True
+    assert raised
+    open(os.path.join(out_dir, f"{case}{rank}"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["no_id", "partial"])
+def test_rccl_start_failures_fall_back_to_the_peer_allreduce_on_every_rank(tmp_path, case):
+    """attach_comm(fallback=True): (1) rank 0 cannot create the id — the other ranks must not block in the broadcast; (2) RCCL comes
+    up on some ranks only — those drop their communicator before exporting a mailbox. Both end with every rank on the peer path."""
+    world = 2
+    mp.spawn(_fallback_worker, args=(world, _free_port(), str(tmp_path), case), nprocs=world, join=True)
+    for r in range(world):
+        assert (tmp_path / f"{case}{r}").exists()

@@ -24,7 +24,7 @@ def _gpu_count():
 def _run_ranks(world, comm, share_gpu, port):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_SOCKET_IFNAME="lo", OMP_NUM_THREADS="4", DP2_COMM=comm,
-               DP2_SHARE_GPU="1" if share_gpu else "0", CRL_PEER_TIMEOUT_S="60")
+               DP2_SHARE_GPU="1" if share_gpu else "0", DP2_PEER_TIMEOUT_MS="60000")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dp2_worker.py")]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
@@ -79,10 +79,10 @@ def test_bench_falls_back_to_the_peer_allreduce_when_rccl_cannot_start():
 
 
 def test_peer_allreduce_times_out_instead_of_hanging():
-    """One rank issues an all-reduce its peer never joins: the kernel gives up after CRL_PEER_TIMEOUT_S and the host gets an error."""
+    """One rank issues an all-reduce its peer never joins: the kernel gives up after option peer_timeout_ms and the host gets an error."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", DP2_COMM="peer", DP2_SHARE_GPU="1" if _gpu_count() < 2 else "0",
-               DP2_MODE="timeout", CRL_PEER_TIMEOUT_S="2")
+               DP2_MODE="timeout", DP2_PEER_TIMEOUT_MS="2000")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29613", os.path.join(ROOT, "tests", "dp2_worker.py")]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)

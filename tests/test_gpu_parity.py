@@ -26,7 +26,7 @@ def crl():
 def make_agent(crl, nt=8, k=128, params=None, **kw):
     cfg = crl.PPOConfig(num_envs=nt, num_steps=k, total_timesteps=nt * k * 10, **{a: b for a, b in kw.items() if a in
                         ("num_minibatches", "update_epochs", "clip_value_loss", "anneal_lr", "lr", "clip_coef", "ent_coeff", "v_coef")})
-    shape = {a: b for a, b in kw.items() if a in ("gae_mode", "shuffle_mode", "stale_obs", "env_id_offset", "seed")}
+    shape = {a: b for a, b in kw.items() if a in ("gae_mode", "shuffle_mode", "stale_obs", "env_id_offset", "seed", "options")}
     return crl.Agent(cfg, params=params, **shape)
 
 
@@ -121,12 +121,11 @@ def _oracle_state(nt, k, params, **kw):
 
 @pytest.mark.parametrize("split", ["1", "2", "0"])
 @pytest.mark.parametrize("nt,stale", [(8, 1), (8, 0), (70, 1)])
-def test_rollout_matches_oracle(crl, nt, stale, split, monkeypatch):
-    """split=1: three waves per tile (actor rows 0-31 + sampling + env | actor rows 32-63 | critic), the small-shard kernel;
-    split=2: two waves per tile (actor + env | critic); split=0: one wave per tile."""
-    monkeypatch.setenv("CRL_ROLLOUT_SPLIT", split)
+def test_rollout_matches_oracle(crl, nt, stale, split):
+    """Option rollout_split = 1: three waves per tile (actor rows 0-31 + sampling + env | actor rows 32-63 | critic), the small-shard
+    kernel; 2: two waves per tile (actor + env | critic); 0: one wave per tile."""
     k = 128
-    agent = make_agent(crl, nt=nt, k=k, stale_obs=stale)
+    agent = make_agent(crl, nt=nt, k=k, stale_obs=stale, options={"rollout_split": int(split)})
     params = agent.get_params()
     cfg, st = _oracle_state(nt, k, params, stale_obs=stale)
     h = agent.handle
@@ -309,12 +308,11 @@ def test_full_size_gae_and_scan_linearity(crl):
     assert adv[e, t] == np.float32(np.float64(reward[e, t]) - np.float64(value[e, t]))
 
 
-def test_rccl_path_world1(crl, monkeypatch):
-    """The gradient / advantage-statistics all-reduces go through RCCL (dlopen'ed librccl) even on one GPU when
-    CRL_COMM_FORCE=1: a sum over one rank is the identity, so the iteration must still match the oracle."""
-    monkeypatch.setenv("CRL_COMM_FORCE", "1")
+def test_rccl_path_world1(crl):
+    """The gradient / advantage-statistics all-reduces go through RCCL (dlopen'ed librccl) even on one GPU with option
+    comm_force = 1: a sum over one rank is the identity, so the iteration must still match the oracle."""
     nt, k = 8, 128
-    agent = make_agent(crl, nt=nt, k=k, shuffle_mode=0)
+    agent = make_agent(crl, nt=nt, k=k, shuffle_mode=0, options={"comm_force": 1})
     h = agent.handle
     h.comm_init(crl.comm_unique_id(), 1, 0)
     params = agent.get_params()
@@ -565,17 +563,15 @@ def test_full_size_update_is_deterministic_and_additive(crl):
 
 
 @pytest.mark.parametrize("forced_comm", [False, True])
-def test_iteration_with_live_unclipped_value_branch(crl, forced_comm, monkeypatch):
+def test_iteration_with_live_unclipped_value_branch(crl, forced_comm):
     """γ = 0 makes every return 0 or 1 while a critic head bias of 5 puts u = mean(v − R²) ≈ 4 above every clipped term
     (Q4): the whole iteration must still match the oracle. Inside crl_ppo_iterate the speculative pass raises the sticky flag
     and the guard window repeats the iteration from its snapshot with the exact step — on one GPU and, with an RCCL
     communicator (forced 1-rank), with the count and critic-slice all-reduces. (Host-driven single steps keep the in-line
     fix-up: test_update_gradient_matches_oracle[...0.05-True].)"""
-    if forced_comm:
-        monkeypatch.setenv("CRL_COMM_FORCE", "1")
     nt, k = 8, 128
     cfg = crl.PPOConfig(num_envs=nt, num_steps=k, total_timesteps=nt * k * 10, gamma=0.0)
-    agent = crl.Agent(cfg, shuffle_mode=crl._lib.SHUFFLE_FISHER_YATES)
+    agent = crl.Agent(cfg, shuffle_mode=crl._lib.SHUFFLE_FISHER_YATES, options={"comm_force": int(forced_comm)})
     cfgo = O.make_config(num_envs=nt, num_steps=k, gamma=0.0)
     params = agent.get_params()
     params[O.param_offsets(cfgo)[11]] = 5.0
@@ -598,17 +594,14 @@ def test_iteration_with_live_unclipped_value_branch(crl, forced_comm, monkeypatc
 
 
 @pytest.mark.parametrize("forced_comm", [False, True])
-def test_guard_window_reruns_all_its_iterations(crl, forced_comm, monkeypatch):
+def test_guard_window_reruns_all_its_iterations(crl, forced_comm):
     """Guard window (single GPU, and with a forced 1-rank RCCL communicator): three iterations are enqueued WITHOUT any read-back; the
     speculation fails in each (γ = 0, critic bias 5). The first host-visible read settles the window: the library restores the
     snapshot (parameters, Adam state, env state, episode accumulators) and repeats all three iterations exactly — parameters
     and episode statistics must equal the oracle's three iterations, and anneal_lr must have followed the rewound counter."""
-    if forced_comm:
-        monkeypatch.setenv("CRL_COMM_FORCE", "1")
-    monkeypatch.setenv("CRL_DP_CHECK_EVERY", "8")
     nt, k = 8, 128
     cfg = crl.PPOConfig(num_envs=nt, num_steps=k, total_timesteps=nt * k * 10, gamma=0.0)
-    agent = crl.Agent(cfg, shuffle_mode=crl._lib.SHUFFLE_FISHER_YATES)
+    agent = crl.Agent(cfg, shuffle_mode=crl._lib.SHUFFLE_FISHER_YATES, options={"comm_force": int(forced_comm), "guard_window": 8})
     cfgo = O.make_config(num_envs=nt, num_steps=k, gamma=0.0)
     params = agent.get_params()
     params[O.param_offsets(cfgo)[11]] = 5.0
@@ -630,7 +623,7 @@ def test_guard_window_reruns_all_its_iterations(crl, forced_comm, monkeypatch):
     es = h.episode_stats(); n_ep, ret_sum, len_sum = st.episode_stats
     assert (es["episodes"], es["return_sum"], es["length_sum"]) == (n_ep, ret_sum, len_sum)
     assert h.iteration == 3
-    # a window that closes by itself (CRL_DP_CHECK_EVERY iterations) is settled inside crl_ppo_iterate
+    # a window that closes by itself (option guard_window iterations) is settled inside crl_ppo_iterate
     agent.close(); st.close()
 
 
@@ -657,10 +650,8 @@ def test_episode_record_ring(crl, kind, monkeypatch):
     L = crl._lib
     nt, k = 70, 128
     if kind == "wide":
-        monkeypatch.setenv("CRL_FORCE_WIDE", "1")
-    else:
-        monkeypatch.setenv("CRL_ROLLOUT_SPLIT", "1" if kind == "fused-split" else "0")
-    agent = make_agent(crl, nt=nt, k=k, env_id_offset=1000)
+        monkeypatch.setenv("CRL_FORCE_WIDE", "1")      # read once, by crl_ppo_create
+    agent = make_agent(crl, nt=nt, k=k, env_id_offset=1000, options={"rollout_split": 1 if kind == "fused-split" else 0})
     h = agent.handle
     with pytest.raises(crl.CrlError, match="not enabled"):
         h._ring_cap = 4; h.episode_records()
@@ -699,20 +690,6 @@ def test_iterate_advantage_sums_match_the_permutation(crl, nt, nmb):
         assert abs(sums[mb, 0] - a.sum()) <= 1e-9 * max(1.0, np.abs(a).sum()), (mb, sums[mb, 0], a.sum())
         assert abs(sums[mb, 1] - (a * a).sum()) <= 1e-9 * max(1.0, (a * a).sum()), mb
     agent.close()
-
-
-def test_permute_pass_flavour_still_matches_the_oracle():
-    """CRL_GATHER=0 (records laid out contiguously per epoch by permute_records_kernel instead of being fetched through the
-    permutation by the update kernels) is a process-wide switch: run the iteration / gradient parity tests under it in a child."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, CRL_GATHER="0")
-    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
-                          "full_iteration_matches_oracle or update_gradient_matches_oracle or guard_window or blocked_fisher_yates", "-p", "no:cacheprovider"],
-                         capture_output=True, text=True, env=env, timeout=1200)
-    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
-    assert " passed" in out.stdout and "failed" not in out.stdout
 
 
 @pytest.mark.parametrize("epochs,nmb", [(1, 2), (3, 8), (6, 1)])

@@ -235,15 +235,15 @@ def test_c3_size_minibatch_gradient_matches_oracle(crl):
     agent.close()
 
 
-def test_wide_rccl_path_world1(crl, monkeypatch):
+def test_wide_rccl_path_world1(crl):
     """C3 shape with a forced 1-rank RCCL communicator: the gradient message, the advantage statistics AND the two extra
     value-loss scalars (Σ(v − R²), #{u > q}) travel through ncclAllReduce; a sum over one rank is the identity."""
-    monkeypatch.setenv("CRL_COMM_FORCE", "1")
     D, A, Hd, nt, k = 8, 4, 256, 16, 32
     cfg = ocfg(nt, k, D, A, Hd)
     params = spread_params(cfg, 7)
     agent = make_wide(crl, nt, k, D, A, Hd, params=params, shuffle_mode=0)
     h = agent.handle
+    h.set_option("comm_force", 1)
     h.comm_init(crl.comm_unique_id(), 1, 0)
     st = O.State(cfg); st.params[:] = params; st.env_init()
     h.env_reset()
