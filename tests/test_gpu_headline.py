@@ -1,0 +1,130 @@
+"""Parity of the kernel configuration bench.py's headline actually times (ppo.jl:123-181 at num_envs = 65536 on one GPU):
+`rollout_cartpole_kernel<2, true>` with 8 waves per block (4 at 32768 envs), the start stagger of waves 4-7, the critic on fp16x2
+and the compat-mode GAE fused into the kernel's tail — all inside crl_ppo_iterate, which is the only caller that fuses.
+
+Three checks per configuration, on the buffers crl_ppo_iterate leaves behind (the rollout ran under the initial parameters; the
+optimiser steps that follow do not touch the buffers):
+  (a) F_ADVANTAGE / F_RETURN are bit-equal to the CPU oracle's gae (orc_gae_batch, OpenMP) evaluated on the GPU's OWN value /
+      reward / terminal buffers — the fused tail is the reference's serial Float64 recurrence, so not one bit may differ — and
+      agree with the standalone gae_kernel (crl_gae) up to the ≤ 1e-6 share of last-bit differences its affine-map composition has;
+  (b) the whole 65536 × 128 rollout against orc_rollout: actions, observations, rewards, terminals exact, with the C2 test's
+      knot-margin rule (an env may leave the oracle's trajectory only where its uniform draw sits within 1e-6 of the CDF knot);
+      logprob within 1e-5 relative, value within 1e-5 relative with the parity suite's 1e-6 absolute floor;
+  (c) the same with rollout_stagger = 0, which isolates the stagger.
+The oracle rollout of 8.4 M env-steps takes ≈10 s on the GPU box's host cores (OpenMP); it is cached per env count."""
+import numpy as np
+import pytest
+
+import oraclelib as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-5, 1e-6
+K = 128
+
+
+@pytest.fixture(scope="module")
+def crl():
+    import cleanrl_jl_amd as crl
+    assert crl.device_count() >= 1, "HIP library loaded but no GPU visible"
+    return crl
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.max(np.abs(a - b) / (np.abs(b) + ATOL / RTOL)) if a.size else 0.0
+
+
+_oracle_cache = {}
+
+
+def oracle_rollout(nt, params):
+    """Oracle buffers of the first rollout after a reset under `params` (identical for every option setting)."""
+    if nt not in _oracle_cache:
+        _oracle_cache.clear()                      # one env count at a time: ≈0.4 GB of arrays each
+        cfg = O.make_config(num_envs=nt, num_steps=K)
+        st = O.State(cfg)
+        st.params[:] = params
+        st.env_init(); st.rollout(); st.compute_gae()
+        keep = {n: np.array(getattr(st, n), copy=True) for n in ("obs", "action", "logprob", "reward", "terminal", "value", "adv", "ret",
+                                                                 "next_done", "env_state")}
+        keep["episode_stats"] = st.episode_stats
+        keep["params"] = np.array(params, copy=True)
+        st.close()
+        _oracle_cache[nt] = (cfg, keep)
+    cfg, keep = _oracle_cache[nt]
+    assert np.array_equal(keep["params"], params), "every configuration starts from the same initial parameters"
+    return cfg, keep
+
+
+def knot_margin(cfg, params, obs_col, e, t, seed=0x5EED):
+    u = O.lib().orc_u53(seed, int(e), int(t), 0)
+    _, _, _, margin = O.get_action(cfg, params, np.asfortranarray(obs_col[:, None]), np.array([u]))
+    return float(margin[0])
+
+
+@pytest.mark.parametrize("nt,stagger,expect", [(65536, 6, "8 waves per block, staggered"), (65536, 0, "8 waves per block, no stagger"),
+                                                (32768, 6, "4 waves per block")])
+def test_headline_rollout_and_fused_gae_match_the_oracle(crl, nt, stagger, expect):
+    F = crl._lib
+    cfg = crl.PPOConfig(num_envs=nt, num_steps=K, total_timesteps=nt * K * 10)
+    agent = crl.Agent(cfg, options={"rollout_stagger": stagger})
+    h = agent.handle
+    assert h.get_option("gemm") == 2 and h.get_option("gae_fuse") == 1 and h.get_option("rollout_split_max_tiles") < nt // 32, \
+        "defaults must select the one-wave-per-tile kernel with the fused GAE tail at this size"
+    params = agent.get_params()
+    h.env_reset()
+    h.iterate(1, want_stats=False)
+    value, reward, term = h.read(F.F_VALUE), h.read(F.F_REWARD), h.read(F.F_TERMINAL)
+    adv, ret = h.read(F.F_ADVANTAGE), h.read(F.F_RETURN)
+
+    # (a) the fused tail against the oracle's gae on the SAME inputs: bit for bit; and against the standalone kernel
+    zeros_f, zeros_b = np.zeros(nt, np.float32), np.zeros(nt, np.uint8)
+    adv_o, ret_o = O.gae_batch(value, reward, term, zeros_f, zeros_b, 0.99, 0.95, 0)
+    assert np.array_equal(adv, adv_o), f"{np.sum(adv != adv_o)} advantages of the fused GAE tail differ from orc_gae on the same inputs"
+    assert np.array_equal(ret, ret_o), f"{np.sum(ret != ret_o)} returns differ"
+    adv_k, ret_k = F.gae_host(value, reward, term, None, None, 0.99, 0.95, 0)
+    assert np.sum(adv_k != adv) <= adv.size * 1e-6 and rel_err(adv_k, adv) < 1e-6 and rel_err(ret_k, ret) < 1e-6
+    assert not adv[:, -1].any(), "compat mode: the last slot is defined as 0 (Q1)"
+
+    # (b) / (c) the rollout itself against orc_rollout
+    cfgo, o = oracle_rollout(nt, params)
+    act = h.read(F.F_ACTION)
+    diff = act != o["action"]
+    clean = ~diff.any(axis=1)
+    for e in np.flatnonzero(~clean):
+        t = int(np.argmax(diff[e]))
+        m = knot_margin(cfgo, params, o["obs"][:, e, t], e, t)
+        assert m <= 1e-6, f"env {e} step {t}: action differs although the draw is {m:.3e} away from the CDF knot ({expect})"
+    assert clean.mean() > 0.9995, f"{(~clean).sum()} envs left the oracle's trajectory; knot hits are ~1e-7 per draw"
+    obs = h.read(F.F_OBS)
+    assert np.array_equal(obs[:, clean], o["obs"][:, clean]), "env dynamics are bit-exact by construction"
+    del obs
+    assert np.array_equal(term[clean], o["terminal"][clean]) and np.array_equal(reward[clean], o["reward"][clean])
+    assert np.array_equal(h.read(F.F_NEXT_DONE)[clean], o["next_done"][clean])
+    assert np.array_equal(h.read(F.F_ENV_STATE)[:, clean], o["env_state"][:, clean])
+    assert rel_err(h.read(F.F_LOGPROB)[clean], o["logprob"][clean]) < RTOL
+    assert rel_err(value[clean], o["value"][clean]) < RTOL
+    # advantages end to end (GPU values differ from the oracle's in the last bits, so this one is a tolerance, not bits)
+    assert rel_err(adv[clean], o["adv"][clean]) < RTOL and rel_err(ret[clean], o["ret"][clean]) < RTOL
+    if clean.all():
+        es = h.episode_stats(); n_ep, ret_sum, len_sum = o["episode_stats"]
+        assert (es["episodes"], es["return_sum"], es["length_sum"]) == (n_ep, ret_sum, len_sum)
+    agent.close()
+
+
+def test_unfused_and_fused_gae_agree_at_the_headline_size(crl):
+    """gae_fuse = 0 sends crl_ppo_iterate through the standalone gae_kernel: same rollout bits, advantages equal up to the standalone
+    kernel's last-bit differences (its segments compose affine maps instead of running the serial recurrence)."""
+    F = crl._lib
+    nt = 65536
+    cfg = crl.PPOConfig(num_envs=nt, num_steps=K, total_timesteps=nt * K * 10)
+    a1 = crl.Agent(cfg)
+    a2 = crl.Agent(cfg, params=a1.get_params(), options={"gae_fuse": 0})
+    for a in (a1, a2):
+        a.handle.env_reset(); a.handle.iterate(1, want_stats=False)
+    for f in (F.F_ACTION, F.F_VALUE, F.F_REWARD, F.F_TERMINAL, F.F_LOGPROB):
+        assert np.array_equal(a1.handle.read(f), a2.handle.read(f)), f
+    adv1, adv2 = a1.handle.read(F.F_ADVANTAGE), a2.handle.read(F.F_ADVANTAGE)
+    assert np.sum(adv1 != adv2) <= adv1.size * 1e-6 and rel_err(adv2, adv1) < 1e-6
+    a1.close(); a2.close()

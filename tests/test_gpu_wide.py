@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import oraclelib as O
-from test_gpu_parity import ATOL, RTOL, _grad_close, crl, rel_err  # noqa: F401  (crl is the module fixture)
+from test_gpu_parity import ATOL, RTOL, _grad_close, crl, loss_close, rel_err  # noqa: F401  (crl is the module fixture)
 
 pytestmark = pytest.mark.gpu
 
@@ -131,7 +131,7 @@ def test_wide_update_gradient_matches_oracle(crl, D, A, Hd, nt, k, ret_scale, cl
         if ret_scale < 1 and clipv:
             assert so["n_unclipped_wins"] > 0 and gs["n_unclipped_wins"] == so["n_unclipped_wins"]
         for key in ("loss", "pg_loss", "v_loss", "entropy_loss"):
-            assert abs(gs[key] - so[key]) <= RTOL * max(1.0, abs(so[key])), (key, gs[key], so[key])
+            assert loss_close(key, gs[key], so[key], RTOL), (key, gs[key], so[key])
         _grad_close(g_gpu, g_orc, off)
     agent.close(); st.close()
 
@@ -178,7 +178,7 @@ def test_wide_full_iteration_matches_oracle(crl, D, A, Hd, nt, k):
         assert rel_err(h.read(F.F_ADVANTAGE), st.adv) < RTOL
         for a, b in zip(gs, os_):
             for key in ("loss", "pg_loss", "v_loss", "entropy_loss"):
-                assert abs(a[key] - b[key]) <= 2e-5 * max(1.0, abs(b[key])), (it, key, a[key], b[key])
+                assert loss_close(key, a[key], b[key], RTOL), (it, key, a[key], b[key])
         assert np.max(np.abs(h.read(F.F_PARAMS) - st.params)) < 2e-5
     agent.close(); st.close()
 
@@ -230,7 +230,7 @@ def test_c3_size_minibatch_gradient_matches_oracle(crl):
     g_o, so = O.loss_grad(cfg, params, h.read(F.F_OBS).reshape(D, -1, order="F"), h.read(F.F_ACTION), h.read(F.F_LOGPROB),
                           h.read(F.F_VALUE), h.read(F.F_ADVANTAGE), h.read(F.F_RETURN), perm[2 * M:3 * M])
     for key in ("loss", "pg_loss", "v_loss", "entropy_loss"):
-        assert abs(gs[key] - so[key]) <= RTOL * max(1.0, abs(so[key])), (key, gs[key], so[key])
+        assert loss_close(key, gs[key], so[key], RTOL), (key, gs[key], so[key])
     _grad_close(g, g_o, O.param_offsets(cfg), tol=RTOL)
     agent.close()
 
@@ -251,7 +251,7 @@ def test_wide_rccl_path_world1(crl):
     gs = h.iterate(1); os_ = st.iterate(10, gen_perm=True)
     assert h.prof_read()["allreduce"][1] == 16
     for a, b in zip(gs, os_):
-        assert abs(a["loss"] - b["loss"]) <= 2e-5 * max(1.0, abs(b["loss"]))
+        assert loss_close("loss", a["loss"], b["loss"], RTOL), (a["loss"], b["loss"])
     assert np.max(np.abs(h.read(crl._lib.F_PARAMS) - st.params)) < 2e-5
     agent.close(); st.close()
 
