@@ -12,11 +12,23 @@ iteration one more carries the advantage sums of all 16 minibatches.
       N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N … bench.py --gpus N …` (one rank per
              GPU; RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the env), or as the bare command above — then this process,
              which never touches the GPU, starts exactly that launcher as a child and exits with its code.
+  --workload c2|c3    BASELINE configs[1] (num_envs=4096) / configs[2] (obs 8 / act 4 / 2x256, num_envs=16384): side measurements
+  --suite             N = 1 only: after the headline run, also C2, C3 and the standalone GAE kernel at 4096 / 8192 / 16384 / 65536 envs
+                      (SURVEY §8d); the records go to stderr, into the line's "suite" field and to profiles/<tag>_suite.json
+  --opt key=value     crl_ppo_set_option (kernel-flavour switches of include/cleanrl_hip.h); recorded in config.options
   --dry-run           print the launcher command and the per-rank environment instead of running (works without a GPU)
   --rendezvous-only   ranks meet over gloo, exchange a communicator id and exit (CPU test of the spawn + id exchange)
   --minibatches 1     north_star's "single all-reduce per update epoch" (one optimiser step per epoch, ppo.jl:5)
+  --strict-profiles   exit 2 (instead of reporting traffic = null) when the committed PMC summaries were taken with other kernel sources
+
+The `roofline` record of the headline prices the dominant kernel (update_x2_kernel, ≈80 % of the iteration) against what PMC shows
+it bound by: vector-instruction ISSUE. achieved = issue slots per launch (static ISA count of the tile loop × tiles,
+profiles/<tag>_update_kernel_isa.json, cross-checked against SQ_INSTS_VALU) ÷ HIP-event launch time; peak = 1 wave64 VALU
+instruction per 2 cycles per SIMD-32 × 1024 SIMDs × 2.4 GHz (MI355X_MICROARCH.md). The matrix-pipe utilisation and the
+f32-equivalent TFLOP/s are secondary fields; no field named `frac` exceeds 1.
 """
 import argparse
+import hashlib
 import json
 import os
 import socket
@@ -32,16 +44,48 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 TOTAL_ENVS = 65536
 NUM_STEPS = 128
 FWD_FLOPS_PER_SAMPLE = 17792          # actor + critic forward, 2x64, obs 4, act 2
+FWD_FLOPS_PER_SAMPLE_C3 = 272896      # 2x256, obs 8, act 4
 GAE_BYTES_PER_STEP, GAE_BYTES_PER_ENV = 17, 5
 UPDATE_BYTES_PER_SAMPLE = 36          # obs 16 + action 4 + old logprob 4 + adv 4 + return 4 + old value 4
-PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 MFMA
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= the f32 vector peak)
+PEAK_F16_MFMA_TFLOPS = 2500.0         # dense f16 / bf16 MFMA
 PEAK_HBM_GBPS = 8000.0
-PROFILE_TAG = "r02"                   # profiles/<tag>_* hold the rocprofv3 summaries of this round
+SIMDS, CLOCK_HZ = 1024, 2.4e9         # 256 CUs x 4 SIMD-32; max clock
+PEAK_VALU_GSLOTS = SIMDS * CLOCK_HZ / 2 / 1e9   # one wave64 VALU instruction per 2 cycles per SIMD: 1228.8 G slots/s
+MEASURED_VALU_GSLOTS_2WAVES = SIMDS / 1.25      # scripts/micro/valu_rate.hip: two waves per SIMD retire one v_fma_f32 per 1.25 ns (819 G/s)
+PROFILE_TAG = "r03"                   # profiles/<tag>_* hold the rocprofv3 summaries of this round
+DTYPE = "f32 (64x64 products as fp16x2 split operands: 22 significant bits, 3 f16 MFMAs per product, f32 accumulate)"
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def source_hash():
+    """sha256 over the kernel sources (same function as scripts/count_isa.py): a profile taken with other sources is stale."""
+    csrc = os.path.join(ROOT, "cleanrl.jl_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".hpp", ".cpp")) or f == "Makefile":
+            h.update(f.encode()); h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_profile(name, strict):
+    """A committed profiles/<tag>_<name>.json, or (None, reason) when it is missing or was taken with other kernel sources."""
+    path = os.path.join("profiles", f"{PROFILE_TAG}_{name}.json")
+    try:
+        d = json.load(open(os.path.join(ROOT, path)))
+    except Exception as e:   # noqa: BLE001
+        return None, f"{path}: {e}"
+    want = source_hash()
+    if d.get("source_hash") != want:
+        msg = f"STALE {path}: taken with kernel sources {d.get('source_hash')}, this build is {want} — rerun scripts/final_measure.sh"
+        log("=" * 100 + f"\nbench.py: {msg}\n" + "=" * 100)
+        if strict:
+            sys.exit(2)
+        return None, msg
+    return d, path
 
 
 def physical_cores():
@@ -101,6 +145,9 @@ def cpu_baseline():
     return {"value": v_all, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"num_envs=4096, num_steps={NUM_STEPS}, {it_all} full PPO iterations (rollout+GAE+16 optimiser steps) in {dt_all:.1f}s, "
                       f"OpenMP threads = {cores} physical cores ({logical} logical cpus)",
+            "note": "a reported baseline, not a target: the port is scalar strided C that follows the reference's operation order and "
+                    "promotions (≈25 GFLOP/s on 128 cores); the reference itself (Julia/Flux on BLAS) cannot run here and would sit one to "
+                    "two orders of magnitude above this figure on the same cores",
             "single_thread": {"value": v_1, "unit": "env-steps/s", "cores": 1,
                               "sample": f"C1: num_envs=8, num_steps={NUM_STEPS}, {it_1} iterations in {dt_1:.1f}s"},
             "c1_multi_thread": {"value": v_c1, "unit": "env-steps/s", "cores": min(cores, 8),
@@ -140,12 +187,268 @@ def spawn_ranks(args, argv):
     return subprocess.call(cmd, env=env)
 
 
+def rccl_version():
+    """librccl's own version number, for the stderr diagnostics of a multi-rank run (never fails the run)."""
+    import ctypes
+    for name in ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"):
+        try:
+            lib = ctypes.CDLL(name)
+            v = ctypes.c_int(0)
+            if lib.ncclGetVersion(ctypes.byref(v)) == 0:
+                return v.value
+        except OSError:
+            continue
+    return None
+
+
+WORKLOADS = {
+    "cartpole": dict(envs=TOTAL_ENVS, c3=False, name="C4 shape on this many GPUs"),
+    "c2": dict(envs=4096, c3=False, name="BASELINE configs[1]: num_envs=4096, 2x64, 1 GPU"),
+    "c3": dict(envs=16384, c3=True, name="BASELINE configs[2]: LunarLander-shaped obs 8 / act 4, 2x256, num_envs=16384"),
+}
+
+
+def parse_opts(items):
+    out = {}
+    for it in items or []:
+        if "=" not in it:
+            raise SystemExit(f"--opt expects key=value, got {it!r}")
+        k, v = it.split("=", 1)
+        out[k] = int(v)
+    return out
+
+
+def time_gae_standalone(torch, h, nt, device, reps=6):
+    """The standalone gae_kernel (crl_compute_gae) on the resident buffer: cold (caches flushed by a 1 GiB fill first) and warm
+    (launched again right away), median of `reps`; next to it a plain copy of the same footprint through torch (the read + write bytes
+    of one GAE launch as one float tensor copy), cold — the practical ceiling the cold figure should be read against."""
+    gae_bytes = GAE_BYTES_PER_STEP * nt * NUM_STEPS + GAE_BYTES_PER_ENV * nt
+    flush = torch.empty(1 << 28, dtype=torch.float32, device=device)
+    half = max(1, gae_bytes // 8)      # floats: the copy reads half of the footprint and writes the other half
+    src = torch.empty(half, dtype=torch.float32, device=device).normal_()
+    dst = torch.empty_like(src)
+    cold, warm, copy_cold = [], [], []
+    for i in range(reps):
+        flush.fill_(float(i)); torch.cuda.synchronize()
+        h.prof_enable(True); h.prof_reset(); h.compute_gae(); h.sync()
+        cold.append(h.prof_read()["gae"][0])
+        h.prof_reset(); h.compute_gae(); h.sync()
+        warm.append(h.prof_read()["gae"][0]); h.prof_enable(False)
+        flush.fill_(float(i) + 0.5); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); dst.copy_(src); e1.record(); torch.cuda.synchronize()
+        copy_cold.append(e0.elapsed_time(e1))
+    del flush, src, dst
+    med = lambda v: sorted(v)[len(v) // 2]   # noqa: E731
+    rec = {"bound": "hbm", "kernel": "gae_kernel (advantages + returns), standalone launch (crl_compute_gae)", "num_envs": nt,
+           "peak": PEAK_HBM_GBPS, "unit": "GB/s", "bytes_per_launch": gae_bytes}
+    for name, ms in (("cold", med(cold)), ("warm", med(warm))):
+        rec[name] = {"avg_launch_ms": ms, "achieved": gae_bytes / (ms * 1e-3) / 1e9, "frac": gae_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS}
+    cc = med(copy_cold)
+    rec["copy_ceiling"] = {"avg_launch_ms": cc, "achieved": gae_bytes / (cc * 1e-3) / 1e9, "frac": gae_bytes / (cc * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                           "cold_over_copy": cc / med(cold),
+                           "note": "torch float copy moving the same number of bytes (half read, half written), caches flushed first; "
+                                   "cold_over_copy = copy time ÷ GAE cold time (1 = the scan runs at copy speed)"}
+    rec.update({"achieved": rec["cold"]["achieved"], "frac": rec["cold"]["frac"], "avg_launch_ms": rec["cold"]["avg_launch_ms"], "state": "cold"})
+    return rec
+
+
+def run_workload(args, wl, world, rank, local_rank, dist, torch, crl, crl_dist, total_envs=None, steps=None, warmup=None, with_gae=True):
+    """One timed run: W warm-up iterations, then exactly K iterations between barriers. Returns (record or None on ranks > 0)."""
+    L = crl._lib
+    spec = WORKLOADS[wl]
+    c3 = spec["c3"]
+    total_envs = total_envs or (args.total_envs if args.total_envs else spec["envs"])
+    steps = steps or args.steps
+    warmup = args.warmup if warmup is None else warmup
+    fwd_flops = FWD_FLOPS_PER_SAMPLE_C3 if c3 else FWD_FLOPS_PER_SAMPLE
+    upd_flops = 3 * fwd_flops                             # forward + backward (≈2x forward) per sample per optimiser pass
+    nt_local, env_off = crl_dist.shard_envs(total_envs, world, rank)
+    cfg = crl.PPOConfig(num_envs=nt_local, num_steps=NUM_STEPS, num_minibatches=args.minibatches,
+                        total_timesteps=total_envs * NUM_STEPS * (steps + warmup + 1))
+    shape = dict(obs_dim=8, n_act=4, hidden=256, env_kind=L.ENV_SYNTHETIC) if c3 else {}
+    opts = parse_opts(args.opt)
+    force = bool(os.environ.get("CRL_COMM_FORCE")) or opts.get("comm_force") == 1
+    if force:
+        opts["comm_force"] = 1
+    agent = crl.Agent(cfg, device=local_rank, env_id_offset=env_off, options=opts, **shape,
+                      shuffle_mode={"bijection": L.SHUFFLE_BIJECTION, "fisher-yates": L.SHUFFLE_FISHER_YATES,
+                                    "blocked-fy": L.SHUFFLE_BLOCKED_FY}[args.shuffle])
+    h = agent.handle
+    comm_used = args.comm
+    if world > 1:
+        comm_used = crl_dist.attach_comm(dist, h, world, rank, args.comm, crl.comm_unique_id, fallback=True)
+        if rank == 0:
+            log(f"bench.py: {world} ranks, exchange = {comm_used}, RCCL version = {rccl_version()}, envs per rank = {nt_local}")
+    elif force and args.comm == "peer":
+        h.comm_peer_attach(h.comm_peer_export(1, 0))   # 1-rank mailbox: the all-reduce kernel still runs (push to self)
+    elif force:
+        h.comm_init(crl.comm_unique_id(), 1, 0)        # 1-GPU box: still route the all-reduces through RCCL
+    h.env_reset()
+
+    def barrier():
+        h.sync(); torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(warmup):
+        h.iterate(1, want_stats=False)
+    barrier()
+    # level 2 = only the update kernel, whose events ride on the dispatch (no extra packets in the timed stream); --kernel-breakdown
+    # (and the layer-wise workload, whose optimiser pass is a group of launches) records events around every kernel class instead
+    h.prof_enable(1 if (args.kernel_breakdown or c3) else 2); h.prof_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        h.iterate(1, want_stats=False)
+    barrier()
+    dt = time.perf_counter() - t0
+    h.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    prof = h.prof_read()
+    ep = h.episode_stats()
+    stats = h.iterate(1)  # one extra, untimed, to read the loss records back
+    reruns = h.exact_reruns
+    options = h.options()
+    fallback_seen = h.get_option("gemm_fallback_seen")
+    gae_rec = None
+    if rank == 0 and not c3 and world == 1 and with_gae:
+        gae_rec = time_gae_standalone(torch, h, nt_local, f"cuda:{local_rank}")
+    agent.close()
+    if rank != 0:
+        return None
+
+    env_steps = total_envs * NUM_STEPS * steps
+    M = nt_local * NUM_STEPS // cfg.num_minibatches
+    upd_ms, upd_n = prof["update"]
+    gae_ms, gae_n = prof["gae"]
+    upd_avg_s = upd_ms / max(upd_n, 1) * 1e-3
+    upd_tflops = upd_flops * M / upd_avg_s / 1e12 if upd_n else 0.0
+    x2 = (options["wide_gemm"] if c3 else options["gemm"]) == 2
+    # matrix-pipe products issued per f32 product of the hidden-layer GEMMs: fp16x2 = 3 f16 MFMAs, bf16x3 = 6 bf16 MFMAs
+    issue_factor = 3.0 if x2 else 6.0
+    hh = 2 * 2 * 64 * 64 if not c3 else 2 * 2 * 256 * 256      # share of the algorithmic flops that runs as h x h products
+    mfma_share = hh / fwd_flops
+    pipe_tflops = upd_tflops * mfma_share * issue_factor
+    strict = args.strict_profiles
+    headline_shape = world == 1 and total_envs == TOTAL_ENVS and wl == "cartpole" and args.minibatches == 4 and not parse_opts(args.opt)
+    traffic, traffic_src = {"update": None, "gae": None}, None
+    if headline_shape:
+        pm, traffic_src = load_profile("pmc_hbm_traffic", strict)
+        if pm:
+            for key, frag in (("update", "update_x2_kernel"), ("gae", "gae_kernel")):
+                for name, rec in pm.get("kernels", {}).items():
+                    if frag in name:
+                        # how FETCH_SIZE compares with bytes for this kernel's access pattern (scripts/summarize_pmc.py)
+                        traffic[key] = (float(rec.get("fetch_factor", 1.0)) * rec["FETCH_SIZE_KB_per_launch_mean"] + rec["WRITE_SIZE_KB_per_launch_mean"]) * 1024
+                        break
+    workload = (f"PPO CartPole-v1-shaped on-device env, num_envs={total_envs} total ({nt_local}/GPU), num_steps={NUM_STEPS}, "
+                f"2x64 actor+critic MLP, update_epochs=4, num_minibatches={cfg.num_minibatches}, anneal_lr") if not c3 else \
+               (f"PPO LunarLander-shaped synthetic env (obs 8, act 4), num_envs={total_envs} total ({nt_local}/GPU), "
+                f"num_steps={NUM_STEPS}, 2x256 actor+critic MLP, update_epochs=4, num_minibatches={cfg.num_minibatches}, anneal_lr")
+    defaults = {k: v for k, v in zip(L.option_names(), [None] * 99)}
+    metric = {"cartpole": "env-steps/sec (whole node), CartPole PPO num_envs=65536 at 1/2/4/8 GPUs",
+              "c2": "env-steps/sec, CartPole PPO num_envs=4096, 2x64 (BASELINE configs[1], side measurement)",
+              "c3": "env-steps/sec, PPO LunarLander-shaped (obs 8 / act 4, 2x256) num_envs=16384 (BASELINE configs[2], side measurement)"}[wl]
+    if c3:
+        roofline = {"bound": "mfma", "kernel": "wide.hip: all forward/backward launches of one minibatch (HIP events around the group)",
+                    "achieved": pipe_tflops, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": pipe_tflops / PEAK_F16_MFMA_TFLOPS,
+                    "traffic": None, "avg_launch_ms": upd_avg_s * 1e3, "launches": upd_n, "flops_per_launch": upd_flops * M,
+                    "f32_equivalent": {"tflops": upd_tflops, "over_f32_mfma_peak": upd_tflops / PEAK_F32_MFMA_TFLOPS},
+                    "note": f"achieved = what the f16 matrix pipe is ISSUED: the 256x256 products ({mfma_share:.0%} of the algorithmic f32 flops, "
+                            f"3 x {fwd_flops:,} per sample) x {issue_factor:g} partial products per f32 product; f32_equivalent = algorithmic flops ÷ time"}
+    else:
+        isa, isa_src = load_profile("update_kernel_isa", strict)
+        tiles_per_role = (M + 31) // 32
+        slots = valu = None
+        if isa:
+            r = isa["roles"]
+            slots = tiles_per_role * (r["actor"]["issue_slots_per_tile"] + r["critic"]["issue_slots_per_tile"])
+            valu = tiles_per_role * (r["actor"]["valu_total"] + r["critic"]["valu_total"])
+        gslots = slots / upd_avg_s / 1e9 if (slots and upd_n) else None
+        roofline = {"bound": "valu-issue", "kernel": "update_x2_kernel (forward + backward of one minibatch, actor and critic blocks)",
+                    "achieved": gslots, "peak": PEAK_VALU_GSLOTS, "unit": "G issue slots/s", "frac": (gslots / PEAK_VALU_GSLOTS) if gslots else None,
+                    "traffic": traffic["update"], "traffic_source": traffic_src if traffic["update"] else None,
+                    "algorithmic_bytes_per_launch": UPDATE_BYTES_PER_SAMPLE * M,
+                    "avg_launch_ms": upd_avg_s * 1e3, "launches": upd_n,
+                    "issue_slots_per_launch": slots, "valu_instructions_per_launch": valu, "isa_source": isa_src,
+                    "frac_of_measured_two_wave_ceiling": (gslots / MEASURED_VALU_GSLOTS_2WAVES) if gslots else None,
+                    "matrix_pipe": {"name": "f16 mfma" if x2 else "bf16 mfma", "issued_tflops": pipe_tflops, "peak": PEAK_F16_MFMA_TFLOPS,
+                                    "frac": pipe_tflops / PEAK_F16_MFMA_TFLOPS},
+                    "f32_equivalent": {"tflops": upd_tflops, "flops_per_launch": upd_flops * M, "over_f32_mfma_peak": upd_tflops / PEAK_F32_MFMA_TFLOPS,
+                                       "note": "algorithmic f32 flops (3 x 17,792 per sample) ÷ launch time; NOT a utilisation: the products do not run on the f32 pipe"},
+                    "note": "the kernel is bound by vector-instruction issue (PMC: profiles/" + PROFILE_TAG + "_pmc_summary.json — the matrix pipe is busy about a quarter of the time, "
+                            "the waves issue or wait for an issue slot most of it). achieved = issue slots per launch ÷ HIP-event launch time, a slot = one plain wave64 "
+                            "VALU instruction (transcendental, Float64 and MFMA issue count 2); peak = one slot per 2 cycles per SIMD x 1024 SIMDs x 2.4 GHz; "
+                            "frac_of_measured_two_wave_ceiling uses what two waves per SIMD were measured to sustain on independent v_fma_f32 (scripts/micro/valu_rate.hip)"}
+    out = {
+        "metric": metric,
+        "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": DTYPE if x2 else "f32 (hidden-layer products as bf16x3 split operands, f32 accumulate)", "data": "synthetic",
+        "config": {"workload": workload, "global_batch": total_envs * NUM_STEPS, "parallelism": f"dp{world}",
+                   "comm": (None if world == 1 and not force else
+                            "rccl all-reduce" if comm_used == "rccl" else
+                            "one-shot peer-mapped all-reduce (csrc/peer.hip)" + (" — RCCL initialisation failed" if "failed" in comm_used else "")),
+                   **({"shared_gpu": f"all {world} ranks time-share GPU 0 (functional check of the multi-rank path, NOT a scaling "
+                                     "measurement)"} if args.share_gpu and world > 1 else {}),
+                   "shuffle": args.shuffle,
+                   "gemm": ("f32 results via fp16x2 split products (3 per f32 product) on the f16 matrix pipe; activation tanh(x) = 1 - 2/(2^(2x·log2 e) + 1) "
+                            "in the update pass and the critic, NNlib tanh_fast in the rollout's actor" if x2 else
+                            "f32 results via bf16x3 split products (6 per f32 product) on the bf16 matrix pipe"),
+                   "options": options, "gemm_fallback_seen": fallback_seen},
+        "roofline": roofline,
+        "kernel_ms_per_step": {k: v[0] / steps for k, v in prof.items() if (args.kernel_breakdown or c3 or v[1] > 0)},
+        "kernel_ms_scope": ("every kernel class (events recorded around the launches; they cost about 0.3 ms per iteration)"
+                            if (args.kernel_breakdown or c3) else
+                            "update kernel only (events attached to its dispatch: no extra packets in the timed stream), plus the all-reduces of a "
+                            "multi-rank run; --kernel-breakdown times every class"),
+        "last_iteration": {"loss": stats[-1]["loss"], "episodes": ep["episodes"],
+                           "mean_episode_return": ep["return_sum"] / max(ep["episodes"], 1.0), "exact_reruns": reruns},
+    }
+    del defaults
+    if gae_rec is not None:
+        gae_rec["traffic"] = traffic["gae"]
+        gae_rec["traffic_source"] = traffic_src if traffic["gae"] else None
+        gae_rec["in_loop"] = ({"launches": gae_n, "avg_launch_ms": gae_ms / max(gae_n, 1)} if gae_n else
+                              {"launches": 0, "note": "inside crl_ppo_iterate the compat-mode scan is fused into the tail of the rollout kernel (each wave "
+                                                      "scans the 32 envs it just stepped, inputs still in L2): no launch, no HBM read of the scan's inputs; "
+                                                      "the figures here are the standalone kernel's"})
+        out["roofline_gae"] = gae_rec
+    return out
+
+
+def run_suite(args, dist, torch, crl, crl_dist):
+    """SURVEY §8(d)'s other lines on one GPU: C2, C3, and the standalone GAE kernel at the four micro-benchmark sizes."""
+    suite = {}
+    for wl, steps in (("c2", 40), ("c3", 5)):
+        a2 = argparse.Namespace(**vars(args)); a2.total_envs = 0; a2.kernel_breakdown = False
+        rec = run_workload(a2, wl, 1, 0, 0, dist, torch, crl, crl_dist, steps=steps, warmup=3, with_gae=False)
+        suite[wl] = {k: rec[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline", "kernel_ms_per_step")}
+        log(f"suite {wl}: {json.dumps(suite[wl])}")
+    gae = {}
+    for nt in (4096, 8192, 16384, 65536):
+        agent = crl.Agent(crl.PPOConfig(num_envs=nt, num_steps=NUM_STEPS), options=parse_opts(args.opt))
+        h = agent.handle
+        h.env_reset(); h.rollout_run()
+        for _ in range(3):
+            h.compute_gae()
+        h.sync()
+        gae[str(nt)] = time_gae_standalone(torch, h, nt, "cuda:0")
+        agent.close()
+        log(f"suite gae nt={nt}: {json.dumps(gae[str(nt)])}")
+    suite["gae_standalone"] = gae
+    return suite
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--total-envs", type=int, default=TOTAL_ENVS)
+    ap.add_argument("--total-envs", type=int, default=0, help="override the workload's env count (0 = the workload's own)")
     ap.add_argument("--minibatches", type=int, default=4, help="num_minibatches (ppo.jl:5); 1 = one optimiser step and one gradient all-reduce per epoch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-breakdown", action="store_true",
@@ -162,10 +465,13 @@ def main():
                          "one device and the run falls back to the peer all-reduce). The line is labelled shared_gpu and is not a scaling measurement")
     ap.add_argument("--shuffle", choices=["bijection", "fisher-yates", "blocked-fy"], default="blocked-fy",
                     help="blocked-fy = exact parallel Fisher-Yates (uniform over S_B like the reference shuffle; default); "
-                         "bijection = keyed pseudo-random permutation (faster, not a uniform draw); fisher-yates = serial exact")
-    ap.add_argument("--workload", choices=["cartpole", "c3"], default="cartpole",
-                    help="cartpole = the headline workload (BASELINE metric); c3 = BASELINE configs[2]: LunarLander-shaped obs 8 / "
-                         "act 4, 2x256 MLP, num_envs=16384 on the synthetic env (a side measurement, not the driver's line)")
+                         "bijection = keyed pseudo-random permutation (not a uniform draw); fisher-yates = serial exact")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cartpole",
+                    help="cartpole = the headline workload (BASELINE metric); c2 = BASELINE configs[1] (num_envs=4096); c3 = BASELINE "
+                         "configs[2]: LunarLander-shaped obs 8 / act 4, 2x256 MLP, num_envs=16384 on the synthetic env (side measurements)")
+    ap.add_argument("--suite", action="store_true", help="N = 1: also measure C2, C3 and the standalone GAE kernel at 4096/8192/16384/65536 envs")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="crl_ppo_set_option for every handle of the run")
+    ap.add_argument("--strict-profiles", action="store_true", help="exit 2 when a committed profile summary is stale (default: report null + warn)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.dry_run or (world == 1 and args.gpus > 1):
@@ -174,11 +480,6 @@ def main():
             return 0
         return spawn_ranks(args, sys.argv[1:])
 
-    c3 = args.workload == "c3"
-    if c3 and args.total_envs == TOTAL_ENVS:
-        args.total_envs = 16384
-    fwd_flops = 272896 if c3 else FWD_FLOPS_PER_SAMPLE
-    upd_flops = 3 * fwd_flops                             # forward + backward (≈2x forward) per sample per optimiser pass
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
@@ -202,7 +503,7 @@ def main():
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)  # control plane; gradients go over RCCL
     if args.rendezvous_only:
         uid = crl_dist.exchange_unique_id(dist, rank, lambda: bytes((7 * i + 3) % 256 for i in range(128))) if world > 1 else b""
-        nt_local, env_off = crl_dist.shard_envs(args.total_envs, world, rank)
+        nt_local, env_off = crl_dist.shard_envs(args.total_envs or TOTAL_ENVS, world, rank)
         ok = torch.tensor([1.0 if (world == 1 or uid[5] == 38) else 0.0])
         if world > 1:
             dist.all_reduce(ok)
@@ -215,168 +516,17 @@ def main():
         return 0
 
     import cleanrl_jl_amd as crl
-    L = crl._lib
     torch.cuda.set_device(local_rank)
-
-    nt_local, env_off = crl_dist.shard_envs(args.total_envs, world, rank)
-    cfg = crl.PPOConfig(num_envs=nt_local, num_steps=NUM_STEPS, num_minibatches=args.minibatches,
-                        total_timesteps=args.total_envs * NUM_STEPS * (args.steps + args.warmup + 1))
-    shape = dict(obs_dim=8, n_act=4, hidden=256, env_kind=L.ENV_SYNTHETIC) if c3 else {}
-    agent = crl.Agent(cfg, device=local_rank, env_id_offset=env_off, **shape,
-                      shuffle_mode={"bijection": L.SHUFFLE_BIJECTION, "fisher-yates": L.SHUFFLE_FISHER_YATES,
-                                    "blocked-fy": L.SHUFFLE_BLOCKED_FY}[args.shuffle])
-    h = agent.handle
-    comm_used = args.comm
-    if world > 1:
-        comm_used = crl_dist.attach_comm(dist, h, world, rank, args.comm, crl.comm_unique_id, fallback=True)
-    elif os.environ.get("CRL_COMM_FORCE") and args.comm == "peer":
-        h.comm_peer_attach(h.comm_peer_export(1, 0))   # 1-rank mailbox: the all-reduce kernel still runs (push to self)
-    elif os.environ.get("CRL_COMM_FORCE"):
-        h.comm_init(crl.comm_unique_id(), 1, 0)  # 1-GPU box: still route the all-reduces through RCCL
-    h.env_reset()
-
-    def barrier():
-        h.sync(); torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        h.iterate(1, want_stats=False)
-    barrier()
-    # level 2 = only the update kernel, whose events ride on the dispatch (no extra packets in the timed stream); --kernel-breakdown
-    # (and the layer-wise workload, whose optimiser pass is a group of launches) records events around every kernel class instead
-    h.prof_enable(1 if (args.kernel_breakdown or c3) else 2); h.prof_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        h.iterate(1, want_stats=False)
-    barrier()
-    dt = time.perf_counter() - t0
-    h.prof_enable(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    prof = h.prof_read()
-    ep = h.episode_stats()
-    stats = h.iterate(1)  # one extra, untimed, to read the loss records back
-    reruns = h.exact_reruns
-
-    # GAE alone, cold (caches flushed by a 1 GiB fill first) and warm (launched again right away): the in-loop launch above
-    # runs right behind the rollout that produced its inputs, so part of what it reads is still cache-resident.
-    gae_bytes = GAE_BYTES_PER_STEP * nt_local * NUM_STEPS + GAE_BYTES_PER_ENV * nt_local
-    gae_cold = gae_warm = None
-    if rank == 0 and not c3 and world == 1:
-        flush = torch.empty(1 << 28, dtype=torch.float32, device=f"cuda:{local_rank}")
-        cold, warm = [], []
-        for i in range(6):
-            flush.fill_(float(i)); torch.cuda.synchronize()
-            h.prof_enable(True); h.prof_reset(); h.compute_gae(); h.sync()
-            cold.append(h.prof_read()["gae"][0])
-            h.prof_reset(); h.compute_gae(); h.sync()
-            warm.append(h.prof_read()["gae"][0]); h.prof_enable(False)
-        del flush
-        cold.sort(); warm.sort()
-        gae_cold, gae_warm = cold[len(cold) // 2], warm[len(warm) // 2]
-    agent.close()
-
+    out = run_workload(args, args.workload, world, rank, local_rank, dist, torch, crl, crl_dist)
     if rank == 0:
-        env_steps = args.total_envs * NUM_STEPS * args.steps
-        M = nt_local * NUM_STEPS // cfg.num_minibatches
-        upd_ms, upd_n = prof["update"]
-        gae_ms, gae_n = prof["gae"]
-        upd_avg_s = upd_ms / max(upd_n, 1) * 1e-3
-        gae_avg_s = gae_ms / max(gae_n, 1) * 1e-3
-        upd_tflops = upd_flops * M / upd_avg_s / 1e12 if upd_n else 0.0
-        gae_gbps = gae_bytes / gae_avg_s / 1e9 if gae_n else 0.0
-        gemm = os.environ.get("CRL_GEMM", "x2")
-        x3 = gemm != "f32"
-        # matrix-pipe products issued per f32 product of the three hidden-layer GEMMs (forward, backward-data, weight gradient):
-        # x2 = fp16x2: 3 (a tile whose cotangents fall outside the launch's scale window takes bf16x3 for its weight gradient: 6);
-        # x3 = bf16x3 everywhere: 6; C3 (wide.hip) runs bf16x3
-        issue_factor = 1.0 if not x3 else (6.0 if (gemm == "x3" or c3) else 3.0)
-        # share of the algorithmic flops that runs as 64x64 (256x256) products = what goes to the matrix pipe
-        hh = 2 * 2 * 64 * 64 if not c3 else 2 * 2 * 256 * 256
-        mfma_share = hh / fwd_flops
-        # HBM traffic per launch from committed rocprofv3 PMC passes of this same command (FETCH_SIZE and WRITE_SIZE in
-        # separate passes, scripts/final_measure.sh): NOT measured inside this run — `traffic_source` names the file.
-        traffic = {"update": None, "gae": None}
-        traffic_file = os.path.join("profiles", f"{PROFILE_TAG}_pmc_hbm_traffic.json")
-        try:
-            pm = json.load(open(os.path.join(ROOT, traffic_file)))
-            if world == 1 and args.total_envs == TOTAL_ENVS and not c3 and args.minibatches == 4:
-                for key, frag in (("update", "update_"), ("gae", "gae_kernel")):
-                    for name, rec in pm.items():
-                        if frag in name and "vfix" not in name:
-                            # how FETCH_SIZE compares with bytes for this kernel's access pattern (scripts/summarize_pmc.py): 2 for
-                            # 16-B-per-lane streaming reads (the guide's gfx950 correction), 1 for gathered 64-byte records
-                            fx = float(rec.get("fetch_factor", 2.0 if rec.get("fetch_x2_corrected") else 1.0))
-                            traffic[key] = (fx * rec["FETCH_SIZE_KB_per_launch_mean"] + rec["WRITE_SIZE_KB_per_launch_mean"]) * 1024
-                            break
-        except Exception:
-            traffic_file = None
-        workload = (f"PPO CartPole-v1-shaped on-device env, num_envs={args.total_envs} total ({nt_local}/GPU), num_steps={NUM_STEPS}, "
-                    f"2x64 actor+critic MLP, update_epochs=4, num_minibatches={cfg.num_minibatches}, anneal_lr") if not c3 else \
-                   (f"PPO LunarLander-shaped synthetic env (obs 8, act 4), num_envs={args.total_envs} total ({nt_local}/GPU), "
-                    f"num_steps={NUM_STEPS}, 2x256 actor+critic MLP, update_epochs=4, num_minibatches={cfg.num_minibatches}, anneal_lr")
-        out = {
-            "metric": "env-steps/sec (whole node), CartPole PPO num_envs=65536 at 1/2/4/8 GPUs" if not c3 else
-                      "env-steps/sec, PPO LunarLander-shaped (obs 8 / act 4, 2x256) num_envs=16384 (BASELINE configs[2], side measurement)",
-            "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload, "global_batch": args.total_envs * NUM_STEPS, "parallelism": f"dp{world}",
-                       "comm": (None if world == 1 and not os.environ.get("CRL_COMM_FORCE") else
-                                "rccl all-reduce" if comm_used == "rccl" else
-                                "one-shot peer-mapped all-reduce (csrc/peer.hip)" + (" — RCCL initialisation failed" if "failed" in comm_used else "")),
-                       **({"shared_gpu": f"all {world} ranks time-share GPU 0 (functional check of the multi-rank path, NOT a scaling "
-                                         "measurement)"} if args.share_gpu and world > 1 else {}),
-                       "shuffle": args.shuffle,
-                       "gemm": ("v_mfma_f32_32x32x2_f32" if not x3 else
-                                "f32 results via bf16x3 split products on the bf16 matrix pipe" if issue_factor == 6.0 else
-                                "f32 results via fp16x2 split products (3 per f32 product) on the f16 matrix pipe")},
-            "roofline": {"bound": "mfma",
-                         "kernel": "update kernel (fwd+bwd of one minibatch, actor+critic)" if not c3 else
-                                   "wide.hip: all forward/backward launches of one minibatch (HIP events around the group)",
-                         "achieved": upd_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": upd_tflops / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": traffic["update"], "traffic_source": traffic_file if traffic["update"] else None,
-                         "algorithmic_bytes_per_launch": UPDATE_BYTES_PER_SAMPLE * M if not c3 else None,
-                         "avg_launch_ms": upd_avg_s * 1e3, "launches": upd_n, "flops_per_launch": upd_flops * M,
-                         "pipe": {"name": "f16/bf16 mfma" if x3 else "f32 mfma",
-                                  "issued_tflops": upd_tflops * mfma_share * issue_factor,
-                                  "peak": PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS,
-                                  "frac": upd_tflops * mfma_share * issue_factor / (PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS)},
-                         "note": f"achieved = ALGORITHMIC f32 flops (3 x {fwd_flops:,} per sample) / HIP-event launch time, against the dense "
-                                 "f32-MFMA peak (SURVEY 8d's denominator): an f32-equivalent figure, which can exceed 1 because that pipe is not the one used. `pipe` prices what is actually issued: the hidden-layer products "
-                                 f"({mfma_share:.0%} of the flops) run as {issue_factor:g} f16/bf16 partial products per f32 product on the matrix pipe, so "
-                                 "pipe.frac is that pipe's utilisation; the rest (tanh, splits, loss, skinny gradients) is VALU work — see "
-                                 f"profiles/{PROFILE_TAG}_*pmc* for the measured issue/wait split"},
-            "roofline_gae": {"bound": "hbm", "kernel": "gae_kernel (advantages + returns), standalone launch (crl_compute_gae)",
-                             "peak": PEAK_HBM_GBPS, "unit": "GB/s", "traffic": traffic["gae"],
-                             "traffic_source": traffic_file if traffic["gae"] else None, "bytes_per_launch": gae_bytes,
-                             "in_loop": ({"launches": gae_n, "avg_launch_ms": gae_avg_s * 1e3, "achieved": gae_gbps, "frac": gae_gbps / PEAK_HBM_GBPS,
-                                          "note": "timed inside the iteration, right behind the rollout (inputs partly cache-resident)"} if gae_n else
-                                         {"launches": 0, "note": "inside crl_ppo_iterate the compat-mode scan is fused into the tail of the rollout "
-                                                                 "kernel (each wave scans the 32 envs it just stepped, inputs still in L2): no launch, no "
-                                                                 "HBM read of the scan's inputs; the figures here are the standalone kernel's"})},
-            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if (args.kernel_breakdown or c3 or v[1] > 0)},
-            "kernel_ms_scope": ("every kernel class (events recorded around the launches; they cost about 0.3 ms per iteration)"
-                                if (args.kernel_breakdown or c3) else
-                                "update kernel only (events attached to its dispatch: no extra packets in the timed stream); "
-                                "--kernel-breakdown times every class"),
-            "last_iteration": {"loss": stats[-1]["loss"], "episodes": ep["episodes"],
-                               "mean_episode_return": ep["return_sum"] / max(ep["episodes"], 1.0), "exact_reruns": reruns},
-        }
-        if gae_cold is not None:
-            for name, ms in (("cold", gae_cold), ("warm", gae_warm)):
-                out["roofline_gae"][name] = {"avg_launch_ms": ms, "achieved": gae_bytes / (ms * 1e-3) / 1e9,
-                                             "frac": gae_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS}
-            # headline figure of the GAE roofline: the standalone launch on cache-cold inputs (caches flushed by a 1 GiB fill)
-            out["roofline_gae"].update({"achieved": out["roofline_gae"]["cold"]["achieved"], "frac": out["roofline_gae"]["cold"]["frac"],
-                                        "avg_launch_ms": gae_cold, "state": "cold"})
-        elif gae_n:
-            out["roofline_gae"].update({"achieved": gae_gbps, "frac": gae_gbps / PEAK_HBM_GBPS, "avg_launch_ms": gae_avg_s * 1e3, "state": "in-loop"})
-        if world == 1 and not args.no_cpu_baseline and not c3:
+        if args.suite and world == 1:
+            out["suite"] = run_suite(args, dist, torch, crl, crl_dist)
+            try:
+                with open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_suite.json"), "w") as f:
+                    json.dump({"source_hash": source_hash(), "headline_value": out["value"], **out["suite"]}, f, indent=1)
+            except OSError as e:
+                log(f"bench.py: could not write the suite file: {e}")
+        if world == 1 and not args.no_cpu_baseline and args.workload == "cartpole":
             out["cpu_baseline"] = cpu_baseline()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
