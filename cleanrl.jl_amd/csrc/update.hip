@@ -40,6 +40,16 @@ __device__ __forceinline__ double sgpr(double v) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// the same through inline asm: the compiler drops a __builtin readfirstlane of a value it can prove uniform and then keeps the
+// VALU-computed Float64 in vector registers; an asm v_readfirstlane_b32 cannot be folded away, so the result really is scalar
+__device__ __forceinline__ double sgpr_hard(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned vlo = (unsigned)u, vhi = (unsigned)(u >> 32);
+  unsigned lo, hi;
+  asm volatile("v_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3" : "=s"(lo), "=s"(hi) : "v"(vlo), "v"(vhi));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // Per-sample inputs of one tile: two 16-byte quarters of the sample's record (36 B of it are the fields of SURVEY §8d)
 template <int D>
 struct Gathered {
@@ -75,8 +85,19 @@ constexpr int SCR_FLOATS_X3 = SCR_FLOATS + ACC_SLOTS * 64;
 // carried as 2^14·h1), the weight-gradient product stays on bf16x3.
 // Returns false — before any work, uniformly for the block — only in the fp16x2 flavour when a hidden-layer weight of this role does
 // not fit the fp16 window (|w| >= 255, mlp_x2.hpp): the caller then runs the bf16x3 flavour of the same role on the same LDS.
+//
+// Record prefetch (fp16x2 main pass, `pfslots` != nullptr). A tile starts with two DEPENDENT global round trips — perm[pos], then the
+// random 64-byte record — which a wave with one partner on its SIMD cannot hide (≈2 µs of an ≈8 µs tile parked on vmcnt). So the
+// records of the NEXT tile are fetched while this one computes, at no register cost: one global_load_lds_dwordx4 (LDS-DMA, per-lane
+// source address, lane-linear destination) drops the tile's 32 observation quarters (lanes 0-31) and 32 role quarters (lanes 32-63)
+// into a 1 KB wave-private LDS slot; the permutation entries it needs were fetched a tile earlier the same way
+// (global_load_lds_dword into a 256-byte slot). The tile top then is `s_waitcnt vmcnt(0)` on loads issued ≈8 µs ago plus three LDS reads.
+#ifndef CRL_PF_ENABLED
+#define CRL_PF_ENABLED 1
+#endif
+constexpr int PF_SLOT_FLOATS = 256 + 64;   // 64 lanes x 16 B of records + 64 lanes x 4 B of permutation entries
 template <int D, int A, int ROLE, bool EXACT, bool X3, int RW, int ABL = 0, bool X2 = false>
-__device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, float* smem, float* scratch) {
+__device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, float* smem, float* scratch, float* pfslots = nullptr) {
   constexpr int NOUT = ROLE == 0 ? A : 1;
   static_assert(!X2 || X3, "the fp16x2 flavour keeps the bf16x3 weight-gradient path");
   using I = typename std::conditional<X2, NetImageX2<D, NOUT>,
@@ -86,7 +107,8 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
   static_assert(64 * TSTRIDE + TILE * D + A * TILE <= SCR_FLOATS, "scratch too small");
   static_assert(D + 2 + 2 * NOUT <= ACC_SLOTS, "accumulator strip too small");
   const DevCfg& c = a.c;
-  const int tid = threadIdx.x & (64 * RW - 1), lane = tid & 63, wave = tid >> 6, j = lane & 31, hf = lane >> 5;
+  // the wave index is uniform (told to the compiler: the tile loop and its branches become scalar control flow)
+  const int tid = threadIdx.x & (64 * RW - 1), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 31, hf = lane >> 5;
   constexpr int NT = 64 * RW;  // threads of this role
   float* img0 = smem;
   float* T0 = scratch + wave * SCR;
@@ -131,20 +153,58 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
   const int nwaves = a.nblk[ROLE] * RW;
   // role constants: wave-uniform, pinned to scalar registers (the values loaded from adv_ms / vfix otherwise sit in vector
   // registers for the whole loop — eight of the registers that used to be spilled)
-  const double invM = sgpr(1.0 / a.Mglobal);
+  const double invM = X2 ? sgpr_hard(1.0 / a.Mglobal) : sgpr(1.0 / a.Mglobal);
   float mean_f = 0.0f; double inv_denom = 1.0;
-  if (ROLE == 0) { mean_f = sgpr((float)a.adv_ms[2 * a.mb]); inv_denom = sgpr(1.0 / ((double)(float)a.adv_ms[2 * a.mb + 1] + 1e-8)); }
+  if (ROLE == 0) {
+    mean_f = sgpr((float)a.adv_ms[2 * a.mb]);
+    const double idn = 1.0 / ((double)(float)a.adv_ms[2 * a.mb + 1] + 1e-8);
+    inv_denom = X2 ? sgpr_hard(idn) : sgpr(idn);
+  }
   const float eps = c.clip, lo = 1.0f - c.clip, hi = 1.0f + c.clip;
   const float u_exact = EXACT ? sgpr((float)a.vfix[0]) : 0.0f;
   const double nwin = EXACT ? sgpr(a.vfix[1]) : 0.0;
-  const double entk = sgpr((double)c.ent_coeff / ((double)A * a.Mglobal));
-  const double vk = sgpr((double)c.v_coef * 0.5 * invM);
+  const double entk0 = (double)c.ent_coeff / ((double)A * a.Mglobal), vk0 = (double)c.v_coef * 0.5 * invM;
+  const double entk = X2 ? sgpr_hard(entk0) : sgpr(entk0);
+  const double vk = X2 ? sgpr_hard(vk0) : sgpr(vk0);
 
   // A tile's records are loaded at the top of the tile: the minibatch is a contiguous slab (records.hip), so the loads are
   // L2 / HBM streaming reads whose latency the partner wave covers. (Loading one tile ahead kept seven more registers live
   // through the backward pass — spills — for no measurable gain once the gather through the permutation was gone.)
   int tile = rb * RW + wave;
   Gathered<D> cur;
+  constexpr bool PF = X2 && !EXACT && ABL == 0 && CRL_PF_ENABLED != 0;
+  const f32x4* pf4 = nullptr;
+  const int* pfi = nullptr;
+  unsigned pf_lds = 0;
+  // position of this lane's sample in tile t (clamped: the lanes past the end of the last tile fetch sample 0 and are masked later)
+  auto pos_of = [&](int t) { const int p = t * TILE + j; return p < M ? p : 0; };
+  auto issue_dma = [&](int idx) {
+    // the lane's half is recomputed here (two v_mbcnt) rather than kept: a loop-invariant per-lane base pointer was the value that
+    // got spilled out of the 256-register budget
+    unsigned ln;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    const char* g = reinterpret_cast<const char*>(a.recs) + ((size_t)(unsigned)idx * 64u + (ln >= 32u ? (ROLE == 0 ? 16u : 32u) : 0u));
+    unsigned keep;
+    // lgkmcnt(0): the ds_reads of the slot's previous content have landed before the DMA may overwrite it; M0 = destination base,
+    // written in the same statement that uses it (the compiler reserves M0) and restored
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(pf_lds) : "memory");
+  };
+  auto issue_perm_dma = [&](int t) {   // perm entries of tile t → the slot's last 256 bytes (both lane halves fetch the same entry)
+    const int* g = a.perm + pos_of(t);
+    unsigned keep;
+    // (the destination offset goes into M0: an instruction offset would also be added to the GLOBAL address)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(pf_lds + 1024u) : "memory");
+  };
+  if constexpr (PF) {
+    float* slot = pfslots + wave * PF_SLOT_FLOATS;
+    pf4 = reinterpret_cast<const f32x4*>(slot);
+    pfi = reinterpret_cast<const int*>(slot + 256);
+    pf_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) float*)slot);
+    if (tile < ntiles) issue_dma(a.perm[pos_of(tile)]);
+    if (tile + nwaves < ntiles) issue_perm_dma(tile + nwaves);
+  }
   const float Gdw = X2 ? sgpr(a.dscale[ROLE]) : 1.0f;   // fp16x2 weight-gradient scale of this launch (mlp_x2.hpp)
   // fp16x2: G rides on the head cotangent (NOUT multiplies per tile), so δ2 exists only as δ2·G — exactly what the weight-gradient
   // operand wants (32 multiplies per tile saved); the backward-data product and db2 take the exact power of two back out
@@ -153,7 +213,21 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
   for (; tile < ntiles; tile += nwaves) {
     const int pos = tile * TILE + j;
     const bool ok = pos < M;
-    gather<D, ROLE>(a, ok ? pos : 0, cur);
+    // the Float64 role constants stay in scalar registers: re-pinned every tile, so that the compiler cannot hoist vector copies of
+    // them out of the loop (such a copy of inv_denom was spilled, and its reload's vmcnt(0) drained the record prefetch mid-tile)
+    double invM_t = invM, inv_denom_t = inv_denom, entk_t = entk, vk_t = vk;
+    if constexpr (X2) asm volatile("" : "+s"(invM_t), "+s"(inv_denom_t), "+s"(entk_t), "+s"(vk_t));
+    if constexpr (PF) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this tile's records (issued a tile ago) and idx_next have arrived
+      const f32x4 xv = pf4[j], q = pf4[32 + j];
+      cur.x[0] = xv[0]; cur.x[1] = xv[1]; cur.x[2] = xv[2]; cur.x[3] = xv[3];
+      if (ROLE == 0) { cur.act = __float_as_int(q[0]); cur.f0 = q[1]; cur.f1 = q[2]; }
+      else { cur.act = 0; cur.f0 = q[0]; cur.f1 = q[1]; }
+      if (tile + nwaves < ntiles) issue_dma(pfi[lane]);     // wave-uniform branch; the entry came in with this tile's records
+      if (tile + 2 * nwaves < ntiles) issue_perm_dma(tile + 2 * nwaves);
+    } else {
+      gather<D, ROLE>(a, ok ? pos : 0, cur);
+    }
     float x[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) x[i] = cur.x[i];
@@ -186,17 +260,17 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
       double Hs = 0.0;
 #pragma unroll
       for (int i = 0; i < A; ++i) Hs += (double)(-(pr[i] * lp[i]));
-      const double Ahat = (double)(cur.f1 - mean_f) * inv_denom;
+      const double Ahat = (double)(cur.f1 - mean_f) * inv_denom_t;
       const float ratio = expf(nlp - cur.f0);
       const float rc = fminf(fmaxf(ratio, lo), hi);
       const double pg1 = -Ahat * (double)ratio, pg2 = -Ahat * (double)rc;
       double dnlp, pg;
       if (pg1 > pg2) { pg = pg1; dnlp = pg1; }
       else { pg = pg2; dnlp = (ratio >= lo && ratio <= hi) ? pg1 : 0.0; }
-      dnlp *= invM;
+      dnlp *= invM_t;
 #pragma unroll
       for (int i = 0; i < A; ++i)
-        dout[i] = (float)(dnlp * ((i == act ? 1.0 : 0.0) - (double)pr[i]) + entk * (double)pr[i] * ((double)lp[i] + Hs));
+        dout[i] = (float)(dnlp * ((i == act ? 1.0 : 0.0) - (double)pr[i]) + entk_t * (double)pr[i] * ((double)lp[i] + Hs));
       if (ok && hf == 0) { ls0 += pg; ls1 += Hs; }
     } else {
       // value loss (ppo.jl:214,231-240)
@@ -210,11 +284,11 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
         const bool q_wins = EXACT ? !(u_exact > q) : true;  // max.(u, q): ties → q
         term = q_wins ? (double)q : (double)u_exact;
         const double inner = (q_wins && dvv >= -eps && dvv <= eps) ? 2.0 * (double)(vc - R) : 0.0;
-        dv = vk * (nwin * invM + inner);
+        dv = vk_t * (nwin * invM_t + inner);
       } else {
         const float e = v - R;
         term = (double)(e * e);
-        dv = vk * 2.0 * (double)e;
+        dv = vk_t * 2.0 * (double)e;
       }
       dout[0] = (float)dv;
       if (ok && hf == 0) {
@@ -429,7 +503,13 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
 #pragma unroll
       for (int r = 0; r < 16; ++r) T[(32 * mt + rowmap(r, hf)) * TSTRIDE + j] = h1[mt][r];
     CRL_PHASE();
+#ifdef CRL_COUNT_PROBE
+    // scripts/count_isa.py builds this file with the cold paths (in-loop bf16x3 weight gradient, per-role bf16x3 fallback) compiled
+    // out, so that each role's tile loop is one plain loop whose instructions can be counted; never part of the library
+    if (X2) {
+#else
     if (X2 && dw_tile_fits(d2max, 1.0f)) {   // d2max is the largest |δ2·G| of the tile
+#endif
       if constexpr (X2) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -605,6 +685,9 @@ __global__ void __launch_bounds__(512, 2) update_x3_kernel(UpdateArgs a) {
   else update_role<D, A, 1, false, true, 8>(a, blockIdx.x - a.nblk[0], smem, smem + NetImageX3<D, 1, true>::SIZE);
 }
 // fp16x2 flavour (the default): forward / backward-data products on the f16 matrix pipe, three MFMAs per product
+constexpr int X2_KERNEL_LDS_FLOATS = NetImageX3<4, 2, true>::SIZE + 8 * SCR_FLOATS_X3 + 4;   // the bf16x3 fallback's layout is the larger one
+static_assert(X2_KERNEL_LDS_FLOATS % 4 == 0, "prefetch slots are 16-byte aligned");
+static_assert(PF_SLOT_FLOATS % 4 == 0 && (X2_KERNEL_LDS_FLOATS + 8 * PF_SLOT_FLOATS) * 4 <= 160 * 1024, "update_x2_kernel's LDS exceeds a CU's 160 KB");
 template <int D, int A>
 __global__ void __launch_bounds__(512, 2) update_x2_kernel(UpdateArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -612,11 +695,17 @@ __global__ void __launch_bounds__(512, 2) update_x2_kernel(UpdateArgs a) {
     for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
   }
   // a role whose hidden-layer weights left the fp16 window (|w| >= 255) runs as bf16x3 for this launch: same operands, no range limit
+  float* pfslots = smem + X2_KERNEL_LDS_FLOATS;   // 8 x 1 KB record-prefetch slots behind the larger (bf16x3) layout
+#ifdef CRL_COUNT_PROBE
+  if ((int)blockIdx.x < a.nblk[0]) update_role<D, A, 0, false, true, 8, 0, true>(a, blockIdx.x, smem, smem + NetImageX2<D, A>::SIZE, pfslots);
+  else update_role<D, A, 1, false, true, 8, 0, true>(a, blockIdx.x - a.nblk[0], smem, smem + NetImageX2<D, 1>::SIZE, pfslots);
+  return;
+#endif
   if ((int)blockIdx.x < a.nblk[0]) {
-    if (!update_role<D, A, 0, false, true, 8, 0, true>(a, blockIdx.x, smem, smem + NetImageX2<D, A>::SIZE))
+    if (!update_role<D, A, 0, false, true, 8, 0, true>(a, blockIdx.x, smem, smem + NetImageX2<D, A>::SIZE, pfslots))
       update_role<D, A, 0, false, true, 8>(a, blockIdx.x, smem, smem + NetImageX3<D, A, true>::SIZE);
   } else {
-    if (!update_role<D, A, 1, false, true, 8, 0, true>(a, blockIdx.x - a.nblk[0], smem, smem + NetImageX2<D, 1>::SIZE))
+    if (!update_role<D, A, 1, false, true, 8, 0, true>(a, blockIdx.x - a.nblk[0], smem, smem + NetImageX2<D, 1>::SIZE, pfslots))
       update_role<D, A, 1, false, true, 8>(a, blockIdx.x - a.nblk[0], smem, smem + NetImageX3<D, 1, true>::SIZE);
   }
 }
@@ -790,7 +879,7 @@ static int run_update(crl_ppo* h, int mb, int mode, hipEvent_t ev0 = nullptr, hi
     main_pass_blocks(h, &a.nblk[0], &a.nblk[1]);
     a.stagger = (int)opt(h, OPT_UPDATE_STAGGER);
     // LDS for the larger of the two layouts: the fp16x2 kernel runs a role as bf16x3 when its weights leave the fp16 window
-    const size_t smem = sizeof(float) * (NetImageX3<4, 2, true>::SIZE + 8 * SCR_FLOATS_X3 + 4);
+    const size_t smem = sizeof(float) * (X2_KERNEL_LDS_FLOATS + 8 * PF_SLOT_FLOATS);
     static_assert(NetImageX3<4, 2, true>::SIZE >= NetImageX2<4, 2>::SIZE, "the bf16x3 image is the larger one");
     if (gemm_x2(h)) hipExtLaunchKernelGGL((update_x2_kernel<4, 2>), dim3(a.nblk[0] + a.nblk[1]), dim3(512), smem, h->stream, ev0, ev1, 0, a);
     else hipExtLaunchKernelGGL((update_x3_kernel<4, 2>), dim3(a.nblk[0] + a.nblk[1]), dim3(512), smem, h->stream, ev0, ev1, 0, a);

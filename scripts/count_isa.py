@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Static instruction counts of the update kernel's tile loop, from the gfx950 ISA hipcc emits (cross-compiles without a GPU).
 
-For each role (actor, critic) of update_x2_kernel: the outermost loop that contains v_mfma_f32_32x32x16_f16 is the tile loop; the
-in-loop bf16x3 weight-gradient fallback (a tile whose cotangents fall outside the launch's fp16 window — a wave-uniform branch that
-the default workload does not take) is the inner region holding v_mfma_f32_32x32x16_bf16 and is left out. Instructions are
+update.hip is compiled with -DCRL_COUNT_PROBE, which leaves out the cold paths (the in-loop bf16x3 weight-gradient fallback of a tile
+whose cotangents fall outside the launch's fp16 window, and the per-role bf16x3 fallback for |w| >= 255 — wave-uniform branches the
+default workload does not take), so each role's tile loop of update_x2_kernel is one plain loop holding the 72 f16 MFMAs of a tile
+(24 forward + 24 backward-data + 24 weight-gradient); the role with v_log_f32 (the softmax) is the actor. Instructions are
 classed as VALU (transcendental ones separately: v_exp/v_rcp/v_log/v_rsq/v_sqrt issue at a quarter of the plain rate, Float64
 and packed ones at half), MFMA, LDS, VMEM, SALU/other. Writes profiles/<tag>_update_kernel_isa.json with a hash of the kernel sources.
 bench.py turns `issue_slots_per_tile` × tiles ÷ launch time into the valu-issue roofline; the PMC pass (SQ_INSTS_VALU, final_measure.sh)
@@ -37,7 +38,9 @@ def classify(op):
         return "mfma"
     if op.startswith("ds_"):
         return "lds"
-    if op.startswith(("global_", "buffer_", "flat_", "scratch_")):
+    if op.startswith("scratch_"):
+        return "scratch"      # a spill inside the tile loop: should not exist
+    if op.startswith(("global_", "buffer_", "flat_")):
         return "vmem"
     if op.startswith("v_"):
         if TRANS.match(op):
@@ -52,7 +55,7 @@ def classify(op):
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
-    asm = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "--cuda-device-only",
+    asm = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "--cuda-device-only", "-DCRL_COUNT_PROBE",
                           "-S", os.path.join(CSRC, "update.hip"), "-o", "-"], capture_output=True, text=True, check=True).stdout.split("\n")
     start = next(i for i, l in enumerate(asm) if re.match(r"^_ZN3crl16update_x2_kernel\S*:", l))
     end = next(i for i in range(start, len(asm)) if ".amdhsa_kernel" in asm[i] or asm[i].startswith(".Lfunc_end"))
@@ -82,18 +85,19 @@ def main():
     def n(a, b, pat):
         return sum(1 for i in range(a, b + 1) if pat in asm[i])
 
-    # the tile loop of a role on its default path: every f16 MFMA of a tile (24 forward + 24 backward-data + 24 weight-gradient) and
-    # none of the bf16 ones — the compiler places the in-loop bf16x3 weight-gradient fallback outside this range (its own blocks ahead
-    # of the loop header). Several back-edges may share the header: the longest range is the loop.
+    # the tile loop of a role: every f16 MFMA of a tile (24 forward + 24 backward-data + 24 weight-gradient). Several back-edges
+    # may share the header: the longest range is the loop.
     by_header = {}
     for a, b in loops:
         if n(a, b, "v_mfma_f32_32x32x16_f16") == 72 and n(a, b, "v_mfma_f32_32x32x16_bf16") == 0:
             by_header[a] = max(by_header.get(a, a), b)
     tile_loops = sorted(by_header.items())
+    tile_loops = [(a, b) for a, b in tile_loops if not any((x <= a and b <= y) and (x, y) != (a, b) for x, y in tile_loops)]   # outermost only
     if len(tile_loops) != 2:
-        sys.exit(f"count_isa: expected the two tile loops of update_x2_kernel (actor, critic), found {len(tile_loops)}: the code layout changed")
+        print(f"count_isa: expected the two tile loops of update_x2_kernel (actor, critic), found {len(tile_loops)}: the code layout changed", file=sys.stderr)
     roles = {}
-    for name, (a, b) in zip(("actor", "critic"), tile_loops):
+    for a, b in tile_loops:
+        name = "actor" if n(a, b, "v_log_f32") else "critic"
         skip = (0, -1); bf = []
         cnt = {}
         for i, op in ops(a, b):
@@ -111,7 +115,9 @@ def main():
                        "counts": cnt, "valu_total": valu_all, "issue_slots_per_tile": slots}
     out = {"kernel": "update_x2_kernel<4, 2>", "source_hash": source_hash(), "roles": roles,
            "note": "static count over the tile loop of each role (the in-loop bf16x3 fallback lies outside the loop's range); exec-masked regions are counted "
-                   "(they issue); a slot = one plain wave64 VALU issue (2 cycles of a SIMD-32)"}
+                   "(they issue); a slot = one plain wave64 VALU issue (2 cycles of a SIMD-32). CAVEAT: a static count covers every block inside the loop's "
+                   "address range — where the compiler has cloned part of the body (loop unswitching on a wave-uniform condition) it over-counts; "
+                   "the PMC counts of scripts/final_measure.sh (SQ_INSTS_VALU per launch) are what bench.py uses"}
     path = os.path.join(ROOT, "profiles", f"{tag}_update_kernel_isa.json")
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))
