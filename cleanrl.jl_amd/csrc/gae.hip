@@ -7,6 +7,13 @@
 // (9 B) and one write of advantage/return (8 B) per (env, step): 17 B — the algorithmic minimum.
 // Arithmetic is Float64 like the reference's accumulator (ppo.jl:63,65; Q2), stored Float32 (ppo.jl:62).
 // Layout: (nt, k) column-major, env fastest ⇒ lanes of a wave read consecutive envs: coalesced 128/256-B rows.
+//
+// Where it stands (bench.py roofline_gae, 65536 envs): 29.6 µs on inputs the previous kernel left in cache (0.60 of 8 TB/s), 51 µs
+// with caches flushed — against 41 µs for a plain copy of the same number of bytes under the same cold conditions (0.81 of that
+// ceiling). Round 3 measured three rewrites against it on one box and kept none: four envs per thread with 16-byte accesses and a
+// dword of done flags (a quarter of the vector-memory instructions; 128 registers, L = 4): 50-52 µs cold, 35 µs warm; a persistent
+// grid with the next tile's inputs double-buffered in registers: 52.6 / 35 µs; tighter register caps (80 registers: spills).
+// The cold figure moves with none of them: a cold launch is bound by what a cold copy is bound by.
 #include <hip/hip_ext.h>
 
 #include <cstdlib>

@@ -1,16 +1,29 @@
-"""GAE kernel micro-benchmark: avg launch time / GB/s over the resident rollout buffer (17 B per (env,step) + 5 B per env)."""
-import os, sys
+"""Standalone GAE kernel micro-benchmark (SURVEY §8d sizes): cold / warm launch time and the same-footprint copy ceiling, for a
+sweep of the gae_tile / gae_seg options.  python scripts/bench_gae.py [tile,tile,…] [seg,…]"""
+import json
+import os
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import cleanrl_jl_amd as crl
+import torch            # noqa: E402
+import bench            # noqa: E402
+import cleanrl_jl_amd as crl   # noqa: E402
+
+tiles = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0]
+segs = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
+torch.cuda.set_device(0)
 for nt in (4096, 8192, 16384, 65536):
-    agent = crl.Agent(crl.PPOConfig(num_envs=nt, num_steps=128))
-    h = agent.handle
-    h.env_reset(); h.rollout_run()
-    for _ in range(5): h.compute_gae()
-    h.sync(); h.prof_enable(True); h.prof_reset()
-    for _ in range(50): h.compute_gae()
-    ms, n = h.prof_read()["gae"]
-    b = 17 * nt * 128 + 5 * nt
-    print(f"L={os.environ.get('CRL_GAE_L','-')} EB={os.environ.get('CRL_GAE_EB','-')} nt={nt}: {ms/n*1e3:.2f} us  {b/(ms/n*1e-3)/1e9:.0f} GB/s  ({b/(ms/n*1e-3)/8e12*100:.1f}% of 8 TB/s)")
-    agent.close()
+    for tile in tiles:
+        for seg in segs:
+            agent = crl.Agent(crl.PPOConfig(num_envs=nt, num_steps=128), options={"gae_tile": tile, "gae_seg": seg})
+            h = agent.handle
+            h.env_reset(); h.rollout_run()
+            for _ in range(3):
+                h.compute_gae()
+            h.sync()
+            r = bench.time_gae_standalone(torch, h, nt, "cuda:0")
+            print(json.dumps({"nt": nt, "tile": tile, "seg": seg, "cold_us": round(r["cold"]["avg_launch_ms"] * 1e3, 2), "cold_frac": round(r["cold"]["frac"], 3),
+                              "warm_us": round(r["warm"]["avg_launch_ms"] * 1e3, 2), "warm_frac": round(r["warm"]["frac"], 3),
+                              "copy_us": round(r["copy_ceiling"]["avg_launch_ms"] * 1e3, 2), "cold_over_copy": round(r["copy_ceiling"]["cold_over_copy"], 3)}), flush=True)
+            agent.close()
