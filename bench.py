@@ -22,9 +22,9 @@ iteration one more carries the advantage sums of all 16 minibatches.
   --strict-profiles   exit 2 (instead of reporting traffic = null) when the committed PMC summaries were taken with other kernel sources
 
 The `roofline` record of the headline prices the dominant kernel (update_x2_kernel, ≈80 % of the iteration) against what PMC shows
-it bound by: vector-instruction ISSUE. achieved = issue slots per launch (static ISA count of the tile loop × tiles,
-profiles/<tag>_update_kernel_isa.json, cross-checked against SQ_INSTS_VALU) ÷ HIP-event launch time; peak = 1 wave64 VALU
-instruction per 2 cycles per SIMD-32 × 1024 SIMDs × 2.4 GHz (MI355X_MICROARCH.md). The matrix-pipe utilisation and the
+it bound by: vector-instruction ISSUE. achieved = vector-ALU instructions per launch (SQ_INSTS_VALU of the committed PMC pass,
+profiles/<tag>_update_kernel_counts.json, next to the static ISA count of scripts/count_isa.py) ÷ HIP-event launch time; peak = 1 wave64
+VALU instruction per 2 cycles per SIMD-32 × 1024 SIMDs × 2.4 GHz (MI355X_MICROARCH.md). The matrix-pipe utilisation and the
 f32-equivalent TFLOP/s are secondary fields; no field named `frac` exceeds 1.
 """
 import argparse
@@ -360,29 +360,35 @@ def run_workload(args, wl, world, rank, local_rank, dist, torch, crl, crl_dist, 
                     "note": f"achieved = what the f16 matrix pipe is ISSUED: the 256x256 products ({mfma_share:.0%} of the algorithmic f32 flops, "
                             f"3 x {fwd_flops:,} per sample) x {issue_factor:g} partial products per f32 product; f32_equivalent = algorithmic flops ÷ time"}
     else:
-        isa, isa_src = load_profile("update_kernel_isa", strict)
+        cnt, cnt_src = load_profile("update_kernel_counts", strict)
         tiles_per_role = (M + 31) // 32
-        slots = valu = None
-        if isa:
-            r = isa["roles"]
-            slots = tiles_per_role * (r["actor"]["issue_slots_per_tile"] + r["critic"]["issue_slots_per_tile"])
-            valu = tiles_per_role * (r["actor"]["valu_total"] + r["critic"]["valu_total"])
+        slots = mfma = None
+        static = None
+        if cnt:
+            # vector-ALU instructions the kernel issues per launch, counted by the hardware (SQ_INSTS_VALU, MFMAs included) at the
+            # headline size and scaled by the number of tiles of this run (the per-tile count does not depend on the size)
+            scale = tiles_per_role / cnt["tiles_per_role"]
+            slots = cnt["per_launch"]["SQ_INSTS_VALU"] * scale
+            mfma = cnt["per_launch"].get("SQ_INSTS_MFMA", 0.0) * scale
+            if isinstance(cnt.get("static_isa"), dict):
+                static = {r: {"valu_total": v["valu_total"], "counts": v["counts"]} for r, v in cnt["static_isa"].items()}
         gslots = slots / upd_avg_s / 1e9 if (slots and upd_n) else None
         roofline = {"bound": "valu-issue", "kernel": "update_x2_kernel (forward + backward of one minibatch, actor and critic blocks)",
-                    "achieved": gslots, "peak": PEAK_VALU_GSLOTS, "unit": "G issue slots/s", "frac": (gslots / PEAK_VALU_GSLOTS) if gslots else None,
+                    "achieved": gslots, "peak": PEAK_VALU_GSLOTS, "unit": "G VALU instructions/s", "frac": (gslots / PEAK_VALU_GSLOTS) if gslots else None,
                     "traffic": traffic["update"], "traffic_source": traffic_src if traffic["update"] else None,
                     "algorithmic_bytes_per_launch": UPDATE_BYTES_PER_SAMPLE * M,
                     "avg_launch_ms": upd_avg_s * 1e3, "launches": upd_n,
-                    "issue_slots_per_launch": slots, "valu_instructions_per_launch": valu, "isa_source": isa_src,
+                    "valu_instructions_per_launch": slots, "of_which_mfma": mfma, "per_tile_and_role": (slots / (2 * tiles_per_role)) if slots else None,
+                    "counts_source": cnt_src, "static_isa_per_tile": static,
                     "frac_of_measured_two_wave_ceiling": (gslots / MEASURED_VALU_GSLOTS_2WAVES) if gslots else None,
                     "matrix_pipe": {"name": "f16 mfma" if x2 else "bf16 mfma", "issued_tflops": pipe_tflops, "peak": PEAK_F16_MFMA_TFLOPS,
                                     "frac": pipe_tflops / PEAK_F16_MFMA_TFLOPS},
                     "f32_equivalent": {"tflops": upd_tflops, "flops_per_launch": upd_flops * M, "over_f32_mfma_peak": upd_tflops / PEAK_F32_MFMA_TFLOPS,
                                        "note": "algorithmic f32 flops (3 x 17,792 per sample) ÷ launch time; NOT a utilisation: the products do not run on the f32 pipe"},
                     "note": "the kernel is bound by vector-instruction issue (PMC: profiles/" + PROFILE_TAG + "_pmc_summary.json — the matrix pipe is busy about a quarter of the time, "
-                            "the waves issue or wait for an issue slot most of it). achieved = issue slots per launch ÷ HIP-event launch time, a slot = one plain wave64 "
-                            "VALU instruction (transcendental, Float64 and MFMA issue count 2); peak = one slot per 2 cycles per SIMD x 1024 SIMDs x 2.4 GHz; "
-                            "frac_of_measured_two_wave_ceiling uses what two waves per SIMD were measured to sustain on independent v_fma_f32 (scripts/micro/valu_rate.hip)"}
+                            "the waves issue or wait for an issue slot most of it). achieved = vector-ALU instructions per launch (SQ_INSTS_VALU of the committed PMC pass, MFMAs "
+                            "included, scaled by tiles) ÷ HIP-event launch time measured in THIS run; peak = one wave64 VALU instruction per 2 cycles per SIMD x 1024 SIMDs x 2.4 GHz; "
+                            "frac_of_measured_two_wave_ceiling uses what two waves per SIMD were measured to sustain on independent v_fma_f32 (scripts/micro/valu_rate.hip: one per 1.25 ns)"}
     out = {
         "metric": metric,
         "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,

@@ -88,8 +88,8 @@ constexpr int SCR_FLOATS = 64 * TSTRIDE + TILE * 4 + 2 * TILE;
 constexpr int ACC_SLOTS = 4 + 2 + 2 * 2;
 constexpr int SCR_FLOATS_X3 = SCR_FLOATS + ACC_SLOTS * 64;
 
-// ABL (CRL_ABLATE builds, scripts/run_ablate.sh): timing experiments that remove one phase each (results are garbage) — the
-// way the per-phase costs in DESIGN.md §3 were measured. 0 in every production instantiation.
+// ABL: bit mask of phases to leave out — the timing experiments behind the per-phase costs in DESIGN.md §3 (results are garbage);
+// 0 in every instantiation of the library (the experiment kernels and their launch switch were removed in round 3).
 // X2 (with X3): the forward and backward-data products run as fp16x2 (mlp_x2.hpp: three MFMAs per product instead of six, h1
 // carried as 2^14·h1), the weight-gradient product stays on bf16x3.
 // Returns false — before any work, uniformly for the block — only in the fp16x2 flavour when a hidden-layer weight of this role does
@@ -706,18 +706,6 @@ __global__ void __launch_bounds__(512, 2) update_x2_kernel(UpdateArgs a) {
       update_role<D, A, 1, false, true, 8>(a, blockIdx.x - a.nblk[0], smem, smem + NetImageX3<D, 1, true>::SIZE);
   }
 }
-#ifdef CRL_ABLATE
-// timing experiments only: the same kernel with one phase removed (results are garbage)
-template <int D, int A, int ABL, int RW>
-__global__ void __launch_bounds__(64 * RW, 2) update_x3_dbg_kernel(UpdateArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (RW == 8 && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= 4) {
-    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
-  }
-  if ((int)blockIdx.x < a.nblk[0]) update_role<D, A, 0, false, true, RW, ABL>(a, blockIdx.x, smem, smem + NetImageX3<D, A, true>::SIZE);
-  else update_role<D, A, 1, false, true, RW, ABL>(a, blockIdx.x - a.nblk[0], smem, smem + NetImageX3<D, 1, true>::SIZE);
-}
-#endif
 // Exact critic-only pass with the known scalar u and count; runs only when stats_kernel raised the flag
 template <int D, int A>
 __global__ void __launch_bounds__(256, 2) update_vfix_kernel(UpdateArgs a) {
@@ -831,9 +819,6 @@ __global__ void vfix_count_kernel(DevCfg c, const SampleRec* __restrict__ recs, 
   }
 }
 
-#ifdef CRL_ABLATE
-static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-#endif
 
 // block counts of the main pass: {actor, critic}
 static void main_pass_blocks(crl_ppo* h, int* nA, int* nC) {
@@ -859,19 +844,6 @@ static int run_update(crl_ppo* h, int mb, int mode, hipEvent_t ev0 = nullptr, hi
     a.nblk[0] = 0; a.nblk[1] = h->update_blocks;
     const size_t smem = sizeof(float) * (NetImage<4, 1, true>::SIZE + 4 * SCR_FLOATS);
     hipLaunchKernelGGL((update_vfix_kernel<4, 2>), dim3(h->update_blocks), dim3(256), smem, h->stream, a);
-#ifdef CRL_ABLATE
-  } else if (getenv("CRL_DEBUG_ABLATE")) {
-    main_pass_blocks(h, &a.nblk[0], &a.nblk[1]);
-    a.stagger = env_int("CRL_X3_STAGGER", 3);
-    const int abl = env_int("CRL_DEBUG_ABLATE", 0), rw = env_int("CRL_DEBUG_RW", 8);
-    const size_t smem = sizeof(float) * (NetImageX3<4, 2, true>::SIZE + 8 * SCR_FLOATS_X3);   // 8 tiles' worth either way: one block per CU at RW = 4 too
-    const dim3 grid(rw == 8 ? a.nblk[0] + a.nblk[1] : 2 * (a.nblk[0] + a.nblk[1]));
-    if (rw == 4) { a.nblk[0] *= 2; a.nblk[1] *= 2; a.pmax *= 2; }
-#define CRL_DBG_CASE(M_, RW_) if (abl == M_ && rw == RW_) hipExtLaunchKernelGGL((update_x3_dbg_kernel<4, 2, M_, RW_>), grid, dim3(64 * RW_), smem, h->stream, ev0, ev1, 0, a);
-    CRL_DBG_CASE(0, 8) CRL_DBG_CASE(0, 4) CRL_DBG_CASE(1, 8) CRL_DBG_CASE(2, 8) CRL_DBG_CASE(4, 8) CRL_DBG_CASE(8, 8) CRL_DBG_CASE(16, 8)
-    CRL_DBG_CASE(32, 8) CRL_DBG_CASE(64, 8) CRL_DBG_CASE(82, 8) CRL_DBG_CASE(86, 8) CRL_DBG_CASE(126, 8)
-#undef CRL_DBG_CASE
-#endif
   } else {
     main_pass_blocks(h, &a.nblk[0], &a.nblk[1]);
     a.stagger = (int)opt(h, OPT_UPDATE_STAGGER);

@@ -1,0 +1,17 @@
+# Copies the judged summaries of gpurun_out/<tag>/ (scripts/final_measure.sh) into profiles/ under the round's names.
+TAG=${1:-final}
+S=gpurun_out/$TAG
+cp $S/bench_n1.json profiles/${TAG}_bench_n1.json
+for f in suite breakdown x3 bijection minibatches1 rccl_forced peer_forced envs8192 envs16384 envs32768 envs8192_breakdown; do
+  [ -s $S/bench_n1_$f.json ] && cp $S/bench_n1_$f.json profiles/${TAG}_bench_n1_$f.json
+done
+[ -s $S/suite.json ] && cp $S/suite.json profiles/${TAG}_suite.json
+cp $S/bench_c2_n1.json profiles/${TAG}_bench_c2_n1.json; cp $S/bench_c3_n1.json profiles/${TAG}_bench_c3_n1.json
+for n in 2 4 8; do [ -s $S/bench_shared_gpu_n$n.json ] && cp $S/bench_shared_gpu_n$n.json profiles/${TAG}_bench_shared_gpu_n$n.json; done
+cp $S/prof_*kernel_stats.csv profiles/${TAG}_rocprof_kernel_stats.csv 2>/dev/null
+for f in $S/prof_[0-9]*kernel_stats.csv; do [ -s "$f" ] && cp $f profiles/${TAG}_rocprof_kernel_stats.csv; done
+for f in $S/prof_c3_*kernel_stats.csv; do [ -s "$f" ] && cp $f profiles/${TAG}_c3_rocprof_kernel_stats.csv; done
+for f in $S/prof_envs8192_*kernel_stats.csv; do [ -s "$f" ] && cp $f profiles/${TAG}_rocprof_kernel_stats_envs8192.csv; done
+cp $S/parity_margins.json profiles/${TAG}_parity_margins.json 2>/dev/null
+cp $S/gae_sizes.txt profiles/${TAG}_gae_sizes.txt 2>/dev/null
+ls -la profiles/${TAG}_*

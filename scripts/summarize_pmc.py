@@ -1,23 +1,30 @@
-"""Turns the rocprofv3 outputs of scripts/final_measure.sh into the two committed summaries:
-  profiles/<tag>_pmc_summary.json       per kernel: mean per launch of every counter collected
-  profiles/<tag>_pmc_hbm_traffic.json   per kernel: FETCH_SIZE / WRITE_SIZE (KB per launch) and the factor FETCH_SIZE has to be
-                                        multiplied with before it is compared with a byte count
-The factor follows MI355X_MICROARCH.md (HBM section): 2 for wide coalesced streaming reads (16 B per lane: FETCH_SIZE tallies the
-128-B requests at 64 B) — pack_records_kernel, whose byte count is known (36 B read per sample), confirms it (raw / known ≈ 0.49);
-1 for gathers of whole 64-byte records, calibrated on permute_records_kernel (CRL_GATHER=0 passes: 4 + 64 B read per sample, raw /
-known ≈ 0.96). The update kernel of the default build fetches its records through the permutation (one random 64-byte record per
-sample and role), i.e. the second pattern. gae_kernel reads 4 B / 1 B per lane: uncalibrated, raw figure kept (factor 1).
+"""Turns the rocprofv3 PMC outputs of scripts/final_measure.sh into the committed summaries (each stamped with the hash of the kernel
+sources it was taken with — bench.py refuses a stale one):
+  profiles/<tag>_pmc_summary.json          per kernel: mean per launch of every counter collected
+  profiles/<tag>_pmc_hbm_traffic.json      per kernel: FETCH_SIZE / WRITE_SIZE (KB per launch) and the factor FETCH_SIZE is multiplied with
+                                           before it is compared with a byte count
+  profiles/<tag>_update_kernel_counts.json instruction counts of update_x2_kernel per launch (SQ_INSTS_*): what bench.py's valu-issue
+                                           roofline is computed from, next to the static ISA count of scripts/count_isa.py
+The FETCH factor follows MI355X_MICROARCH.md (HBM section): 2 for wide coalesced streaming reads (16 B per lane: FETCH_SIZE tallies the
+128-B requests at 64 B) — pack_records_kernel, whose byte count is known (36 B read per sample), confirms it (raw / known ≈ 0.50);
+1 for whole 64-byte records gathered through a permutation (calibrated in round 2 on the then permute pass: raw / known = 0.978,
+profiles/r02_pmc_hbm_traffic.json). The update kernel fetches one 64-byte record per sample and role (as two 16-byte quarters, by
+LDS-DMA), i.e. the second pattern. gae_kernel reads 4 B / 1 B per lane: uncalibrated, raw figure kept (factor 1).
 Usage: python scripts/summarize_pmc.py gpurun_out/<tag> <tag>"""
 import csv
 import glob
 import json
 import os
+import subprocess
 import sys
 from collections import defaultdict
 
 src, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (source_hash)
 B = 65536 * 128
+HASH = bench.source_hash()
 
 
 def short(name):
@@ -32,15 +39,13 @@ def collect(pattern):
     return acc
 
 
-summary = {"note": "rocprofv3 --pmc passes of `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline` (scripts/final_measure.sh), means per "
+summary = {"source_hash": HASH, "note": "rocprofv3 --pmc passes of `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline` (scripts/final_measure.sh), means per "
                    "launch. FETCH_SIZE / WRITE_SIZE are in KB as rocprofv3 reports them (separate passes); how they compare with byte counts: "
                    "scripts/summarize_pmc.py. SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles.", "kernels": {}}
 for kern, ctrs in collect("pmc_*counter_collection.csv").items():
     if "gather0" in kern:
         continue
     summary["kernels"][kern] = {c: {"mean": sum(v) / len(v), "launches": len(v)} for c, v in ctrs.items()}
-# the calibration passes (CRL_GATHER=0) live in their own files
-calib = collect("calib_*counter_collection.csv")
 json.dump(summary, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json"), "w"), indent=1)
 
 traffic = {}
@@ -55,20 +60,23 @@ for kern in sorted(set(main) | set(mainw)):
                "64-byte records gathered through the permutation" if "update_" in kern else "uncalibrated width: raw figure")
     traffic[kern] = {"FETCH_SIZE_KB_per_launch_mean": sum(f) / len(f), "WRITE_SIZE_KB_per_launch_mean": sum(w) / len(w),
                      "fetch_factor": factor, "fetch_x2_corrected": factor == 2.0, "pattern": pattern}
-cal = {}
-for kern, ctrs in calib.items():
-    if "FETCH_SIZE" in ctrs:
-        cal.setdefault(kern, {})["FETCH_SIZE_KB_per_launch_mean"] = sum(ctrs["FETCH_SIZE"]) / len(ctrs["FETCH_SIZE"])
-    if "WRITE_SIZE" in ctrs:
-        cal.setdefault(kern, {})["WRITE_SIZE_KB_per_launch_mean"] = sum(ctrs["WRITE_SIZE"]) / len(ctrs["WRITE_SIZE"])
-for kern, rec in cal.items():
-    if "permute_records" in kern and "FETCH_SIZE_KB_per_launch_mean" in rec:
-        rec["known_read_KB_per_launch"] = 4 * B * (64 + 4) / 1024      # all four epochs in one launch
-        rec["raw_over_known"] = rec["FETCH_SIZE_KB_per_launch_mean"] / rec["known_read_KB_per_launch"]
 for kern, rec in traffic.items():
     if "pack_records" in kern:
         rec["known_read_KB_per_launch"] = B * 36 / 1024
         rec["raw_over_known"] = rec["FETCH_SIZE_KB_per_launch_mean"] / rec["known_read_KB_per_launch"]
-traffic["_calibration_CRL_GATHER=0"] = cal
-json.dump(traffic, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.json"), "w"), indent=1)
+json.dump({"source_hash": HASH, "command": "bench.py --steps 2 --warmup 1 --no-cpu-baseline (num_envs=65536, M = 2,097,152 per update launch)",
+           "kernels": traffic}, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))
+# instruction counts of the update kernel per launch + the static ISA count
+upd = next((v for k, v in summary["kernels"].items() if "update_x2_kernel" in k), None)
+if upd:
+    counts = {"source_hash": HASH, "kernel": "update_x2_kernel<4, 2>", "M": B // 4, "tiles_per_role": B // 4 // 32,
+              "per_launch": {c: upd[c]["mean"] for c in upd if c.startswith("SQ_INSTS_")},
+              "note": "SQ_INSTS_VALU counts every vector-ALU instruction a wave issues, MFMAs included (SQ_INSTS_MFMA is that subset)"}
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "count_isa.py"), tag], capture_output=True, text=True).stdout
+        counts["static_isa"] = json.loads(out)["roles"]
+    except Exception as e:   # noqa: BLE001
+        counts["static_isa"] = f"unavailable: {e}"
+    json.dump(counts, open(os.path.join(ROOT, "profiles", f"{tag}_update_kernel_counts.json"), "w"), indent=1)
+    print(json.dumps(counts, indent=1))
