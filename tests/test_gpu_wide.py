@@ -183,6 +183,36 @@ def test_wide_full_iteration_matches_oracle(crl, D, A, Hd, nt, k):
     agent.close(); st.close()
 
 
+def test_c3_shaped_iteration_at_1024_envs_matches_oracle(crl):
+    """BASELINE configs[2]'s shape (obs 8 / act 4 / 2x256, synthetic env) at num_envs = 1024 — 32 tiles per launch, so the multi-tile
+    paths of the layer-wise kernels run (chunked weight gradients, several blocks per GEMM) — for one whole iteration against the
+    oracle at the north_star bar: actions and permutation bit-equal, advantages / losses within 1e-5 relative, parameters within 1e-5
+    relative L2 per array and 1e-5 absolute."""
+    D, A, Hd, nt, k = 8, 4, 256, 1024, 16
+    cfg = ocfg(nt, k, D, A, Hd)
+    params = spread_params(cfg, 9)
+    off = O.param_offsets(cfg)
+    params[off[4]:off[5]] /= 10
+    agent = make_wide(crl, nt, k, D, A, Hd, params=params, shuffle_mode=0)
+    st = O.State(cfg); st.params[:] = params; st.env_init()
+    h = agent.handle; F = crl._lib
+    h.env_reset()
+    gs = h.iterate(1)
+    os_ = st.iterate(10, gen_perm=True)
+    assert np.array_equal(h.read(F.F_PERM), st.perm)
+    assert np.array_equal(h.read(F.F_ACTION), st.action)
+    assert rel_err(h.read(F.F_ADVANTAGE), st.adv) < RTOL
+    for a, b in zip(gs, os_):
+        for key in ("loss", "pg_loss", "v_loss", "entropy_loss"):
+            assert loss_close(key, a[key], b[key], RTOL), (key, a[key], b[key])
+    pg, po = h.read(F.F_PARAMS).astype(np.float64), st.params.astype(np.float64)
+    for i in range(12):
+        err = np.linalg.norm(pg[off[i]:off[i + 1]] - po[off[i]:off[i + 1]]) / max(np.linalg.norm(po[off[i]:off[i + 1]]), 1e-12)
+        assert err < RTOL, (i, err)
+    assert np.max(np.abs(pg - po)) < 1e-5
+    agent.close(); st.close()
+
+
 def test_wide_rejects_unsupported_shapes(crl):
     for kw, msg in ((dict(hidden=96), "hidden"), (dict(n_act=17, hidden=256), "n_act"), (dict(obs_dim=65, hidden=256), "obs_dim")):
         with pytest.raises(crl.CrlError, match=msg):
