@@ -7,7 +7,8 @@
 # tests/test_host_cpu.py::test_config_struct_matches_header_and_reference_defaults pins (104 bytes).
 module CleanRLHip
 
-export PPOConfig, ppo, get_action, logprob_actions, gae, a2c, dqn, q_values, comm_unique_id, comm_init!, comm_peer_export!, comm_peer_attach!
+export PPOConfig, ppo, get_action, logprob_actions, gae, a2c, dqn, q_values, comm_unique_id, comm_init!, comm_peer_export!, comm_peer_attach!,
+       comm_destroy!, set_option!, get_option
 
 const libcrl = get(ENV, "CLEANRL_HIP_LIB", joinpath(@__DIR__, "..", "cleanrl.jl_amd", "libcleanrl_hip.so"))
 
@@ -126,6 +127,19 @@ function comm_peer_export!(a::Agent, world_size::Integer, rank::Integer)
 end
 comm_peer_attach!(a::Agent, handles::Vector{UInt8}) =
   GC.@preserve handles check(ccall((:crl_comm_peer_attach, libcrl), Int32, (Ptr{Cvoid}, Ptr{UInt8}), a.h, handles))
+
+# Detaches whatever exchange is attached (a launcher falling back from a partially failed RCCL start to the peer all-reduce)
+comm_destroy!(a::Agent) = check(ccall((:crl_comm_destroy, libcrl), Int32, (Ptr{Cvoid},), a.h))
+
+# Per-handle options (include/cleanrl_hip.h lists them): kernel-flavour / numerics switches, integer-valued, by name, e.g.
+# set_option!(agent, "gemm", 1) selects the bf16x3 flavour, set_option!(agent, "guard_window", 1) a read-back per iteration.
+set_option!(a::Agent, key::AbstractString, value::Integer) =
+  check(ccall((:crl_ppo_set_option, libcrl), Int32, (Ptr{Cvoid}, Cstring, Int64), a.h, key, value))
+function get_option(a::Agent, key::AbstractString)
+  v = Ref{Int64}(0)
+  check(ccall((:crl_ppo_get_option, libcrl), Int32, (Ptr{Cvoid}, Cstring, Ref{Int64}), a.h, key, v))
+  v[]
+end
 
 # ppo.jl:75 — same signature; the loop body (ppo.jl:117-253) runs on the GPU, one ccall per update.
 # episode_records > 0 turns on the device ring (crl_episode_ring_enable): every finished episode leaves {return, length, env,

@@ -168,7 +168,8 @@ def test_julia_shell_structs_and_symbols_follow_the_header(crl):
         assert names == [n for n, _ in mirror._fields_], (jname, names)
     called = set(re.findall(r"ccall\(\(:(crl_[a-z_0-9]+),", jl))
     assert called and called <= set(L.EXPORTS), called - set(L.EXPORTS)
-    for must in ("crl_comm_init", "crl_comm_unique_id", "crl_episode_ring_enable", "crl_episode_ring_read", "crl_dqn_run", "crl_dqn_q_values"):
+    for must in ("crl_comm_init", "crl_comm_unique_id", "crl_episode_ring_enable", "crl_episode_ring_read", "crl_dqn_run", "crl_dqn_q_values",
+                 "crl_ppo_set_option", "crl_ppo_get_option", "crl_comm_destroy"):
         assert must in called, must
     assert "shuffle_mode=2" in jl     # exact blocked Fisher-Yates by default, like the ctypes mirror
 
