@@ -69,12 +69,14 @@ __device__ __forceinline__ f32x16 mfma_x2(const P2& a, const P2& b, f32x16 c) {
 //   wf2h[piece][mo][ks][lane][8]  forward A-fragments of W2·2^8, wb2h … of W2ᵀ·2^8; k order = kmap (mlp_x3.hpp)
 //   wf1 / b1c / b2c / w3 / b3 as in NetImage (f32)
 // ------------------------------------------------------------------------------------------------------
-template <int D, int NOUT>
+// BWD = false (the rollout's critic: forward only) leaves the W2ᵀ pieces out: 16 KB less LDS per block, which is what lets a second
+// shuffle block share a CU with a rollout block inside crl_ppo_iterate
+template <int D, int NOUT, bool BWD = true>
 struct NetImageX2 {
   static constexpr int PIECE = 2048;
   static constexpr int WF2H = 0;
   static constexpr int WB2H = WF2H + 2 * PIECE;
-  static constexpr int WF1 = WB2H + 2 * PIECE;
+  static constexpr int WF1 = WB2H + (BWD ? 2 * PIECE : 0);
   static constexpr int B1C = WF1 + 2 * (D / 2) * 64;
   static constexpr int B2C = B1C + 64;
   static constexpr int W3 = B2C + 64;
@@ -83,9 +85,9 @@ struct NetImageX2 {
 };
 
 // returns false (for every thread of the block) when a weight of the hidden layer does not fit the fp16 window
-template <int D, int NOUT>
+template <int D, int NOUT, bool BWD = true>
 __device__ __forceinline__ bool stage_net_x2(float* img, const float* __restrict__ p, int tid, int nthreads, int* lds_flag) {
-  using I = NetImageX2<D, NOUT>;
+  using I = NetImageX2<D, NOUT, BWD>;
   using P = NetParams<D, NOUT>;
   _Float16* wf = reinterpret_cast<_Float16*>(img + I::WF2H);
   _Float16* wb = reinterpret_cast<_Float16*>(img + I::WB2H);
@@ -103,7 +105,7 @@ __device__ __forceinline__ bool stage_net_x2(float* img, const float* __restrict
       const _Float16 h = (_Float16)w;
       wf[idx] = h; wf[4096 + idx] = (_Float16)(w - (float)h);
     }
-    {
+    if (BWD) {
       const float w = p[P::W2 + k + H * row] * X2_W_SCALE;
       const _Float16 h = (_Float16)w;
       wb[idx] = h; wb[4096 + idx] = (_Float16)(w - (float)h);
@@ -169,10 +171,10 @@ __device__ __forceinline__ float tanh_exp2(float x, float pre, float S) { return
 
 // Forward of one network for a 32-sample tile: h1s = 2^14·h1 (what the next product and the backward pass consume), h2 and
 // the head outputs unscaled
-template <int D, int NOUT>
+template <int D, int NOUT, bool BWD = true>
 __device__ __forceinline__ void mlp_forward_x2(const float* img, const float (&x)[D], f32x16 (&h1s)[2], f32x16 (&h2)[2],
                                                float (&out)[NOUT], int lane) {
-  using I = NetImageX2<D, NOUT>;
+  using I = NetImageX2<D, NOUT, BWD>;
   const int hf = lane >> 5;
   f32x16 a0 = load16(img + I::B1C + hf * 32);
   f32x16 a1 = load16(img + I::B1C + hf * 32 + 16);

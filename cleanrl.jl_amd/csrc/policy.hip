@@ -194,9 +194,9 @@ __global__ void __launch_bounds__(512, 2) rollout_cartpole_kernel(RolloutArgs a)
   bool cx2 = CX2;   // block-uniform
   stage_net_x3<D, A, false>(imgA0, a.params, threadIdx.x, blockDim.x);
   if (CX2) {
-    static_assert(NetImageX2<D, 1>::SIZE >= NetImageX3<D, 1, false>::SIZE, "the fp16x2 critic image (forward + backward pieces) is the larger one");
-    int* flag = reinterpret_cast<int*>(imgC0 + NetImageX2<D, 1>::SIZE);
-    if (!stage_net_x2<D, 1>(imgC0, a.params + NetParams<D, A>::SIZE, threadIdx.x, blockDim.x, flag)) {
+    static_assert(NetImageX3<D, 1, false>::SIZE >= NetImageX2<D, 1, false>::SIZE, "the bf16x3 critic image (three pieces) is the larger one");
+    int* flag = reinterpret_cast<int*>(imgC0 + NetImageX3<D, 1, false>::SIZE);
+    if (!stage_net_x2<D, 1, false>(imgC0, a.params + NetParams<D, A>::SIZE, threadIdx.x, blockDim.x, flag)) {
       if (threadIdx.x == 0 && blockIdx.x == 0) a.range_err[0] = 1.0;   // informational: the fallback ran
       cx2 = false;
     }
@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(512, 2) rollout_cartpole_kernel(RolloutArgs a)
     float lpa = lp[0];
 #pragma unroll
     for (int i = 1; i < A; ++i) lpa = (act == i) ? lp[i] : lpa;
-    if (CX2 && cx2) mlp_forward_x2<D, 1>(imgC, co, h1, h2, v, lane);  // ppo.jl:128
+    if (CX2 && cx2) mlp_forward_x2<D, 1, false>(imgC, co, h1, h2, v, lane);  // ppo.jl:128
     else mlp_forward_x3<D, 1, false>(imgC, co, h1, h2, v, lane);
     const bool done = cartpole_step(s, t_env, act);                  // ppo.jl:130
     const float rew = done ? 0.0f : 1.0f;                            // ppo.jl:132 (RLEnvs: reward 0 on the terminal step)
@@ -420,17 +420,19 @@ template <int A>
 __global__ void __launch_bounds__(192) rollout_split3_kernel(RolloutArgs a) {
   constexpr int D = 4;
   using IA = NetImageX3<D, A, false>;
-  using IC = NetImageX2<D, 1>;
+  using IC = NetImageX2<D, 1, false>;
+  constexpr int ICMAX = NetImageX3<D, 1, false>::SIZE;   // room for the bf16x3 fallback image of the critic
+  static_assert(ICMAX >= IC::SIZE, "the bf16x3 critic image (three pieces) is the larger one");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* imgA0 = smem;
   float* imgC0 = imgA0 + IA::SIZE;
-  float4* xch = reinterpret_cast<float4*>(imgC0 + IC::SIZE);               // [2][TILE] observations
+  float4* xch = reinterpret_cast<float4*>(imgC0 + ICMAX);                  // [2][TILE] observations
   bf16x8* pcs = reinterpret_cast<bf16x8*>(reinterpret_cast<float*>(xch) + 2 * TILE * 4);   // [2 waves][2 k-steps][3 pieces][64 lanes]
   float* hd = reinterpret_cast<float*>(pcs + 2 * 2 * 3 * 64);              // [A][64] wave 0's partial head sums
   int* flag = reinterpret_cast<int*>(hd + A * 64);
   stage_net_x3<D, A, false>(imgA0, a.params, threadIdx.x, blockDim.x);
   bool cx2 = true;   // block-uniform: false = the critic's weights left the fp16 window (|w| >= 255) and it runs as bf16x3
-  if (!stage_net_x2<D, 1>(imgC0, a.params + NetParams<D, A>::SIZE, threadIdx.x, blockDim.x, flag)) {
+  if (!stage_net_x2<D, 1, false>(imgC0, a.params + NetParams<D, A>::SIZE, threadIdx.x, blockDim.x, flag)) {
     if (threadIdx.x == 0 && blockIdx.x == 0) a.range_err[0] = 1.0;   // informational: the fallback ran
     cx2 = false;
     stage_net_x3<D, 1, false>(imgC0, a.params + NetParams<D, A>::SIZE, threadIdx.x, blockDim.x);
@@ -714,13 +716,13 @@ int launch_rollout(crl_ppo* h, bool fuse_gae) {
   a.range_err = h->vfix + 5;
   if (gemm_x2(h) && split == 1 && small) {
     // three waves per tile: the actor's hidden rows split over two waves, the critic (fp16x2) on the third
-    const size_t smem = sizeof(float) * (NetImageX3<4, 2, false>::SIZE + NetImageX2<4, 1>::SIZE + 2 * TILE * 4 + 2 * 2 * 3 * 64 * 4 + 2 * 64 + 4);
+    const size_t smem = sizeof(float) * (NetImageX3<4, 2, false>::SIZE + NetImageX3<4, 1, false>::SIZE + 2 * TILE * 4 + 2 * 2 * 3 * 64 * 4 + 2 * 64 + 4);
     hipLaunchKernelGGL((rollout_split3_kernel<2>), dim3(tiles), dim3(192), smem, h->stream, a);
   } else if (split != 0 && small) {   // two waves per tile (actor + env | critic), all bf16x3: rollout_split = 2, or gemm = 1
     const size_t smem = sizeof(float) * (NetImageX3<4, 2, false>::SIZE + NetImageX3<4, 1, false>::SIZE + 2 * TILE * 4);
     hipLaunchKernelGGL((rollout_split_kernel<2>), dim3(tiles), dim3(128), smem, h->stream, a);
   } else {
-    const size_t smem = sizeof(float) * (NetImageX3<4, 2, false>::SIZE + NetImageX2<4, 1>::SIZE + 4);
+    const size_t smem = sizeof(float) * (NetImageX3<4, 2, false>::SIZE + NetImageX3<4, 1, false>::SIZE + 4);   // 53 KB: critic image sized for its bf16x3 fallback
     if (gemm_x2(h)) hipLaunchKernelGGL((rollout_cartpole_kernel<2, true>), dim3(blocks), dim3(64 * wpb), smem, h->stream, a);
     else hipLaunchKernelGGL((rollout_cartpole_kernel<2, false>), dim3(blocks), dim3(64 * wpb), smem, h->stream, a);
   }
