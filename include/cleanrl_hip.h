@@ -142,7 +142,9 @@ int32_t crl_episode_stats_read(crl_ppo* h, crl_episode_stats* out);
 /* Per-episode records of the last rollout (the fields of ppo.jl:157's "Episode Statistics"): off by default; once enabled
  * every episode end appends {return, length, global env id, step of the rollout} to a device ring of `capacity` records
  * (episodes beyond that are counted, not stored). Records come back in arrival order — sort by (step, env) for the
- * reference's logging order (ppo.jl:147-165 walks the done envs of one step in ascending order). */
+ * reference's logging order (ppo.jl:147-165 walks the done envs of one step in ascending order). The ring holds the LAST rollout only:
+ * when a speculation guard window is replayed (crl_ppo_exact_reruns), the records are those of the replayed rollouts — the
+ * speculative ones they overwrite are not kept. */
 typedef struct crl_episode_record { float episode_return; int32_t episode_length; int32_t env; int32_t step; } crl_episode_record;
 int32_t crl_episode_ring_enable(crl_ppo* h, int32_t capacity);
 int32_t crl_episode_ring_read(crl_ppo* h, crl_episode_record* out, int32_t max_records, int32_t* n_stored, int64_t* n_episodes);
