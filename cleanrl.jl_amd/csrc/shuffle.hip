@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256, 4) bfy_leaf_kernel(uint32_t K1, uint64_t 
   int32_t* perm = perm0 + (size_t)blockIdx.y * n;
   if (*err) return;
   __shared__ int32_t buf[BFY_CAP], buf2[BFY_CAP];
-  __shared__ uint8_t dig[BFY_CAP];
+  __shared__ uint8_t dig[BFY_CAP], dsub[BFY_CAP];   // sub-bucket of the element at a pre-scatter / post-scatter position
   __shared__ uint32_t cnt[256], soff[257], run[256];
   const uint32_t d1 = blockIdx.x;
   const uint32_t base = off[d1], c = off[d1 + 1] - base;
@@ -165,16 +165,16 @@ __global__ void __launch_bounds__(256, 4) bfy_leaf_kernel(uint32_t K1, uint64_t 
 #pragma unroll 1
   for (uint32_t idx = t; idx < c; idx += 256) {
     const uint32_t d2 = dig[idx];
-    buf[soff[d2] + atomicAdd(&run[d2], 1u)] = buf2[idx];
+    const uint32_t pos = soff[d2] + atomicAdd(&run[d2], 1u);
+    buf[pos] = buf2[idx];
+    dsub[pos] = (uint8_t)d2;     // travels with the element: the rank pass below needs no search for the sub-bucket that owns a position
   }
   __syncthreads();
   // canonical order: every element counts the smaller members of its sub-bucket (values are distinct) and moves there
 #pragma unroll 1
   for (uint32_t idx = t; idx < c; idx += 256) {
     const int32_t v = buf[idx];
-    uint32_t d2 = 0;                        // the sub-bucket that owns position idx: soff[d2] <= idx < soff[d2+1]
-#pragma unroll
-    for (uint32_t step = 128; step >= 1; step >>= 1) d2 += (soff[d2 + step] <= idx) ? step : 0u;
+    const uint32_t d2 = dsub[idx];          // the sub-bucket that owns position idx: soff[d2] <= idx < soff[d2+1]
     const uint32_t lo = soff[d2], hi = soff[d2 + 1];
     uint32_t r = 0;
     for (uint32_t p = lo; p < hi; ++p) r += (buf[p] < v) ? 1u : 0u;
@@ -248,8 +248,8 @@ static int launch_blocked_fy(crl_ppo* h, uint64_t epoch_id, int nslots, bool fus
   uint32_t* ws = h->bfy_ws + (size_t)h->cur_slot * BFY_WS_STRIDE;
   const size_t sstride = (size_t)K1 * BFY_CAP;
   int32_t* S = h->perm_tmp + (size_t)h->cur_slot * sstride;
-  for (int z = 0; z < nslots; ++z)   // the buckets' cursors
-    CRL_HIP_CHECK(hipMemsetAsync(ws + (size_t)z * BFY_WS_STRIDE + 2 * BFY_MAXK1 + 1, 0, sizeof(uint32_t) * K1, h->stream));
+  // the buckets' cursors of all slots in one strided fill
+  CRL_HIP_CHECK(hipMemset2DAsync(ws + 2 * BFY_MAXK1 + 1, sizeof(uint32_t) * BFY_WS_STRIDE, 0, sizeof(uint32_t) * K1, (size_t)nslots, h->stream));
   const uint64_t seed = shuffle_seed(h);
   const bool big = n >= (4 << 20);
   const int t1 = big ? 1024 : 256, chunks = (n + t1 * 32 - 1) / (t1 * 32);
