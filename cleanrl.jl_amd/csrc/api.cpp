@@ -566,16 +566,6 @@ int32_t crl_compute_gae(crl_ppo* h) {
 
 static int check_bfy(crl_ppo* h) {
   if (peer_check(h)) return 1;
-  if (wide_x2_active(h)) {
-    double re = 0.0;
-    CRL_HIP_CHECK(hipMemcpyAsync(&re, h->vfix + 6, sizeof(re), hipMemcpyDeviceToHost, h->stream));
-    CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
-    if (re != 0.0) {
-      set_error("a 256-wide hidden-layer weight reached |w| >= 255: outside the fp16x2 window of the layer-wise path (wide.hip); "
-                "results since the last check are invalid — set option wide_gemm = 1 (bf16x3) and rerun");
-      return 1;
-    }
-  }
   if (h->cfg.shuffle_mode != CRL_SHUFFLE_BLOCKED_FY) return 0;
   uint32_t err = 0;
   for (int z = 0; z < h->cfg.update_epochs && !err; ++z) {
@@ -903,6 +893,7 @@ int32_t crl_ppo_get_option(crl_ppo* h, const char* key, int64_t* value) {
   if (key && std::strcmp(key, "gemm_fallback_seen") == 0) {
     // read-only: 1 once a launch has run a role as bf16x3 because a hidden-layer weight left the fp16x2 window (|w| >= 255)
     double re = 0.0;
+    if (h->wide) { *value = 0; return 0; }   // the layer-wise path scales its fp16x2 weight pieces per step: it has no fallback to take
     CRL_HIP_CHECK(hipMemcpyAsync(&re, h->vfix + 5, sizeof(re), hipMemcpyDeviceToHost, h->stream));
     CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
     *value = re != 0.0 ? 1 : 0;

@@ -55,6 +55,7 @@ struct WideWs {
   WideNetPack pk[2]; int pk_base[2];
   float* pack = nullptr;         // padded / transposed weight copies, rebuilt after every parameter change
   bool pack_dirty = true;
+  float* wsc = nullptr;          // [2 networks][scale, 1/scale]: the power of two the fp16x2 pieces of W2 are staged with (wide_w2scale_kernel)
   float *h1[2] = {nullptr, nullptr}, *h2[2] = {nullptr, nullptr};  // [H × Mw] tanh activations, actor / critic
   float* z = nullptr;            // [A8 × Mw] logits, overwritten by their cotangent
   float* v = nullptr;            // [Mw] critic outputs
@@ -89,7 +90,7 @@ void wide_destroy(crl_ppo* h) {
   if (!w) return;
   void* ptrs[] = {w->pack, w->h1[0], w->h1[1], w->h2[0], w->h2[1], w->z, w->v, w->dv8, w->dA, w->dB, w->pW2[0], w->pW2[1],
                   w->pB2[0], w->pB2[1], w->pW1[0], w->pW1[1], w->pB1[0], w->pB1[1], w->pW3[0], w->pW3[1], w->lpart, w->vpart,
-                  w->u_dev};
+                  w->u_dev, w->wsc};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete w;
   h->wide_ws = nullptr;
@@ -109,6 +110,7 @@ int wide_create(crl_ppo* h) {
   const size_t H = (size_t)w->H, Mw = (size_t)w->Mw;
   int rc = 0;
   rc |= walloc(&w->pack, (size_t)w->pk[0].size + w->pk[1].size);
+  rc |= walloc(&w->wsc, 4);
   for (int n = 0; n < 2; ++n) { rc |= walloc(&w->h1[n], H * Mw); rc |= walloc(&w->h2[n], H * Mw); }
   rc |= walloc(&w->z, (size_t)w->A8 * Mw); rc |= walloc(&w->v, Mw); rc |= walloc(&w->dv8, 8 * Mw);
   rc |= walloc(&w->dA, H * Mw); rc |= walloc(&w->dB, H * Mw);
@@ -181,10 +183,29 @@ __global__ void __launch_bounds__(256) wide_pack_x3_kernel(const float* __restri
   reinterpret_cast<bf16x8*>(dst)[2 * 1024 + fr] = p3.lo;
 }
 
-// fp16x2 A-fragments of W2·2^8 / W2ᵀ·2^8 (same fragment order as wide_pack_x3_kernel, two pieces); a weight that does not
-// fit the fp16 window (|w| ≥ 255) raises *range_err (checked by the host at its next synchronisation)
+// The power of two the 256-wide fp16x2 weight pieces are staged with: largest |w|·scale lands in [2^14, 2^15), so W2 fits the fp16
+// window whatever its magnitude (the fused 64-wide kernels use a fixed 2^8 and fall back to bf16x3 for |w| >= 255; round 2 raised an
+// error here instead). A power of two is exact, and the GEMM epilogues take it back out of the f32 accumulator (DenseX3Args::wsc).
+__global__ void __launch_bounds__(1024) wide_w2scale_kernel(const float* __restrict__ W2, int n, float* __restrict__ wsc) {
+  __shared__ float sm[16];
+  float m = 0.0f;
+  for (int i = threadIdx.x; i < n; i += 1024) m = __builtin_fmaxf(m, __builtin_fabsf(W2[i]));
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) m = __builtin_fmaxf(m, sm[w]);
+    int e = (int)((__float_as_uint(m) >> 23) & 0xFFu);          // biased exponent: m in [2^(e-127), 2^(e-126))
+    if (!(m > 0.0f) || e >= 255) e = 127 + 6;                   // all zero / non-finite weights: 2^8 as in the fused kernels
+    e = e < 40 ? 40 : (e > 220 ? 220 : e);
+    wsc[0] = __uint_as_float((unsigned)(127 + 14 + 127 - e) << 23);   // 2^(14 − (e − 127)): m·scale in [2^14, 2^15)
+    wsc[1] = __uint_as_float((unsigned)(e - 14) << 23);               // its inverse
+  }
+}
+// fp16x2 A-fragments of W2·scale / W2ᵀ·scale (same fragment order as wide_pack_x3_kernel, two pieces)
 __global__ void __launch_bounds__(256) wide_pack_x2_kernel(const float* __restrict__ params, float* __restrict__ pack, int pbase,
-                                                          int kbase, WideNetPack pk, double* range_err) {
+                                                          int kbase, WideNetPack pk, const float* __restrict__ wsc) {
   constexpr int H = 256;
   const int t = blockIdx.x * 256 + threadIdx.x;          // (dir, s, kstep, ntile, lane)
   if (t >= 2 * 8 * 2 * 8 * 64) return;
@@ -192,14 +213,12 @@ __global__ void __launch_bounds__(256) wide_pack_x2_kernel(const float* __restri
   const int n = 32 * ntile + (lane & 31), k0 = 32 * sl + 16 * kstep + 8 * (lane >> 5);
   float x[8];
   const float* W = params + pbase;
-  bool bad = false;
+  const float scale = wsc[0];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const float w = dir ? W[(k0 + e) + H * n] : W[n + H * (k0 + e)];
-    bad |= !(__builtin_fabsf(w) < X2_W_LIMIT);
-    x[e] = w * X2_W_SCALE;
+    x[e] = w * scale;
   }
-  if (bad) *range_err = 1.0;
   const P2 p2 = split2(x);
   _Float16* dst = reinterpret_cast<_Float16*>(pack + kbase + (dir ? pk.x2b : pk.x2f)) + (size_t)sl * X2_SLAB_F16;
   const int fr = (kstep * 8 + ntile) * 64 + lane;
@@ -234,8 +253,10 @@ static int ensure_pack(crl_ppo* h) {
     if (w->H == 256) {
       hipLaunchKernelGGL(wide_pack_x3_kernel, dim3(2 * 8 * 2 * 8 * 64 / 256), dim3(256), 0, h->stream, h->params, w->pack,
                          (n ? (int)h->Pa : 0) + w->H * w->D + w->H, w->pk_base[n], w->pk[n]);
+      hipLaunchKernelGGL(wide_w2scale_kernel, dim3(1), dim3(1024), 0, h->stream, h->params + (n ? (int)h->Pa : 0) + w->H * w->D + w->H,
+                         w->H * w->H, w->wsc + 2 * n);
       hipLaunchKernelGGL(wide_pack_x2_kernel, dim3(2 * 8 * 2 * 8 * 64 / 256), dim3(256), 0, h->stream, h->params, w->pack,
-                         (n ? (int)h->Pa : 0) + w->H * w->D + w->H, w->pk_base[n], w->pk[n], h->vfix + 6);
+                         (n ? (int)h->Pa : 0) + w->H * w->D + w->H, w->pk_base[n], w->pk[n], w->wsc + 2 * n);
     }
     hipLaunchKernelGGL(wide_wmax_kernel, dim3(1), dim3(64), 0, h->stream,
                        h->params + (n ? (int)h->Pa : 0) + w->H * w->D + w->H + w->H * w->H + w->H, NO, w->H,
@@ -509,6 +530,7 @@ struct DenseX3Args {
   // fp16x2 backward-data (wide_dense_x2_kernel<EPI_DTANH>): the head cotangent and wmax, from which each sample's scale comes
   const float* bz; int bld; int bA; const float* wmax;
   int fast_act = 0;   // as DenseArgs::fast_act
+  const float* wsc = nullptr;   // fp16x2 kernels: {scale, 1/scale} of this network's W2 pieces (wide_w2scale_kernel)
 };
 constexpr int X3ROW = 40;                // bf16 per staged sample row per piece: 32 k + 8 pad (80 B: conflict-free b128)
 
@@ -857,7 +879,7 @@ __device__ __forceinline__ void wide_dense_x2_body(const DenseX3Args& a) {
     wave_lds_fence();
 #pragma unroll
     for (int y = 0; y < TM; ++y)
-      tile_tanh_head(scr, acc[y], lane, wave * 32, 32 * y, m0 + 32 * y, a.M, a.bias, a.Y, a.W3t, a.A, hp, hs, X2_FWD_UNSCALE, a.fast_act != 0);
+      tile_tanh_head(scr, acc[y], lane, wave * 32, 32 * y, m0 + 32 * y, a.M, a.bias, a.Y, a.W3t, a.A, hp, hs, a.wsc[1] * (1.0f / X2_ACT_SCALE), a.fast_act != 0);
     __syncthreads();
     for (int i = tid; i < MB * a.A; i += NT) {
       const int m = i / a.A, aa = i - m * a.A;
@@ -871,7 +893,7 @@ __device__ __forceinline__ void wide_dense_x2_body(const DenseX3Args& a) {
 #pragma unroll
   for (int y = 0; y < TM; ++y)
     tile_out_x2<EPI>(scr, acc[y], lane, wave * 32, 32 * y, m0 + 32 * y, a.M, a.bias, a.S, a.Y,
-                     EPI == EPI_TANH ? X2_FWD_UNSCALE : 1.0f / X2_W_SCALE, sc + MB, a.fast_act != 0);
+                     EPI == EPI_TANH ? a.wsc[1] * (1.0f / X2_ACT_SCALE) : a.wsc[1], sc + MB, a.fast_act != 0);
 }
 
 template <int EPI, int TM>
@@ -953,7 +975,7 @@ static int wide_forward(crl_ppo* h, int net, const float* X, int ldx, const int3
     const bool fuse = true;   // the head comes out of the layer-2 epilogue (tile_tanh_head)
     x.W3t = pk + w->pk[net].w3t; x.b3 = P + o.b3; x.Z = fuse ? out : nullptr; x.A = NO; x.ldz = ldo;
     x.dZ = nullptr; x.ldd = 0; x.Ad = 0; x.bz = nullptr; x.bld = 0; x.bA = 0; x.wmax = nullptr; x.fast_act = fast_act ? 1 : 0;
-    if (wide_x2(h)) { x.Wx3 = pk + w->pk[net].x2f; if (dense_x2_launch<EPI_TANH>(h->stream, x)) return 1; }
+    if (wide_x2(h)) { x.Wx3 = pk + w->pk[net].x2f; x.wsc = w->wsc + 2 * net; if (dense_x2_launch<EPI_TANH>(h->stream, x)) return 1; }
     else if (dense_x3_launch<EPI_TANH>(h->stream, x)) return 1;
     if (fuse) return 0;   // the head came out of the layer-2 epilogue
   } else {
@@ -989,6 +1011,7 @@ static int wide_forward_pair(crl_ppo* h, const float* X, int ldx, int M, float* 
     x[net].Wx3 = pk + w->pk[net].x2f; x[net].X = w->h1[net]; x[net].K = H; x[net].bias = P + o.b2; x[net].S = nullptr; x[net].Y = w->h2[net]; x[net].M = M;
     x[net].W3t = pk + w->pk[net].w3t; x[net].b3 = P + o.b3; x[net].Z = net ? outC : outA; x[net].A = NO; x[net].ldz = net ? ldoC : ldoA;
     x[net].dZ = nullptr; x[net].ldd = 0; x[net].Ad = 0; x[net].bz = nullptr; x[net].bld = 0; x[net].bA = 0; x[net].wmax = nullptr; x[net].fast_act = fast;
+    x[net].wsc = w->wsc + 2 * net;
   }
   hipLaunchKernelGGL((wide_dense_pair_kernel<4, 2, 1, 1, EPI_TANH>), dim3((M + 31) / 32, 2), dim3(256), sizeof(float) * (32 * 256 + 32 * WXS), h->stream, a[0], a[1]);
   const size_t s0 = dense_x2_smem(x[0], 32), s1 = dense_x2_smem(x[1], 32);
@@ -1973,7 +1996,7 @@ static int wide_backward(crl_ppo* h, int net, const float* dOut, int ldd, const 
     x.W3t = pk + w->pk[net].w3t; x.b3 = nullptr; x.Z = nullptr; x.A = 0; x.ldz = 0;
     x.dZ = fuse2 ? dOut : nullptr; x.ldd = ldd; x.Ad = NO;
     x.bz = dOut; x.bld = ldd; x.bA = NO; x.wmax = pk + w->pk[net].wmax;
-    if (x2) { x.Wx3 = pk + w->pk[net].x2b; if (dense_x2_launch<EPI_DTANH>(h->stream, x)) return 1; }
+    if (x2) { x.Wx3 = pk + w->pk[net].x2b; x.wsc = w->wsc + 2 * net; if (dense_x2_launch<EPI_DTANH>(h->stream, x)) return 1; }
     else if (dense_x3_launch<EPI_DTANH>(h->stream, x)) return 1;
   } else {
     d.W = pk + w->pk[net].w2t; d.Kp = H; d.X = w->dA; d.ldx = H; d.Kt = H; d.S = w->h1[net]; d.lds = H; d.Y = w->dB; d.ldy = H; d.Nt = H;

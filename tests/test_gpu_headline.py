@@ -128,3 +128,33 @@ def test_unfused_and_fused_gae_agree_at_the_headline_size(crl):
     adv1, adv2 = a1.handle.read(F.F_ADVANTAGE), a2.handle.read(F.F_ADVANTAGE)
     assert np.sum(adv1 != adv2) <= adv1.size * 1e-6 and rel_err(adv2, adv1) < 1e-6
     a1.close(); a2.close()
+
+
+@pytest.mark.parametrize("nt,gae_mode,stale", [(40013, 0, 1), (20011, 1, 0)])
+def test_ragged_large_shards_match_the_oracle(crl, nt, gae_mode, stale):
+    """Env counts that are no multiple of 32 (a partly filled last tile, 8 and 4 waves per block) at sizes the small ragged cases (33,
+    37, 70 envs) do not reach, with the other GAE mode (fixed: bootstrap critic pass + standalone scan, never fused) and fresh
+    observations after a reset: one whole iteration's buffers against the oracle."""
+    F = crl._lib
+    cfg = crl.PPOConfig(num_envs=nt, num_steps=K, total_timesteps=nt * K * 10, num_minibatches=1)
+    agent = crl.Agent(cfg, gae_mode=gae_mode, stale_obs=stale)
+    h = agent.handle
+    params = agent.get_params()
+    cfgo = O.make_config(num_envs=nt, num_steps=K, num_minibatches=1, gae_mode=gae_mode, stale_obs=stale)
+    st = O.State(cfgo); st.params[:] = params
+    st.env_init(); st.rollout(); st.compute_gae()
+    h.env_reset()
+    h.iterate(1, want_stats=False)
+    act = h.read(F.F_ACTION)
+    diff = act != st.action
+    clean = ~diff.any(axis=1)
+    for e in np.flatnonzero(~clean):
+        t = int(np.argmax(diff[e]))
+        m = knot_margin(cfgo, params, st.obs[:, e, t], e, t)
+        assert m <= 1e-6, f"env {e} step {t}: action differs although the draw is {m:.3e} away from the CDF knot"
+    assert clean.mean() > 0.999
+    assert np.array_equal(h.read(F.F_OBS)[:, clean], st.obs[:, clean])
+    assert np.array_equal(h.read(F.F_TERMINAL)[clean], st.terminal[clean]) and np.array_equal(h.read(F.F_REWARD)[clean], st.reward[clean])
+    assert rel_err(h.read(F.F_VALUE)[clean], st.value[clean]) < RTOL and rel_err(h.read(F.F_LOGPROB)[clean], st.logprob[clean]) < RTOL
+    assert rel_err(h.read(F.F_ADVANTAGE)[clean], st.adv[clean]) < RTOL and rel_err(h.read(F.F_RETURN)[clean], st.ret[clean]) < RTOL
+    agent.close(); st.close()

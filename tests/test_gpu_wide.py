@@ -136,6 +136,45 @@ def test_wide_update_gradient_matches_oracle(crl, D, A, Hd, nt, k, ret_scale, cl
     agent.close(); st.close()
 
 
+def test_wide_fp16x2_weight_scale_follows_the_weights(crl):
+    """The 256-wide fp16x2 products stage W2 with a power of two taken from the largest |w| of the network at every optimiser step
+    (wide_w2scale_kernel), so a weight of 300 — outside the fixed 2^8 window of rounds 1-2, where it raised an error — and a network
+    whose weights are all tiny both run on the fp16x2 path at full accuracy: gradient, rollout actions and values match the oracle,
+    nothing raises. (Bars: 1e-5 as everywhere; 3e-5 on the gradient arrays of the 300-weight case, whose pre-activations are 300 times
+    larger and carry float32 summation-order noise in proportion on both sides.)"""
+    D, A, Hd, nt, k = 8, 4, 256, 8, 128
+    rng = np.random.default_rng(5)
+    cfg = ocfg(nt, k, D, A, Hd)
+    base = O.orthogonal_params(cfg, 5) + (0.05 * rng.standard_normal(O.lib().orc_param_count(cfg))).astype(np.float32)
+    off = O.param_offsets(cfg)
+    agent = make_wide(crl, nt, k, D, A, Hd, params=base)
+    h = agent.handle; F = crl._lib
+    st = O.State(cfg)
+    for case in ("big", "tiny", "plain"):
+        params = base.copy()
+        if case == "big":
+            params[off[8] + 7] = 300.0               # critic W2
+            params[off[2] + 11] = -300.0             # actor W2
+        elif case == "tiny":
+            params[off[2]:off[3]] *= 1e-4; params[off[8]:off[9]] *= 1e-4
+        agent.set_params(params); st.params[:] = params
+        inject(crl, agent, st, rng, D, A, 10.0)
+        h.adv_stats()
+        M = nt * k // 4
+        gs = h.update_minibatch(2, 0.0, apply_update=False)
+        g_o, so = O.loss_grad(cfg, params, st.obs.reshape(D, -1, order="F"), st.action, st.logprob, st.value, st.adv, st.ret, st.perm[2 * M:3 * M])
+        for key in ("loss", "pg_loss", "v_loss", "entropy_loss"):
+            assert loss_close(key, gs[key], so[key], RTOL), (case, key, gs[key], so[key])
+        _grad_close(h.read(F.F_GRADS), g_o, off, tol=3e-5 if case == "big" else RTOL)
+        h.sync()                                     # no error is pending
+    params = base.copy(); params[off[8] + 7] = 300.0
+    agent.set_params(params)
+    st2 = O.State(cfg); st2.params[:] = params; st2.env_init()
+    h.env_reset(); h.rollout_run(); st2.rollout()
+    assert np.array_equal(h.read(F.F_ACTION), st2.action) and rel_err(h.read(F.F_VALUE), st2.value) < RTOL
+    agent.close(); st.close(); st2.close()
+
+
 def test_wide_and_fused_paths_agree_on_the_cartpole_shape(crl, monkeypatch):
     """Same 4/2/64 minibatch through update.hip (fused, bf16x3) and wide.hip (layer-wise f32 MFMA)."""
     from test_gpu_parity import _inject_batch, make_agent
