@@ -268,7 +268,7 @@ def run_workload(args, wl, world, rank, local_rank, dist, torch, crl, crl_dist, 
                         total_timesteps=total_envs * NUM_STEPS * (steps + warmup + 1))
     shape = dict(obs_dim=8, n_act=4, hidden=256, env_kind=L.ENV_SYNTHETIC) if c3 else {}
     opts = parse_opts(args.opt)
-    force = bool(os.environ.get("CRL_COMM_FORCE")) or opts.get("comm_force") == 1
+    force = opts.get("comm_force") == 1
     if force:
         opts["comm_force"] = 1
     agent = crl.Agent(cfg, device=local_rank, env_id_offset=env_off, options=opts, **shape,

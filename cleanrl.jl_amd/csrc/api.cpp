@@ -633,7 +633,7 @@ int32_t crl_ppo_update_minibatch(crl_ppo* h, int32_t mb, double eta, int32_t app
 // Speculation guard (Q4). The fused kernels speculate on u = mean(v − R²) ≤ 0 (ppo.jl:232-237). Inside crl_ppo_iterate the
 // exact fix-up is NOT enqueued per optimiser step (three early-exit launches on one GPU, two more collectives under RCCL):
 // the common path stays speculative and a (global, sticky) device flag records a failed speculation. The flag is read back
-// once per WINDOW of iterations (CRL_DP_CHECK_EVERY, default 8) or whenever the host reads results — never per iteration. A window starts with a snapshot of everything an
+// once per WINDOW of iterations (option guard_window, default 8) or whenever the host reads results — never per iteration. A window starts with a snapshot of everything an
 // iteration mutates (parameters, Adam state, env state, episode accumulators); if the flag is up at the end, every rank
 // restores the snapshot and repeats the window's iterations with the exact step. The flag derives from all-reduced sums,
 // so all ranks take the same branch as long as they issue the same sequence of library calls.

@@ -9,8 +9,8 @@
 // by an exact power of two into that window, and the scale comes back out of the f32 accumulator:
 //   * activations h = tanh(·) ∈ (−1, 1):  h·2^14, produced directly by the activation (tanh_exp2 with S = 2^14: the scale is
 //     the constant of its last fused multiply-add);
-//   * weights:  W·2^8 — full precision for |w| ≥ 2^-11, absolute error 2^-33 below; |w| ≥ 255 does not fit and makes the
-//     kernel raise an error flag instead of computing (CRL_GEMM=x3 is the fallback flavour);
+//   * weights:  W·2^8 — full precision for |w| ≥ 2^-11, absolute error 2^-33 below; |w| ≥ 255 does not fit: the block that finds
+//     one while staging runs that network as bf16x3 for the launch (update.hip, policy.hip; option gemm = 1 selects bf16x3 everywhere);
 //   * backward cotangents δ: any magnitude — each SAMPLE (= lane: the N index of the product) is scaled by its own power of
 //     two, taken from the largest |δ| of that sample, and unscaled after the product (a per-column scale commutes with A·B).
 // The weight-gradient product sums over samples (K = samples), where a per-sample scale does not commute: it takes ONE scale

@@ -14,7 +14,7 @@
 // A workgroup owns one 256-element chunk end to end (push → flag → wait → sum), so chunks never wait on each other and a grid
 // larger than the chip still drains. Parity = sequence & 1: a rank can only be two messages ahead of a peer's slot after that
 // peer has raised the flag of the message in between, which it does after it finished reading the older one (stream order).
-// A lost peer turns into a time-out (CRL_PEER_TIMEOUT_S, default 20 s) that raises a sticky error word, never a hang.
+// A lost peer turns into a time-out (option peer_timeout_ms, default 20 s) that raises a sticky error word, never a hang.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>

@@ -146,7 +146,7 @@ struct crl_ppo {
   size_t snap_env_bytes = 0;
   int64_t snap_iteration = 0;
   int window_count = 0;        // iterations run speculatively since the snapshot
-  int window_len = 8;          // CRL_DP_CHECK_EVERY
+  int window_len = 8;          // option guard_window
   // staging for host-pointer calls
   void* stage = nullptr; size_t stage_bytes = 0;
   void* pinned = nullptr; size_t pinned_bytes = 0;

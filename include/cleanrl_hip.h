@@ -182,7 +182,7 @@ int32_t crl_comm_init(crl_ppo* h, const uint8_t id[128], int32_t world_size, int
  * rank's mailbox and returns its 64-byte hipIpcMemHandle_t; the host launcher all-gathers the handles (that all-gather is the
  * barrier the protocol needs) and hands all world_size * 64 bytes, in rank order, to crl_comm_peer_attach. world_size <= 16;
  * ranks may share a GPU (that is how a 1-GPU box runs the multi-rank tests). A rank that stops answering raises a sticky
- * time-out error (CRL_PEER_TIMEOUT_S, default 20) reported by crl_sync / crl_ppo_iterate instead of hanging the GPU. */
+ * time-out error (option peer_timeout_ms, default 20000) reported by crl_sync / crl_ppo_iterate instead of hanging the GPU. */
 int32_t crl_comm_peer_export(crl_ppo* h, int32_t world_size, int32_t rank, uint8_t handle[64]);
 int32_t crl_comm_peer_attach(crl_ppo* h, const uint8_t* handles);
 /* Declares this handle one of `world_size` shards WITHOUT attaching a communicator: every 1/M uses the global
