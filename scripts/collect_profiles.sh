@@ -1,6 +1,7 @@
 # Copies the judged summaries of gpurun_out/<tag>/ (scripts/final_measure.sh) into profiles/ under the round's names.
 TAG=${1:-final}
 S=gpurun_out/$TAG
+cp $S/generated/*.json profiles/ 2>/dev/null
 cp $S/bench_n1.json profiles/${TAG}_bench_n1.json
 for f in suite breakdown x3 bijection minibatches1 rccl_forced peer_forced envs8192 envs16384 envs32768 envs8192_breakdown; do
   [ -s $S/bench_n1_$f.json ] && cp $S/bench_n1_$f.json profiles/${TAG}_bench_n1_$f.json

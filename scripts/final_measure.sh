@@ -1,26 +1,12 @@
 # Measurement set of a round, ONE script (run on the GPU box): bench lines, rocprofv3 kernel stats, PMC passes, parity margins.
-#   bash scripts/final_measure.sh <tag>      → gpurun_out/<tag>/ ; then, back in the container:
-#   python scripts/summarize_pmc.py gpurun_out/<tag> <tag>  and  bash scripts/collect_profiles.sh <tag>   (copies into profiles/)
+#   bash scripts/final_measure.sh <tag>      → gpurun_out/<tag>/ ; then, back in the container:  bash scripts/collect_profiles.sh <tag>
+# Order: profiler passes first, scripts/summarize_pmc.py on the box, then the bench lines (which read those summaries).
 # Every PMC pass is its own rocprofv3 run with --pmc only (no trace domains), as the MI355X guide prescribes.
 TAG=${1:-final}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 B="python3 $R/bench.py"
-timeout 900 $B --strict-profiles > $O/bench_n1.json 2> $O/bench_n1.err || timeout 900 $B > $O/bench_n1.json 2> $O/bench_n1.err
-timeout 900 $B --suite --no-cpu-baseline > $O/bench_n1_suite.json 2> $O/bench_n1_suite.err; cp $R/profiles/${TAG}_suite.json $O/suite.json 2>/dev/null
-timeout 300 $B --kernel-breakdown --no-cpu-baseline > $O/bench_n1_breakdown.json 2> /dev/null
-timeout 300 $B --opt gemm=1 --no-cpu-baseline > $O/bench_n1_x3.json 2> /dev/null
-timeout 300 $B --shuffle bijection --no-cpu-baseline > $O/bench_n1_bijection.json 2> /dev/null
-timeout 300 $B --minibatches 1 --no-cpu-baseline > $O/bench_n1_minibatches1.json 2> /dev/null
-timeout 300 $B --opt comm_force=1 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_n1_rccl_forced.json 2>/dev/null
-timeout 300 $B --opt comm_force=1 --comm peer --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_n1_peer_forced.json 2>/dev/null
-for nt in 8192 16384 32768; do
-  timeout 300 $B --total-envs $nt --no-cpu-baseline > $O/bench_n1_envs$nt.json 2>/dev/null
-  timeout 300 $B --total-envs $nt --no-cpu-baseline --kernel-breakdown > $O/bench_n1_envs${nt}_breakdown.json 2>/dev/null
-done
-timeout 300 $B --workload c2 --steps 40 --no-cpu-baseline > $O/bench_c2_n1.json 2>/dev/null
-timeout 600 $B --workload c3 --steps 5 --warmup 2 > $O/bench_c3_n1.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3 -- python3 $R/bench.py --workload c3 --steps 3 --warmup 1 > /dev/null 2> $O/prof_c3.log
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --no-cpu-baseline > $O/prof_bench.json 2> $O/prof.log
@@ -41,6 +27,24 @@ for d in prof prof_c3 prof_envs8192 pmc_fetch pmc_write pmc_fetch_gae pmc_write_
   for f in $(find $d -name "*kernel_stats.csv" -o -name "*counter_collection.csv" 2>/dev/null); do cp $f ${d}_$(basename $f); done
   rm -rf $d
 done
+# the summaries bench.py's roofline reads (stamped with the kernel-source hash) are made HERE, before the bench lines, so that the
+# line of this very run carries them; a copy travels back in gpurun_out/<tag>/generated/ for scripts/collect_profiles.sh
+cd $R && python3 scripts/summarize_pmc.py $O $TAG > $O/summarize_pmc.log 2>&1
+mkdir -p $O/generated && cp profiles/${TAG}_pmc_summary.json profiles/${TAG}_pmc_hbm_traffic.json profiles/${TAG}_update_kernel_counts.json $O/generated/
+timeout 900 $B --strict-profiles > $O/bench_n1.json 2> $O/bench_n1.err 
+timeout 900 $B --suite --no-cpu-baseline > $O/bench_n1_suite.json 2> $O/bench_n1_suite.err; cp $R/profiles/${TAG}_suite.json $O/suite.json 2>/dev/null
+timeout 300 $B --kernel-breakdown --no-cpu-baseline > $O/bench_n1_breakdown.json 2> /dev/null
+timeout 300 $B --opt gemm=1 --no-cpu-baseline > $O/bench_n1_x3.json 2> /dev/null
+timeout 300 $B --shuffle bijection --no-cpu-baseline > $O/bench_n1_bijection.json 2> /dev/null
+timeout 300 $B --minibatches 1 --no-cpu-baseline > $O/bench_n1_minibatches1.json 2> /dev/null
+timeout 300 $B --opt comm_force=1 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_n1_rccl_forced.json 2>/dev/null
+timeout 300 $B --opt comm_force=1 --comm peer --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_n1_peer_forced.json 2>/dev/null
+for nt in 8192 16384 32768; do
+  timeout 300 $B --total-envs $nt --no-cpu-baseline > $O/bench_n1_envs$nt.json 2>/dev/null
+  timeout 300 $B --total-envs $nt --no-cpu-baseline --kernel-breakdown > $O/bench_n1_envs${nt}_breakdown.json 2>/dev/null
+done
+timeout 300 $B --workload c2 --steps 40 --no-cpu-baseline > $O/bench_c2_n1.json 2>/dev/null
+timeout 600 $B --workload c3 --steps 5 --warmup 2 > $O/bench_c3_n1.json 2>/dev/null
 # multi-rank functional runs on this one GPU (peer all-reduce) — labelled shared_gpu, not scaling points
 for n in 2 4 8; do
   timeout 600 python3 $R/bench.py --gpus $n --comm peer --share-gpu --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | grep '^{' > $O/bench_shared_gpu_n$n.json

@@ -722,6 +722,26 @@ def test_options_are_validated_and_fallback_is_automatic(crl):
     agent.close(); st.close()
 
 
+def test_crl_options_environment_hook_is_read_at_create_and_validated(crl, monkeypatch):
+    """CRL_OPTIONS="k=v,…" is the one environment hook for options (bench A/B runs without touching the host code): applied by
+    crl_ppo_create before anything is sized, overridden by later crl_ppo_set_option calls, and rejected loudly when malformed."""
+    monkeypatch.setenv("CRL_OPTIONS", "gemm=1,guard_window=3,,rollout_stagger=0")
+    agent = make_agent(crl, nt=8, k=128)
+    o = agent.handle.options()
+    assert (o["gemm"], o["guard_window"], o["rollout_stagger"]) == (1, 3, 0) and o["gae_fuse"] == 1
+    agent.handle.set_option("gemm", 2)
+    assert agent.handle.get_option("gemm") == 2
+    agent.close()
+    for bad, msg in (("gemm", "key=value"), ("gemm=two", "not an integer"), ("gemm=9", "outside"), ("nope=1", "unknown option")):
+        monkeypatch.setenv("CRL_OPTIONS", bad)
+        with pytest.raises(crl.CrlError, match=msg):
+            make_agent(crl, nt=8, k=128)
+    monkeypatch.delenv("CRL_OPTIONS")
+    agent = make_agent(crl, nt=8, k=128, options={"guard_window": 2})
+    assert agent.handle.get_option("guard_window") == 2 and agent.handle.get_option("gemm") == 2
+    agent.close()
+
+
 def _episodes_from_buffers(reward, terminal, next_done, env_id_offset=0):
     """Episode records of the FIRST rollout after a reset, rebuilt from the buffer: done at step t is terminal[e, t+1]
     (next_done for the last step); return / length accumulate like ppo.jl:125,145."""
