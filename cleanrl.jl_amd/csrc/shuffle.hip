@@ -44,9 +44,6 @@ __global__ void bijection_kernel(int32_t* __restrict__ perm, int n, int bits, ui
 // shuffled by the textbook Fisher–Yates loop run by one lane. Sub-buckets are concatenated in (d1,d2) order.
 // Bit-identical to orc_shuffle_blocked_fy.
 // ------------------------------------------------------------------------------------------------------
-// L1 passes: T1 threads x 32 elements per block. Large batches use 1024 threads (32 K elements: ≈16 per bucket and block at
-// K1 = 2048, so one global reservation per bucket and block serves a 64-B run of stores; 8 K-element blocks paid 4x the
-// reservations for 16-B runs); small shards keep 256 threads so that the grid still covers the chip.
 constexpr int BFY_L1 = 4096;        // expected elements per L1 bucket
 constexpr int BFY_CAP = 5632;       // LDS capacity of one L1 bucket (+24 sigma)
 constexpr int BFY_MAXK1 = 16384;    // batches up to 2^26 samples
@@ -64,38 +61,52 @@ __device__ __forceinline__ void bfy_digits(uint32_t i, uint32_t K1, uint64_t see
 // update_epochs in ONE launch per pass (epoch e works in workspace slice e, perm slot e) — 4x fewer, 4x larger launches.
 constexpr int BFY_WS_STRIDE = 4 * 16384 + 8;   // u32 words of workspace per epoch: (unused) | off | cur | err
 
+// One block covers 8192 elements (1024 threads x 8, or 256 x 32 for small shards so that the grid still covers the chip): measured on
+// one box at n = 8.4 M x 4 epochs, 64 / 32 / 16 / 8 / 4 elements per thread of a 1024-thread block took 0.96 / 0.87 / 0.80 / 0.76 / 0.76 ms
+// for the whole shuffle — the pass is bound by latency (LDS atomics, the reservation round trip), which more and smaller blocks hide;
+// the 2 K global reservations per block are not what it waits for. ONE LDS atomic per element: its return value is the element's rank
+// inside the block's share of the bucket and rides in a register to the store. When n <= 2^24 the element's second digit travels in
+// the top byte of its S entry, so the leaf pass needs no Philox call to find it again.
 template <int BFY_T1>
 __global__ void __launch_bounds__(BFY_T1) bfy_l1_kernel(int n, uint32_t K1, uint64_t seed, uint64_t epoch0, uint32_t* __restrict__ ws,
-                                                     int32_t* __restrict__ S0, size_t sstride) {
+                                                     int32_t* __restrict__ S0, size_t sstride, int packed) {
+  constexpr int EPT = 8192 / BFY_T1;
   const uint64_t epoch = epoch0 + blockIdx.y;
   uint32_t* tot = ws + (size_t)blockIdx.y * BFY_WS_STRIDE;
   uint32_t* cur = tot + 2 * BFY_MAXK1 + 1;
   uint32_t* err = cur + BFY_MAXK1;
   int32_t* S = S0 + (size_t)blockIdx.y * sstride;
-  extern __shared__ uint32_t lds[];   // hist[K1] + base[K1]
+  extern __shared__ uint32_t lds[];   // hist[K1] → (after the reservations) the block's base inside every bucket
   uint32_t* hist = lds;
-  uint32_t* base = lds + K1;
   for (uint32_t d = threadIdx.x; d < K1; d += BFY_T1) hist[d] = 0;
   __syncthreads();
-  uint32_t dig[32];
-  const int i0 = blockIdx.x * (BFY_T1 * 32) + threadIdx.x;
-#pragma unroll 4
-  for (int q = 0; q < 32; ++q) {
+  uint32_t dig[EPT];                  // d1 (14 bits) | rank inside the block's share (13 bits) << 14 ; 0xFFFFFFFF = past the end
+  uint32_t d2p[EPT / 4];              // the second digits, four to a register
+  const int i0 = blockIdx.x * 8192 + threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < EPT / 4; ++q) d2p[q] = 0;
+#pragma unroll
+  for (int q = 0; q < EPT; ++q) {
     const int i = i0 + q * BFY_T1;
-    uint32_t d1 = 0xFFFFFFFFu, d2;
-    if (i < n) { bfy_digits((uint32_t)i, K1, seed, epoch, d1, d2); atomicAdd(&hist[d1], 1u); }
-    dig[q] = d1;
+    uint32_t d1, d2, w = 0xFFFFFFFFu;
+    if (i < n) {
+      bfy_digits((uint32_t)i, K1, seed, epoch, d1, d2);
+      w = d1 | (atomicAdd(&hist[d1], 1u) << 14);
+      d2p[q >> 2] |= d2 << (8 * (q & 3));
+    }
+    dig[q] = w;
   }
   __syncthreads();
-  for (uint32_t d = threadIdx.x; d < K1; d += BFY_T1) { base[d] = hist[d] ? atomicAdd(&cur[d], hist[d]) : 0u; hist[d] = 0; }
+  for (uint32_t d = threadIdx.x; d < K1; d += BFY_T1) { const uint32_t c = hist[d]; hist[d] = c ? atomicAdd(&cur[d], c) : 0u; }
   __syncthreads();
-#pragma unroll 4
-  for (int q = 0; q < 32; ++q) {
+#pragma unroll
+  for (int q = 0; q < EPT; ++q) {
     const int i = i0 + q * BFY_T1;
     if (i < n) {
-      const uint32_t d1 = dig[q];
-      const uint32_t at = base[d1] + atomicAdd(&hist[d1], 1u);
-      if (at < (uint32_t)BFY_CAP) S[(size_t)d1 * BFY_CAP + at] = i;
+      const uint32_t d1 = dig[q] & 0x3FFFu;
+      const uint32_t at = hist[d1] + (dig[q] >> 14);
+      const uint32_t d2 = (d2p[q >> 2] >> (8 * (q & 3))) & 255u;
+      if (at < (uint32_t)BFY_CAP) S[(size_t)d1 * BFY_CAP + at] = (int32_t)((uint32_t)i | (packed ? d2 << 24 : 0u));
       else *err = 1u;                       // the bucket does not fit its leaf (the scan flags it too); never written out of bounds
     }
   }
@@ -121,14 +132,20 @@ __global__ void __launch_bounds__(1024) bfy_scan_kernel(uint32_t K1, uint32_t* _
 }
 
 // leaves: one block per L1 bucket; 256 sub-buckets ↔ 256 lanes for the Fisher–Yates tail. No per-thread arrays and no
-// unrolling: a low register count keeps several blocks per CU resident, which hides the dependent Philox→swap chain.
+// unrolling: a low register count keeps several blocks per CU resident. The Fisher–Yates draws do not depend on the data, so every
+// thread computes the draws of the positions it owns (16 Philox calls each, no divergence) while it ranks them; the serial tail
+// that one lane runs per sub-bucket is then swaps only. (The tail used to call Philox per swap: a wave waited for its longest
+// sub-bucket, ≈27 dependent Philox chains for 16 useful ones, and the pass took 0.48 ms for four epochs of 8.4 M.)
 // With adv != nullptr the block also leaves Σadv, Σadv² of its slice per minibatch in part[mb][bucket][2] (Float64, fixed
 // order): the advantage statistics of ppo.jl:221 then need no separate gather pass over the permutation. Requires
 // M >= BFY_CAP so that a bucket touches at most two minibatches.
-__global__ void __launch_bounds__(256, 4) bfy_leaf_kernel(uint32_t K1, uint64_t seed, uint64_t epoch0, int n, const uint32_t* __restrict__ ws,
+// threads of a leaf block: LDS allows two blocks per CU, so the thread count is what hides latency — 256 / 512 / 1024 threads: 0.72 / 0.58 /
+// 0.53 ms for the four epochs' shuffles at n = 8.4 M (one box, nothing else running); 52 registers, no scratch
+constexpr int BFY_LT = 1024;
+__global__ void __launch_bounds__(BFY_LT, 2) bfy_leaf_kernel(uint32_t K1, uint64_t seed, uint64_t epoch0, int n, const uint32_t* __restrict__ ws,
                                                           const int32_t* __restrict__ S0, size_t sstride, int32_t* __restrict__ perm0,
                                                           const float* __restrict__ adv, int M, int nmb, double* __restrict__ part,
-                                                          uint16_t* __restrict__ bucket_mb0, uint8_t* __restrict__ mbid0) {
+                                                          uint16_t* __restrict__ bucket_mb0, uint8_t* __restrict__ mbid0, int packed) {
   const uint64_t epoch = epoch0 + blockIdx.y;
   const uint32_t* off = ws + (size_t)blockIdx.y * BFY_WS_STRIDE + BFY_MAXK1;
   const uint32_t* err = off + 2 * BFY_MAXK1 + 1;
@@ -136,18 +153,20 @@ __global__ void __launch_bounds__(256, 4) bfy_leaf_kernel(uint32_t K1, uint64_t 
   int32_t* perm = perm0 + (size_t)blockIdx.y * n;
   if (*err) return;
   __shared__ int32_t buf[BFY_CAP], buf2[BFY_CAP];
+  __shared__ uint16_t draw[BFY_CAP];                // draw[p]: the Fisher–Yates partner of position p inside its sub-bucket
   __shared__ uint8_t dig[BFY_CAP], dsub[BFY_CAP];   // sub-bucket of the element at a pre-scatter / post-scatter position
   __shared__ uint32_t cnt[256], soff[257], run[256];
   const uint32_t d1 = blockIdx.x;
   const uint32_t base = off[d1], c = off[d1 + 1] - base;
   const int t = threadIdx.x;
-  cnt[t] = 0; run[t] = 0;
+  if (t < 256) { cnt[t] = 0; run[t] = 0; }
   __syncthreads();
 #pragma unroll 1
-  for (uint32_t idx = t; idx < c; idx += 256) {
-    const int32_t v = S[idx];
+  for (uint32_t idx = t; idx < c; idx += BFY_LT) {
+    int32_t v = S[idx];
     uint32_t a, d2;
-    bfy_digits((uint32_t)v, K1, seed, epoch, a, d2);
+    if (packed) { d2 = (uint32_t)v >> 24; v &= 0xFFFFFF; }
+    else bfy_digits((uint32_t)v, K1, seed, epoch, a, d2);
     buf2[idx] = v; dig[idx] = (uint8_t)d2;
     atomicAdd(&cnt[d2], 1u);
   }
@@ -163,40 +182,47 @@ __global__ void __launch_bounds__(256, 4) bfy_leaf_kernel(uint32_t K1, uint64_t 
   }
   __syncthreads();
 #pragma unroll 1
-  for (uint32_t idx = t; idx < c; idx += 256) {
+  for (uint32_t idx = t; idx < c; idx += BFY_LT) {
     const uint32_t d2 = dig[idx];
     const uint32_t pos = soff[d2] + atomicAdd(&run[d2], 1u);
     buf[pos] = buf2[idx];
     dsub[pos] = (uint8_t)d2;     // travels with the element: the rank pass below needs no search for the sub-bucket that owns a position
   }
   __syncthreads();
-  // canonical order: every element counts the smaller members of its sub-bucket (values are distinct) and moves there
-#pragma unroll 1
-  for (uint32_t idx = t; idx < c; idx += 256) {
+  // canonical order: every element counts the smaller members of its sub-bucket (values are distinct) and moves there; and the
+  // draw of the Fisher–Yates step that will visit this POSITION (Random.shuffle!: for i = n:-1:2, swap with rand(1:i))
+#pragma unroll 2
+  for (uint32_t idx = t; idx < c; idx += BFY_LT) {
     const int32_t v = buf[idx];
     const uint32_t d2 = dsub[idx];          // the sub-bucket that owns position idx: soff[d2] <= idx < soff[d2+1]
     const uint32_t lo = soff[d2], hi = soff[d2 + 1];
+    const uint32_t j = idx - lo;
+    uint32_t x = 0;
+    if (j >= 1) {
+      const u32x4 o = philox(d1 * 256u + d2, j, (uint32_t)epoch ^ 0x9E3779B9u, (uint32_t)(epoch >> 32) ^ 0xF15A7E5u, (uint32_t)seed,
+                             (uint32_t)(seed >> 32));
+      const uint64_t r = ((uint64_t)o.x << 32) | o.y;
+      x = (uint32_t)__umul64hi(r, (uint64_t)(j + 1));
+    }
+    draw[idx] = (uint16_t)x;
     uint32_t r = 0;
     for (uint32_t p = lo; p < hi; ++p) r += (buf[p] < v) ? 1u : 0u;
     buf2[lo + r] = v;
   }
   __syncthreads();
-  {
+  if (t < 256) {
     int32_t* m = buf2 + soff[t];
+    const uint16_t* dr = draw + soff[t];
     const int n2 = (int)cnt[t];
-    const uint32_t g = d1 * 256u + (uint32_t)t;
 #pragma unroll 1
-    for (int j = n2 - 1; j >= 1; --j) {          // Fisher–Yates (Random.shuffle!: for i = n:-1:2, swap with rand(1:i))
-      const u32x4 o = philox(g, (uint32_t)j, (uint32_t)epoch ^ 0x9E3779B9u, (uint32_t)(epoch >> 32) ^ 0xF15A7E5u, (uint32_t)seed,
-                             (uint32_t)(seed >> 32));
-      const uint64_t r = ((uint64_t)o.x << 32) | o.y;
-      const uint32_t x = (uint32_t)__umul64hi(r, (uint64_t)(j + 1));
+    for (int j = n2 - 1; j >= 1; --j) {
+      const uint32_t x = dr[j];
       const int32_t tmp = m[j]; m[j] = m[x]; m[x] = tmp;
     }
   }
   __syncthreads();
   if (!adv) {
-    for (uint32_t idx = t; idx < c; idx += 256) perm[base + idx] = buf2[idx];
+    for (uint32_t idx = t; idx < c; idx += BFY_LT) perm[base + idx] = buf2[idx];
     if (bucket_mb0) {
       // which minibatch this bucket's positions [base, base + c) belong to; a bucket across a boundary also says it per member
       const uint32_t mbf = base / (uint32_t)M, cutp = (mbf + 1u) * (uint32_t)M;
@@ -204,7 +230,7 @@ __global__ void __launch_bounds__(256, 4) bfy_leaf_kernel(uint32_t K1, uint64_t 
       if (t == 0) bucket_mb0[(size_t)blockIdx.y * BFY_MAXK1 + d1] = (uint16_t)(mbf | (straddle ? 0x8000u : 0u));
       if (straddle) {
         uint8_t* mbid = mbid0 + (size_t)blockIdx.y * n;
-        for (uint32_t idx = t; idx < c; idx += 256) mbid[buf2[idx]] = (uint8_t)((base + idx) / (uint32_t)M);
+        for (uint32_t idx = t; idx < c; idx += BFY_LT) mbid[buf2[idx]] = (uint8_t)((base + idx) / (uint32_t)M);
       }
     }
     return;
@@ -214,24 +240,25 @@ __global__ void __launch_bounds__(256, 4) bfy_leaf_kernel(uint32_t K1, uint64_t 
   // phase 1: all gathers in flight together (results parked in the dead `buf`), phase 2: ordered sums from LDS
   float* abuf = reinterpret_cast<float*>(buf);
 #pragma unroll 8
-  for (uint32_t idx = t; idx < c; idx += 256) {
+  for (uint32_t idx = t; idx < c; idx += BFY_LT) {
     const int32_t v = buf2[idx];
     perm[base + idx] = v;
     abuf[idx] = adv[v];
   }
   double sa = 0.0, sa2 = 0.0, sb = 0.0, sb2 = 0.0;
-  for (uint32_t idx = t; idx < c; idx += 256) {
+  for (uint32_t idx = t; idx < c; idx += BFY_LT) {
     const double a = (double)abuf[idx];
     if (base + idx < cut) { sa += a; sa2 += a * a; } else { sb += a; sb2 += a * a; }
   }
-  __shared__ double red[4][4];
+  __shared__ double red[BFY_LT / 64][4];
   sa = wave_sum(sa); sa2 = wave_sum(sa2); sb = wave_sum(sb); sb2 = wave_sum(sb2);
   if ((t & 63) == 0) { red[t >> 6][0] = sa; red[t >> 6][1] = sa2; red[t >> 6][2] = sb; red[t >> 6][3] = sb2; }
   __syncthreads();
   if (t < nmb) {
     double v0 = 0.0, v1 = 0.0;
-    if (t == mb0) { v0 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]); v1 = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]); }
-    else if (t == mb0 + 1) { v0 = (red[0][2] + red[1][2]) + (red[2][2] + red[3][2]); v1 = (red[0][3] + red[1][3]) + (red[2][3] + red[3][3]); }
+    const int o = t == mb0 ? 0 : 2;
+    if (t == mb0 || t == mb0 + 1)
+      for (int w = 0; w < BFY_LT / 64; ++w) { v0 += red[w][o]; v1 += red[w][o + 1]; }     // fixed order
     part[((size_t)t * K1 + d1) * 2] = v0; part[((size_t)t * K1 + d1) * 2 + 1] = v1;
   }
 }
@@ -252,16 +279,16 @@ static int launch_blocked_fy(crl_ppo* h, uint64_t epoch_id, int nslots, bool fus
   CRL_HIP_CHECK(hipMemset2DAsync(ws + 2 * BFY_MAXK1 + 1, sizeof(uint32_t) * BFY_WS_STRIDE, 0, sizeof(uint32_t) * K1, (size_t)nslots, h->stream));
   const uint64_t seed = shuffle_seed(h);
   const bool big = n >= (4 << 20);
-  const int t1 = big ? 1024 : 256, chunks = (n + t1 * 32 - 1) / (t1 * 32);
+  const int chunks = (n + 8191) / 8192, packed = n <= (1 << 24) ? 1 : 0;
   const dim3 g1(chunks, nslots);
-  if (big) hipLaunchKernelGGL((bfy_l1_kernel<1024>), g1, dim3(1024), sizeof(uint32_t) * 2 * K1, h->stream, n, K1, seed, epoch_id, ws, S, sstride);
-  else hipLaunchKernelGGL((bfy_l1_kernel<256>), g1, dim3(256), sizeof(uint32_t) * 2 * K1, h->stream, n, K1, seed, epoch_id, ws, S, sstride);
+  if (big) hipLaunchKernelGGL((bfy_l1_kernel<1024>), g1, dim3(1024), sizeof(uint32_t) * K1, h->stream, n, K1, seed, epoch_id, ws, S, sstride, packed);
+  else hipLaunchKernelGGL((bfy_l1_kernel<256>), g1, dim3(256), sizeof(uint32_t) * K1, h->stream, n, K1, seed, epoch_id, ws, S, sstride, packed);
   hipLaunchKernelGGL(bfy_scan_kernel, dim3(nslots), dim3(1024), 0, h->stream, K1, ws);
   const bool fuse = fused && nslots == 1 && h->bfy_adv_part && h->dc.M >= BFY_CAP && h->dc.nmb <= 256;
   // the bucket → minibatch tables (sequential advantage statistics, below) describe slots [0, nslots) of one iterate call
   const bool tables = !fuse && h->bfy_bucket_mb && h->cur_slot == 0 && h->dc.nmb <= 255;
-  hipLaunchKernelGGL(bfy_leaf_kernel, dim3(K1, nslots), dim3(256), 0, h->stream, K1, seed, epoch_id, n, ws, S, sstride, h->perm, fuse ? h->adv : nullptr,
-                     h->dc.M, h->dc.nmb, h->bfy_adv_part, tables ? h->bfy_bucket_mb : nullptr, h->bfy_mbid);
+  hipLaunchKernelGGL(bfy_leaf_kernel, dim3(K1, nslots), dim3(BFY_LT), 0, h->stream, K1, seed, epoch_id, n, ws, S, sstride, h->perm, fuse ? h->adv : nullptr,
+                     h->dc.M, h->dc.nmb, h->bfy_adv_part, tables ? h->bfy_bucket_mb : nullptr, h->bfy_mbid, packed);
   CRL_HIP_CHECK(hipGetLastError());
   h->bfy_adv_parts = fuse ? (int)K1 : 0;
   for (int z = 0; z < nslots; ++z) h->bfy_tbl_slots &= ~(1u << (h->cur_slot + z));

@@ -128,6 +128,104 @@ __global__ void __launch_bounds__(1024) k_mfma_valu(float* out, int iters) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+
+// waves with an even index issue only MFMAs, odd ones only v_fma_f32 (NV per MFMA of the partner): do the two pipes of a SIMD overlap
+// ACROSS waves? block = 4 SIMDs x 2 waves; wave w sits on SIMD w % 4, so waves w and w + 4 share a SIMD
+template <int NV, int ACC_AGPR>
+__global__ void __launch_bounds__(512) k_split(float* out, int iters) {
+  const int wave = threadIdx.x >> 6;
+  f16x8 a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(threadIdx.x * 0.001f + i); b[i] = (_Float16)(i * 0.01f); }
+  float s = 0;
+  if (wave < 4) {
+    f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (ACC_AGPR) {
+          asm volatile("v_mfma_f32_32x32x16_f16 %0, %4, %5, %0\n v_mfma_f32_32x32x16_f16 %1, %4, %5, %1\n"
+                       "v_mfma_f32_32x32x16_f16 %2, %4, %5, %2\n v_mfma_f32_32x32x16_f16 %3, %4, %5, %3\n"
+                       : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3) : "v"(a), "v"(b));
+        } else {
+          c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c1, 0, 0, 0);
+          c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c2, 0, 0, 0);
+          c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c3, 0, 0, 0);
+        }
+      }
+    }
+    for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
+  } else {
+    float a0 = threadIdx.x + 1.5f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    const float bb = 1.0000001f, cc = 1e-9f;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v)       // NV groups of 8 = NV vector instructions per partner MFMA (8 MFMAs per iteration)
+        asm volatile(I_FMA(0) I_FMA(1) I_FMA(2) I_FMA(3) I_FMA(4) I_FMA(5) I_FMA(6) I_FMA(7)
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(bb), "v"(cc));
+    }
+    s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// same-wave interleave with the accumulators in AGPRs / with 16x16x32 tiles
+template <int NV, int SHAPE16>
+__global__ void __launch_bounds__(1024) k_mfma_valu_a(float* out, int iters) {
+  f32x16 c0 = {}, c1 = {};
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 d0 = {}, d1 = {};
+  f16x8 a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(threadIdx.x * 0.001f + i); b[i] = (_Float16)(i * 0.01f); }
+  float a0 = threadIdx.x + 1.5f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+  const float bb = 1.0000001f, cc = 1e-9f;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (SHAPE16) { if (u & 1) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(d1) : "v"(a), "v"(b)); else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(d0) : "v"(a), "v"(b)); }
+      else { if (u & 1) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c1) : "v"(a), "v"(b)); else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c0) : "v"(a), "v"(b)); }
+#pragma unroll
+      for (int v = 0; v < NV / 8; ++v)
+        asm volatile(I_FMA(0) I_FMA(1) I_FMA(2) I_FMA(3) I_FMA(4) I_FMA(5) I_FMA(6) I_FMA(7)
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(bb), "v"(cc));
+    }
+  }
+  float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+  for (int i = 0; i < 16; ++i) s += c0[i] + c1[i];
+  for (int i = 0; i < 4; ++i) s += d0[i] + d1[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+
+// NCH dependent chains of v_fma_f32 (1 = every instruction waits for the previous one): the result-to-use latency a wave sees
+template <int NCH>
+__global__ void __launch_bounds__(1024) k_chain(float* out, int iters) {
+  float a0 = threadIdx.x + 1.5f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
+  const float b = 1.0000001f, c = 1e-9f;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 64 / NCH; ++u) {
+      if (NCH == 1) asm volatile("v_fma_f32 %0, %0, %1, %2\n" : "+v"(a0) : "v"(b), "v"(c));
+      if (NCH == 2) asm volatile("v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n" : "+v"(a0), "+v"(a1) : "v"(b), "v"(c));
+      if (NCH == 4) asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n"
+                                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));
+    }
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3;
+}
+
+template <typename K>
+static void run_split(const char* name, K kern, float* out) {
+  const int iters = 4000;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(kern, dim3(256), dim3(512), 0, 0, out, 50);
+  hipDeviceSynchronize();
+  hipEventRecord(e0); hipLaunchKernelGGL(kern, dim3(256), dim3(512), 0, 0, out, iters); hipEventRecord(e1);
+  hipDeviceSynchronize();
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  printf("%-44s %7.3f ns per MFMA of the matrix wave (alone: 14.7)\n", name, (double)ms * 1e6 / ((double)iters * 8));
+}
+
 template <typename K>
 static void run(const char* name, K kern, int per_iter, float* out) {
   printf("%-28s", name);
@@ -148,6 +246,9 @@ static void run(const char* name, K kern, int per_iter, float* out) {
 int main() {
   float* out; hipMalloc(&out, 256 * 1024 * 4);
   run("v_fma_f32", k_fma, 64, out);
+  run("v_fma_f32, 1 dependent chain", k_chain<1>, 64, out);
+  run("v_fma_f32, 2 chains", k_chain<2>, 64, out);
+  run("v_fma_f32, 4 chains", k_chain<4>, 64, out);
   run("v_xor_b32", k_xor, 64, out);
   run("v_perm_b32", k_perm, 64, out);
   run("v_cvt_pk_f16_f32", k_cvtpk, 64, out);
@@ -166,5 +267,16 @@ int main() {
   run("mfma + 8 v_fma (per group)", k_mfma_valu<8>, 8, out);
   run("mfma + 16 v_fma (per group)", k_mfma_valu<16>, 8, out);
   run("mfma + 32 v_fma (per group)", k_mfma_valu<32>, 8, out);
+  run("AGPR acc: mfma + 8 v_fma (per group)", k_mfma_valu_a<8, 0>, 8, out);
+  run("AGPR acc: mfma + 16 v_fma (per group)", k_mfma_valu_a<16, 0>, 8, out);
+  run("16x16x32 (AGPR) alone (per mfma)", k_mfma_valu_a<0, 1>, 8, out);
+  run("16x16x32 (AGPR) + 8 v_fma (per group)", k_mfma_valu_a<8, 1>, 8, out);
+  run_split("matrix wave | vector wave, 0 v_fma per mfma", k_split<0, 0>, out);
+  run_split("matrix wave | vector wave, 2 v_fma per mfma", k_split<2, 0>, out);
+  run_split("matrix wave | vector wave, 4 v_fma per mfma", k_split<4, 0>, out);
+  run_split("matrix wave | vector wave, 6 v_fma per mfma", k_split<6, 0>, out);
+  run_split("matrix wave | vector wave, 8 v_fma per mfma", k_split<8, 0>, out);
+  run_split("same, accumulators in AGPRs, 4 per mfma", k_split<4, 1>, out);
+  run_split("same, accumulators in AGPRs, 6 per mfma", k_split<6, 1>, out);
   return 0;
 }
