@@ -146,11 +146,24 @@ static int sample_weights(const float* p, int A, double u, double* margin) {
   return i;
 }
 
+/* OpenMP team size for a loop of n items: one thread per `grain` items, at most the machine's. The parity tests call these
+ * functions on a few hundred samples from a host with hundreds of hardware threads, possibly shared with other jobs: a full team
+ * per call (and, in orc_loss_grad, a P-sized accumulator per thread) cost more than the loop. */
+static int orc_team(long n, long grain) {
+  int t = 1;
+#ifdef _OPENMP
+  t = omp_get_max_threads();
+#endif
+  long want = n / grain;
+  if (want < 1) want = 1;
+  return want < t ? (int)want : t;
+}
+
 /* get_action (ppo.jl:21-32) + value = critic(next_obs) (ppo.jl:128) */
 void orc_get_action(const orc_config* c, const float* params, const float* obs, const double* u, int32_t n,
                     int32_t* action, float* logprob, float* value, double* margin) {
   int A = c->n_act, d = c->obs_dim;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_team(n, 64))
   for (int b = 0; b < n; ++b) {
     float z[16], p[16], lp[16], v;
     orc_mlp_forward(c, params, 0, obs + (size_t)d * b, z, NULL, NULL);
@@ -166,7 +179,7 @@ void orc_get_action(const orc_config* c, const float* params, const float* obs, 
 void orc_logprob_actions(const orc_config* c, const float* params, const float* obs, const int32_t* actions,
                          int32_t n, float* logprob, float* entropy) {
   int A = c->n_act, d = c->obs_dim;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_team(n, 64))
   for (int b = 0; b < n; ++b) {
     float z[16], p[16], lp[16];
     orc_mlp_forward(c, params, 0, obs + (size_t)d * b, z, NULL, NULL);
@@ -201,7 +214,7 @@ void orc_gae(const float* values, ptrdiff_t vs, const float* rewards, ptrdiff_t 
 void orc_gae_batch(const float* value, const float* reward, const uint8_t* terminal, const float* next_value,
                    const uint8_t* next_done, int32_t nt, int32_t k, float gamma, float lambda, int32_t mode,
                    float* adv, float* ret) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_team(nt, 16))
   for (int e = 0; e < nt; ++e) {
     float vrow[4097]; uint8_t trow[4097];
     float* vr = k + 1 <= 4097 ? vrow : (float*)malloc(sizeof(float) * (k + 1));
@@ -277,7 +290,7 @@ void orc_loss_grad(const orc_config* c, const float* params, const float* states
   /* pass 1: newvalue for the whole minibatch → u = mean(newvalue .- mb_returns .^ 2) (ppo.jl:232, Q4) */
   float* newv = (float*)malloc(sizeof(float) * (size_t)M);
   double usum = 0.0;
-#pragma omp parallel for schedule(static) reduction(+ : usum)
+#pragma omp parallel for schedule(static) reduction(+ : usum) num_threads(orc_team(M, 64))
   for (int j = 0; j < M; ++j) {
     int s = mb_inds[j];
     float v;
@@ -299,14 +312,11 @@ void orc_loss_grad(const orc_config* c, const float* params, const float* states
     }
   }
 
-  int nthreads = 1;
-#ifdef _OPENMP
-  nthreads = omp_get_max_threads();
-#endif
+  const int nthreads = orc_team(M, 64);
   double* gacc = (double*)calloc((size_t)P * nthreads, sizeof(double));
   double pg_sum = 0.0, vmax_sum = 0.0, ent_sum = 0.0;
 
-#pragma omp parallel reduction(+ : pg_sum, vmax_sum, ent_sum)
+#pragma omp parallel reduction(+ : pg_sum, vmax_sum, ent_sum) num_threads(nthreads)
   {
     int tid = 0;
 #ifdef _OPENMP
@@ -507,7 +517,7 @@ void orc_env_init(const orc_config* c, orc_state* s) {
 void orc_rollout(const orc_config* c, orc_state* s) {
   const int nt = c->num_envs, k = c->num_steps, d = c->obs_dim, A = c->n_act;
   double epc = 0, eprs = 0, epls = 0;
-#pragma omp parallel for schedule(static) reduction(+ : epc, eprs, epls)
+#pragma omp parallel for schedule(static) reduction(+ : epc, eprs, epls) num_threads(orc_team(nt, 4))
   for (int e = 0; e < nt; ++e) {
     uint32_t gid = (uint32_t)(c->env_id_offset + e);
     float* es = s->env_state + (size_t)d * e;
