@@ -228,6 +228,7 @@ def time_gae_standalone(torch, h, nt, device, reps=6):
     src = torch.empty(half, dtype=torch.float32, device=device).normal_()
     dst = torch.empty_like(src)
     cold, warm, copy_cold = [], [], []
+    dst.copy_(src); torch.cuda.synchronize()      # first-use overheads of the copy stay out of the medians
     for i in range(reps):
         flush.fill_(float(i)); torch.cuda.synchronize()
         h.prof_enable(True); h.prof_reset(); h.compute_gae(); h.sync()
