@@ -36,6 +36,7 @@ static const OptDesc kOpts[OPT_COUNT] = {
     {"wide_tanh_rational", 0, 0, 1},
     {"gae_seg", 0, 0, 16},
     {"gae_tile", 0, 0, 64},
+    {"fuse_optim", 1, 0, 1},
 };
 static int opt_find(const char* key) {
   if (!key) return -1;
@@ -271,7 +272,7 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
   rc |= dalloc(&h->next_value, nt); rc |= dalloc(&h->ep_stats, 4);
   rc |= dalloc(&h->params, h->P); rc |= dalloc(&h->adam_m, h->P); rc |= dalloc(&h->adam_v, h->P);
   const size_t E = (size_t)cfg->update_epochs;
-  rc |= dalloc(&h->betap, 24); rc |= dalloc(&h->perm_base, E * B); rc |= dalloc(&h->optim_part, (size_t)h->P / 4096 + 16);
+  rc |= dalloc(&h->betap, 24); rc |= dalloc(&h->perm_base, E * B); rc |= dalloc(&h->optim_part, (size_t)h->P / 4096 + 16 + 12 * ((size_t)h->P / 64 + 1)); rc |= dalloc(&h->ticket, 1);
   if (!wide) rc |= dalloc(&h->recs, B);   // the update kernels fetch records through the epoch's permutation: no permuted copies
   {
     // advantage-sum pass: blocks per minibatch (≈1 K samples each, at most 512); the partial-sum scratch also serves the
@@ -327,7 +328,7 @@ int32_t crl_ppo_destroy(crl_ppo* h) {
   wide_destroy(h);
   void* ptrs[] = {h->obs, h->action, h->logprob, h->reward, h->terminal, h->value, h->adv, h->ret, h->env_state, h->env_t,
                   h->cur_obs, h->next_done, h->ep_return, h->ep_length, h->next_value, h->ep_stats, h->ep_ring, h->ep_ring_count, h->params,
-                  h->adam_m, h->adam_v, h->betap, h->optim_part, h->perm_base, h->recs, h->adv_part, h->perm_tmp, h->bfy_ws, h->bfy_adv_part, h->bfy_bucket_mb, h->bfy_mbid, h->gpart, h->lpart,
+                  h->adam_m, h->adam_v, h->betap, h->optim_part, h->ticket, h->perm_base, h->recs, h->adv_part, h->perm_tmp, h->bfy_ws, h->bfy_adv_part, h->bfy_bucket_mb, h->bfy_mbid, h->gpart, h->lpart,
                   h->adv_sums_base, h->adv_ms_base, h->newv, h->vfix, h->dscale, h->stats_dev, h->comm_buf, h->snap, h->snap_betap, h->snap_env, h->stage};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int k = 0; k < CRL_K_COUNT; ++k)
@@ -610,10 +611,12 @@ static int update_step(crl_ppo* h, int mb, double eta, int apply, int slot, bool
   // with a communicator attached and the optimiser following, the statistics ride in the optimiser launch (optim.hip);
   // the inline value-loss fix-up reads the flag the statistics raise, so it keeps them as their own launch
   h->defer_stats = apply && !h->wide && has_comm(h) && !(inline_fix && h->cfg.clip_value_loss && h->world == 1);
-  const int rc = launch_update(h, mb, h->stats_dev + slot, inline_fix);
+  // one GPU and nothing between the gradient and the optimiser (no all-reduce, no inline value-loss fix-up): one launch does both
+  const bool fused = apply && !h->wide && !has_comm(h) && !(inline_fix && h->cfg.clip_value_loss) && opt(h, OPT_FUSE_OPTIM) && h->P <= 32768;
+  const int rc = launch_update(h, mb, h->stats_dev + slot, inline_fix, fused, eta);
   h->defer_stats = false;
   if (rc) return 1;
-  if (apply && launch_optim(h, eta)) return 1;
+  if (apply && !fused && launch_optim(h, eta)) return 1;
   return 0;
 }
 

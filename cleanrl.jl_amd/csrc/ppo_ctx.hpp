@@ -62,6 +62,7 @@ enum OptId {
   OPT_WIDE_TANH_RATIONAL,     // 1 = the layer-wise path evaluates tanh_fast everywhere (default 0: exp2 form outside the actor's rollout forward)
   OPT_GAE_SEG,                // standalone GAE kernel: steps per segment (0 = automatic)
   OPT_GAE_TILE,               // standalone GAE kernel: envs per block (0 = automatic)
+  OPT_FUSE_OPTIM,             // 1 = single-GPU speculative steps run reduce + ClipNorm + Adam as one launch (reduce_optim_kernel)
   OPT_COUNT
 };
 
@@ -99,7 +100,9 @@ struct crl_ppo {
   // optimiser
   float* params = nullptr; float* adam_m = nullptr; float* adam_v = nullptr;  // the gradient lives in comm_buf[0..P)
   double* betap = nullptr;     // [24]
-  double* optim_part = nullptr;  // per-slice Σg² of the sliced optimiser step (large networks)
+  double* optim_part = nullptr;  // per-slice Σg² of the sliced optimiser step (large networks); [12][blocks] of the fused reduce + optimiser launch
+  unsigned* ticket = nullptr;    // grid meeting point of reduce_optim_kernel: counts arrivals, never reset
+  unsigned ticket_target = 0;    // arrivals after the launch being enqueued
   // One permutation per update epoch (ppo.jl:194): crl_ppo_iterate draws all update_epochs of them right after GAE, so the
   // advantage statistics of every minibatch of the iteration are known (and all-reduced, once) before the first optimiser
   // step. `perm` / `adv_ms` point at the CURRENT slot; the host-driven entry points (crl_shuffle, …) use slot 0.
@@ -224,7 +227,7 @@ int launch_adv_bucket_sums(crl_ppo* h, int slot0, int nslots, double* part, int 
 int launch_adv_stats_finish(crl_ppo* h, int slot0 = -1, int nslots = 1);
 int launch_pack_records(crl_ppo* h);
 int launch_slot_adv_sums(crl_ppo* h, int slot0, int nslots);   // records.hip: Σadv, Σadv² of every minibatch of the slots
-int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot, bool inline_fix = true);
+int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot, bool inline_fix = true, bool with_optim = false, double eta = 0.0);
 int launch_update_exact_dp(crl_ppo* h, int mb, crl_ppo_stats* stats_slot);
 int launch_optim(crl_ppo* h, double eta);
 int comm_allreduce(crl_ppo* h, void* buf, size_t count, bool is_double);

@@ -787,6 +787,129 @@ __global__ void __launch_bounds__(64 * RG) reduce_kernel(const float* __restrict
   }
 }
 
+// reduce_kernel<0> + Optimiser(ClipNorm(0.5), Adam(η)) in ONE launch (single GPU, speculative step: nothing sits between the
+// gradient and the optimiser). Same blocks, same fixed summation order as reduce_kernel; then every block leaves Σg² of its 64
+// outputs per parameter array, the grid meets at a ticket (144 blocks of 1024 threads: all resident — nothing else runs on the
+// device between an update kernel and the next one), every block sums the partials of the arrays it touches in block order
+// (all blocks that touch an array compute the same norm bit for bit) and applies ClipNorm + Adam to its 64 entries with the
+// arithmetic of clipnorm_adam_kernel (optim.hip; oracle: orc_clipnorm_adam). The β powers are read before the ticket and
+// advanced after it by the block that holds an array's first entry. Saves a launch, a launch gap and the one-block-per-array
+// walk of the 4,096-entry arrays per optimiser step.
+struct FusedOptimArgs {
+  int off[13];
+  float* params; float* m; float* v; double* betap; double* part /* [12][gridDim.x] */; unsigned* ticket; unsigned target;
+  double eta, thresh;
+};
+__global__ void __launch_bounds__(64 * RG) reduce_optim_kernel(const float* __restrict__ gpart, const double* __restrict__ lpart,
+                                                               int nblkA, int nblkC, int pmax, int gstride, int Pa, int Pc,
+                                                               float* __restrict__ msg, StatsArgs st, FusedOptimArgs oa) {
+#pragma clang fp contract(off)
+  __shared__ float sm[RG][64];
+  __shared__ double smd[RG][4];
+  __shared__ double nrm2[12];
+  const int P = Pa + Pc;
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + o;
+  float s = 0.0f;
+  const bool live = i < P;
+  if (live) {
+    const int role = i >= Pa;
+    const float* gp = gpart + (size_t)role * pmax * gstride + (role ? i - Pa : i);
+    const int blocks_per_role = role ? nblkC : nblkA;
+    int b = g;
+    for (; b + 3 * RG < blocks_per_role; b += 4 * RG) {
+      const float v0 = gp[(size_t)b * gstride], v1 = gp[(size_t)(b + RG) * gstride], v2 = gp[(size_t)(b + 2 * RG) * gstride],
+                  v3 = gp[(size_t)(b + 3 * RG) * gstride];
+      s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; b < blocks_per_role; b += RG) s += gp[(size_t)b * gstride];
+  }
+  sm[g][o] = s;
+  double ds = 0.0;
+  const bool last = blockIdx.x == gridDim.x - 1;
+  if (last && o < 4) {
+    const int which = o, lrole = which >> 1;
+    const double* l = lpart + (size_t)lrole * pmax * 2 + (which & 1);
+    const int nb = lrole ? nblkC : nblkA;
+    for (int b = g; b < nb; b += RG) ds += l[b * 2];
+    smd[g][o] = ds;
+  }
+  __syncthreads();
+  // the arrays this block's 64 outputs belong to: [a_lo, a_hi]
+  const int i_lo = blockIdx.x * 64, i_hi = (i_lo + 63 < P - 1) ? i_lo + 63 : P - 1;
+  int a_lo = 0, a_hi = 0;
+  while (a_lo < 11 && i_lo >= oa.off[a_lo + 1]) ++a_lo;
+  while (a_hi < 11 && i_hi >= oa.off[a_hi + 1]) ++a_hi;
+  int arr = a_lo;
+  float grad = 0.0f;
+  double bp0 = 0.0, bp1 = 0.0;
+  float m_old = 0.0f, v_old = 0.0f, p_old = 0.0f;   // this entry's optimiser state: fetched before the meeting point, under its latency
+  if (g == 0) {
+    if (live) {
+      m_old = oa.m[i]; v_old = oa.v[i]; p_old = oa.params[i];
+      float t = sm[0][o];
+#pragma unroll
+      for (int q = 1; q < RG; ++q) t += sm[q][o];
+      msg[i] = t;
+      grad = t;
+      while (arr < 11 && i >= oa.off[arr + 1]) ++arr;
+      bp0 = oa.betap[2 * arr]; bp1 = oa.betap[2 * arr + 1];
+    }
+    const double gsq = live ? (double)grad * (double)grad : 0.0;
+    for (int a = a_lo; a <= a_hi; ++a) {
+      const double t = wave_sum((live && arr == a) ? gsq : 0.0);
+      if (o == 0) __hip_atomic_store(oa.part + (size_t)a * gridDim.x + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (last && g == 0 && o < 4) {
+    double t = smd[0][o];
+#pragma unroll
+    for (int q = 1; q < RG; ++q) t += smd[q][o];
+    msg[P + o] = (float)t;
+  }
+  if (last && st.dscale && threadIdx.x < 2) {
+    unsigned* mx = reinterpret_cast<unsigned*>(st.dscale + 2);
+    st.dscale[threadIdx.x] = dw_next_scale(mx[threadIdx.x], st.dscale[threadIdx.x]);
+    mx[threadIdx.x] = 0u;
+  }
+  if (last) {
+    __syncthreads();
+    if (threadIdx.x == 0) compute_stats(msg, P, st.c, st.Mglobal, st.adv_ms, st.mb, st.vfix, st.out, 0);
+  }
+  if (g != 0) return;                       // the optimiser half runs on the block's first wave
+  // grid-wide meeting point. Everything that crosses blocks (the Σg² partials, the ticket) moves through agent-scope atomic
+  // stores / loads, which are served at the device's coherent level: no release / acquire fences — on this GPU those write
+  // back and invalidate a whole L2, which cost as much as the kernel boundary this launch exists to save (17.8 µs with fences).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the partials have arrived before the ticket moves
+  if (o == 0) {
+    __hip_atomic_fetch_add(oa.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(oa.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - oa.target > 0x7FFFFFFFu) __builtin_amdgcn_s_sleep(1);
+  }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+  for (int a = a_lo; a <= a_hi; ++a) {
+    const int b0 = oa.off[a] / 64, b1 = (oa.off[a + 1] - 1) / 64;
+    double t = 0.0;
+    for (int b = b0 + o; b <= b1; b += 64) t += __hip_atomic_load(oa.part + (size_t)a * gridDim.x + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = wave_sum(t);
+    if (o == 0) nrm2[a] = t;
+  }
+  wave_lds_fence();
+  if (!live) return;
+  const float nrm = (float)sqrt(nrm2[arr]);
+  const bool clip = (double)nrm > oa.thresh;
+  const double sc = clip ? oa.thresh / (double)nrm : 1.0;
+  const double b1c = 0.9, b2c = 0.999, epsn = 1e-8;
+  double gd = (double)grad;
+  if (clip) gd = (double)(float)(gd * sc);
+  const float mi = (float)(b1c * (double)m_old + (1 - b1c) * gd);
+  const float vi = (float)(b2c * (double)v_old + (1 - b2c) * gd * gd);
+  oa.m[i] = mi; oa.v[i] = vi;
+  const double delta = (double)mi / (1 - bp0) / (sqrt((double)vi / (1 - bp1)) + epsn) * oa.eta;
+  oa.params[i] = p_old - (float)delta;
+  if (i == oa.off[arr]) { oa.betap[2 * arr] = bp0 * b1c; oa.betap[2 * arr + 1] = bp1 * b2c; }
+}
+
 // data-parallel path: the sums are global only after the all-reduce, so the statistics get their own tiny launch
 __global__ void stats_kernel(const float* __restrict__ msg, int P, StatsArgs st, int mode) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -874,7 +997,7 @@ static StatsArgs stats_args(crl_ppo* h, int mb, crl_ppo_stats* slot, int fused) 
 // the rare exact value-loss pass (three early-exit launches). The gradient message ends up in comm_buf.
 // inline_fix: follow the speculative pass with the three early-exit launches of the exact value-loss pass (host-driven single
 // steps). crl_ppo_iterate passes false: there a failed speculation is caught by the guard window (api.cpp) instead.
-int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot, bool inline_fix) {
+int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot, bool inline_fix, bool with_optim, double eta) {
   if (h->wide) return wide_update(h, mb, stats_slot);
   if (h->cfg.obs_dim != 4 || h->cfg.n_act != 2 || h->cfg.hidden != 64) {
     set_error("this build of libcleanrl_hip supports obs_dim=4, n_act=2, hidden=64 (2x64 MLP) only");
@@ -890,8 +1013,25 @@ int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot, bool inline_fix
     int nA, nC;
     main_pass_blocks(h, &nA, &nC);
     ProfScope ps(h, CRL_K_REDUCE);
-    hipLaunchKernelGGL(reduce_kernel<0>, dim3((P + 63) / 64), dim3(64 * RG), 0, h->stream, h->gpart, h->lpart, nA, nC,
-                       h->update_blocks, (int)h->Pa, (int)h->Pa, (int)h->Pc, h->comm_buf, stats_args(h, mb, stats_slot, dp ? 0 : 1));
+    if (with_optim) {
+      // single GPU, no fix-up between gradient and optimiser: reduce + ClipNorm + Adam in one launch (reduce_optim_kernel)
+      if (dp || (inline_fix && h->cfg.clip_value_loss)) { set_error("internal: the fused optimiser step needs a local, speculative step"); return 1; }
+      FusedOptimArgs oa;
+      const int hN = h->cfg.hidden, d = h->cfg.obs_dim, A = h->cfg.n_act;
+      const int sizes[12] = {hN * d, hN, hN * hN, hN, A * hN, A, hN * d, hN, hN * hN, hN, hN, 1};
+      oa.off[0] = 0;
+      for (int q = 0; q < 12; ++q) oa.off[q + 1] = oa.off[q] + sizes[q];
+      const unsigned nb = (unsigned)((P + 63) / 64);
+      h->ticket_target += nb;
+      oa.params = h->params; oa.m = h->adam_m; oa.v = h->adam_v; oa.betap = h->betap; oa.part = h->optim_part; oa.ticket = h->ticket;
+      oa.target = h->ticket_target; oa.eta = eta; oa.thresh = 0.5;
+      hipLaunchKernelGGL(reduce_optim_kernel, dim3(nb), dim3(64 * RG), 0, h->stream, h->gpart, h->lpart, nA, nC, h->update_blocks, (int)h->Pa,
+                         (int)h->Pa, (int)h->Pc, h->comm_buf, stats_args(h, mb, stats_slot, 1), oa);
+      wide_mark_params_changed(h);
+    } else {
+      hipLaunchKernelGGL(reduce_kernel<0>, dim3((P + 63) / 64), dim3(64 * RG), 0, h->stream, h->gpart, h->lpart, nA, nC,
+                         h->update_blocks, (int)h->Pa, (int)h->Pa, (int)h->Pc, h->comm_buf, stats_args(h, mb, stats_slot, dp ? 0 : 1));
+    }
     CRL_HIP_CHECK(hipGetLastError());
   }
   if (dp) {

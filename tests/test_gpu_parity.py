@@ -260,11 +260,12 @@ def test_shuffle_bijection_is_a_permutation(crl, nt, k):
     agent.close()
 
 
-@pytest.mark.parametrize("n_iters", [1, 3])
-def test_full_iteration_matches_oracle(crl, n_iters):
-    """C1 (BASELINE configs[0]): num_envs=8, num_steps=128 — whole ppo.jl:117-253 loop body, exact Fisher–Yates."""
+@pytest.mark.parametrize("n_iters,fuse_optim", [(1, 1), (3, 1), (3, 0)])
+def test_full_iteration_matches_oracle(crl, n_iters, fuse_optim):
+    """C1 (BASELINE configs[0]): num_envs=8, num_steps=128 — whole ppo.jl:117-253 loop body, exact Fisher–Yates; with the gradient
+    reduction + ClipNorm + Adam as one launch (the default inside crl_ppo_iterate on one GPU) and as two."""
     nt, k = 8, 128
-    agent = make_agent(crl, nt=nt, k=k, shuffle_mode=0)
+    agent = make_agent(crl, nt=nt, k=k, shuffle_mode=0, options={"fuse_optim": fuse_optim})
     params = agent.get_params()
     cfgo, st = _oracle_state(nt, k, params)
     h = agent.handle
@@ -283,6 +284,23 @@ def test_full_iteration_matches_oracle(crl, n_iters):
         assert np.max(np.abs(pg - po)) < IT_PARAM, np.max(np.abs(pg - po))
     assert h.iteration == n_iters
     agent.close(); st.close()
+
+
+def test_fused_and_two_launch_optimiser_steps_agree_at_c2_size(crl):
+    """reduce_optim_kernel (one launch, grid-wide meeting point) against reduce_kernel + clipnorm_adam_kernel on 4096 envs x 128 steps,
+    two whole iterations = 32 optimiser steps: the gradients are the same bits, the per-array norms differ at most in the order their
+    Float64 partial sums are added, so parameters and Adam state agree to a few ulps."""
+    F = crl._lib
+    a1 = make_agent(crl, nt=4096, k=128)
+    a0 = make_agent(crl, nt=4096, k=128, params=a1.get_params(), options={"fuse_optim": 0})
+    for a in (a1, a0):
+        a.handle.env_reset(); a.handle.iterate(2, want_stats=False)
+    for f in (F.F_PARAMS, F.F_ADAM_M, F.F_ADAM_V):
+        x, y = a1.handle.read(f), a0.handle.read(f)
+        assert np.max(np.abs(x - y)) <= 1e-7 * max(1.0, float(np.max(np.abs(y)))), (f, np.max(np.abs(x - y)))
+    assert np.array_equal(a1.handle.read(F.F_BETAP), a0.handle.read(F.F_BETAP))
+    assert np.array_equal(a1.handle.read(F.F_ACTION), a0.handle.read(F.F_ACTION))
+    a1.close(); a0.close()
 
 
 def test_errors_are_reported_not_thrown(crl):
