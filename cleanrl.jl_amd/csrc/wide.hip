@@ -915,15 +915,12 @@ static size_t dense_x2_smem(const DenseX3Args& a, int MB) {
 template <int EPI>
 static int dense_x2_launch(hipStream_t st, const DenseX3Args& a) {
   if (a.M <= 0) return 0;
-  const bool big = a.M > 32768;
-  const int MB = big ? 64 : 32;
-  size_t region = (size_t)X2_SLAB_F16 * 2 + (size_t)2 * MB * X3ROW * 2;
-  const size_t epi = (size_t)8 * 32 * 36 * 4;
-  if (epi > region) region = epi;
-  size_t smem = region + (size_t)2 * MB * 4;                              // + per-sample scale / inverse
-  const size_t head = a.Z ? epi + (size_t)8 * MB * a.ldz * 4 : 0;         // fused head partials (forward only: no scales needed)
-  if (head > smem) smem = head;
-  if (big) hipLaunchKernelGGL((wide_dense_x2_kernel<EPI, 2>), dim3((a.M + 63) / 64), dim3(512), smem, st, a);
+  // samples per block: 32 (rollout-sized batches: the grid still covers the chip), 64, or 128 for minibatches — every block
+  // streams all of W2 (256 KB as fp16x2 fragments), so a larger block halves that traffic and doubles the MFMAs per staged slab
+  const int MB = a.M > 131072 ? 128 : a.M > 32768 ? 64 : 32;
+  const size_t smem = dense_x2_smem(a, MB);
+  if (MB == 128) hipLaunchKernelGGL((wide_dense_x2_kernel<EPI, 4>), dim3((a.M + 127) / 128), dim3(512), smem, st, a);
+  else if (MB == 64) hipLaunchKernelGGL((wide_dense_x2_kernel<EPI, 2>), dim3((a.M + 63) / 64), dim3(512), smem, st, a);
   else hipLaunchKernelGGL((wide_dense_x2_kernel<EPI, 1>), dim3((a.M + 31) / 32), dim3(512), smem, st, a);
   CRL_HIP_CHECK(hipGetLastError());
   return 0;
