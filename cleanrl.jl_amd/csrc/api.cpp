@@ -36,6 +36,7 @@ static const OptDesc kOpts[OPT_COUNT] = {
     {"wide_tanh_rational", 0, 0, 1},
     {"gae_seg", 0, 0, 16},
     {"gae_tile", 0, 0, 64},
+    {"wide_rollout_persist", 1, 0, 1},
     {"fuse_optim", 1, 0, 1},
 };
 static int opt_find(const char* key) {

@@ -62,6 +62,7 @@ enum OptId {
   OPT_WIDE_TANH_RATIONAL,     // 1 = the layer-wise path evaluates tanh_fast everywhere (default 0: exp2 form outside the actor's rollout forward)
   OPT_GAE_SEG,                // standalone GAE kernel: steps per segment (0 = automatic)
   OPT_GAE_TILE,               // standalone GAE kernel: envs per block (0 = automatic)
+  OPT_WIDE_ROLLOUT_PERSIST,   // layer-wise path, 2x256 fp16x2: the whole rollout as one launch (0 = three launches per step)
   OPT_FUSE_OPTIM,             // 1 = single-GPU speculative steps run reduce + ClipNorm + Adam as one launch (reduce_optim_kernel)
   OPT_COUNT
 };

@@ -824,14 +824,10 @@ __device__ __forceinline__ void wide_dense_x2_body(const DenseX3Args& a) {
     xsrc[u] = reinterpret_cast<const f32x4*>(a.X + (size_t)(xok[u] ? m : 0) * a.K) + q;
     xs[u] = EPI == EPI_DTANH ? sc[i < MB * 8 ? mm : 0] : X2_ACT_SCALE;
   }
-  u32x4v wr[WR]; f32x4 xr[XR];
   const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-  for (int u = 0; u < WR; ++u) wr[u] = wsrc[NT * u];
-#pragma unroll
-  for (int u = 0; u < XR; ++u) xr[u] = xok[u] ? xsrc[u][0] : zero4;
   const int nslab = a.K >> 5;
-  for (int sl = 0; sl < nslab; ++sl) {
+  // one slab: registers → LDS (split on the way), barrier, refill the registers with slab `next` (if any), multiply out of LDS
+  auto slab = [&](u32x4v (&wr)[WR], f32x4 (&xr)[XR], int sl, int next) {
     if (sl) __syncthreads();
 #pragma unroll
     for (int u = 0; u < WR; ++u) reinterpret_cast<u32x4v*>(Wl)[tid + NT * u] = wr[u];
@@ -846,11 +842,11 @@ __device__ __forceinline__ void wide_dense_x2_body(const DenseX3Args& a) {
       }
     }
     __syncthreads();
-    if (sl + 1 < nslab) {
+    if (next < nslab) {
 #pragma unroll
-      for (int u = 0; u < WR; ++u) wr[u] = wsrc[(size_t)(sl + 1) * (X2_SLAB_F16 / 8) + NT * u];
+      for (int u = 0; u < WR; ++u) wr[u] = wsrc[(size_t)next * (X2_SLAB_F16 / 8) + NT * u];
 #pragma unroll
-      for (int u = 0; u < XR; ++u) xr[u] = xok[u] ? xsrc[u][(sl + 1) * 8] : zero4;
+      for (int u = 0; u < XR; ++u) xr[u] = xok[u] ? xsrc[u][next * 8] : zero4;
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -867,7 +863,16 @@ __device__ __forceinline__ void wide_dense_x2_body(const DenseX3Args& a) {
 #pragma unroll
       for (int y = 0; y < TM; ++y) acc[y] = mfma_x2(af, bf[y], acc[y]);
     }
-  }
+  };
+  auto fetch = [&](u32x4v (&wr)[WR], f32x4 (&xr)[XR], int sl) {
+#pragma unroll
+    for (int u = 0; u < WR; ++u) wr[u] = wsrc[(size_t)sl * (X2_SLAB_F16 / 8) + NT * u];
+#pragma unroll
+    for (int u = 0; u < XR; ++u) xr[u] = xok[u] ? xsrc[u][sl * 8] : zero4;
+  };
+  u32x4v wr[WR]; f32x4 xr[XR];
+  fetch(wr, xr, 0);
+  for (int sl = 0; sl < nslab; ++sl) slab(wr, xr, sl, sl + 1);
   __syncthreads();
   float* scr = reinterpret_cast<float*>(smx) + wave * (32 * 36);
   if (EPI == EPI_TANH && a.Z) {
@@ -1599,73 +1604,135 @@ struct WStepArgs {
   uint64_t iteration; int step;
 };
 
-__global__ void __launch_bounds__(256) wide_step_kernel(WStepArgs a) {
+// one env, one step; the episode statistics of a finished episode are added to the caller's running sums
+__device__ __forceinline__ void wide_step_env(const WStepArgs& a, int e, int step, double& st_n, double& st_ret, double& st_len, double& st_max) {
   const DevCfg& c = a.c;
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  const bool ok = e < c.nt;
-  double st_n = 0.0, st_ret = 0.0, st_len = 0.0, st_max = 0.0;
-  if (ok) {
-    const int D = c.D, A = c.A;
-    const uint32_t gid = c.env_id_offset + (uint32_t)e;
-    const uint64_t gstep = a.iteration * (uint64_t)c.k + (uint64_t)a.step;
-    const size_t b = (size_t)e + (size_t)c.nt * a.step;
-    int ep_len = a.ep_length[e] + 1;                                   // ppo.jl:125
-    float z[AMAX], p[AMAX], lp[AMAX];
-    load_logits(a.Z, a.A8, A, (size_t)e, z);
-    softmax_rt(z, A, p, lp);                                          // ppo.jl:127 get_action
-    const double u = u53(philox_env(c.seed, gid, gstep, 0));
-    const int act = sample_rt(p, A, u);
-    const float lpa = pick_rt(lp, A, act);
-    float* co = a.cur_obs + (size_t)D * e;
-    float* es = a.env_state + (size_t)D * e;
-    float* ob = a.obs + b * (size_t)D;
-    for (int i = 0; i < D; ++i) ob[i] = co[i];                        // ppo.jl:133-140 Buffer.add!
-    a.action[b] = act; a.logprob[b] = lpa; a.terminal[b] = a.next_done[e]; a.value[b] = a.V[e];
-    bool done; float rew;
-    if (c.env_kind == CRL_ENV_CARTPOLE) {
-      float s[4] = {es[0], es[1], es[2], es[3]};
-      int t_env = a.env_t[e];
-      done = cartpole_step(s, t_env, act);                             // ppo.jl:130
-      rew = done ? 0.0f : 1.0f;                                        // ppo.jl:132
-      for (int i = 0; i < 4; ++i) co[i] = s[i];                        // ppo.jl:143 (before reset!, Q7)
-      if (done) {
-        cartpole_reset(s, c.seed, gid, gstep, 1);                      // ppo.jl:164
-        t_env = 0;
-        if (!c.stale_obs) for (int i = 0; i < 4; ++i) co[i] = s[i];
-      }
-      for (int i = 0; i < 4; ++i) es[i] = s[i];
-      a.env_t[e] = t_env;
-    } else {
-      for (int q = 0; 4 * q < D; ++q) {
-        float o4[4];
-        synth_obs4(c.seed, gid, gstep, q, o4);
-        for (int i = 0; i < 4 && 4 * q + i < D; ++i) { es[4 * q + i] = o4[i]; co[4 * q + i] = o4[i]; }
-      }
-      synth_reward_done(c.seed, gid, gstep, rew, done);
+  const int D = c.D, A = c.A;
+  const uint32_t gid = c.env_id_offset + (uint32_t)e;
+  const uint64_t gstep = a.iteration * (uint64_t)c.k + (uint64_t)step;
+  const size_t b = (size_t)e + (size_t)c.nt * step;
+  int ep_len = a.ep_length[e] + 1;                                   // ppo.jl:125
+  float z[AMAX], p[AMAX], lp[AMAX];
+  load_logits(a.Z, a.A8, A, (size_t)e, z);
+  softmax_rt(z, A, p, lp);                                          // ppo.jl:127 get_action
+  const double u = u53(philox_env(c.seed, gid, gstep, 0));
+  const int act = sample_rt(p, A, u);
+  const float lpa = pick_rt(lp, A, act);
+  float* co = a.cur_obs + (size_t)D * e;
+  float* es = a.env_state + (size_t)D * e;
+  float* ob = a.obs + b * (size_t)D;
+  for (int i = 0; i < D; ++i) ob[i] = co[i];                        // ppo.jl:133-140 Buffer.add!
+  a.action[b] = act; a.logprob[b] = lpa; a.terminal[b] = a.next_done[e]; a.value[b] = a.V[e];
+  bool done; float rew;
+  if (c.env_kind == CRL_ENV_CARTPOLE) {
+    float s[4] = {es[0], es[1], es[2], es[3]};
+    int t_env = a.env_t[e];
+    done = cartpole_step(s, t_env, act);                             // ppo.jl:130
+    rew = done ? 0.0f : 1.0f;                                        // ppo.jl:132
+    for (int i = 0; i < 4; ++i) co[i] = s[i];                        // ppo.jl:143 (before reset!, Q7)
+    if (done) {
+      cartpole_reset(s, c.seed, gid, gstep, 1);                      // ppo.jl:164
+      t_env = 0;
+      if (!c.stale_obs) for (int i = 0; i < 4; ++i) co[i] = s[i];
     }
-    a.reward[b] = rew;
-    a.next_done[e] = done ? 1 : 0;                                     // ppo.jl:144
-    float ep_ret = a.ep_return[e] + rew;                               // ppo.jl:145
-    if (done) {                                                        // ppo.jl:147-165
-      st_n = 1.0; st_ret = (double)ep_ret; st_len = (double)ep_len; st_max = fmax(0.0, (double)ep_ret);
-      if (a.ring_cap > 0) {
-        const uint32_t slot = atomicAdd(a.ring_count, 1u);
-        if (slot < (uint32_t)a.ring_cap) a.ring[slot] = crl_episode_record{ep_ret, ep_len, (int32_t)gid, a.step};
-      }
-      ep_ret = 0.0f; ep_len = 0;
+    for (int i = 0; i < 4; ++i) es[i] = s[i];
+    a.env_t[e] = t_env;
+  } else {
+    for (int q = 0; 4 * q < D; ++q) {
+      float o4[4];
+      synth_obs4(c.seed, gid, gstep, q, o4);
+      for (int i = 0; i < 4 && 4 * q + i < D; ++i) { es[4 * q + i] = o4[i]; co[4 * q + i] = o4[i]; }
     }
-    a.ep_return[e] = ep_ret; a.ep_length[e] = ep_len;
+    synth_reward_done(c.seed, gid, gstep, rew, done);
   }
+  a.reward[b] = rew;
+  a.next_done[e] = done ? 1 : 0;                                     // ppo.jl:144
+  float ep_ret = a.ep_return[e] + rew;                               // ppo.jl:145
+  if (done) {                                                        // ppo.jl:147-165
+    st_n += 1.0; st_ret += (double)ep_ret; st_len += (double)ep_len; st_max = fmax(st_max, fmax(0.0, (double)ep_ret));
+    if (a.ring_cap > 0) {
+      const uint32_t slot = atomicAdd(a.ring_count, 1u);
+      if (slot < (uint32_t)a.ring_cap) a.ring[slot] = crl_episode_record{ep_ret, ep_len, (int32_t)gid, step};
+    }
+    ep_ret = 0.0f; ep_len = 0;
+  }
+  a.ep_return[e] = ep_ret; a.ep_length[e] = ep_len;
+}
+// a wave's episode statistics into the handle's four accumulators
+__device__ __forceinline__ void wide_step_stats(double* ep_stats, double st_n, double st_ret, double st_len, double st_max) {
   st_n = wave_sum(st_n);
   if (st_n > 0.0) {
     st_ret = wave_sum(st_ret); st_len = wave_sum(st_len);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) st_max = fmax(st_max, __shfl_xor(st_max, o, 64));
     if ((threadIdx.x & 63) == 0) {
-      atomicAdd(&a.ep_stats[0], st_n); atomicAdd(&a.ep_stats[1], st_ret); atomicAdd(&a.ep_stats[2], st_len);
-      atomicMax(reinterpret_cast<unsigned long long*>(&a.ep_stats[3]), (unsigned long long)__double_as_longlong(st_max));
+      atomicAdd(&ep_stats[0], st_n); atomicAdd(&ep_stats[1], st_ret); atomicAdd(&ep_stats[2], st_len);
+      atomicMax(reinterpret_cast<unsigned long long*>(&ep_stats[3]), (unsigned long long)__double_as_longlong(st_max));
     }
   }
+}
+
+__global__ void __launch_bounds__(256) wide_step_kernel(WStepArgs a) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  double st_n = 0.0, st_ret = 0.0, st_len = 0.0, st_max = 0.0;
+  if (e < a.c.nt) wide_step_env(a, e, a.step, st_n, st_ret, st_len, st_max);
+  wide_step_stats(a.ep_stats, st_n, st_ret, st_len, st_max);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// The whole rollout of the 2×256 fp16x2 configuration as ONE launch (ppo.jl:123-166). Envs are independent, so a block owns a tile
+// of 32 envs for all num_steps steps: per step layer 1 of both networks on the VALU (thread = hidden row, its 8 + 1 weights stay in
+// registers for the launch; the actor with tanh_fast, the critic with the exp2 activation as in the per-step path), then the two
+// 256×256 layers with their fused heads by the per-step path's own block body (wide_dense_x2_body<EPI_TANH, 1>: W2 streams from L2,
+// h1 passes through a 32 KB per-block slice of the workspace that never leaves the caches), then 32 threads sample, step the env
+// and append to the buffer. Was three launches per step (57 µs x 128 steps at C3).
+// ------------------------------------------------------------------------------------------------------
+// The layer body inlined into the step loop: everything it derives from (thread index, argument) pairs is loop-invariant, gets hoisted
+// out of the step loop for both networks, and the kernel then needs 227 registers (one block per CU) or spills 448 bytes at 128. The
+// arguments those values hang on are made opaque once per step, which keeps the per-step body what it is in the per-step kernel.
+__device__ __forceinline__ void wide_rollout_layer2(DenseX3Args x) {
+  asm volatile("" : "+s"(x.Wx3), "+s"(x.X), "+s"(x.Y), "+s"(x.Z), "+s"(x.bias), "+s"(x.W3t), "+s"(x.M));
+  wide_dense_x2_body<EPI_TANH, 1>(x);
+}
+struct WRollArgs {
+  DenseX3Args x[2]; WStepArgs s;
+  const float* W1[2]; const float* b1[2]; float* h1[2]; int fast[2]; int D; size_t obs_off;   // obs_off: byte offset of the obs tile in LDS
+};
+__global__ void __launch_bounds__(512, 4) wide_rollout_persist_kernel(WRollArgs r) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
+  float* xt = reinterpret_cast<float*>(smx + r.obs_off);                 // [32 envs][D] current observations of the tile
+  const int tid = threadIdx.x, net = tid >> 8, n = tid & 255, D = r.D;
+  const int m0 = blockIdx.x * 32, nt = r.s.c.nt;
+  float w1[16];                                                          // this thread's row of W1 (obs_dim <= 16) and its bias
+#pragma unroll
+  for (int k = 0; k < 16; ++k) w1[k] = k < D ? r.W1[net][n + 256 * k] : 0.0f;
+  const float bias1 = r.b1[net][n];
+  const bool fast = r.fast[net] != 0;
+  double st_n = 0.0, st_ret = 0.0, st_len = 0.0, st_max = 0.0;
+  for (int step = 0; step < r.s.c.k; ++step) {
+    for (int i = tid; i < 32 * D; i += 512) { const int m = m0 + i / D; xt[i] = m < nt ? r.s.cur_obs[(size_t)m0 * D + i] : 0.0f; }
+    __syncthreads();
+    {
+      float* h1 = r.h1[net] + (size_t)m0 * 256 + n;
+#pragma unroll 2
+      for (int m = 0; m < 32; ++m) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if (k < D) acc = __builtin_fmaf(w1[k], xt[m * D + k], acc);
+        if (m0 + m < nt) h1[(size_t)m * 256] = wide_tanh(acc + bias1, fast);
+      }
+    }
+    __syncthreads();
+    wide_rollout_layer2(r.x[0]);
+    __syncthreads();
+    wide_rollout_layer2(r.x[1]);
+    __syncthreads();
+    int e = m0 + tid;
+    asm volatile("" : "+v"(e));          // as above: the dozen per-env addresses are formed per step, not kept across the loop
+    if (tid < 32 && e < nt) wide_step_env(r.s, e, step, st_n, st_ret, st_len, st_max);
+    __syncthreads();
+  }
+  if (tid < 64) wide_step_stats(r.s.ep_stats, st_n, st_ret, st_len, st_max);
 }
 
 // env construction for the synthetic env (oracle: orc_env_init, gstep = ~0)
@@ -1940,6 +2007,29 @@ int wide_rollout(crl_ppo* h) {
   a.ring = h->ep_ring; a.ring_count = h->ep_ring_count; a.ring_cap = h->ep_ring_cap;
   if (h->ep_ring_cap > 0) CRL_HIP_CHECK(hipMemsetAsync(h->ep_ring_count, 0, sizeof(uint32_t), h->stream));
   ProfScope ps(h, CRL_K_ROLLOUT);
+  if (w->H == 256 && wide_x2(h) && w->D <= 16 && opt(h, OPT_WIDE_ROLLOUT_PERSIST)) {   // one launch for all steps (wide_rollout_persist_kernel)
+    WRollArgs r;
+    const bool fast_ok = !opt(h, OPT_WIDE_TANH_RATIONAL);
+    for (int net = 0; net < 2; ++net) {
+      const int NO = net ? 1 : w->A;
+      const NetOff o = net_off(256, w->D, NO);
+      const float* P = h->params + (net ? h->Pa : 0);
+      const float* pk = w->pack + w->pk_base[net];
+      DenseX3Args& x = r.x[net];
+      x.Wx3 = pk + w->pk[net].x2f; x.X = w->h1[net]; x.K = 256; x.bias = P + o.b2; x.S = nullptr; x.Y = w->h2[net]; x.M = h->dc.nt;
+      x.W3t = pk + w->pk[net].w3t; x.b3 = P + o.b3; x.Z = net ? w->v : w->z; x.A = NO; x.ldz = net ? 1 : w->A8;
+      x.dZ = nullptr; x.ldd = 0; x.Ad = 0; x.bz = nullptr; x.bld = 0; x.bA = 0; x.wmax = nullptr;
+      x.fast_act = (net == 1 && fast_ok) ? 1 : 0;      // the actor keeps tanh_fast: its logits decide bit-compared action indices
+      x.wsc = w->wsc + 2 * net;
+      r.W1[net] = P + o.W1; r.b1[net] = P + o.b1; r.h1[net] = w->h1[net]; r.fast[net] = x.fast_act;
+    }
+    r.s = a; r.D = w->D;
+    const size_t s0 = dense_x2_smem(r.x[0], 32), s1 = dense_x2_smem(r.x[1], 32);
+    r.obs_off = ((s0 > s1 ? s0 : s1) + 15) & ~(size_t)15;
+    hipLaunchKernelGGL(wide_rollout_persist_kernel, dim3((h->dc.nt + 31) / 32), dim3(512), r.obs_off + (size_t)32 * w->D * 4, h->stream, r);
+    CRL_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   for (int step = 0; step < h->dc.k; ++step) {
     if (wide_forward_pair(h, h->cur_obs, w->D, h->dc.nt, w->z, w->A8, w->v, 1)) return 1;   // ppo.jl:127-128
     a.step = step;

@@ -25,7 +25,7 @@ def rel_err_s(a, b):
 def make_wide(crl, nt, k, D, A, Hd, params=None, **kw):
     cfg = crl.PPOConfig(num_envs=nt, num_steps=k, total_timesteps=nt * k * 10, **{a: b for a, b in kw.items() if a in
                         ("num_minibatches", "update_epochs", "clip_value_loss", "anneal_lr", "lr")})
-    shape = {a: b for a, b in kw.items() if a in ("gae_mode", "shuffle_mode", "stale_obs", "env_id_offset", "seed")}
+    shape = {a: b for a, b in kw.items() if a in ("gae_mode", "shuffle_mode", "stale_obs", "env_id_offset", "seed", "options")}
     return crl.Agent(cfg, params=params, obs_dim=D, n_act=A, hidden=Hd, env_kind=crl._lib.ENV_SYNTHETIC, **shape)
 
 
@@ -222,8 +222,10 @@ def test_wide_full_iteration_matches_oracle(crl, D, A, Hd, nt, k):
     agent.close(); st.close()
 
 
-def test_c3_shaped_iteration_at_1024_envs_matches_oracle(crl):
-    """BASELINE configs[2]'s shape (obs 8 / act 4 / 2x256, synthetic env) at num_envs = 1024 — 32 tiles per launch, so the multi-tile
+@pytest.mark.parametrize("persist", [1, 0])
+def test_c3_shaped_iteration_at_1024_envs_matches_oracle(crl, persist):
+    """(wide_rollout_persist = 1: the rollout as one launch, wide_rollout_persist_kernel; 0: three launches per step.)
+    BASELINE configs[2]'s shape (obs 8 / act 4 / 2x256, synthetic env) at num_envs = 1024 — 32 tiles per launch, so the multi-tile
     paths of the layer-wise kernels run (chunked weight gradients, several blocks per GEMM) — for one whole iteration against the
     oracle at the north_star bar: actions and permutation bit-equal, advantages / losses within 1e-5 relative, parameters within 1e-5
     relative L2 per array and 1e-5 absolute."""
@@ -232,7 +234,7 @@ def test_c3_shaped_iteration_at_1024_envs_matches_oracle(crl):
     params = spread_params(cfg, 9)
     off = O.param_offsets(cfg)
     params[off[4]:off[5]] /= 10
-    agent = make_wide(crl, nt, k, D, A, Hd, params=params, shuffle_mode=0)
+    agent = make_wide(crl, nt, k, D, A, Hd, params=params, shuffle_mode=0, options={"wide_rollout_persist": persist})
     st = O.State(cfg); st.params[:] = params; st.env_init()
     h = agent.handle; F = crl._lib
     h.env_reset()
@@ -240,6 +242,8 @@ def test_c3_shaped_iteration_at_1024_envs_matches_oracle(crl):
     os_ = st.iterate(10, gen_perm=True)
     assert np.array_equal(h.read(F.F_PERM), st.perm)
     assert np.array_equal(h.read(F.F_ACTION), st.action)
+    assert np.array_equal(h.read(F.F_OBS), st.obs) and np.array_equal(h.read(F.F_REWARD), st.reward) and np.array_equal(h.read(F.F_TERMINAL), st.terminal)
+    assert rel_err(h.read(F.F_LOGPROB), st.logprob) < RTOL and rel_err(h.read(F.F_VALUE), st.value) < RTOL
     assert rel_err(h.read(F.F_ADVANTAGE), st.adv) < RTOL
     for a, b in zip(gs, os_):
         for key in ("loss", "pg_loss", "v_loss", "entropy_loss"):
