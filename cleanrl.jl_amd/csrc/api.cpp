@@ -38,6 +38,7 @@ static const OptDesc kOpts[OPT_COUNT] = {
     {"gae_tile", 0, 0, 64},
     {"wide_rollout_persist", 1, 0, 1},
     {"fuse_optim", 1, 0, 1},
+    {"update_xcd_align", 1, 0, 1},
 };
 static int opt_find(const char* key) {
   if (!key) return -1;

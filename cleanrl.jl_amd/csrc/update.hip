@@ -179,7 +179,17 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
   // A tile's records are loaded at the top of the tile: the minibatch is a contiguous slab (records.hip), so the loads are
   // L2 / HBM streaming reads whose latency the partner wave covers. (Loading one tile ahead kept seven more registers live
   // through the backward pass — spills — for no measurable gain once the gather through the permutation was gone.)
-  int tile = rb * RW + wave;
+  int tile = rb * RW + wave, tstride = nwaves;
+  if (a.xcd_align) {
+    // Workgroups go to the 8 XCDs round-robin by index, and each XCD has its own L2. Actor and critic read the SAME 64-byte record of a
+    // sample (different quarters), from different blocks: with the plain striding the two readers of a tile sit on different XCDs and
+    // the record comes from HBM twice (FETCH_SIZE 252 MB per launch for 134 MB of records). Here tile t belongs to XCD t % 8 in both
+    // roles — block counts are multiples of 8, so a role-local block index ≡ its launch index (mod 8) — and both roles walk their XCD's
+    // tiles in the same order at the same relative pace: the second reader finds the line in L2.
+    const int gx = rb & 7;
+    tile = gx + 8 * ((rb >> 3) * RW + wave);
+    tstride = 8 * (a.nblk[ROLE] >> 3) * RW;
+  }
   Gathered<D> cur;
   constexpr bool PF = X2 && !EXACT && ABL == 0 && CRL_PF_ENABLED != 0;
   const f32x4* pf4 = nullptr;
@@ -212,14 +222,14 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
     pfi = reinterpret_cast<const int*>(slot + 256);
     pf_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) float*)slot);
     if (tile < ntiles) issue_dma(a.perm[pos_of(tile)]);
-    if (tile + nwaves < ntiles) issue_perm_dma(tile + nwaves);
+    if (tile + tstride < ntiles) issue_perm_dma(tile + tstride);
   }
   const float Gdw = X2 ? sgpr(a.dscale[ROLE]) : 1.0f;   // fp16x2 weight-gradient scale of this launch (mlp_x2.hpp)
   // fp16x2: G rides on the head cotangent (NOUT multiplies per tile), so δ2 exists only as δ2·G — exactly what the weight-gradient
   // operand wants (32 multiplies per tile saved); the backward-data product and db2 take the exact power of two back out
   const float invG = X2 ? sgpr(1.0f / Gdw) : 1.0f;
   float d2run = 0.0f;
-  for (; tile < ntiles; tile += nwaves) {
+  for (; tile < ntiles; tile += tstride) {
     const int pos = tile * TILE + j;
     const bool ok = pos < M;
     // the Float64 role constants stay in scalar registers: re-pinned every tile, so that the compiler cannot hoist vector copies of
@@ -232,8 +242,8 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
       cur.x[0] = xv[0]; cur.x[1] = xv[1]; cur.x[2] = xv[2]; cur.x[3] = xv[3];
       if (ROLE == 0) { cur.act = __float_as_int(q[0]); cur.f0 = q[1]; cur.f1 = q[2]; }
       else { cur.act = 0; cur.f0 = q[0]; cur.f1 = q[1]; }
-      if (tile + nwaves < ntiles) issue_dma(pfi[lane]);     // wave-uniform branch; the entry came in with this tile's records
-      if (tile + 2 * nwaves < ntiles) issue_perm_dma(tile + 2 * nwaves);
+      if (tile + tstride < ntiles) issue_dma(pfi[lane]);     // wave-uniform branch; the entry came in with this tile's records
+      if (tile + 2 * tstride < ntiles) issue_perm_dma(tile + 2 * tstride);
     } else {
       gather<D, ROLE>(a, ok ? pos : 0, cur);
     }
@@ -952,6 +962,8 @@ static void main_pass_blocks(crl_ppo* h, int* nA, int* nC) {
   if (a < 1) a = 1;
   if (a > total - 1) a = total - 1;
   if (total < 2) { *nA = 1; *nC = 1; return; }
+  // multiples of 8 where the grid allows: a role-local block index then names the block's XCD (UpdateArgs::xcd_align)
+  if (total % 8 == 0 && total >= 32 && opt(h, OPT_UPDATE_XCD_ALIGN)) { a = ((a + 4) / 8) * 8; if (a < 8) a = 8; if (a > total - 8) a = total - 8; }
   *nA = a; *nC = total - a;
 }
 
@@ -969,6 +981,7 @@ static int run_update(crl_ppo* h, int mb, int mode, hipEvent_t ev0 = nullptr, hi
     hipLaunchKernelGGL((update_vfix_kernel<4, 2>), dim3(h->update_blocks), dim3(256), smem, h->stream, a);
   } else {
     main_pass_blocks(h, &a.nblk[0], &a.nblk[1]);
+    a.xcd_align = (a.nblk[0] % 8 == 0 && a.nblk[1] % 8 == 0 && opt(h, OPT_UPDATE_XCD_ALIGN)) ? 1 : 0;
     a.stagger = (int)opt(h, OPT_UPDATE_STAGGER);
     // LDS for the larger of the two layouts: the fp16x2 kernel runs a role as bf16x3 when its weights leave the fp16 window
     const size_t smem = sizeof(float) * (X2_KERNEL_LDS_FLOATS + 8 * PF_SLOT_FLOATS);

@@ -19,6 +19,7 @@ struct UpdateArgs {
   int nblk[2];            // blocks working on the actor / the critic
   int pmax;               // capacity (blocks per role) of the partial buffers
   int stagger;            // x3 kernel: start delay of waves 4-7 (units of 1024 clocks)
+  int xcd_align = 0;      // 1 (both block counts multiples of 8): tile t is worked on by blocks with index ≡ t (mod 8) in BOTH roles — same XCD, same L2
   double Mglobal;         // minibatch size over all ranks (the 1/M of every mean)
 };
 

@@ -212,6 +212,7 @@ int32_t crl_comm_destroy(crl_ppo* h);
  *   wide_tanh_rational      1 = the layer-wise path evaluates NNlib's rational tanh_fast everywhere (default 0)
  *   gae_seg, gae_tile       standalone GAE kernel: steps per segment / envs per block, 0 = automatic
  *   wide_rollout_persist (1)  layer-wise path, 2x256 fp16x2, obs_dim <= 16: the whole rollout as one launch (0 = three per step)
+ *   update_xcd_align (1)    update kernel: tile t is worked on by blocks ≡ t (mod 8) of both roles (same XCD / L2 for a record's two readers)
  *   fuse_optim (1)          single GPU, speculative step: gradient reduction + ClipNorm + Adam as ONE launch (0 = two launches)
  * Read-only through crl_ppo_get_option: gemm_fallback_seen (1 once any launch of the fused 4/2/64 path took the bf16x3 fallback; the
  * layer-wise path needs none: it scales its fp16x2 weight pieces by the largest |w| of the layer at every optimiser step).

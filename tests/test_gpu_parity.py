@@ -583,6 +583,13 @@ def test_full_size_update_is_deterministic_and_additive(crl):
     s2 = h.update_minibatch(1, 0.0, apply_update=False); g2 = h.read(F.F_GRADS)
     assert np.array_equal(g1, g2) and s1["loss"] == s2["loss"]
     assert np.isfinite(g1).all() and np.linalg.norm(g1) > 0
+    # the plain tile striding (update_xcd_align = 0: a tile's actor and critic blocks on different XCDs) sums the same samples in
+    # another grouping: same gradient up to float32 summation order
+    h.set_option("update_xcd_align", 0)
+    h.update_minibatch(1, 0.0, apply_update=False, want_stats=False)
+    s3 = h.update_minibatch(1, 0.0, apply_update=False); g3 = h.read(F.F_GRADS)
+    assert np.linalg.norm(g3.astype(np.float64) - g1) <= 2e-6 * np.linalg.norm(g1.astype(np.float64)) and loss_close("loss", s3["loss"], s1["loss"], 2e-6)
+    h.set_option("update_xcd_align", 1)
     # advantages: a terminal cuts the scan (δ only) — same property as the standalone GAE test, on the resident buffer
     adv = h.read(F.F_ADVANTAGE); term = h.read(F.F_TERMINAL); rew = h.read(F.F_REWARD); val = h.read(F.F_VALUE)
     e, t = np.argwhere(term[:, 1:] == 1)[0]
