@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(256) a2c_wgrad_kernel(int net, const double* _
                                                        float* __restrict__ grads) {
 #pragma clang fp contract(off)
   const int n_out = net ? 1 : AA;
-  const int oW1 = 0, ob1 = AH * AD, oW2 = ob1 + AH, ob2 = oW2 + AH * AH, oW3 = ob2 + AH, ob3 = oW3 + n_out * AH, total = ob3 + n_out;
+  const int ob1 = AH * AD, oW2 = ob1 + AH, ob2 = oW2 + AH * AH, oW3 = ob2 + AH, ob3 = oW3 + n_out * AH, total = ob3 + n_out;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   double g = 0.0;

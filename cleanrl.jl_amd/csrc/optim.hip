@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(1024) clipnorm_adam_kernel(OptimArgs a) {
 // 100 µs serial walk: slices of 4,096 entries per block. Three launches: per-slice Σg² partials (Float64) → every slice sums its
 // array's partials in slice order (one norm, identical in all slices), clips and applies Adam to its entries → the running β
 // powers advance. Same arithmetic per element as clipnorm_adam_kernel; only the order of the Σg² sum differs (by slices).
-constexpr int OPT_SLICE = 4096, OPT_MAXS = 32;
+constexpr int OPT_SLICE = 4096;
 struct OptimSliceArgs {
   int off[13]; int first_blk[13];   // first_blk[a] = index of array a's first slice; first_blk[12] = number of slices
   float* params; const float* grads; float* m; float* v; double* betap; double* part;

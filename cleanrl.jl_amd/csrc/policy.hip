@@ -24,7 +24,6 @@ __global__ void __launch_bounds__(256) policy_act_kernel(const float* __restrict
                                                          const double* __restrict__ u, int n, int32_t* __restrict__ action,
                                                          float* __restrict__ logprob, float* __restrict__ value) {
   using IA = NetImage<D, A, false>;
-  using IC = NetImage<D, 1, false>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* imgA = smem;
   float* imgC = smem + IA::SIZE;

@@ -1141,7 +1141,7 @@ __global__ void __launch_bounds__(256) wide_wgrad_kernel(WgradArgs a) {
 // ------------------------------------------------------------------------------------------------------
 template <int WNB>   // output tile = (64·WNB rows of dY) × (128 rows of X); 2·WNB waves, each 2×2 MFMA tiles
 __global__ void __launch_bounds__(128 * WNB) wide_wgrad_x3_kernel(WgradArgs a) {
-  constexpr int BN = 64 * WNB, BK = 128, NT = 128 * WNB;
+  constexpr int BN = 64 * WNB, BK = 128;
   extern __shared__ __attribute__((aligned(16))) unsigned char smw[];
   __bf16* Yp = reinterpret_cast<__bf16*>(smw);                 // [3][BN][X3ROW]
   __bf16* Xp = Yp + 3 * BN * X3ROW;                            // [3][BK][X3ROW]
