@@ -614,7 +614,7 @@ static int update_step(crl_ppo* h, int mb, double eta, int apply, int slot, bool
   // the inline value-loss fix-up reads the flag the statistics raise, so it keeps them as their own launch
   h->defer_stats = apply && !h->wide && has_comm(h) && !(inline_fix && h->cfg.clip_value_loss && h->world == 1);
   // one GPU and nothing between the gradient and the optimiser (no all-reduce, no inline value-loss fix-up): one launch does both
-  const bool fused = apply && !h->wide && !has_comm(h) && !(inline_fix && h->cfg.clip_value_loss) && opt(h, OPT_FUSE_OPTIM) && h->P <= 32768;
+  const bool fused = apply && !h->wide && !has_comm(h) && !h->external_comm && !(inline_fix && h->cfg.clip_value_loss) && opt(h, OPT_FUSE_OPTIM) && h->P <= 32768;
   const int rc = launch_update(h, mb, h->stats_dev + slot, inline_fix, fused, eta);
   h->defer_stats = false;
   if (rc) return 1;
