@@ -71,6 +71,22 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def pipes_busy(strict):
+    """Share of a SIMD's time its vector pipe / its matrix pipe / both are busy during the update kernel, from the hardware's own busy
+    counters of the committed PMC pass (SQ_ACTIVE_INST_VALU counts quad-cycles, the MFMA counters cycles; the denominator is the launch's
+    cycles x 1024 SIMDs, GRBM_GUI_ACTIVE being summed over the 8 XCDs). Headline size only: that is what the pass was taken at."""
+    pm, src = load_profile("pmc_summary", strict)
+    if not pm:
+        return None
+    k = next((v for n, v in pm["kernels"].items() if "update_x2_kernel" in n), None)
+    need = ("GRBM_GUI_ACTIVE", "SQ_ACTIVE_INST_VALU", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_VALU_MFMA_COEXEC_CYCLES")
+    if not k or any(c not in k for c in need):
+        return None
+    cyc = k["GRBM_GUI_ACTIVE"]["mean"] / 8 * SIMDS
+    v, m, b = k["SQ_ACTIVE_INST_VALU"]["mean"] * 4 / cyc, k["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / cyc, k["SQ_VALU_MFMA_COEXEC_CYCLES"]["mean"] / cyc
+    return {"vector": v, "matrix": m, "both": b, "either": v + m - b, "source": src}
+
+
 def load_profile(name, strict):
     """A committed profiles/<tag>_<name>.json, or (None, reason) when it is missing or was taken with other kernel sources."""
     path = os.path.join("profiles", f"{PROFILE_TAG}_{name}.json")
@@ -382,6 +398,7 @@ def run_workload(args, wl, world, rank, local_rank, dist, torch, crl, crl_dist, 
                     "valu_instructions_per_launch": slots, "of_which_mfma": mfma, "per_tile_and_role": (slots / (2 * tiles_per_role)) if slots else None,
                     "counts_source": cnt_src, "static_isa_per_tile": static,
                     "frac_of_measured_two_wave_ceiling": (gslots / MEASURED_VALU_GSLOTS_2WAVES) if gslots else None,
+                    "pipes_busy": pipes_busy(strict) if headline_shape else None,
                     "matrix_pipe": {"name": "f16 mfma" if x2 else "bf16 mfma", "issued_tflops": pipe_tflops, "peak": PEAK_F16_MFMA_TFLOPS,
                                     "frac": pipe_tflops / PEAK_F16_MFMA_TFLOPS},
                     "f32_equivalent": {"tflops": upd_tflops, "flops_per_launch": upd_flops * M, "over_f32_mfma_peak": upd_tflops / PEAK_F32_MFMA_TFLOPS,
