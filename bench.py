@@ -243,14 +243,21 @@ def time_gae_standalone(torch, h, nt, device, reps=6):
     half = max(1, gae_bytes // 8)      # floats: the copy reads half of the footprint and writes the other half
     src = torch.empty(half, dtype=torch.float32, device=device).normal_()
     dst = torch.empty_like(src)
-    cold, warm, copy_cold = [], [], []
+    cold, warm, copy_cold, cold_nt = [], [], [], []
     dst.copy_(src); torch.cuda.synchronize()      # first-use overheads of the copy stay out of the medians
+    nt_default = h.get_option("gae_nt_loads")
     for i in range(reps):
         flush.fill_(float(i)); torch.cuda.synchronize()
         h.prof_enable(True); h.prof_reset(); h.compute_gae(); h.sync()
         cold.append(h.prof_read()["gae"][0])
         h.prof_reset(); h.compute_gae(); h.sync()
-        warm.append(h.prof_read()["gae"][0]); h.prof_enable(False)
+        warm.append(h.prof_read()["gae"][0])
+        # the flavour the library uses when the inputs are known not to be cached (host-driven rollouts, crl_gae): nontemporal loads
+        h.set_option("gae_nt_loads", 1)
+        flush.fill_(float(i) + 0.25); torch.cuda.synchronize()
+        h.prof_reset(); h.compute_gae(); h.sync()
+        cold_nt.append(h.prof_read()["gae"][0]); h.prof_enable(False)
+        h.set_option("gae_nt_loads", nt_default)
         flush.fill_(float(i) + 0.5); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); dst.copy_(src); e1.record(); torch.cuda.synchronize()
@@ -261,9 +268,12 @@ def time_gae_standalone(torch, h, nt, device, reps=6):
            "peak": PEAK_HBM_GBPS, "unit": "GB/s", "bytes_per_launch": gae_bytes}
     for name, ms in (("cold", med(cold)), ("warm", med(warm))):
         rec[name] = {"avg_launch_ms": ms, "achieved": gae_bytes / (ms * 1e-3) / 1e9, "frac": gae_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS}
+    cn = med(cold_nt)
+    rec["cold_nt_loads"] = {"avg_launch_ms": cn, "achieved": gae_bytes / (cn * 1e-3) / 1e9, "frac": gae_bytes / (cn * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                            "note": "option gae_nt_loads = 1 (what host-driven rollouts and crl_gae use: their inputs arrive by copies): nontemporal input loads"}
     cc = med(copy_cold)
     rec["copy_ceiling"] = {"avg_launch_ms": cc, "achieved": gae_bytes / (cc * 1e-3) / 1e9, "frac": gae_bytes / (cc * 1e-3) / 1e9 / PEAK_HBM_GBPS,
-                           "cold_over_copy": cc / med(cold),
+                           "cold_over_copy": cc / med(cold), "cold_nt_loads_over_copy": cc / cn,
                            "note": "torch float copy moving the same number of bytes (half read, half written), caches flushed first; "
                                    "cold_over_copy = copy time ÷ GAE cold time (1 = the scan runs at copy speed)"}
     rec.update({"achieved": rec["cold"]["achieved"], "frac": rec["cold"]["frac"], "avg_launch_ms": rec["cold"]["avg_launch_ms"], "state": "cold"})

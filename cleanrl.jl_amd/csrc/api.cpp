@@ -36,6 +36,7 @@ static const OptDesc kOpts[OPT_COUNT] = {
     {"wide_tanh_rational", 0, 0, 1},
     {"gae_seg", 0, 0, 16},
     {"gae_tile", 0, 0, 64},
+    {"gae_nt_loads", 2, 0, 2},
     {"wide_rollout_persist", 1, 0, 1},
     {"fuse_optim", 1, 0, 1},
     {"update_xcd_align", 1, 0, 1},
@@ -462,7 +463,7 @@ int32_t crl_gae(int32_t device, const float* value, const float* reward, const u
   if (!rc)
     rc = launch_gae(nullptr, (const float*)(buf + o_v), (const float*)(buf + o_r), (const uint8_t*)(buf + o_t),
                     next_value ? (const float*)(buf + o_nv) : nullptr, next_done ? (const uint8_t*)(buf + o_nd) : nullptr, nt, k,
-                    gamma, lambda, mode, (float*)(buf + o_a), (float*)(buf + o_ret));
+                    gamma, lambda, mode, (float*)(buf + o_a), (float*)(buf + o_ret), nullptr, nullptr, 0, 0, /*nt_loads=*/B >= ((size_t)1 << 22) ? 1 : 0);   // inputs arrived by copies; streaming loads pay from ~4 M samples
   if (!rc && (e = hipDeviceSynchronize()) != hipSuccess) fail(e, "gae kernel");
   if (!rc && (e = hipMemcpy(adv, buf + o_a, B * 4, hipMemcpyDeviceToHost)) != hipSuccess) fail(e, "copy adv");
   if (!rc && ret && (e = hipMemcpy(ret, buf + o_ret, B * 4, hipMemcpyDeviceToHost)) != hipSuccess) fail(e, "copy ret");
@@ -560,7 +561,7 @@ static int compute_gae(crl_ppo* h) {
   ProfScope ps(h, CRL_K_GAE, /*attach=*/true);
   return launch_gae(h->stream, h->value, h->reward, h->terminal, fixed ? h->next_value : nullptr, h->next_done, h->dc.nt,
                     h->dc.k, h->cfg.gamma, h->cfg.gae_lambda, h->cfg.gae_mode, h->adv, h->ret, ps.a, ps.b, (int)opt(h, OPT_GAE_SEG),
-                    (int)opt(h, OPT_GAE_TILE));
+                    (int)opt(h, OPT_GAE_TILE), opt(h, OPT_GAE_NT_LOADS) == 2 ? ((h->cfg.env_kind == CRL_ENV_EXTERNAL && h->dc.B >= (1 << 22)) ? 1 : 0) : (int)opt(h, OPT_GAE_NT_LOADS));
 }
 int32_t crl_compute_gae(crl_ppo* h) {
   CRL_GUARD_SETTLED(h);

@@ -8,12 +8,12 @@
 // Arithmetic is Float64 like the reference's accumulator (ppo.jl:63,65; Q2), stored Float32 (ppo.jl:62).
 // Layout: (nt, k) column-major, env fastest ⇒ lanes of a wave read consecutive envs: coalesced 128/256-B rows.
 //
-// Where it stands (bench.py roofline_gae, 65536 envs): 29.6 µs on inputs the previous kernel left in cache (0.60 of 8 TB/s), 51 µs
-// with caches flushed — against 41 µs for a plain copy of the same number of bytes under the same cold conditions (0.81 of that
-// ceiling). Round 3 measured three rewrites against it on one box and kept none: four envs per thread with 16-byte accesses and a
-// dword of done flags (a quarter of the vector-memory instructions; 128 registers, L = 4): 50-52 µs cold, 35 µs warm; a persistent
-// grid with the next tile's inputs double-buffered in registers: 52.6 / 35 µs; tighter register caps (80 registers: spills).
-// The cold figure moves with none of them: a cold launch is bound by what a cold copy is bound by.
+// Where it stands (bench.py roofline_gae, 65536 envs): 29.6 µs on inputs the previous kernel left in cache (0.60 of 8 TB/s); with caches
+// flushed 51 µs with cached loads and 41 µs with nontemporal loads (the NTL flavour: 0.43 of 8 TB/s) — exactly what a plain copy of the
+// same number of bytes takes under the same cold conditions (41 µs). Below ~4 M samples the streaming loads do not pay (18.5 vs 17.8 µs at
+// 16384 envs). Round 3 also measured three rewrites and kept none: four envs per thread with 16-byte accesses and a dword of done flags
+// (a quarter of the vector-memory instructions; 128 registers, L = 4): 50-52 µs cold, 35 µs warm; a persistent grid with the next tile's
+// inputs double-buffered in registers: 52.6 / 35 µs; tighter register caps (80 registers: spills).
 #include <hip/hip_ext.h>
 
 #include <cstdlib>
@@ -22,7 +22,10 @@
 
 namespace crl {
 
-template <int EB, int GAE_L>
+// NTL: nontemporal loads of the three input streams — for inputs that are NOT in the caches (host-driven rollouts whose buffers arrive
+// by copies; bench.py's flushed-cache measurement): 41 µs instead of 50 at 65536 x 128, the time of a plain copy of the same bytes.
+// Behind an on-device rollout the inputs sit in L2 / Infinity Cache and the cached loads are the faster ones (29.6 vs 37 µs).
+template <int EB, int GAE_L, bool NTL>
 __global__ void __launch_bounds__(512) gae_kernel(const float* __restrict__ value, const float* __restrict__ reward,
                                                    const uint8_t* __restrict__ terminal,
                                                    const float* __restrict__ next_value,
@@ -46,14 +49,14 @@ __global__ void __launch_bounds__(512) gae_kernel(const float* __restrict__ valu
     const int t = lo + i;
     const bool ok = ev && t < k;
     const size_t idx = (size_t)e + (size_t)nt * t;
-    v[i] = ok ? value[idx] : 0.0f;
-    r[i] = ok ? reward[idx] : 0.0f;
+    v[i] = ok ? (NTL ? __builtin_nontemporal_load(value + idx) : value[idx]) : 0.0f;
+    r[i] = ok ? (NTL ? __builtin_nontemporal_load(reward + idx) : reward[idx]) : 0.0f;
     // done flag that gates step t is terminal[t+1]; beyond the buffer it is next_done (ppo.jl:176)
-    tm[i] = ok ? ((t + 1 < k) ? terminal[idx + nt] : (next_done ? next_done[e] : (uint8_t)0)) : (uint8_t)0;
+    tm[i] = ok ? ((t + 1 < k) ? (NTL ? __builtin_nontemporal_load(terminal + idx + nt) : terminal[idx + nt]) : (next_done ? next_done[e] : (uint8_t)0)) : (uint8_t)0;
   }
   {
     const int t = lo + GAE_L;
-    v[GAE_L] = (ev && t < k) ? value[(size_t)e + (size_t)nt * t] : 0.0f;
+    v[GAE_L] = (ev && t < k) ? (NTL ? __builtin_nontemporal_load(value + (size_t)e + (size_t)nt * t) : value[(size_t)e + (size_t)nt * t]) : 0.0f;
   }
   // the bootstrap value follows the LAST buffered step (ppo.jl:174 hcat(value, next_values'))
   const float nv = (ev && next_value) ? next_value[e] : 0.0f;
@@ -112,7 +115,7 @@ __global__ void __launch_bounds__(512) gae_kernel(const float* __restrict__ valu
 
 int launch_gae(hipStream_t st, const float* value, const float* reward, const uint8_t* terminal,
                const float* next_value, const uint8_t* next_done, int nt, int k, float gamma, float lambda, int mode,
-               float* adv, float* ret, hipEvent_t ev_start, hipEvent_t ev_stop, int seg, int tile) {
+               float* adv, float* ret, hipEvent_t ev_start, hipEvent_t ev_stop, int seg, int tile, int nt_loads) {
   if (nt <= 0 || k <= 0) { set_error("gae: empty input"); return 1; }
   const float gl = gamma * lambda;  // Float32 product, as `γ * λ` with both T=Float32 (ppo.jl:68)
   // segment length L and env tile EB: S = ceil(k/L) segments, block = S*EB <= 512 threads.
@@ -130,8 +133,10 @@ int launch_gae(hipStream_t st, const float* value, const float* reward, const ui
   const size_t smem = sizeof(double) * 2 * S * EB;
 #define CRL_GAE_CASE(eb, l)                                                                                          \
   if (EB == eb && L == l) {                                                                                          \
-    hipExtLaunchKernelGGL((gae_kernel<eb, l>), grid, block, smem, st, ev_start, ev_stop, 0, value, reward, terminal,   \
-                          next_value, next_done, nt, k, gamma, gl, mode, adv, ret, env_nts);                         \
+    if (nt_loads) hipExtLaunchKernelGGL((gae_kernel<eb, l, true>), grid, block, smem, st, ev_start, ev_stop, 0, value, reward, terminal, \
+                                        next_value, next_done, nt, k, gamma, gl, mode, adv, ret, env_nts);           \
+    else hipExtLaunchKernelGGL((gae_kernel<eb, l, false>), grid, block, smem, st, ev_start, ev_stop, 0, value, reward, terminal,   \
+                               next_value, next_done, nt, k, gamma, gl, mode, adv, ret, env_nts);                    \
   } else
   CRL_GAE_CASE(64, 8) CRL_GAE_CASE(32, 8) CRL_GAE_CASE(16, 8) CRL_GAE_CASE(8, 8)
   CRL_GAE_CASE(64, 16) CRL_GAE_CASE(32, 16) CRL_GAE_CASE(16, 16) CRL_GAE_CASE(8, 16)

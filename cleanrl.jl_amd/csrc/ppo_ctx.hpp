@@ -62,6 +62,7 @@ enum OptId {
   OPT_WIDE_TANH_RATIONAL,     // 1 = the layer-wise path evaluates tanh_fast everywhere (default 0: exp2 form outside the actor's rollout forward)
   OPT_GAE_SEG,                // standalone GAE kernel: steps per segment (0 = automatic)
   OPT_GAE_TILE,               // standalone GAE kernel: envs per block (0 = automatic)
+  OPT_GAE_NT_LOADS,           // standalone GAE kernel: 1 = nontemporal input loads (inputs not in the caches), 0 = cached, 2 = external env and >= 4 M samples: 1
   OPT_WIDE_ROLLOUT_PERSIST,   // layer-wise path, 2x256 fp16x2: the whole rollout as one launch (0 = three launches per step)
   OPT_FUSE_OPTIM,             // 1 = single-GPU speculative steps run reduce + ClipNorm + Adam as one launch (reduce_optim_kernel)
   OPT_UPDATE_XCD_ALIGN,       // 1 = update kernel: a tile's actor and critic blocks on the same XCD (the record's second reader hits L2)
@@ -214,7 +215,7 @@ struct ProfScope {
 // kernel launchers (each in its own translation unit)
 int launch_gae(hipStream_t st, const float* value, const float* reward, const uint8_t* terminal,
                const float* next_value, const uint8_t* next_done, int nt, int k, float gamma, float lambda, int mode,
-               float* adv, float* ret, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int seg = 0, int tile = 0);
+               float* adv, float* ret, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int seg = 0, int tile = 0, int nt_loads = 0);
 int launch_policy_act(crl_ppo* h, const float* obs_d, const double* u_d, int n, int32_t* action_d, float* logprob_d,
                       float* value_d);
 int launch_logprob_actions(crl_ppo* h, const float* obs_d, const int32_t* act_d, int n, float* logprob_d, float* ent_d);

@@ -25,5 +25,7 @@ for nt in (4096, 8192, 16384, 65536):
             r = bench.time_gae_standalone(torch, h, nt, "cuda:0")
             print(json.dumps({"nt": nt, "tile": tile, "seg": seg, "cold_us": round(r["cold"]["avg_launch_ms"] * 1e3, 2), "cold_frac": round(r["cold"]["frac"], 3),
                               "warm_us": round(r["warm"]["avg_launch_ms"] * 1e3, 2), "warm_frac": round(r["warm"]["frac"], 3),
-                              "copy_us": round(r["copy_ceiling"]["avg_launch_ms"] * 1e3, 2), "cold_over_copy": round(r["copy_ceiling"]["cold_over_copy"], 3)}), flush=True)
+                              "cold_nt_us": round(r["cold_nt_loads"]["avg_launch_ms"] * 1e3, 2), "cold_nt_frac": round(r["cold_nt_loads"]["frac"], 3),
+                              "copy_us": round(r["copy_ceiling"]["avg_launch_ms"] * 1e3, 2), "cold_over_copy": round(r["copy_ceiling"]["cold_over_copy"], 3),
+                              "cold_nt_over_copy": round(r["copy_ceiling"]["cold_nt_loads_over_copy"], 3)}), flush=True)
             agent.close()
