@@ -53,7 +53,7 @@ EXPORTS = [
     "crl_shuffle", "crl_adv_stats", "crl_ppo_update_minibatch", "crl_ppo_iterate", "crl_ppo_iteration",
     "crl_comm_unique_id", "crl_comm_init", "crl_comm_init_external", "crl_comm_peer_export", "crl_comm_peer_attach", "crl_adv_stats_local", "crl_adv_stats_finish",
     "crl_prof_enable", "crl_prof_read", "crl_prof_reset", "crl_ppo_exact_reruns", "crl_episode_ring_enable",
-    "crl_episode_ring_read", "crl_comm_destroy", "crl_ppo_set_option", "crl_ppo_get_option", "crl_ppo_option_name",
+    "crl_episode_ring_read", "crl_comm_destroy", "crl_ppo_set_option", "crl_ppo_get_option", "crl_ppo_option_name", "crl_ppo_option_count",
     "crl_a2c_create", "crl_a2c_destroy", "crl_a2c_param_count", "crl_a2c_write_params", "crl_a2c_read_params",
     "crl_a2c_read_env", "crl_a2c_read_buffer", "crl_a2c_run_until_update", "crl_a2c_discounted_future_rewards",
     "crl_dqn_create", "crl_dqn_destroy", "crl_dqn_write_params", "crl_dqn_read_params", "crl_dqn_status_read", "crl_dqn_run",
@@ -161,6 +161,7 @@ def load():
     L.crl_ppo_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     L.crl_ppo_get_option.argtypes = [vp, C.c_char_p, i64p]
     L.crl_ppo_option_name.argtypes = [C.c_int32, C.POINTER(C.c_char_p), i64p]
+    L.crl_ppo_option_count.argtypes = [ip]
     L.crl_a2c_create.argtypes = [C.POINTER(CrlA2CConfig), C.c_int32, C.POINTER(vp)]
     L.crl_a2c_destroy.argtypes = [vp]
     L.crl_a2c_param_count.argtypes = [vp, i64p]
@@ -389,13 +390,14 @@ class Handle:
 
 def option_names():
     """Names of every option crl_ppo_set_option accepts, in table order."""
+    n = C.c_int32()
+    check(load().crl_ppo_option_count(C.byref(n)))
     out = []
-    i = 0
-    while True:
+    for i in range(n.value):
         name = C.c_char_p(); d = C.c_int64()
-        if load().crl_ppo_option_name(i, C.byref(name), C.byref(d)) != 0:
-            return out
-        out.append(name.value.decode()); i += 1
+        check(load().crl_ppo_option_name(i, C.byref(name), C.byref(d)))
+        out.append(name.value.decode())
+    return out
 
 
 def comm_unique_id() -> bytes:

@@ -77,7 +77,7 @@ static int opt_apply_env(crl_ppo* h) {
     if (eq == std::string::npos) { set_error("CRL_OPTIONS: expected key=value, got '" + item + "'"); return 1; }
     char* endp = nullptr;
     const long long v = std::strtoll(item.c_str() + eq + 1, &endp, 10);
-    if (!endp || *endp) { set_error("CRL_OPTIONS: value of '" + item + "' is not an integer"); return 1; }
+    if (!endp || endp == item.c_str() + eq + 1 || *endp) { set_error("CRL_OPTIONS: value of '" + item + "' is not an integer"); return 1; }
     if (opt_set(h, item.substr(0, eq).c_str(), (int64_t)v)) return 1;
   }
   return 0;
@@ -275,7 +275,7 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
   rc |= dalloc(&h->next_value, nt); rc |= dalloc(&h->ep_stats, 4);
   rc |= dalloc(&h->params, h->P); rc |= dalloc(&h->adam_m, h->P); rc |= dalloc(&h->adam_v, h->P);
   const size_t E = (size_t)cfg->update_epochs;
-  rc |= dalloc(&h->betap, 24); rc |= dalloc(&h->perm_base, E * B); rc |= dalloc(&h->optim_part, (size_t)h->P / 4096 + 16 + 12 * ((size_t)h->P / 64 + 1)); rc |= dalloc(&h->ticket, 1);
+  rc |= dalloc(&h->betap, 24); rc |= dalloc(&h->perm_base, E * B); rc |= dalloc(&h->optim_part, (size_t)h->P / 4096 + 16 + 12 * ((size_t)h->P / 64 + 1)); rc |= dalloc(&h->ticket, 2);
   if (!wide) rc |= dalloc(&h->recs, B);   // the update kernels fetch records through the epoch's permutation: no permuted copies
   {
     // advantage-sum pass: blocks per minibatch (≈1 K samples each, at most 512); the partial-sum scratch also serves the
@@ -311,6 +311,7 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
   { char* p = nullptr; rc |= dalloc(&p, h->snap_env_bytes); h->snap_env = p; }
   if (rc) { crl_ppo_destroy(h); return 1; }
   if (reset_dw_scale(h)) { crl_ppo_destroy(h); return 1; }
+  if (!wide && h->P <= 32768 && fused_optim_fits(h, &h->fuse_optim_fits)) { crl_ppo_destroy(h); return 1; }
   select_slot(h, 0);
   if (wide && wide_create(h)) { crl_ppo_destroy(h); return 1; }
   double bp[24];
@@ -570,6 +571,7 @@ int32_t crl_compute_gae(crl_ppo* h) {
 
 static int check_bfy(crl_ppo* h) {
   if (peer_check(h)) return 1;
+  if (fused_optim_check(h)) return 1;
   if (h->cfg.shuffle_mode != CRL_SHUFFLE_BLOCKED_FY) return 0;
   uint32_t err = 0;
   for (int z = 0; z < h->cfg.update_epochs && !err; ++z) {
@@ -615,7 +617,7 @@ static int update_step(crl_ppo* h, int mb, double eta, int apply, int slot, bool
   // the inline value-loss fix-up reads the flag the statistics raise, so it keeps them as their own launch
   h->defer_stats = apply && !h->wide && has_comm(h) && !(inline_fix && h->cfg.clip_value_loss && h->world == 1);
   // one GPU and nothing between the gradient and the optimiser (no all-reduce, no inline value-loss fix-up): one launch does both
-  const bool fused = apply && !h->wide && !has_comm(h) && !h->external_comm && !(inline_fix && h->cfg.clip_value_loss) && opt(h, OPT_FUSE_OPTIM) && h->P <= 32768;
+  const bool fused = apply && !h->wide && !has_comm(h) && !h->external_comm && !(inline_fix && h->cfg.clip_value_loss) && opt(h, OPT_FUSE_OPTIM) && h->fuse_optim_fits;
   const int rc = launch_update(h, mb, h->stats_dev + slot, inline_fix, fused, eta);
   h->defer_stats = false;
   if (rc) return 1;
@@ -911,6 +913,11 @@ int32_t crl_ppo_get_option(crl_ppo* h, const char* key, int64_t* value) {
   return 0;
 }
 
+int32_t crl_ppo_option_count(int32_t* n) {
+  if (!n) { set_error("null argument"); return 1; }
+  *n = OPT_COUNT;
+  return 0;
+}
 int32_t crl_ppo_option_name(int32_t index, const char** name, int64_t* dflt) {
   if (index < 0 || index >= OPT_COUNT || !name) { set_error("crl_ppo_option_name: index out of range"); return 1; }
   *name = kOpts[index].name;

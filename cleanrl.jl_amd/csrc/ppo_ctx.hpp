@@ -104,7 +104,8 @@ struct crl_ppo {
   float* params = nullptr; float* adam_m = nullptr; float* adam_v = nullptr;  // the gradient lives in comm_buf[0..P)
   double* betap = nullptr;     // [24]
   double* optim_part = nullptr;  // per-slice Σg² of the sliced optimiser step (large networks); [12][blocks] of the fused reduce + optimiser launch
-  unsigned* ticket = nullptr;    // grid meeting point of reduce_optim_kernel: counts arrivals, never reset
+  unsigned* ticket = nullptr;    // grid meeting point of reduce_optim_kernel: [0] counts arrivals, never reset; [1] sticky time-out flag
+  bool fuse_optim_fits = false;  // the whole grid of reduce_optim_kernel can be resident on this device (checked at crl_ppo_create)
   unsigned ticket_target = 0;    // arrivals after the launch being enqueued
   // One permutation per update epoch (ppo.jl:194): crl_ppo_iterate draws all update_epochs of them right after GAE, so the
   // advantage statistics of every minibatch of the iteration are known (and all-reduced, once) before the first optimiser
@@ -253,6 +254,8 @@ int peer_attach(crl_ppo* h, const uint8_t* handles);
 bool peer_active(const crl_ppo* h);
 int peer_allreduce(crl_ppo* h, void* buf, size_t count, bool is_double);
 int peer_check(crl_ppo* h);
+int fused_optim_fits(crl_ppo* h, bool* fits);   // update.hip: occupancy of reduce_optim_kernel's grid on this device
+int fused_optim_check(crl_ppo* h);              // update.hip: sticky time-out word of its meeting point
 void peer_destroy(crl_ppo* h);
 inline bool has_comm(const crl_ppo* h) { return h->comm != nullptr || h->peer != nullptr; }
 }  // namespace crl

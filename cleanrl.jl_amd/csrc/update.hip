@@ -826,7 +826,8 @@ __global__ void __launch_bounds__(64 * RG) reduce_kernel(const float* __restrict
 // walk of the 4,096-entry arrays per optimiser step.
 struct FusedOptimArgs {
   int off[13];
-  float* params; float* m; float* v; double* betap; double* part /* [12][gridDim.x] */; unsigned* ticket; unsigned target;
+  float* params; float* m; float* v; double* betap; double* part /* [12][gridDim.x] */; unsigned* ticket /* [0] arrivals, [1] sticky time-out flag */; unsigned target;
+  unsigned long long timeout;   // ticks of the 100 MHz wall clock a block waits at the meeting point before it gives up (2 s)
   double eta, thresh;
 };
 __global__ void __launch_bounds__(64 * RG) reduce_optim_kernel(const float* __restrict__ gpart, const double* __restrict__ lpart,
@@ -909,10 +910,21 @@ __global__ void __launch_bounds__(64 * RG) reduce_optim_kernel(const float* __re
   // grid-wide meeting point. Everything that crosses blocks (the Σg² partials, the ticket) moves through agent-scope atomic
   // stores / loads, which are served at the device's coherent level: no release / acquire fences — on this GPU those write
   // back and invalidate a whole L2, which cost as much as the kernel boundary this launch exists to save (17.8 µs with fences).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+#error "reduce_optim_kernel's fence-free meeting point relies on gfx942 / gfx950 behaviour (sc1 atomics are write-through and counted in vmcnt): port the ordering (release on the ticket add, acquire after the wait) before building for another target"
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the partials have arrived before the ticket moves
   if (o == 0) {
     __hip_atomic_fetch_add(oa.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(oa.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - oa.target > 0x7FFFFFFFu) __builtin_amdgcn_s_sleep(1);
+    // bounded: if a block of the grid is not resident (a partitioned device, CUs held by another tenant — crl_ppo_create checks the
+    // occupancy and turns the fused step off where the grid cannot fit, this is the second line of defence) or an arrival is lost, the
+    // wait ends after oa.timeout ticks of the 100 MHz wall clock with a sticky error word instead of hanging the GPU; crl_sync /
+    // crl_ppo_iterate / every read-back report it
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(oa.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - oa.target > 0x7FFFFFFFu) {
+      __builtin_amdgcn_s_sleep(1);
+      if (wall_clock64() - t0 > oa.timeout) { __hip_atomic_store(oa.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
   }
   __builtin_amdgcn_wave_barrier();
   asm volatile("" ::: "memory");
@@ -937,6 +949,29 @@ __global__ void __launch_bounds__(64 * RG) reduce_optim_kernel(const float* __re
   const double delta = (double)mi / (1 - bp0) / (sqrt((double)vi / (1 - bp1)) + epsn) * oa.eta;
   oa.params[i] = p_old - (float)delta;
   if (i == oa.off[arr]) { oa.betap[2 * arr] = bp0 * b1c; oa.betap[2 * arr + 1] = bp1 * b2c; }
+}
+
+// Can the whole grid of reduce_optim_kernel be resident at once on this device? Its meeting point needs every block running: (P+63)/64
+// blocks of 1024 threads (144 for the 4/2/64 networks = 72 CUs at two blocks per CU). On a partitioned (CPX) device or a smaller GPU it
+// may not fit; the handle then keeps the two-launch optimiser step (reduce_kernel + clipnorm_adam_kernel).
+int fused_optim_fits(crl_ppo* h, bool* fits) {
+  int per_cu = 0;
+  CRL_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reduce_optim_kernel, 64 * RG, 0));
+  hipDeviceProp_t prop;
+  CRL_HIP_CHECK(hipGetDeviceProperties(&prop, h->device));
+  // one block per CU of margin: the occupancy query can read one high near a register-file edge (MI355X guide, "Residency")
+  const long resident = (long)(per_cu > 1 ? per_cu - 1 : per_cu) * (long)prop.multiProcessorCount;
+  *fits = resident >= (long)((h->P + 63) / 64);
+  return 0;
+}
+// sticky time-out word of the meeting point (ticket[1]): read where the host synchronises anyway
+int fused_optim_check(crl_ppo* h) {
+  if (!h->ticket || h->ticket_target == 0) return 0;
+  unsigned e = 0;
+  CRL_HIP_CHECK(hipMemcpyAsync(&e, h->ticket + 1, sizeof(e), hipMemcpyDeviceToHost, h->stream));
+  CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  if (e) { set_error("reduce_optim_kernel: a block timed out at the grid meeting point (the grid was not fully resident, or the device is shared); set option fuse_optim = 0"); return 1; }
+  return 0;
 }
 
 // data-parallel path: the sums are global only after the all-reduce, so the statistics get their own tiny launch
@@ -1054,12 +1089,18 @@ int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot, bool inline_fix
       oa.off[0] = 0;
       for (int q = 0; q < 12; ++q) oa.off[q + 1] = oa.off[q] + sizes[q];
       const unsigned nb = (unsigned)((P + 63) / 64);
+      CRL_HIP_CHECK(hipGetLastError());   // an error left behind by an earlier call is reported as such, not mistaken for this launch's
       h->ticket_target += nb;
       oa.params = h->params; oa.m = h->adam_m; oa.v = h->adam_v; oa.betap = h->betap; oa.part = h->optim_part; oa.ticket = h->ticket;
-      oa.target = h->ticket_target; oa.eta = eta; oa.thresh = 0.5;
+      oa.target = h->ticket_target; oa.eta = eta; oa.thresh = 0.5; oa.timeout = 200000000ull;
       hipLaunchKernelGGL(reduce_optim_kernel, dim3(nb), dim3(64 * RG), 0, h->stream, h->gpart, h->lpart, nA, nC, h->update_blocks, (int)h->Pa,
                          (int)h->Pa, (int)h->Pc, h->comm_buf, stats_args(h, mb, stats_slot, 1), oa);
-      if (hipPeekAtLastError() != hipSuccess) h->ticket_target -= nb;   // a launch that never ran must not leave later ones waiting for its arrivals
+      const hipError_t le = hipGetLastError();
+      if (le != hipSuccess) {             // a launch that never ran must not leave later ones waiting for its arrivals
+        h->ticket_target -= nb;
+        set_error(std::string("reduce_optim_kernel launch failed: ") + hipGetErrorString(le));
+        return 1;
+      }
       wide_mark_params_changed(h);
     } else {
       hipLaunchKernelGGL(reduce_kernel<0>, dim3((P + 63) / 64), dim3(64 * RG), 0, h->stream, h->gpart, h->lpart, nA, nC,

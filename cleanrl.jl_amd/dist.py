@@ -65,6 +65,23 @@ def attach_comm(dist, handle, world_size: int, rank: int, kind: str, make_id, fa
         return "peer"
     if kind != "rccl":
         raise ValueError(f"unknown communicator kind {kind!r} (rccl | peer)")
+    # Probe round BEFORE anybody enters crl_comm_init: that call ends in ncclCommInitRank, a collective — a rank that cannot even load
+    # librccl would leave the others blocked inside it, beyond the reach of the agreement below. Every rank creates an id of its own
+    # (crl_comm_unique_id dlopens librccl; the ids of ranks > 0 are thrown away) and the outcomes are all-gathered. A failure INSIDE
+    # ncclCommInitRank on some rank (after everyone passed the probe) still cannot be recovered from: RCCL has no time-out there.
+    probe_err = None
+    if make_id is not None:
+        try:
+            make_id()
+        except Exception as e:   # noqa: BLE001 — agreed on below
+            probe_err = e
+    probes = [None] * world_size
+    dist.all_gather_object(probes, probe_err is None)
+    if not all(probes):
+        if not fallback:
+            raise probe_err if probe_err is not None else RuntimeError("librccl could not be loaded on another rank")
+        attach_peer_comm(dist, handle, world_size, rank)
+        return "peer (RCCL initialisation failed: librccl not loadable on rank(s) " + ",".join(str(r) for r, ok in enumerate(probes) if not ok) + ")"
     uid = exchange_unique_id(dist, rank, make_id, allow_failure=fallback)
     err = None
     if uid is None:

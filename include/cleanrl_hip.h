@@ -196,7 +196,7 @@ int32_t crl_comm_destroy(crl_ppo* h);
 
 /* Per-handle options: every switch that selects a kernel flavour or changes numerics (earlier rounds: process-wide CRL_*
  * environment variables). Integer-valued, by name; unknown names and out-of-range values are errors. The defaults are what
- * bench.py measures. crl_ppo_option_name enumerates them (index 0 … until it fails).
+ * bench.py measures. crl_ppo_option_count / crl_ppo_option_name enumerate them.
  *   gemm                    2 = 64x64 products as fp16x2 split operands (default); 1 = bf16x3 everywhere — the fallback flavour, which
  *                           a launch also takes by itself, per role, when a hidden-layer weight leaves the fp16 window (|w| >= 255)
  *   rollout_split           small-shard rollout kernel: 1 = three waves per 32-env tile (default), 2 = two, 0 = one
@@ -221,6 +221,7 @@ int32_t crl_comm_destroy(crl_ppo* h);
 int32_t crl_ppo_set_option(crl_ppo* h, const char* key, int64_t value);
 int32_t crl_ppo_get_option(crl_ppo* h, const char* key, int64_t* value);
 int32_t crl_ppo_option_name(int32_t index, const char** name, int64_t* dflt);
+int32_t crl_ppo_option_count(int32_t* n);   /* number of options: enumerate with crl_ppo_option_name(0 … n-1) */
 
 /* Profiling: HIP-event timing of each kernel class on the handle's stream (bench.py roofline). on = 1: every class, events
  * recorded around the launches (extra packets between dependent kernels: a breakdown, not a throughput run); on = 2: only the

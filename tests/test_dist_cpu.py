@@ -204,6 +204,16 @@ def _fallback_worker(rank, world, port, out_dir, case):
         def make_id():
             raise RuntimeError("cannot load librccl")
         h = _FakeCommHandle(rank, rccl_fails=False)
+    elif case == "no_lib_rank1":  # librccl loads on rank 0 only: rank 0 must NOT enter comm_init (a collective that would never return)
+        def make_id():
+            if rank == 1:
+                raise RuntimeError("cannot load librccl")
+            return bytes(range(128))
+
+        class _NeverInit(_FakeCommHandle):
+            def comm_init(self, uid, world, rank):
+                raise AssertionError("comm_init entered although a rank cannot load librccl: it would block in ncclCommInitRank")
+        h = _NeverInit(rank, rccl_fails=False)
     else:                        # partial failure: rank 1's communicator does not come up, rank 0's does
         def make_id():
             return bytes(range(128))
@@ -214,7 +224,7 @@ def _fallback_worker(rank, world, port, out_dir, case):
     if case == "partial":
         assert h.destroyed == (1 if rank == 0 else 0)
     # without fallback every rank raises (and none hangs)
-    h2 = _FakeCommHandle(rank, rccl_fails=(rank == 1) if case == "partial" else False)
+    h2 = _FakeCommHandle(rank, rccl_fails=(rank == 1) if case == "partial" else False) if case != "no_lib_rank1" else type(h)(rank, rccl_fails=False)
     try:
         crl_dist.attach_comm(dist, h2, world, rank, "rccl", make_id, fallback=False)
         raised = False
@@ -226,7 +236,7 @@ def _fallback_worker(rank, world, port, out_dir, case):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["no_id", "partial"])
+@pytest.mark.parametrize("case", ["no_id", "partial", "no_lib_rank1"])
 def test_rccl_start_failures_fall_back_to_the_peer_allreduce_on_every_rank(tmp_path, case):
     """attach_comm(fallback=True): (1) rank 0 cannot create the id — the other ranks must not block in the broadcast; (2) RCCL comes
     up on some ranks only — those drop their communicator before exporting a mailbox. Both end with every rank on the peer path."""
