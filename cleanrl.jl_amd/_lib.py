@@ -53,7 +53,7 @@ EXPORTS = [
     "crl_shuffle", "crl_adv_stats", "crl_ppo_update_minibatch", "crl_ppo_iterate", "crl_ppo_iteration",
     "crl_comm_unique_id", "crl_comm_init", "crl_comm_init_external", "crl_comm_peer_export", "crl_comm_peer_attach", "crl_adv_stats_local", "crl_adv_stats_finish",
     "crl_prof_enable", "crl_prof_read", "crl_prof_reset", "crl_ppo_exact_reruns", "crl_episode_ring_enable",
-    "crl_episode_ring_read", "crl_comm_destroy", "crl_ppo_set_option", "crl_ppo_get_option", "crl_ppo_option_name", "crl_ppo_option_count",
+    "crl_episode_ring_read", "crl_comm_destroy", "crl_ppo_set_option", "crl_ppo_get_option", "crl_ppo_option_name", "crl_ppo_option_count", "crl_gae_bench",
     "crl_a2c_create", "crl_a2c_destroy", "crl_a2c_param_count", "crl_a2c_write_params", "crl_a2c_read_params",
     "crl_a2c_read_env", "crl_a2c_read_buffer", "crl_a2c_run_until_update", "crl_a2c_discounted_future_rewards",
     "crl_dqn_create", "crl_dqn_destroy", "crl_dqn_write_params", "crl_dqn_read_params", "crl_dqn_status_read", "crl_dqn_run",
@@ -162,6 +162,7 @@ def load():
     L.crl_ppo_get_option.argtypes = [vp, C.c_char_p, i64p]
     L.crl_ppo_option_name.argtypes = [C.c_int32, C.POINTER(C.c_char_p), i64p]
     L.crl_ppo_option_count.argtypes = [ip]
+    L.crl_gae_bench.argtypes = [C.c_int32] * 8 + [dp, dp]
     L.crl_a2c_create.argtypes = [C.POINTER(CrlA2CConfig), C.c_int32, C.POINTER(vp)]
     L.crl_a2c_destroy.argtypes = [vp]
     L.crl_a2c_param_count.argtypes = [vp, i64p]
@@ -418,6 +419,13 @@ def gae_host(value, reward, terminal, next_value, next_done, gamma, lam, mode=GA
                          _ptr(nv, C.c_float) if nv is not None else None, _ptr(nd, C.c_uint8) if nd is not None else None,
                          nt, k, gamma, lam, mode, _ptr(adv, C.c_float), _ptr(ret, C.c_float)))
     return adv, ret
+
+
+def gae_bench(nt, k=128, seg=0, tile=0, nt_loads=0, flush_mb=0, reps=10, device=0):
+    """crl_gae_bench: (gae launch times, same-byte-count float4 copy launch times), ms each, `reps` of them."""
+    g = np.zeros(reps, np.float64); c = np.zeros(reps, np.float64)
+    check(load().crl_gae_bench(device, nt, k, seg, tile, nt_loads, flush_mb, reps, _ptr(g, C.c_double), _ptr(c, C.c_double)))
+    return g, c
 
 
 class A2CHandle:

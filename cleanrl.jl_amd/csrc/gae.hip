@@ -146,4 +146,88 @@ int launch_gae(hipStream_t st, const float* value, const float* reward, const ui
   return 0;
 }
 
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+// ---- measurement helpers (crl_gae_bench): synthetic inputs of SURVEY §8d's shape and a hand-written same-byte-count copy -------------
+__global__ void __launch_bounds__(256) gae_bench_fill_kernel(float* value, float* reward, uint8_t* terminal, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    uint32_t x = (uint32_t)i * 0x9E3779B9u + (uint32_t)(i >> 32) * 0x85EBCA6Bu + 0x5EEDu;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    value[i] = ((float)(x >> 8) * 0x1.0p-24f - 0.5f) * 20.0f;        // spread like N(0,1)·10
+    reward[i] = ((x & 0xFFu) < 5u) ? 0.0f : 1.0f;                    // P(0) ≈ 0.02
+    terminal[i] = (((x >> 8) & 0xFFu) < 5u) ? 1 : 0;                 // Bernoulli(≈0.02)
+  }
+}
+// the ceiling: a plain streaming copy, 16 B per lane, four pieces in flight per thread, nontemporal both ways
+__global__ void __launch_bounds__(256) gae_bench_copy_kernel(const f32x4v* __restrict__ src, f32x4v* __restrict__ dst, size_t n4) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const f32x4v a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride),
+                 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+    __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + stride);
+    __builtin_nontemporal_store(c, dst + i + 2 * stride); __builtin_nontemporal_store(d, dst + i + 3 * stride);
+  }
+  for (; i < n4; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
 }  // namespace crl
+
+// Standalone GAE scan on synthetic device-resident inputs of any size (the handle-bound crl_compute_gae is tied to a rollout buffer):
+// `reps` timed launches of gae_kernel with the given flavour, each followed by a timed launch of a hand-written float4 copy that moves
+// the same number of bytes (half read, half written). For footprints beyond the 256 MiB Infinity Cache every launch reads from HBM
+// (bench.py roofline_gae.beyond_cache); for smaller ones pass flush_mb > 0 and a fill of that size runs before every timed launch.
+extern "C" int32_t crl_gae_bench(int32_t device, int32_t nt, int32_t k, int32_t seg, int32_t tile, int32_t nt_loads, int32_t flush_mb,
+                                 int32_t reps, double* gae_ms, double* copy_ms) {
+  using namespace crl;
+  if (nt <= 0 || k <= 0 || reps <= 0 || !gae_ms || !copy_ms) { set_error("crl_gae_bench: bad arguments"); return 1; }
+  CRL_HIP_CHECK(hipSetDevice(device));
+  const size_t n = (size_t)nt * (size_t)k;
+  const size_t bytes = 17 * n + 5 * (size_t)nt;
+  float *value = nullptr, *reward = nullptr, *adv = nullptr, *ret = nullptr, *nv = nullptr, *flush = nullptr;
+  uint8_t *terminal = nullptr, *nd = nullptr;
+  f32x4v *csrc = nullptr, *cdst = nullptr;
+  const size_t n4 = bytes / 32;
+  hipStream_t st = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = 0;
+  auto body = [&]() -> int {
+    CRL_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    CRL_HIP_CHECK(hipEventCreate(&e0)); CRL_HIP_CHECK(hipEventCreate(&e1));
+    CRL_HIP_CHECK(hipMalloc(&value, n * 4)); CRL_HIP_CHECK(hipMalloc(&reward, n * 4)); CRL_HIP_CHECK(hipMalloc(&terminal, n));
+    CRL_HIP_CHECK(hipMalloc(&adv, n * 4)); CRL_HIP_CHECK(hipMalloc(&ret, n * 4));
+    CRL_HIP_CHECK(hipMalloc(&nv, (size_t)nt * 4)); CRL_HIP_CHECK(hipMalloc(&nd, (size_t)nt));
+    CRL_HIP_CHECK(hipMalloc(&csrc, n4 * 16)); CRL_HIP_CHECK(hipMalloc(&cdst, n4 * 16));
+    CRL_HIP_CHECK(hipMemsetAsync(nv, 0, (size_t)nt * 4, st)); CRL_HIP_CHECK(hipMemsetAsync(nd, 0, (size_t)nt, st));
+    CRL_HIP_CHECK(hipMemsetAsync(csrc, 0x3C, n4 * 16, st));
+    if (flush_mb > 0) CRL_HIP_CHECK(hipMalloc(&flush, (size_t)flush_mb << 20));
+    hipLaunchKernelGGL(gae_bench_fill_kernel, dim3(4096), dim3(256), 0, st, value, reward, terminal, n);
+    CRL_HIP_CHECK(hipGetLastError());
+    CRL_HIP_CHECK(hipStreamSynchronize(st));
+    for (int r = -2; r < reps; ++r) {       // two untimed rounds first
+      float ms = 0.f;
+      if (flush) CRL_HIP_CHECK(hipMemsetAsync(flush, r & 0xFF, (size_t)flush_mb << 20, st));
+      if (launch_gae(st, value, reward, terminal, nv, nd, nt, k, 0.99f, 0.95f, CRL_GAE_FIXED, adv, ret, e0, e1, seg, tile, nt_loads)) return 1;
+      CRL_HIP_CHECK(hipEventSynchronize(e1));
+      CRL_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+      if (r >= 0) gae_ms[r] = ms;
+      if (flush) CRL_HIP_CHECK(hipMemsetAsync(flush, (r + 1) & 0xFF, (size_t)flush_mb << 20, st));
+      size_t blocks = (n4 + 256 * 4 - 1) / (256 * 4);
+      if (blocks > 8192) blocks = 8192;
+      if (blocks < 1) blocks = 1;
+      hipExtLaunchKernelGGL(gae_bench_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, st, e0, e1, 0, csrc, cdst, n4);
+      CRL_HIP_CHECK(hipGetLastError());
+      CRL_HIP_CHECK(hipEventSynchronize(e1));
+      CRL_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+      if (r >= 0) copy_ms[r] = ms;
+    }
+    return 0;
+  };
+  rc = body();
+  if (st) (void)hipStreamSynchronize(st);
+  for (void* p : {(void*)value, (void*)reward, (void*)terminal, (void*)adv, (void*)ret, (void*)nv, (void*)nd, (void*)csrc, (void*)cdst, (void*)flush})
+    if (p) (void)hipFree(p);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (st) (void)hipStreamDestroy(st);
+  return rc;
+}

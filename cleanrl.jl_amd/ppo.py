@@ -178,14 +178,20 @@ def train(agent: Agent, num_updates=None, log_every=1, episode_records=0):
     return agent
 
 
-def ppo(config: PPOConfig = None, *, device=0, seed=0x5EED, init_seed=0, run_name="ppo-2-test", **logger_kw):
-    """ppo.jl:75 — `ppo(config::PPOConfig=PPOConfig())`: CartPole, 2x64 actor/critic, whole loop on one MI355X."""
+def ppo(config: PPOConfig = None, *, device=0, seed=0x5EED, init_seed=0, params=None, episode_records=4096, run_name="ppo-2-test",
+        logger_kw=None, **shape):
+    """ppo.jl:75 — `ppo(config::PPOConfig=PPOConfig())`: CartPole, 2x64 actor/critic, whole loop on one MI355X. Like the Julia shell
+    (julia/CleanRLHip.jl) it logs ONE "Episode Statistics" record per finished episode in the reference's order (ppo.jl:147-165), up
+    to `episode_records` per rollout (the device ring's capacity; 0 = one aggregate record per update), and the 16 "Training
+    Statistics" records of every update (ppo.jl:246-248). `logger_kw` goes to Logger.make_logger (logger.jl:7); `shape` keywords
+    (obs_dim, n_act, hidden, env_kind, gae_mode, stale_obs, shuffle_mode) to the Agent — the reference derives them from the env
+    (ppo.jl:85-87)."""
     from . import logger as _logger
     config = config or PPOConfig()
-    _logger.make_logger(run_name, **({"to_terminal": False} | logger_kw))
-    agent = Agent(config, device=device, seed=seed, init_seed=init_seed)
+    _logger.make_logger(run_name, **({"to_terminal": False} | (logger_kw or {})))
+    agent = Agent(config, device=device, seed=seed, init_seed=init_seed, params=params, **shape)
     try:
-        train(agent)
+        train(agent, episode_records=episode_records)
         return agent.get_params()
     finally:
         agent.close()

@@ -230,6 +230,14 @@ int32_t crl_ppo_option_count(int32_t* n);   /* number of options: enumerate with
 enum crl_kernel_id { CRL_K_ROLLOUT = 0, CRL_K_GAE = 1, CRL_K_SHUFFLE = 2, CRL_K_ADV_STATS = 3, CRL_K_UPDATE = 4,
                      CRL_K_REDUCE = 5, CRL_K_OPTIM = 6, CRL_K_ALLREDUCE = 7, CRL_K_PACK = 8, CRL_K_PERMUTE = 9,
                      CRL_K_COUNT = 10 };
+/* Measurement entry (bench.py roofline_gae.beyond_cache, scripts/bench_gae.py): the standalone GAE scan (the kernel behind crl_gae /
+ * crl_compute_gae, ppo.jl:48-73,173-181) on synthetic device-resident inputs of ANY size — value ~ U(-10,10), reward 0 with P 0.02,
+ * terminal ~ B(0.02) — `reps` timed launches (HIP events on the dispatch), each followed by a timed launch of a hand-written float4
+ * streaming copy that moves the same number of bytes (17 B per (env,step) + 5 B per env; half read, half written): the ceiling.
+ * seg / tile / nt_loads as the options gae_seg / gae_tile / gae_nt_loads (0 / 0 / 0 or 1); flush_mb > 0 fills that many MiB before
+ * every timed launch (sizes that fit the 256 MiB Infinity Cache); gae_ms / copy_ms receive `reps` values each. */
+int32_t crl_gae_bench(int32_t device, int32_t nt, int32_t k, int32_t seg, int32_t tile, int32_t nt_loads, int32_t flush_mb,
+                      int32_t reps, double* gae_ms, double* copy_ms);
 int32_t crl_prof_enable(crl_ppo* h, int32_t on);
 int32_t crl_prof_read(crl_ppo* h, int32_t kernel_id, double* total_ms, int64_t* launches);
 int32_t crl_prof_reset(crl_ppo* h);

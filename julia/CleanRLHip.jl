@@ -57,18 +57,32 @@ check(rc::Int32) = rc == 0 || error(unsafe_string(ccall((:crl_last_error, libcrl
 mutable struct Agent
   h::Ptr{Cvoid}
   config::PPOConfig
+  obs_dim::Int; n_act::Int; hidden::Int; device::Int
+  # The reference derives the shapes from the env and the network builder (ppo.jl:85-87: single_state_space / single_action_space;
+  # networks.jl:36-38: make_actor_critic(action_space, obs_space, hidden_sizes = [64, 64])); here they are keywords with the same
+  # defaults — obs_dim = length(single_state_space), n_act = length(single_action_space), hidden = hidden_sizes[1] (both hidden layers
+  # are equal, as in the reference). 4 / 2 / 64 runs the fused kernels; any other shape (obs ≤ 64, act ≤ 16, hidden 64 / 128 / 256 —
+  # e.g. the LunarLander-shaped 8 / 4 / 256 of BASELINE config 3) runs the layer-wise path and needs env_kind 1 (synthetic) or 2 (external).
+  # gae_mode 0 = the reference's loop (ppo.jl:66), 1 = bootstrap from next_value; stale_obs = the reference's Q7 behaviour.
   # shuffle_mode 2 = CRL_SHUFFLE_BLOCKED_FY: an exact uniform shuffle like Random.shuffle (ppo.jl:194); same default as the
   # ctypes mirror (cleanrl.jl_amd/ppo.py). 0 = serial Fisher–Yates, 1 = keyed bijection (pseudo-random, faster).
-  function Agent(config::PPOConfig; device=0, seed=0x5EED, env_id_offset=0, shuffle_mode=2)
+  function Agent(config::PPOConfig; obs_dim::Integer=4, n_act::Integer=2, hidden::Integer=64, env_kind::Integer=(obs_dim == 4 && n_act == 2 ? 0 : 1),
+                 gae_mode::Integer=0, stale_obs::Bool=true, device::Integer=0, seed=0x5EED, env_id_offset::Integer=0, shuffle_mode::Integer=2)
     c = CrlConfig(config.total_timesteps, config.num_steps, config.num_envs, config.num_minibatches, config.update_epochs,
                   config.lr, config.gamma, config.gae_lambda, config.clip_coef, config.ent_coeff, config.v_coef,
                   config.normalize_advantages, config.clip_value_loss, config.anneal_lr,
-                  4, 2, 64, 0, 0, 1, env_id_offset, shuffle_mode, seed)
+                  obs_dim, n_act, hidden, gae_mode, env_kind, stale_obs, env_id_offset, shuffle_mode, seed)
     out = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:crl_ppo_create, libcrl), Int32, (Ref{CrlConfig}, Int32, Ref{Ptr{Cvoid}}), c, device, out))
-    a = new(out[], config)
+    a = new(out[], config, obs_dim, n_act, hidden, device)
     finalizer(x -> ccall((:crl_ppo_destroy, libcrl), Int32, (Ptr{Cvoid},), x.h), a)
   end
+end
+# number of Float32 parameters of Flux.params(actor, critic) for the handle's shapes (networks.jl:36-49)
+function param_count(a::Agent)
+  n = Ref{Int64}(0)
+  check(ccall((:crl_ppo_param_count, libcrl), Int32, (Ptr{Cvoid}, Ref{Int64}), a.h, n))
+  Int(n[])
 end
 
 # Flux.params(actor, critic) → one flat Float32 vector in the same order (ppo.jl:196); W is (out,in) column-major
@@ -89,13 +103,14 @@ end
 # ppo.jl:34-45
 function logprob_actions(obs::AbstractVecOrMat{Float32}, actor::Agent, actions::AbstractVector{Int32})
   n = size(obs, ndims(obs)); o = Array(obs); a0 = Int32.(actions .- 1)
-  logprob = Vector{Float32}(undef, n); entropy = Matrix{Float32}(undef, 2, n)
+  logprob = Vector{Float32}(undef, n); entropy = Matrix{Float32}(undef, actor.n_act, n)   # (n_act, batch): -p .* logp (ppo.jl:42)
   GC.@preserve o a0 logprob entropy check(ccall((:crl_logprob_actions, libcrl), Int32,
     (Ptr{Cvoid}, Ptr{Float32}, Ptr{Int32}, Int32, Ptr{Float32}, Ptr{Float32}), actor.h, o, a0, n, logprob, entropy))
   logprob, entropy
 end
 
 # ppo.jl:48-73 — one env; values [0,k], rewards [1,k], terminals [0,k]. The last slot is 0 (upstream: uninitialised).
+# `device` names the GPU the stateless scan runs on (an Agent's own is agent.device).
 function gae(values::AbstractVector{Float32}, rewards::AbstractVector{Float32}, terminals::AbstractVector{Bool},
              γ::Float32, λ::Float32; mode::Integer=0, device::Integer=0)
   k = length(rewards)
@@ -146,10 +161,13 @@ end
 # step} and `ppo` emits ONE "Episode Statistics" record per episode in the reference's order (ppo.jl:147-165: step by step,
 # done envs ascending; global_step as of that step, ppo.jl:124). With 0 it emits one aggregate record per update (65536 envs
 # finish ~10^5 episodes per rollout). Multi-GPU: pass comm = (id, world_size, rank) and a config whose num_envs is the shard.
-function ppo(config::PPOConfig=PPOConfig(); device=0, params::Union{Nothing,Vector{Float32}}=nothing, episode_records::Integer=4096,
-             comm::Union{Nothing,Tuple{Vector{UInt8},Int,Int}}=nothing)
+# Shapes other than the reference's CartPole 4 / 2 / 64 are keywords forwarded to Agent (obs_dim, n_act, hidden, env_kind, gae_mode,
+# stale_obs): ppo(cfg; obs_dim = 8, n_act = 4, hidden = 256) is BASELINE config 3 on the synthetic env.
+function ppo(config::PPOConfig=PPOConfig(); device::Integer=0, params::Union{Nothing,Vector{Float32}}=nothing, episode_records::Integer=4096,
+             comm::Union{Nothing,Tuple{Vector{UInt8},Int,Int}}=nothing, shape...)
   world, rank = comm === nothing ? (1, 0) : (comm[2], comm[3])
-  agent = Agent(config; device, env_id_offset=rank * config.num_envs)
+  agent = Agent(config; device, env_id_offset=rank * config.num_envs, shape...)
+  params === nothing || length(params) == param_count(agent) || error("params has $(length(params)) entries, the networks have $(param_count(agent))")
   params === nothing || set_params!(agent, params)
   comm === nothing || comm_init!(agent, comm[1], world, rank)
   episode_records > 0 && check(ccall((:crl_episode_ring_enable, libcrl), Int32, (Ptr{Cvoid}, Int32), agent.h, episode_records))

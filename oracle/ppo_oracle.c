@@ -450,6 +450,40 @@ void orc_cartpole_step(float* s, int32_t* t, int32_t action, int32_t max_steps, 
   *done = (fabsf(s[0]) > xthr) || (fabsf(s[2]) > ththr) || (*t > max_steps);
 }
 
+/* The same step with libm's sinf / cosf — what Julia's sin / cos (< 1 ulp) amount to. orc_cartpole_step above replaces them by the
+ * small-angle polynomials the HIP env kernel evaluates (csrc/env.hpp), so that CPU and GPU trajectories can be compared BIT FOR BIT:
+ * that polynomial ORIGINATES IN THE KERNEL, not in the reference. This variant is the reference-side statement; the
+ * tests bound the distance of both the polynomial oracle and the HIP rollout from it, step by step from identical states
+ * (tests/test_oracle.py::test_cartpole_polynomial_step_tracks_libm_step, tests/test_gpu_parity.py::test_rollout_steps_track_the_libm_cartpole). */
+void orc_cartpole_step_libm(float* s, int32_t* t, int32_t action, int32_t max_steps, int32_t* done) {
+  const float gravity = 9.8f, masspole = 0.1f, totalmass = 1.1f, halflength = 0.5f, pml = 0.05f;
+  const float forcemag = 10.0f, dt = 0.02f, ththr = 0.20943951f, xthr = 2.4f;
+  *t += 1;
+  float force = action == 1 ? forcemag : -forcemag;
+  float xdot = s[1], theta = s[2], thetadot = s[3];
+  float costheta = cosf(theta), sintheta = sinf(theta);
+  float tmp = (force + (pml * (thetadot * thetadot)) * sintheta) / totalmass;
+  float num = gravity * sintheta - costheta * tmp;
+  double den = (double)halflength * (4.0 / 3.0 - (double)((masspole * (costheta * costheta)) / totalmass));
+  double thetaacc = (double)num / den;
+  double xacc = (double)tmp - (((double)pml * thetaacc) * (double)costheta) / (double)totalmass;
+  s[0] = s[0] + dt * xdot;
+  s[1] = (float)((double)s[1] + (double)dt * xacc);
+  s[2] = s[2] + dt * thetadot;
+  s[3] = (float)((double)s[3] + (double)dt * thetaacc);
+  *done = (fabsf(s[0]) > xthr) || (fabsf(s[2]) > ththr) || (*t > max_steps);
+}
+/* n independent single steps from given states (4, n) with given actions: libm = 1 → the sinf/cosf variant, 0 → the polynomial one */
+void orc_cartpole_step_batch(const float* s_in, const int32_t* action, int32_t n, int32_t libm, float* s_out, uint8_t* done_out) {
+  for (int i = 0; i < n; ++i) {
+    float s[4]; int32_t t = 0, dn = 0;
+    memcpy(s, s_in + 4 * (size_t)i, sizeof(s));
+    if (libm) orc_cartpole_step_libm(s, &t, action[i], 500, &dn); else orc_cartpole_step(s, &t, action[i], 500, &dn);
+    memcpy(s_out + 4 * (size_t)i, s, sizeof(s));
+    if (done_out) done_out[i] = (uint8_t)dn;
+  }
+}
+
 /* reset!: state = T(0.1) * rand(rng, T, 4) .- T(0.05) [3P-memory]; rand(Float32) shape = 24 bits * 2^-24 */
 void orc_env_reset(const orc_config* c, float* s, uint32_t env_gid, uint64_t gstep, uint32_t stream) {
   uint32_t o[4];

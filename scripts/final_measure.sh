@@ -30,7 +30,7 @@ done
 # the summaries bench.py's roofline reads (stamped with the kernel-source hash) are made HERE, before the bench lines, so that the
 # line of this very run carries them; a copy travels back in gpurun_out/<tag>/generated/ for scripts/collect_profiles.sh
 cd $R && python3 scripts/summarize_pmc.py $O $TAG > $O/summarize_pmc.log 2>&1
-mkdir -p $O/generated && cp profiles/${TAG}_pmc_summary.json profiles/${TAG}_pmc_hbm_traffic.json profiles/${TAG}_update_kernel_counts.json $O/generated/
+mkdir -p $O/generated && cp profiles/${TAG}_pmc_summary.json profiles/${TAG}_pmc_hbm_traffic.json profiles/${TAG}_update_kernel_counts.json profiles/${TAG}_rocprof_update_avg.json $O/generated/
 timeout 900 $B --strict-profiles > $O/bench_n1.json 2> $O/bench_n1.err 
 timeout 900 $B --suite --no-cpu-baseline > $O/bench_n1_suite.json 2> $O/bench_n1_suite.err; cp $R/profiles/${TAG}_suite.json $O/suite.json 2>/dev/null
 timeout 300 $B --kernel-breakdown --no-cpu-baseline > $O/bench_n1_breakdown.json 2> /dev/null

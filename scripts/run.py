@@ -20,7 +20,7 @@ def main():
         raise SystemExit(__doc__)
     algo, argv = sys.argv[1], sys.argv[2:]
     if algo == "ppo":
-        crl.ppo(config_parser.argparse_struct(crl.PPOConfig(), argv), to_terminal=True, to_tensorboard=False)
+        crl.ppo(config_parser.argparse_struct(crl.PPOConfig(), argv), logger_kw=dict(to_terminal=True, to_tensorboard=False))
     elif algo == "a2c":
         crl.a2c(config_parser.argparse_struct(crl.A2CConfig(), argv), to_terminal=True, to_tensorboard=False).close()
     else:

@@ -80,3 +80,17 @@ if upd:
         counts["static_isa"] = f"unavailable: {e}"
     json.dump(counts, open(os.path.join(ROOT, "profiles", f"{tag}_update_kernel_counts.json"), "w"), indent=1)
     print(json.dumps(counts, indent=1))
+# rocprofv3's own clock for the update kernel at the headline size (bench.py roofline.frac_rocprof): average duration from the
+# kernel-trace statistics of `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline` (the first run of final_measure.sh)
+for f in sorted(glob.glob(os.path.join(src, "prof_*kernel_stats.csv"))):
+    base = os.path.basename(f)
+    if base.startswith(("prof_c3_", "prof_envs")):
+        continue
+    for r in csv.DictReader(open(f)):
+        if "update_x2_kernel" in r["Name"]:
+            rec = {"source_hash": HASH, "kernel": short(r["Name"]), "avg_ns": float(r["AverageNs"]), "calls": int(r["Calls"]),
+                   "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]), "csv": f"profiles/{tag}_rocprof_kernel_stats.csv"}
+            json.dump(rec, open(os.path.join(ROOT, "profiles", f"{tag}_rocprof_update_avg.json"), "w"), indent=1)
+            print(json.dumps(rec))
+            break
+    break

@@ -99,12 +99,45 @@ def lib():
         L.orc_shuffle_blocked_fy.argtypes = [ip, C.c_int32, C.c_uint64, C.c_uint64]
         L.orc_update_minibatch.argtypes = [cp, C.POINTER(OrcState), C.c_int32, C.c_double, C.POINTER(OrcStats)]
         L.orc_iterate.argtypes = [cp, C.POINTER(OrcState), C.c_int32, C.c_int32, C.POINTER(OrcStats)]
+        L.orc_cartpole_step_libm.argtypes = [fp, ip, C.c_int32, C.c_int32, ip]
+        L.orc_cartpole_step_batch.argtypes = [fp, ip, C.c_int32, C.c_int32, fp, u8p]
         _lib = L
     return _lib
 
 
+_batched = None
+
+
+def batched_lib():
+    """oracle/libppo_cpu_batched.so: the batched, -O3 -march=native CPU iteration behind bench.py's cpu_baseline.batched (NOT a
+    parity oracle). Always rebuilt on the box that runs it (`make -B batched`): -march=native code must not travel between hosts."""
+    global _batched
+    if _batched is None:
+        subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle"), "-s", "-B", "batched"])
+        L = C.CDLL(os.path.join(_ROOT, "oracle", "libppo_cpu_batched.so"))
+        cp = C.POINTER(OrcConfig)
+        L.orc_state_create.restype = C.POINTER(OrcState); L.orc_state_create.argtypes = [cp]
+        L.orc_state_destroy.argtypes = [C.POINTER(OrcState)]
+        L.orc_env_init.argtypes = [cp, C.POINTER(OrcState)]
+        L.orc_param_count.restype = C.c_int32; L.orc_param_count.argtypes = [cp]
+        L.orc_batched_iterate.restype = C.c_int32
+        L.orc_batched_iterate.argtypes = [cp, C.POINTER(OrcState), C.c_int32, C.c_int32, C.POINTER(OrcStats)]
+        _batched = L
+    return _batched
+
+
 def _p(a, ct):
     return a.ctypes.data_as(C.POINTER(ct))
+
+
+def cartpole_step_batch(states, actions, libm):
+    """One CartPole step from each of n given states (4, n): libm = True → sinf / cosf (the reference-side statement),
+    False → the polynomial shared with the HIP env kernel. Returns (next states (4, n), done flags)."""
+    st = np.asfortranarray(states, np.float32); n = st.shape[1]
+    a = np.ascontiguousarray(actions, np.int32)
+    out = np.zeros((4, n), np.float32, order="F"); dn = np.zeros(n, np.uint8)
+    lib().orc_cartpole_step_batch(fptr(st), _p(a, C.c_int32), n, int(bool(libm)), fptr(out), _p(dn, C.c_uint8))
+    return out, dn
 
 
 def fptr(a):
@@ -252,6 +285,15 @@ class State:
         n = self.cfg.update_epochs * self.cfg.num_minibatches
         arr = (OrcStats * n)()
         lib().orc_iterate(C.byref(self.cfg), self.ptr, num_updates_total, int(gen_perm), arr)
+        return [a.as_dict() for a in arr]
+
+    def batched_iterate(self, num_updates_total, gen_perm=True):
+        """The same loop body through oracle/ppo_cpu_batched.c (throughput baseline; the state layout is shared)."""
+        n = self.cfg.update_epochs * self.cfg.num_minibatches
+        arr = (OrcStats * n)()
+        rc = batched_lib().orc_batched_iterate(C.byref(self.cfg), self.ptr, num_updates_total, int(gen_perm), arr)
+        if rc:
+            raise ValueError("orc_batched_iterate covers hidden 64 / CartPole / compat GAE only")
         return [a.as_dict() for a in arr]
 
     def close(self):

@@ -855,3 +855,79 @@ def test_iterate_equals_host_driven_steps_for_other_epoch_and_minibatch_counts(c
     p1, p2 = h1.read(crl._lib.F_PARAMS), h2.read(crl._lib.F_PARAMS)
     assert np.max(np.abs(p1 - p2)) < 1e-7, np.max(np.abs(p1 - p2))
     a1.close(); a2.close()
+
+
+def test_ppo_entry_point_emits_the_reference_log_stream(crl, tmp_path):
+    """`ppo(config)` (ppo.jl:75) end to end through the host shell: three updates of 8 envs x 32 steps. The records that reach the
+    "CleanRL" logger (captured through the JSON-lines sink of Logger.make_logger, logger.jl:7-29) must be what ppo.jl produces for
+    the episodes the ORACLE yields from the same parameters and seed: one "Episode Statistics" record per finished episode in
+    (step, env) order with global_step as of that step (ppo.jl:124,147-165), then the 16 "Training Statistics" records of the update
+    (ppo.jl:246-248); log_step_increment = 0 until the first record, then global_step − last_log_step (ppo.jl:155,246)."""
+    import json
+    nt, k, updates = 8, 32, 3
+    cfg = crl.PPOConfig(num_envs=nt, num_steps=k, total_timesteps=nt * k * updates)
+    cfgo = O.make_config(num_envs=nt, num_steps=k)
+    params = O.orthogonal_params(cfgo, 9)
+    crl.ppo(cfg, params=params, shuffle_mode=crl._lib.SHUFFLE_FISHER_YATES, run_name="ppo-entry",
+            logger_kw=dict(to_tensorboard=False, to_json=True, log_dir=str(tmp_path)))
+    got = [json.loads(line) for line in open(tmp_path / "ppo-entry.json")]
+
+    # what ppo.jl:117-253 logs, from the oracle's buffers
+    st = O.State(cfgo); st.params[:] = params; st.env_init()
+    want = []
+    global_step = 0; last = 0
+    ep_ret = np.zeros(nt, np.float32); ep_len = np.zeros(nt, np.int64)
+    for _ in range(updates):
+        stats = st.iterate(updates, gen_perm=True)
+        for t in range(k):
+            global_step += nt                                            # ppo.jl:124
+            ep_len += 1; ep_ret += st.reward[:, t]                       # ppo.jl:125,145
+            done = st.terminal[:, t + 1] if t + 1 < k else st.next_done
+            for e in np.flatnonzero(done):                               # ppo.jl:149-163, ascending env
+                want.append(("Episode Statistics", dict(episode_return=float(ep_ret[e]), episode_length=int(ep_len[e]), global_step=global_step,
+                                                        log_step_increment=0 if last == 0 else global_step - last)))
+                ep_ret[e] = 0; ep_len[e] = 0; last = global_step
+        for s in stats:                                                  # ppo.jl:246-248
+            want.append(("Training Statistics", dict(loss=s["loss"], pg_loss=s["pg_loss"], v_loss=s["v_loss"], entropy_loss=s["entropy_loss"],
+                                                     log_step_increment=0 if last == 0 else global_step - last)))
+            last = global_step
+    st.close()
+    assert [g["msg"] for g in got] == [w[0] for w in want], "record names / order"
+    n_ep = sum(1 for w in want if w[0] == "Episode Statistics")
+    assert n_ep >= 5 and len(got) == n_ep + updates * 16
+    for g, (name, w) in zip(got, want):
+        if name == "Episode Statistics":
+            assert set(g) == {"msg", "episode_return", "episode_length", "global_step", "steps_per_sec", "log_step_increment"}   # ppo.jl:157
+            assert (g["episode_return"], g["episode_length"], g["global_step"], g["log_step_increment"]) == \
+                   (w["episode_return"], w["episode_length"], w["global_step"], w["log_step_increment"]), (g, w)
+            assert g["steps_per_sec"] > 0
+        else:
+            assert set(g) == {"msg", "loss", "pg_loss", "v_loss", "entropy_loss", "log_step_increment"}                          # ppo.jl:247
+            assert g["log_step_increment"] == w["log_step_increment"], (g, w)
+            for key in ("loss", "pg_loss", "v_loss", "entropy_loss"):
+                assert loss_close(key, g[key], w[key], IT_LOSS), (key, g[key], w[key])
+
+
+def test_rollout_steps_track_the_libm_cartpole(crl):
+    """The env kernel evaluates sin / cos by a small-angle polynomial (csrc/env.hpp) and the parity oracle shares it bit for bit — so
+    "observations bit-exact" above is HIP ≡ the kernel's own polynomial. Against the reference-side statement (libm sinf / cosf,
+    orc_cartpole_step_libm — what Julia's sin / cos amount to) every single transition of a 4096-env rollout must stay within 1e-5
+    relative (1e-6 absolute floor): s' = step_libm(s, a) from the GPU's OWN state s and action a, for all steps that do not follow a reset."""
+    F = crl._lib
+    nt, k = 4096, 128
+    agent = make_agent(crl, nt=nt, k=k)
+    h = agent.handle
+    h.env_reset(); h.rollout_run()
+    obs, act, term = h.read(F.F_OBS), h.read(F.F_ACTION), h.read(F.F_TERMINAL)
+    # transition t -> t+1 of env e is visible in the buffer when no reset happened in between: terminal[e, t] == 0 means obs[:, e, t] is the
+    # live state the action was applied to (after a terminal the stored obs is the stale terminal one, Q7, and the env was reset underneath)
+    live = term[:, :k - 1] == 0
+    e_idx, t_idx = np.nonzero(live)
+    s = np.asfortranarray(obs[:, e_idx, t_idx]); a = act[e_idx, t_idx]
+    nxt = obs[:, e_idx, t_idx + 1]
+    lib_next, _ = O.cartpole_step_batch(s, a, libm=True)
+    poly_next, _ = O.cartpole_step_batch(s, a, libm=False)
+    assert np.array_equal(poly_next, nxt), "the shared polynomial: bit for bit"
+    err = np.abs(nxt.astype(np.float64) - lib_next) / (np.abs(lib_next) + 0.1)
+    assert len(e_idx) > 400_000 and err.max() < 1e-5, (len(e_idx), err.max())
+    agent.close()

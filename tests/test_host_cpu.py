@@ -171,7 +171,25 @@ def test_julia_shell_structs_and_symbols_follow_the_header(crl):
     for must in ("crl_comm_init", "crl_comm_unique_id", "crl_episode_ring_enable", "crl_episode_ring_read", "crl_dqn_run", "crl_dqn_q_values",
                  "crl_ppo_set_option", "crl_ppo_get_option", "crl_comm_destroy"):
         assert must in called, must
-    assert "shuffle_mode=2" in jl     # exact blocked Fisher-Yates by default, like the ctypes mirror
+    assert "shuffle_mode::Integer=2" in jl     # exact blocked Fisher-Yates by default, like the ctypes mirror
+    # shapes are arguments, not literals (ppo.jl:85-87, networks.jl:36-38): the constructor forwards them into the C struct in header order,
+    # the entropy matrix is (n_act, batch), and ppo() passes shape keywords through — BASELINE config 3 (obs 8 / act 4 / 2x256) is reachable
+    ctor = re.search(r"function Agent\(config::PPOConfig;(.*?)\)\n(.*?)\n  end", jl, re.S)
+    assert ctor, "Agent constructor not found"
+    kw = ctor.group(1)
+    for name, dflt in (("obs_dim", "4"), ("n_act", "2"), ("hidden", "64"), ("gae_mode", "0"), ("stale_obs", "true"), ("device", "0"), ("env_id_offset", "0")):
+        assert re.search(r"\b%s(::[A-Za-z]+)?=%s\b" % (name, dflt), kw), (name, kw)
+    assert "env_kind" in kw
+    call = re.search(r"c = CrlConfig\((.*?)\)\n", ctor.group(2), re.S).group(1)
+    args = [a.strip() for a in call.replace("\n", " ").split(",")]
+    want = [n for n, _ in L.CrlConfig._fields_]
+    assert len(args) == len(want), (len(args), len(want))
+    for a, w in zip(args, want):
+        assert a in (w, "config." + w), (a, w)      # every field of crl_ppo_config is fed by the like-named keyword / PPOConfig field
+    assert not re.search(r"CrlConfig\([^)]*\b4, 2, 64\b", jl), "shape literals are back in the constructor"
+    assert "Matrix{Float32}(undef, actor.n_act, n)" in jl
+    assert re.search(r"function ppo\(config::PPOConfig=PPOConfig\(\);.*?shape\.\.\.\)", jl, re.S) and "Agent(config; device, env_id_offset=rank * config.num_envs, shape...)" in jl
+    assert "crl_ppo_param_count" in called
 
 
 def _pb_fields(buf):
