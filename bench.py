@@ -136,6 +136,30 @@ def physical_cores():
         return logical, logical
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by a cgroup CPU quota if one is set (a container can see 128 cores
+    in /proc/cpuinfo and be allowed eight of them — a 128-thread OpenMP team then runs slower than an 8-thread one)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
 def _set_omp_threads(n):
     import ctypes
     try:
@@ -163,7 +187,7 @@ def _time_oracle(nt, threads, budget_s, min_iters=1):
     return nt * NUM_STEPS * iters / dt, iters, dt
 
 
-def _time_batched(nt, threads, budget_s):
+def _time_batched(nt, threads, budget_s, min_iters=2):
     """oracle/ppo_cpu_batched.c: the same loop body with batched, vectorised network passes, built -O3 -march=native on this box."""
     import oraclelib as O
     O.batched_lib()
@@ -175,7 +199,7 @@ def _time_batched(nt, threads, budget_s):
     t0 = time.perf_counter()
     st.batched_iterate(1000)
     warm = time.perf_counter() - t0
-    goal = max(2, int(budget_s / max(warm, 1e-3)))
+    goal = max(min_iters, int(budget_s / max(warm, 1e-3)))
     t0 = time.perf_counter()
     for _ in range(goal):
         st.batched_iterate(1000)
@@ -190,14 +214,23 @@ def cpu_baseline():
     (the headline `value`), C1 (nt=8) single-threaded, and C1 on all cores; `batched` = the same loop through
     oracle/ppo_cpu_batched.c (vectorised network passes, -O3 -march=native), the figure to read as "what those cores can do"."""
     cores, logical = physical_cores()
+    usable, quota = usable_cpus()
+    cores = max(1, min(cores, usable))
     v_all, it_all, dt_all = _time_oracle(4096, cores, budget_s=6.0)
     v_1, it_1, dt_1 = _time_oracle(8, 1, budget_s=2.0, min_iters=2)
     v_c1, it_c1, dt_c1 = _time_oracle(8, min(cores, 8), budget_s=1.0, min_iters=2)
     batched = None
     try:
-        v_b, it_b, dt_b = _time_batched(16384, cores, budget_s=6.0)
-        batched = {"value": v_b, "unit": "env-steps/s", "cores": cores, "kind": "port (batched)",
-                   "sample": f"num_envs=16384, num_steps={NUM_STEPS}, {it_b} full PPO iterations in {dt_b:.1f}s, OpenMP threads = {cores}",
+        # the team size is calibrated, not assumed: hosts of this pool report 128 cores and scale to far fewer (shared hosts, NUMA first
+        # touch); one short run per candidate at num_envs=4096, the best one is then timed on the sample
+        tried = {}
+        for th in sorted({cores, max(1, cores // 2), max(1, cores // 4), min(cores, 32), min(cores, 16), min(cores, 8)}, reverse=True):
+            tried[th] = _time_batched(4096, th, budget_s=0.0, min_iters=1)[0]
+        best = max(tried, key=tried.get)
+        v_b, it_b, dt_b = _time_batched(16384, best, budget_s=5.0)
+        batched = {"value": v_b, "unit": "env-steps/s", "cores": best, "kind": "port (batched)", "threads_tried": {str(k): v for k, v in tried.items()},
+                   "sample": f"num_envs=16384, num_steps={NUM_STEPS}, {it_b} full PPO iterations in {dt_b:.1f}s, OpenMP threads = {best} "
+                             f"(best of the calibrated team sizes; {cores} usable cores, cgroup quota {quota})",
                    "note": "oracle/ppo_cpu_batched.c: the same algorithm with the network passes batched over 64-sample blocks and vectorised "
                            "(gcc -O3 -march=native, built on this box); agrees with the parity oracle to float32 summation noise "
                            "(tests/test_oracle.py). Still hand-written C, not Flux on BLAS — the closest stand-in this image allows."}
@@ -338,19 +371,21 @@ def gae_beyond_cache(crl, sizes=(262144, 524288), reps=8):
     for nt in sizes:
         nbytes = GAE_BYTES_PER_STEP * nt * NUM_STEPS + GAE_BYTES_PER_ENV * nt
         row = {"num_envs": nt, "bytes_per_launch": nbytes}
-        for name, ntl in (("cached_loads", 0), ("nt_loads", 1)):
-            g, c = crl._lib.gae_bench(nt, NUM_STEPS, nt_loads=ntl, reps=reps)
+        for name, ntl, tile, seg in (("cached_loads", 0, 0, 0), ("nt_loads", 1, 0, 0), ("segmented_kernel", 1, 64, 16)):
+            g, c = crl._lib.gae_bench(nt, NUM_STEPS, nt_loads=ntl, tile=tile, seg=seg, reps=reps)
             gm, cm = med(list(g)), med(list(c))
             row[name] = {"avg_launch_ms": gm, "achieved": nbytes / (gm * 1e-3) / 1e9, "frac": nbytes / (gm * 1e-3) / 1e9 / PEAK_HBM_GBPS,
                          "over_copy": cm / gm}
             row["copy"] = {"avg_launch_ms": cm, "achieved": nbytes / (cm * 1e-3) / 1e9, "frac": nbytes / (cm * 1e-3) / 1e9 / PEAK_HBM_GBPS,
                            "kernel": "gae_bench_copy_kernel (float4, nontemporal, same byte count: half read, half written)"}
-        best = max(("cached_loads", "nt_loads"), key=lambda k: row[k]["frac"])
+        best = max(("cached_loads", "nt_loads"), key=lambda k: row[k]["frac"])   # the streaming kernel (what sizes like these take by themselves)
         row["best"] = best
         out[str(nt)] = row
     big = out[str(sizes[-1])]
     return {"num_envs": big["num_envs"], "bytes_per_launch": big["bytes_per_launch"], "flavour": big["best"], "unit": "GB/s", "peak": PEAK_HBM_GBPS,
             **big[big["best"]], "copy": big["copy"], "sizes": out,
+            "kernel": "gae_stream_kernel (four envs per thread, 16-byte accesses, serial Float64 recurrence) — what batches of 16.8 M samples or more take; "
+                      "segmented_kernel = gae_kernel<64, 16> on the same inputs",
             "note": "crl_gae_bench: the standalone scan on 0.57 / 1.14 GB of synthetic inputs (past the 256 MiB Infinity Cache), median of "
                     f"{reps} launches; frac = algorithmic bytes ÷ time ÷ 8 TB/s; over_copy = copy time ÷ scan time"}
 

@@ -55,7 +55,7 @@ static int opt_set(crl_ppo* h, const char* key, int64_t value) {
     return 1;
   }
   if (id == OPT_GAE_SEG && value != 0 && value != 8 && value != 16) { set_error("crl_ppo_set_option: gae_seg is 0 (automatic), 8 or 16"); return 1; }
-  if (id == OPT_GAE_TILE && value != 0 && value != 8 && value != 16 && value != 32 && value != 64) { set_error("crl_ppo_set_option: gae_tile is 0 (automatic), 8, 16, 32 or 64"); return 1; }
+  if (id == OPT_GAE_TILE && value != 0 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64) { set_error("crl_ppo_set_option: gae_tile is 0 (automatic), 4 (streaming kernel), 8, 16, 32 or 64"); return 1; }
   h->opt[id] = value;
   if (id == OPT_GUARD_WINDOW) h->window_len = (int)value;
   return 0;

@@ -113,11 +113,101 @@ __global__ void __launch_bounds__(512) gae_kernel(const float* __restrict__ valu
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Streaming flavour for batches past the Infinity Cache (crl_gae on big host arrays, crl_gae_bench: 0.57 / 1.14 GB per launch).
+// One thread owns FOUR consecutive envs for the whole rollout and walks it backwards in chunks of 8 steps, the carry in registers:
+// no segments, no LDS, and every access is 16 bytes per lane (value, reward, advantage, return: 1 KB rows per wave-instruction) or 4
+// (the four done bytes of a step) — 40 memory instructions per 544 bytes instead of 41 per 136. The next chunk's 24 loads are issued
+// before the current chunk is computed (two register sets). The arithmetic is the reference's serial Float64 recurrence in its own
+// order (ppo.jl:63-69), so the result is bit-identical to orc_gae (the segmented kernel composes affine maps: ≤ 1e-6 of its outputs
+// differ in the last bit). Needs nt % 4 == 0; pays only when there are enough envs to fill the chip (one thread per four envs).
+// ------------------------------------------------------------------------------------------------------------------------------
+typedef float gf4 __attribute__((ext_vector_type(4)));
+struct GaeChunk { gf4 v[8], r[8]; uint32_t t[8]; };
+template <bool NTL>
+__device__ __forceinline__ void gae_chunk_load(GaeChunk& c, const float* value, const float* reward, const uint8_t* terminal, size_t e, int nt, int t0, int k) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int t = t0 + i;
+    if (t < k) {
+      const size_t idx = e + (size_t)nt * t;
+      const gf4* pv = reinterpret_cast<const gf4*>(value + idx);
+      const gf4* pr = reinterpret_cast<const gf4*>(reward + idx);
+      const uint32_t* pt = reinterpret_cast<const uint32_t*>(terminal + idx);
+      c.v[i] = NTL ? __builtin_nontemporal_load(pv) : *pv;
+      c.r[i] = NTL ? __builtin_nontemporal_load(pr) : *pr;
+      c.t[i] = NTL ? __builtin_nontemporal_load(pt) : *pt;
+    }
+  }
+}
+template <bool NTL>
+__global__ void __launch_bounds__(256) gae_stream_kernel(const float* __restrict__ value, const float* __restrict__ reward,
+                                                         const uint8_t* __restrict__ terminal, const float* __restrict__ next_value,
+                                                         const uint8_t* __restrict__ next_done, int nt, int k, float gamma, float gl, int mode,
+                                                         float* __restrict__ adv, float* __restrict__ ret) {
+#pragma clang fp contract(off)
+  const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= (size_t)nt) return;
+  double A[4] = {0.0, 0.0, 0.0, 0.0};
+  gf4 vnext = {0.0f, 0.0f, 0.0f, 0.0f};        // value of step t + 1 (bootstrap behind the last step, ppo.jl:174)
+  uint32_t dnext = 0;                           // the done bytes that gate step t: terminal[t + 1] (next_done behind the last step, ppo.jl:176)
+  if (next_value) vnext = *reinterpret_cast<const gf4*>(next_value + e);
+  if (next_done) dnext = *reinterpret_cast<const uint32_t*>(next_done + e);
+  auto compute = [&](const GaeChunk& c, int t0) {
+#pragma unroll
+    for (int i = 7; i >= 0; --i) {
+      const int t = t0 + i;
+      if (t < k) {
+        gf4 a32, r32;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const double nonterm = 1.0 - (double)(((dnext >> (8 * j)) & 0xFFu) ? 1 : 0);
+          double delta = (double)c.r[i][j] + ((double)gamma * nonterm) * (double)vnext[j] - (double)c.v[i][j];
+          double cc = (double)gl * nonterm;
+          if (mode == CRL_GAE_COMPAT && t == k - 1) { delta = 0.0; cc = 0.0; }   // ppo.jl:66: the loop starts at k-1; slot k is defined as 0
+          A[j] = delta + (cc * A[j]);
+          a32[j] = (float)A[j];
+          r32[j] = a32[j] + c.v[i][j];
+        }
+        const size_t idx = e + (size_t)nt * t;
+        *reinterpret_cast<gf4*>(adv + idx) = a32;
+        if (ret) *reinterpret_cast<gf4*>(ret + idx) = r32;
+        vnext = c.v[i]; dnext = c.t[i];
+      }
+    }
+  };
+  GaeChunk ca, cb;
+  int t0 = ((k - 1) / 8) * 8;
+  gae_chunk_load<NTL>(ca, value, reward, terminal, e, nt, t0, k);
+  while (true) {
+    if (t0 >= 8) gae_chunk_load<NTL>(cb, value, reward, terminal, e, nt, t0 - 8, k);
+    compute(ca, t0);
+    t0 -= 8;
+    if (t0 < 0) break;
+    if (t0 >= 8) gae_chunk_load<NTL>(ca, value, reward, terminal, e, nt, t0 - 8, k);
+    compute(cb, t0);
+    t0 -= 8;
+    if (t0 < 0) break;
+  }
+}
+
 int launch_gae(hipStream_t st, const float* value, const float* reward, const uint8_t* terminal,
                const float* next_value, const uint8_t* next_done, int nt, int k, float gamma, float lambda, int mode,
                float* adv, float* ret, hipEvent_t ev_start, hipEvent_t ev_stop, int seg, int tile, int nt_loads) {
   if (nt <= 0 || k <= 0) { set_error("gae: empty input"); return 1; }
   const float gl = gamma * lambda;  // Float32 product, as `γ * λ` with both T=Float32 (ppo.jl:68)
+  // tile = 4 selects the streaming kernel (four envs per thread); tile = 0 takes it by itself for batches past the Infinity Cache
+  const bool can_stream = (nt % 4) == 0 && ((uintptr_t)value % 16) == 0 && ((uintptr_t)reward % 16) == 0 && ((uintptr_t)adv % 16) == 0 &&
+                          (!ret || ((uintptr_t)ret % 16) == 0) && ((uintptr_t)terminal % 4) == 0 && (!next_value || ((uintptr_t)next_value % 16) == 0) &&
+                          (!next_done || ((uintptr_t)next_done % 4) == 0);
+  if (tile == 4 && !can_stream) { set_error("gae: the streaming kernel (gae_tile = 4) needs num_envs % 4 == 0 and 16-byte aligned buffers"); return 1; }
+  if (tile == 4 || (tile == 0 && can_stream && (size_t)nt * (size_t)k >= ((size_t)1 << 24) && nt >= 65536)) {
+    const dim3 grid((unsigned)((nt / 4 + 255) / 256)), block(256);
+    if (nt_loads) hipExtLaunchKernelGGL((gae_stream_kernel<true>), grid, block, 0, st, ev_start, ev_stop, 0, value, reward, terminal, next_value, next_done, nt, k, gamma, gl, mode, adv, ret);
+    else hipExtLaunchKernelGGL((gae_stream_kernel<false>), grid, block, 0, st, ev_start, ev_stop, 0, value, reward, terminal, next_value, next_done, nt, k, gamma, gl, mode, adv, ret);
+    CRL_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   // segment length L and env tile EB: S = ceil(k/L) segments, block = S*EB <= 512 threads.
   // Short segments + narrow tiles give the most loads in flight; long rollouts fall back to longer segments.
   const int env_L = seg, env_EB = tile, env_nts = 0;   // options gae_seg / gae_tile (0 = automatic)

@@ -51,7 +51,8 @@ def rel_err(a, b):
 
 
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("nt,k", [(1, 1), (1, 2), (3, 5), (8, 128), (33, 17), (64, 16), (100, 129), (4096, 128)])
+@pytest.mark.parametrize("nt,k", [(1, 1), (1, 2), (3, 5), (8, 128), (33, 17), (64, 16), (100, 129), (4096, 128),
+                                  (262144, 128)])   # the last one: 0.57 GB per launch, past the Infinity Cache (bench.py roofline_gae.beyond_cache)
 @pytest.mark.parametrize("mode", [0, 1])
 def test_gae_matches_oracle(crl, nt, k, mode):
     rng = np.random.default_rng(nt * 1000 + k)
