@@ -384,7 +384,7 @@ def gae_beyond_cache(crl, sizes=(262144, 524288), reps=8):
     big = out[str(sizes[-1])]
     return {"num_envs": big["num_envs"], "bytes_per_launch": big["bytes_per_launch"], "flavour": big["best"], "unit": "GB/s", "peak": PEAK_HBM_GBPS,
             **big[big["best"]], "copy": big["copy"], "sizes": out,
-            "kernel": "gae_stream_kernel (four envs per thread, 16-byte accesses, serial Float64 recurrence) — what batches of 16.8 M samples or more take; "
+            "kernel": "gae_stream_kernel (four envs per thread, 16-byte accesses, serial Float64 recurrence) — what batches of 67 M samples or more take (the 262144-env rows run the segmented kernel); "
                       "segmented_kernel = gae_kernel<64, 16> on the same inputs",
             "note": "crl_gae_bench: the standalone scan on 0.57 / 1.14 GB of synthetic inputs (past the 256 MiB Infinity Cache), median of "
                     f"{reps} launches; frac = algorithmic bytes ÷ time ÷ 8 TB/s; over_copy = copy time ÷ scan time"}

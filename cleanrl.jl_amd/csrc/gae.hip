@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(512) gae_kernel(const float* __restrict__ valu
 // (the four done bytes of a step) — 40 memory instructions per 544 bytes instead of 41 per 136. The next chunk's 24 loads are issued
 // before the current chunk is computed (two register sets). The arithmetic is the reference's serial Float64 recurrence in its own
 // order (ppo.jl:63-69), so the result is bit-identical to orc_gae (the segmented kernel composes affine maps: ≤ 1e-6 of its outputs
-// differ in the last bit). Needs nt % 4 == 0; pays only when there are enough envs to fill the chip (one thread per four envs).
+// differ in the last bit). Needs nt % 4 == 0; pays only when there are enough envs to fill the chip (one thread per four envs): taken by itself from 2^26 samples.
 // ------------------------------------------------------------------------------------------------------------------------------
 typedef float gf4 __attribute__((ext_vector_type(4)));
 struct GaeChunk { gf4 v[8], r[8]; uint32_t t[8]; };
@@ -201,7 +201,9 @@ int launch_gae(hipStream_t st, const float* value, const float* reward, const ui
                           (!ret || ((uintptr_t)ret % 16) == 0) && ((uintptr_t)terminal % 4) == 0 && (!next_value || ((uintptr_t)next_value % 16) == 0) &&
                           (!next_done || ((uintptr_t)next_done % 4) == 0);
   if (tile == 4 && !can_stream) { set_error("gae: the streaming kernel (gae_tile = 4) needs num_envs % 4 == 0 and 16-byte aligned buffers"); return 1; }
-  if (tile == 4 || (tile == 0 && can_stream && (size_t)nt * (size_t)k >= ((size_t)1 << 24) && nt >= 65536)) {
+  // measured (profiles/r04_gae_beyond_cache.txt): at 524288 envs x 128 (1.14 GB) the streaming kernel runs at the float4 copy's own speed
+  // (216-226 us, 0.63-0.66 of 8 TB/s; the segmented kernel 282-342 us); at 262144 envs its 1024 waves are too few (160-176 us against 128-135)
+  if (tile == 4 || (tile == 0 && can_stream && (size_t)nt * (size_t)k >= ((size_t)1 << 26) && nt >= 262144)) {
     const dim3 grid((unsigned)((nt / 4 + 255) / 256)), block(256);
     if (nt_loads) hipExtLaunchKernelGGL((gae_stream_kernel<true>), grid, block, 0, st, ev_start, ev_stop, 0, value, reward, terminal, next_value, next_done, nt, k, gamma, gl, mode, adv, ret);
     else hipExtLaunchKernelGGL((gae_stream_kernel<false>), grid, block, 0, st, ev_start, ev_stop, 0, value, reward, terminal, next_value, next_done, nt, k, gamma, gl, mode, adv, ret);

@@ -27,6 +27,14 @@
 
 namespace crl {
 
+#ifdef CRL_EXP_STAMPS
+// diagnostic build only (scripts/build_variant.sh stamps -DCRL_EXP_STAMPS; never in the library): per-wave wall-clock stamps (100 MHz)
+// at the phase boundaries of the update kernel and of reduce_optim_kernel, read back by scripts/stamps_probe.py
+__device__ unsigned long long crl_dbg_stamps[512 * 8 * 8];
+#define CRL_STAMP(slot) do { if ((threadIdx.x & 63) == 0) crl_dbg_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define CRL_STAMP(slot) do { } while (0)
+#endif
 constexpr int TSTRIDE = 36;
 // phase boundary: orders the wave's LDS traffic AND stops the scheduler from moving register-only work across it (hoisted
 // loads of the next phase were the source of the spills)
@@ -122,6 +130,7 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
   float* img0 = smem;
   float* T0 = scratch + wave * SCR;
   const float* p = a.params + (ROLE ? NetParams<D, A>::SIZE : 0);
+  CRL_STAMP(0);
   if constexpr (X2) {
     if (!stage_net_x2<D, NOUT>(img0, p, tid, NT, reinterpret_cast<int*>(scratch + RW * SCR))) {
       if (tid == 0 && rb == 0) a.range_err[0] = 1.0;   // informational: the bf16x3 fallback ran (crl_ppo_get_option "gemm_fallback_seen")
@@ -133,6 +142,7 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
   else stage_net<D, NOUT, true>(img0, p, tid, NT);
   __syncthreads();
 
+  CRL_STAMP(1);
   f32x16 dW2t[2][2];  // dW2ᵀ accumulators: [mj = h1-row block][ni = δ2-row block]
 #pragma unroll
   for (int x = 0; x < 2; ++x)
@@ -600,6 +610,7 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
     }
   }
 
+  CRL_STAMP(2);
   // fp16x2: the weight-gradient accumulators carry 2^14 (h1) · G (δ2); the launch's largest |δ2| goes to the next launch's G
   const float dw_unscale = X2 ? (1.0f / X2_ACT_SCALE) / Gdw : 1.0f;
   if constexpr (X2) {
@@ -689,6 +700,7 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
     }
     for (int i = tid; i < P::SIZE; i += NT) gp[i] = R[i];
   }
+  CRL_STAMP(3);
   if (tid == 0) {
     double s0 = 0.0, s1 = 0.0;
     for (int w = 0; w < RW; ++w) { s0 += lsum[w]; s1 += lsum[8 + w]; }
@@ -1166,3 +1178,9 @@ int launch_update_exact_dp(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
 }
 
 }  // namespace crl
+
+#ifdef CRL_EXP_STAMPS
+extern "C" int32_t crl_debug_read_stamps(unsigned long long* out, int32_t n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(crl::crl_dbg_stamps), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -36,7 +36,7 @@ enum { EPI_TANH = 0, EPI_BIAS = 1, EPI_DTANH = 2, EPI_STORE = 3 };
 // ------------------------------------------------------------------------------------------------------
 // Workspace
 // ------------------------------------------------------------------------------------------------------
-struct WideNetPack { int w1, w3, w2t, w3t, x3f, x3b, x2f, x2b, wmax, size; };  // float offsets of the packed weight copies of one network
+struct WideNetPack { int w1, w3, w2t, w3t, x3f, x3b, x2f, x2b, wmax, w1s, size; };  // float offsets of the packed weight copies of one network
 constexpr int X3_SLAB_BF16 = 3 * 2 * 8 * 64 * 8;   // one 32-k slab of a 256-row matrix as bf16x3 A-fragments: [piece][kstep][ntile][lane][8]
 constexpr int X2_SLAB_F16 = 2 * 2 * 8 * 64 * 8;    // the same slab as fp16x2 A-fragments of W·2^8 (mlp_x2.hpp)
 static inline WideNetPack pack_layout(int H, int D8, int O8) {
@@ -46,7 +46,8 @@ static inline WideNetPack pack_layout(int H, int D8, int O8) {
   const int x3 = H == 256 ? (H / 32) * X3_SLAB_BF16 / 2 : 0;   // floats
   p.x3b = p.x3f + x3;
   const int x2 = H == 256 ? (H / 32) * X2_SLAB_F16 / 2 : 0;    // floats
-  p.x2f = p.x3b + x3; p.x2b = p.x2f + x2; p.wmax = p.x2b + x2; p.size = p.wmax + AMAX;
+  p.x2f = p.x3b + x3; p.x2b = p.x2f + x2; p.wmax = p.x2b + x2; p.w1s = p.wmax + AMAX;
+  p.size = p.w1s + (H == 256 ? H * D8 + H : 0);   // wide_fused.hpp: W1·2·log2(e) rows + bias, read through scalar loads
   return p;
 }
 
@@ -69,6 +70,8 @@ struct WideWs {
   double* lpart = nullptr;       // [nlb][WLS]
   double* vpart = nullptr;       // [1024]
   double* u_dev = nullptr;       // [0] u (reserved), [1] = double(count) under DP
+  int cus = 256;                 // compute units of the device (grid of the persistent fused backward)
+  int fb_blocks = 0;             // > 0: the last backward ran fused (wide_fused.hpp) and left this many dW1 / db1 partials per network
 };
 
 static int walloc(float** p, size_t n) {
@@ -104,6 +107,7 @@ int wide_create(crl_ppo* h) {
   w->D8 = (w->D + 7) & ~7; w->A8 = (w->A + 7) & ~7;
   const int M = h->dc.M, nt = h->dc.nt;
   w->Mw = M > nt ? M : nt;
+  { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cu > 0) w->cus = cu; }
   w->pk[0] = pack_layout(w->H, w->D8, w->A8);
   w->pk[1] = pack_layout(w->H, w->D8, 8);
   w->pk_base[0] = 0; w->pk_base[1] = w->pk[0].size;
@@ -243,6 +247,7 @@ static bool wide_x3(const crl_ppo* h) { return opt(h, OPT_WIDE_GEMM) >= 1; }   /
 static bool wide_x2(const crl_ppo* h) { return opt(h, OPT_WIDE_GEMM) == 2; }
 bool wide_x2_active(const crl_ppo* h) { return h->wide && h->cfg.hidden == 256 && wide_x2(h); }
 
+__global__ void wide_pack_w1s_kernel(const float* __restrict__ W1, const float* __restrict__ b1, int H, int D, int DP, float* __restrict__ out);
 static int ensure_pack(crl_ppo* h) {
   WideWs* w = static_cast<WideWs*>(h->wide_ws);
   if (!w->pack_dirty) return 0;
@@ -258,6 +263,9 @@ static int ensure_pack(crl_ppo* h) {
       hipLaunchKernelGGL(wide_pack_x2_kernel, dim3(2 * 8 * 2 * 8 * 64 / 256), dim3(256), 0, h->stream, h->params, w->pack,
                          (n ? (int)h->Pa : 0) + w->H * w->D + w->H, w->pk_base[n], w->pk[n], w->wsc + 2 * n);
     }
+    if (w->H == 256)
+      hipLaunchKernelGGL(wide_pack_w1s_kernel, dim3((w->H * w->D8 + w->H + 255) / 256), dim3(256), 0, h->stream, h->params + (n ? (int)h->Pa : 0),
+                         h->params + (n ? (int)h->Pa : 0) + w->H * w->D, w->H, w->D, w->D8, w->pack + w->pk_base[n] + w->pk[n].w1s);
     hipLaunchKernelGGL(wide_wmax_kernel, dim3(1), dim3(64), 0, h->stream,
                        h->params + (n ? (int)h->Pa : 0) + w->H * w->D + w->H + w->H * w->H + w->H, NO, w->H,
                        w->pack + w->pk_base[n] + w->pk[n].wmax);
@@ -784,6 +792,10 @@ __device__ __forceinline__ void tile_out_x2(float* scr, const f32x16& acc, int l
   }
   wave_lds_fence();
 }
+
+}  // namespace crl
+#include "wide_fused.hpp"
+namespace crl {
 
 template <int EPI, int TM>
 __device__ __forceinline__ void wide_dense_x2_body(const DenseX3Args& a) {
@@ -2095,12 +2107,81 @@ static int wide_backward(crl_ppo* h, int net, const float* dOut, int ldd, const 
   return skinny_launch(h->stream, w->Ss, s);
 }
 
+// The update pass's forward of BOTH networks as one launch of the tile-resident kernel (wide_fused.hpp): 2x256, fp16x2, obs_dim <= 16,
+// exp2-based activation (what wide_forward(…, fast_act = true) computes layer by layer). Option wide_fuse = 0 keeps the layer-wise launches.
+static bool wide_fused_ok(const crl_ppo* h) {
+  const WideWs* w = static_cast<const WideWs*>(h->wide_ws);
+  return w->H == 256 && wide_x2(h) && w->D8 <= 16 && w->A <= AMAX && opt(h, OPT_WIDE_FUSE) != 0 && !opt(h, OPT_WIDE_TANH_RATIONAL);
+}
+static int wide_forward_fused(crl_ppo* h, const int32_t* perm, int M) {
+  WideWs* w = static_cast<WideWs*>(h->wide_ws);
+  FusedFwdArgs a[2];
+  for (int net = 0; net < 2; ++net) {
+    const int NO = net ? 1 : w->A;
+    const NetOff o = net_off(256, w->D, NO);
+    const float* P = h->params + (net ? h->Pa : 0);
+    const float* pk = w->pack + w->pk_base[net];
+    a[net].obs = h->obs; a[net].perm = perm; a[net].D = w->D;
+    a[net].W1s = pk + w->pk[net].w1s; a[net].Wx2 = pk + w->pk[net].x2f; a[net].b2 = P + o.b2; a[net].wsc = w->wsc + 2 * net;
+    a[net].W3t = pk + w->pk[net].w3t; a[net].b3 = P + o.b3; a[net].A = NO; a[net].ldz = net ? 1 : w->A8;
+    a[net].H1 = w->h1[net]; a[net].H2 = w->h2[net]; a[net].Z = net ? w->v : w->z; a[net].M = M;
+  }
+  const dim3 grid((M + FX_MB - 1) / FX_MB, 2);
+  if (w->D8 == 8) hipLaunchKernelGGL((wide_fused_fwd_kernel<8, true>), grid, dim3(512), FX_LDS, h->stream, a[0], a[1]);
+  else hipLaunchKernelGGL((wide_fused_fwd_kernel<16, true>), grid, dim3(512), FX_LDS, h->stream, a[0], a[1]);
+  CRL_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// Backward of BOTH networks: one launch of the tile-resident kernel (δ2 → dA / dB, dW1 / db1 partials), then per network the dW3 sweep over
+// h2 and the 256x256 weight-gradient kernel on the stored δ2 and h1.
+static int wide_backward_fused(crl_ppo* h, const int32_t* perm, int M) {
+  WideWs* w = static_cast<WideWs*>(h->wide_ws);
+  const int ntiles = M / FX_MB;
+  int nb = w->cus / 2; if (nb > ntiles) nb = ntiles; if (nb > w->Ss) nb = w->Ss; if (nb < 1) nb = 1;
+  FusedBwdArgs a[2];
+  for (int net = 0; net < 2; ++net) {
+    const int NO = net ? 1 : w->A;
+    const float* pk = w->pack + w->pk_base[net];
+    a[net].H2 = w->h2[net]; a[net].dZ = net ? w->dv8 : w->z; a[net].ldd = net ? 8 : w->A8; a[net].A = NO;
+    a[net].W3t = pk + w->pk[net].w3t; a[net].wmax = pk + w->pk[net].wmax; a[net].Wx2b = pk + w->pk[net].x2b; a[net].wsc = w->wsc + 2 * net;
+    a[net].obs = h->obs; a[net].perm = perm; a[net].D = w->D; a[net].W1s = pk + w->pk[net].w1s;
+    a[net].D2 = net ? w->dB : w->dA; a[net].pW1 = w->pW1[net]; a[net].pB1 = w->pB1[net]; a[net].M = M;
+  }
+  const size_t lds = (size_t)FB_OFF_W3 + (size_t)w->A * 1024;
+  if (w->D8 == 8 && w->A <= 4) hipLaunchKernelGGL((wide_fused_bwd_kernel<8, 4>), dim3(nb, 2), dim3(512), lds, h->stream, a[0], a[1]);
+  else if (w->D8 == 8) hipLaunchKernelGGL((wide_fused_bwd_kernel<8, 8>), dim3(nb, 2), dim3(512), lds, h->stream, a[0], a[1]);
+  else if (w->A <= 4) hipLaunchKernelGGL((wide_fused_bwd_kernel<16, 4>), dim3(nb, 2), dim3(512), lds, h->stream, a[0], a[1]);
+  else hipLaunchKernelGGL((wide_fused_bwd_kernel<16, 8>), dim3(nb, 2), dim3(512), lds, h->stream, a[0], a[1]);
+  CRL_HIP_CHECK(hipGetLastError());
+  w->fb_blocks = nb;
+  for (int net = 0; net < 2; ++net) {
+    const int NO = net ? 1 : w->A;
+    const float* pk = w->pack + w->pk_base[net];
+    const float* dOut = net ? w->dv8 : w->z; const int ldd = net ? 8 : w->A8;
+    SkinnyArgs s;   // dW3[a, k] = Σ δ3[a]·h2[k]
+    s.Big = w->h2[net]; s.H = 256; s.Small = dOut; s.lds = ldd; s.idx = nullptr; s.M = M; s.chunk = w->chunks;
+    s.pW = w->pW3[net]; s.os_row = NO; s.os_s = 1; s.St = NO; s.wsize = 256 * NO; s.pB = nullptr; s.D2out = nullptr; s.W3t = pk + w->pk[net].w3t;
+    if (skinny_launch(h->stream, w->Ss, s)) return 1;
+    WgradArgs g;    // dW2 = δ2·h1ᵀ, db2 = Σ δ2
+    g.dY = net ? w->dB : w->dA; g.X = w->h1[net]; g.H = 256; g.M = M; g.chunk = w->chunk2; g.pW = w->pW2[net]; g.pB = w->pB2[net];
+    g.dZ = nullptr; g.ldd = ldd; g.Ad = NO; g.W3t = pk + w->pk[net].w3t; g.bz = dOut; g.bld = ldd; g.bA = NO; g.wmax = pk + w->pk[net].wmax;
+    hipLaunchKernelGGL(wide_wgrad_x2_kernel<4>, dim3(w->S2, 2), dim3(512), 2 * (256 + 128) * X3ROW * 2, h->stream, g);
+    CRL_HIP_CHECK(hipGetLastError());
+  }
+  return 0;
+}
+
 // forward → u → loss → backward of one minibatch; leaves the per-chunk gradient partials in the workspace
 static int wide_grad_passes(crl_ppo* h, int mb, const int32_t* perm, double Mglobal, bool dp) {
   WideWs* w = static_cast<WideWs*>(h->wide_ws);
   const int M = h->dc.M;
-  if (wide_forward(h, 1, h->obs, w->D, perm, M, w->v, 1, true)) return 1;
-  if (wide_forward(h, 0, h->obs, w->D, perm, M, w->z, w->A8, true)) return 1;
+  if (wide_fused_ok(h)) {
+    if (wide_forward_fused(h, perm, M)) return 1;
+  } else {
+    if (wide_forward(h, 1, h->obs, w->D, perm, M, w->v, 1, true)) return 1;
+    if (wide_forward(h, 0, h->obs, w->D, perm, M, w->z, w->A8, true)) return 1;
+  }
   if (h->cfg.clip_value_loss) {
     int nb = (M + 255) / 256; if (nb > 1024) nb = 1024;
     hipLaunchKernelGGL(wide_vsum_kernel, dim3(nb), dim3(256), 0, h->stream, w->v, h->ret, perm, M, w->vpart);
@@ -2120,6 +2201,8 @@ static int wide_grad_passes(crl_ppo* h, int mb, const int32_t* perm, double Mglo
     hipLaunchKernelGGL(wide_loss_kernel, dim3(w->nlb), dim3(256), 0, h->stream, a);
     CRL_HIP_CHECK(hipGetLastError());
   }
+  w->fb_blocks = 0;
+  if (wide_fused_ok(h) && M % FX_MB == 0 && w->A <= FB_AMAX && opt(h, OPT_WIDE_FUSE) >= 2) return wide_backward_fused(h, perm, M);
   if (wide_backward(h, 0, w->z, w->A8, perm)) return 1;
   if (wide_backward(h, 1, w->dv8, 8, perm)) return 1;
   return 0;
@@ -2150,8 +2233,8 @@ int wide_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
     for (int i = 0; i < 12; ++i) r.off[i + 1] = r.off[i] + sizes[i];
     for (int n = 0; n < 2; ++n) {
       const int b = 6 * n;
-      r.part[b + 0] = w->pW1[n]; r.nparts[b + 0] = w->Ss;
-      r.part[b + 1] = w->pB1[n]; r.nparts[b + 1] = w->Ss;
+      r.part[b + 0] = w->pW1[n]; r.nparts[b + 0] = w->fb_blocks ? w->fb_blocks : w->Ss;
+      r.part[b + 1] = w->pB1[n]; r.nparts[b + 1] = w->fb_blocks ? w->fb_blocks : w->Ss;
       r.part[b + 2] = w->pW2[n]; r.nparts[b + 2] = w->S2;
       r.part[b + 3] = w->pB2[n]; r.nparts[b + 3] = w->S2;
       r.part[b + 4] = w->pW3[n]; r.nparts[b + 4] = w->Ss;

@@ -211,10 +211,12 @@ int32_t crl_comm_destroy(crl_ppo* h);
  *   wide_gemm               layer-wise path, 256-wide layers: 2 = fp16x2 (default), 1 = bf16x3, 0 = f32 MFMA
  *   wide_tanh_rational      1 = the layer-wise path evaluates NNlib's rational tanh_fast everywhere (default 0)
  *   gae_seg, gae_tile       standalone GAE kernel: steps per segment / envs per block, 0 = automatic; gae_tile = 4 = the streaming kernel
- *                           (four envs per thread, 16-byte accesses, serial Float64 recurrence: what batches of 16.8 M samples or more take by themselves)
+ *                           (four envs per thread, 16-byte accesses, serial Float64 recurrence: what batches of 67 M samples or more take by themselves)
  *   gae_nt_loads (2)        standalone GAE kernel: 1 = nontemporal input loads (inputs not in the caches), 0 = cached, 2 = 1 for an external env with 4 M samples or more per rollout, else 0
  *   wide_rollout_persist (1)  layer-wise path, 2x256 fp16x2, obs_dim <= 16: the whole rollout as one launch (0 = three per step)
  *   update_xcd_align (1)    update kernel: tile t is worked on by blocks ≡ t (mod 8) of both roles (same XCD / L2 for a record's two readers)
+ *   wide_fuse (2)           layer-wise path, 2x256 fp16x2, obs_dim <= 16: the update pass runs the tile-resident fused kernels (csrc/wide_fused.hpp):
+ *                           2 = forward and backward, 1 = forward only, 0 = one launch per layer
  *   fuse_optim (1)          single GPU, speculative step: gradient reduction + ClipNorm + Adam as ONE launch (0 = two launches)
  * Read-only through crl_ppo_get_option: gemm_fallback_seen (1 once any launch of the fused 4/2/64 path took the bf16x3 fallback; the
  * layer-wise path needs none: it scales its fp16x2 weight pieces by the largest |w| of the layer at every optimiser step).

@@ -7,7 +7,7 @@ rounds=$1; shift
 for r in $(seq 1 $rounds); do
   for v in "$@"; do
     if [ "$v" = default ]; then lib=$R/cleanrl.jl_amd/libcleanrl_hip.so; else lib=$R/cleanrl.jl_amd/variants/$v/libcleanrl_hip.so; fi
-    CRL_LIB_PATH=$lib timeout 600 python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline $AB_ARGS 2>/dev/null | python3 -c "
+    CRL_LIB_PATH=$lib timeout 600 python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras $AB_ARGS 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.readline())
 k=d.get('kernel_ms_per_step',{})

@@ -932,3 +932,31 @@ def test_rollout_steps_track_the_libm_cartpole(crl):
     err = np.abs(nxt.astype(np.float64) - lib_next) / (np.abs(lib_next) + 0.1)
     assert len(e_idx) > 400_000 and err.max() < 1e-5, (len(e_idx), err.max())
     agent.close()
+
+
+@pytest.mark.parametrize("nt,k", [(64, 128), (256, 100), (8, 9), (4, 1), (132, 37)])
+def test_streaming_gae_kernel_is_bit_equal_to_the_oracle(crl, nt, k):
+    """gae_stream_kernel (option gae_tile = 4; what batches of 67 M samples or more take by themselves — bench.py roofline_gae.beyond_cache):
+    the reference's serial Float64 recurrence (ppo.jl:63-69) in its own order, four envs per thread, chunks of
+    eight steps from the end — so every advantage and return must equal orc_gae's bit for bit, for step counts that are no multiple of
+    the chunk as well. Driven through a handle's resident buffers (crl_compute_gae, compat mode)."""
+    F = crl._lib
+    rng = np.random.default_rng(nt * 131 + k)
+    agent = make_agent(crl, nt=nt, k=k, num_minibatches=1, options={"gae_tile": 4})
+    h = agent.handle
+    value = np.asfortranarray((rng.standard_normal((nt, k)) * 10).astype(np.float32))
+    reward = np.asfortranarray((rng.random((nt, k)) > 0.02).astype(np.float32))
+    term = np.asfortranarray((rng.random((nt, k)) < 0.05).astype(np.uint8))
+    nd = (rng.random(nt) < 0.3).astype(np.uint8)
+    h.write(F.F_VALUE, value); h.write(F.F_REWARD, reward); h.write(F.F_TERMINAL, term); h.write(F.F_NEXT_DONE, nd)
+    h.compute_gae()
+    adv_o, ret_o = O.gae_batch(value, reward, term, np.zeros(nt, np.float32), nd, 0.99, 0.95, 0)
+    assert np.array_equal(h.read(F.F_ADVANTAGE), adv_o) and np.array_equal(h.read(F.F_RETURN), ret_o)
+    h.set_option("gae_tile", 0)
+    h.compute_gae()                                   # the segmented kernel on the same inputs: last-bit differences only
+    assert rel_err(h.read(F.F_ADVANTAGE), adv_o) < 1e-6
+    agent.close()
+    if nt == 4:
+        with pytest.raises(crl.CrlError, match="num_envs % 4"):
+            a2 = make_agent(crl, nt=6, k=8, num_minibatches=1, options={"gae_tile": 4})
+            a2.handle.compute_gae()
