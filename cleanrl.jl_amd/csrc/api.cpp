@@ -40,7 +40,8 @@ static const OptDesc kOpts[OPT_COUNT] = {
     {"wide_rollout_persist", 1, 0, 1},
     {"fuse_optim", 1, 0, 1},
     {"update_xcd_align", 1, 0, 1},
-    {"wide_fuse", 2, 0, 2},
+    {"wide_fuse_pc", 1, 0, 1},
+    {"wide_fuse", 3, 0, 3},
 };
 static int opt_find(const char* key) {
   if (!key) return -1;

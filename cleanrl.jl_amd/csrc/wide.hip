@@ -36,7 +36,7 @@ enum { EPI_TANH = 0, EPI_BIAS = 1, EPI_DTANH = 2, EPI_STORE = 3 };
 // ------------------------------------------------------------------------------------------------------
 // Workspace
 // ------------------------------------------------------------------------------------------------------
-struct WideNetPack { int w1, w3, w2t, w3t, x3f, x3b, x2f, x2b, wmax, w1s, size; };  // float offsets of the packed weight copies of one network
+struct WideNetPack { int w1, w3, w2t, w3t, x3f, x3b, x2f, x2b, wmax, w1s, w1f, size; };  // float offsets of the packed weight copies of one network
 constexpr int X3_SLAB_BF16 = 3 * 2 * 8 * 64 * 8;   // one 32-k slab of a 256-row matrix as bf16x3 A-fragments: [piece][kstep][ntile][lane][8]
 constexpr int X2_SLAB_F16 = 2 * 2 * 8 * 64 * 8;    // the same slab as fp16x2 A-fragments of W·2^8 (mlp_x2.hpp)
 static inline WideNetPack pack_layout(int H, int D8, int O8) {
@@ -47,7 +47,8 @@ static inline WideNetPack pack_layout(int H, int D8, int O8) {
   p.x3b = p.x3f + x3;
   const int x2 = H == 256 ? (H / 32) * X2_SLAB_F16 / 2 : 0;    // floats
   p.x2f = p.x3b + x3; p.x2b = p.x2f + x2; p.wmax = p.x2b + x2; p.w1s = p.wmax + AMAX;
-  p.size = p.w1s + (H == 256 ? H * D8 + H : 0);   // wide_fused.hpp: W1·2·log2(e) rows + bias, read through scalar loads
+  p.w1f = p.w1s + (H == 256 ? H * D8 + H : 0);    // wide_fused.hpp: W1·2·log2(e) rows + bias, read through scalar loads
+  p.size = p.w1f + (H == 256 ? 4096 + 256 : 0);   // … and W1 as fp16x2 A-fragments + bias for the producers' layer-1 product
   return p;
 }
 
@@ -114,7 +115,7 @@ int wide_create(crl_ppo* h) {
   const size_t H = (size_t)w->H, Mw = (size_t)w->Mw;
   int rc = 0;
   rc |= walloc(&w->pack, (size_t)w->pk[0].size + w->pk[1].size);
-  rc |= walloc(&w->wsc, 4);
+  rc |= walloc(&w->wsc, 8);   // [net][scale, 1/scale] of the W2 pieces, then the same of the W1 fragments (wide_fused.hpp)
   for (int n = 0; n < 2; ++n) { rc |= walloc(&w->h1[n], H * Mw); rc |= walloc(&w->h2[n], H * Mw); }
   rc |= walloc(&w->z, (size_t)w->A8 * Mw); rc |= walloc(&w->v, Mw); rc |= walloc(&w->dv8, 8 * Mw);
   rc |= walloc(&w->dA, H * Mw); rc |= walloc(&w->dB, H * Mw);
@@ -248,6 +249,8 @@ static bool wide_x2(const crl_ppo* h) { return opt(h, OPT_WIDE_GEMM) == 2; }
 bool wide_x2_active(const crl_ppo* h) { return h->wide && h->cfg.hidden == 256 && wide_x2(h); }
 
 __global__ void wide_pack_w1s_kernel(const float* __restrict__ W1, const float* __restrict__ b1, int H, int D, int DP, float* __restrict__ out);
+__global__ void wide_pack_w1f_kernel(const float* __restrict__ W1, const float* __restrict__ b1, int D, const float* __restrict__ w1sc, float* __restrict__ out);
+__global__ void wide_w1scale_kernel(const float* __restrict__ W1, int n, float* __restrict__ w1sc);
 static int ensure_pack(crl_ppo* h) {
   WideWs* w = static_cast<WideWs*>(h->wide_ws);
   if (!w->pack_dirty) return 0;
@@ -262,6 +265,12 @@ static int ensure_pack(crl_ppo* h) {
                          w->H * w->H, w->wsc + 2 * n);
       hipLaunchKernelGGL(wide_pack_x2_kernel, dim3(2 * 8 * 2 * 8 * 64 / 256), dim3(256), 0, h->stream, h->params, w->pack,
                          (n ? (int)h->Pa : 0) + w->H * w->D + w->H, w->pk_base[n], w->pk[n], w->wsc + 2 * n);
+    }
+    if (w->H == 256 && w->D <= 16) {
+      const float* W1 = h->params + (n ? (int)h->Pa : 0);
+      hipLaunchKernelGGL(wide_w1scale_kernel, dim3(1), dim3(256), 0, h->stream, W1, w->H * w->D, w->wsc + 4 + 2 * n);
+      hipLaunchKernelGGL(wide_pack_w1f_kernel, dim3(2), dim3(256), 0, h->stream, W1, W1 + w->H * w->D, w->D, w->wsc + 4 + 2 * n,
+                         w->pack + w->pk_base[n] + w->pk[n].w1f);
     }
     if (w->H == 256)
       hipLaunchKernelGGL(wide_pack_w1s_kernel, dim3((w->H * w->D8 + w->H + 255) / 256), dim3(256), 0, h->stream, h->params + (n ? (int)h->Pa : 0),
@@ -2113,6 +2122,11 @@ static bool wide_fused_ok(const crl_ppo* h) {
   const WideWs* w = static_cast<const WideWs*>(h->wide_ws);
   return w->H == 256 && wide_x2(h) && w->D8 <= 16 && w->A <= AMAX && opt(h, OPT_WIDE_FUSE) != 0 && !opt(h, OPT_WIDE_TANH_RATIONAL);
 }
+// h1 is never stored: the fused backward does not read it and the weight gradient regenerates it (option wide_fuse = 3, the default)
+static bool wide_h1_free(const crl_ppo* h) {
+  const WideWs* w = static_cast<const WideWs*>(h->wide_ws);
+  return opt(h, OPT_WIDE_FUSE) >= 3 && opt(h, OPT_WIDE_FUSE_PC) && w->A <= PC_AMAX && w->A <= FB_AMAX && w->D <= 16;
+}
 static int wide_forward_fused(crl_ppo* h, const int32_t* perm, int M) {
   WideWs* w = static_cast<WideWs*>(h->wide_ws);
   FusedFwdArgs a[2];
@@ -2126,7 +2140,29 @@ static int wide_forward_fused(crl_ppo* h, const int32_t* perm, int M) {
     a[net].W3t = pk + w->pk[net].w3t; a[net].b3 = P + o.b3; a[net].A = NO; a[net].ldz = net ? 1 : w->A8;
     a[net].H1 = w->h1[net]; a[net].H2 = w->h2[net]; a[net].Z = net ? w->v : w->z; a[net].M = M;
   }
+  if (opt(h, OPT_WIDE_FUSE_PC) && w->A <= PC_AMAX) {
+    // producer / consumer form, persistent: one block per CU, half of them per network
+    FusedFwdPCArgs q[2];
+    for (int net = 0; net < 2; ++net) {
+      const float* pk = w->pack + w->pk_base[net];
+      q[net].obs = a[net].obs; q[net].perm = perm; q[net].D = w->D; q[net].W1f = pk + w->pk[net].w1f; q[net].w1sc = w->wsc + 4 + 2 * net;
+      q[net].Wx2 = a[net].Wx2; q[net].b2 = a[net].b2; q[net].wsc = a[net].wsc; q[net].W3t = a[net].W3t; q[net].b3 = a[net].b3; q[net].A = a[net].A;
+      q[net].ldz = a[net].ldz; q[net].H1 = a[net].H1; q[net].H2 = a[net].H2; q[net].Z = a[net].Z; q[net].M = M;
+    }
+    int nb = w->cus / 2; const int ntiles = M / FX_MB; if (nb > ntiles) nb = ntiles; if (nb < 1) nb = 1;
+    if (wide_h1_free(h)) {
+      if (w->D8 == 8) hipLaunchKernelGGL((wide_fused_fwd_pc_kernel<8, false>), dim3(nb, 2), dim3(512), PC_LDS, h->stream, q[0], q[1]);
+      else hipLaunchKernelGGL((wide_fused_fwd_pc_kernel<16, false>), dim3(nb, 2), dim3(512), PC_LDS, h->stream, q[0], q[1]);
+    } else if (w->D8 == 8) hipLaunchKernelGGL((wide_fused_fwd_pc_kernel<8, true>), dim3(nb, 2), dim3(512), PC_LDS, h->stream, q[0], q[1]);
+    else hipLaunchKernelGGL((wide_fused_fwd_pc_kernel<16, true>), dim3(nb, 2), dim3(512), PC_LDS, h->stream, q[0], q[1]);
+    CRL_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   const dim3 grid((M + FX_MB - 1) / FX_MB, 2);
+#ifdef CRL_EXP_NOH1   // timing experiment only (h1 is not stored: the weight gradients that follow are garbage)
+  if (w->D8 == 8) hipLaunchKernelGGL((wide_fused_fwd_kernel<8, false>), grid, dim3(512), FX_LDS, h->stream, a[0], a[1]);
+  else
+#endif
   if (w->D8 == 8) hipLaunchKernelGGL((wide_fused_fwd_kernel<8, true>), grid, dim3(512), FX_LDS, h->stream, a[0], a[1]);
   else hipLaunchKernelGGL((wide_fused_fwd_kernel<16, true>), grid, dim3(512), FX_LDS, h->stream, a[0], a[1]);
   CRL_HIP_CHECK(hipGetLastError());
@@ -2163,10 +2199,24 @@ static int wide_backward_fused(crl_ppo* h, const int32_t* perm, int M) {
     s.Big = w->h2[net]; s.H = 256; s.Small = dOut; s.lds = ldd; s.idx = nullptr; s.M = M; s.chunk = w->chunks;
     s.pW = w->pW3[net]; s.os_row = NO; s.os_s = 1; s.St = NO; s.wsize = 256 * NO; s.pB = nullptr; s.D2out = nullptr; s.W3t = pk + w->pk[net].w3t;
     if (skinny_launch(h->stream, w->Ss, s)) return 1;
-    WgradArgs g;    // dW2 = δ2·h1ᵀ, db2 = Σ δ2
-    g.dY = net ? w->dB : w->dA; g.X = w->h1[net]; g.H = 256; g.M = M; g.chunk = w->chunk2; g.pW = w->pW2[net]; g.pB = w->pB2[net];
-    g.dZ = nullptr; g.ldd = ldd; g.Ad = NO; g.W3t = pk + w->pk[net].w3t; g.bz = dOut; g.bld = ldd; g.bA = NO; g.wmax = pk + w->pk[net].wmax;
-    hipLaunchKernelGGL(wide_wgrad_x2_kernel<4>, dim3(w->S2, 2), dim3(512), 2 * (256 + 128) * X3ROW * 2, h->stream, g);
+    if (!wide_h1_free(h)) {
+      WgradArgs g;    // dW2 = δ2·h1ᵀ, db2 = Σ δ2 from the stored h1
+      g.dY = net ? w->dB : w->dA; g.X = w->h1[net]; g.H = 256; g.M = M; g.chunk = w->chunk2; g.pW = w->pW2[net]; g.pB = w->pB2[net];
+      g.dZ = nullptr; g.ldd = ldd; g.Ad = NO; g.W3t = pk + w->pk[net].w3t; g.bz = dOut; g.bld = ldd; g.bA = NO; g.wmax = pk + w->pk[net].wmax;
+      hipLaunchKernelGGL(wide_wgrad_x2_kernel<4>, dim3(w->S2, 2), dim3(512), 2 * (256 + 128) * X3ROW * 2, h->stream, g);
+      CRL_HIP_CHECK(hipGetLastError());
+    }
+  }
+  if (wide_h1_free(h)) {   // both networks in one launch, h1 regenerated on the CU (wide_wgrad_gen_kernel)
+    WgradGenArgs g[2];
+    for (int net = 0; net < 2; ++net) {
+      const float* pk = w->pack + w->pk_base[net];
+      g[net].dY = net ? w->dB : w->dA; g[net].obs = h->obs; g[net].perm = perm; g[net].D = w->D; g[net].W1f = pk + w->pk[net].w1f; g[net].w1sc = w->wsc + 4 + 2 * net;
+      g[net].bz = net ? w->dv8 : w->z; g[net].bld = net ? 8 : w->A8; g[net].bA = net ? 1 : w->A; g[net].wmax = pk + w->pk[net].wmax;
+      g[net].pW = w->pW2[net]; g[net].pB = w->pB2[net]; g[net].M = M; g[net].chunk = w->chunk2;
+    }
+    if (w->D8 == 8) hipLaunchKernelGGL((wide_wgrad_gen_kernel<8>), dim3(w->S2, 2), dim3(512), WG_LDS, h->stream, g[0], g[1]);
+    else hipLaunchKernelGGL((wide_wgrad_gen_kernel<16>), dim3(w->S2, 2), dim3(512), WG_LDS, h->stream, g[0], g[1]);
     CRL_HIP_CHECK(hipGetLastError());
   }
   return 0;
@@ -2176,7 +2226,7 @@ static int wide_backward_fused(crl_ppo* h, const int32_t* perm, int M) {
 static int wide_grad_passes(crl_ppo* h, int mb, const int32_t* perm, double Mglobal, bool dp) {
   WideWs* w = static_cast<WideWs*>(h->wide_ws);
   const int M = h->dc.M;
-  if (wide_fused_ok(h)) {
+  if (wide_fused_ok(h) && M % FX_MB == 0) {
     if (wide_forward_fused(h, perm, M)) return 1;
   } else {
     if (wide_forward(h, 1, h->obs, w->D, perm, M, w->v, 1, true)) return 1;

@@ -15,6 +15,14 @@
 
 namespace crl {
 
+#ifdef CRL_EXP_WSTAMPS
+// diagnostic build only (bash scripts/build_variant.sh wstamps -DCRL_EXP_WSTAMPS wide): wall-clock stamps (100 MHz) of the first tile of
+// every block of the fused kernels — [kernel 0 fwd / 1 bwd][block][wave][slot], read back by scripts/wstamps_probe.py
+__device__ unsigned long long crl_dbg_wstamps[2 * 256 * 8 * 16];
+#define CRL_WSTAMP(kern, slot) do { const unsigned bx_ = (kern) ? blockIdx.x : blockIdx.x - 2048u; if ((threadIdx.x & 63) == 0 && bx_ < 256u && blockIdx.y == 0) crl_dbg_wstamps[(((kern) * 256 + bx_) * 8 + (threadIdx.x >> 6)) * 16 + (slot)] = wall_clock64(); } while (0)
+#else
+#define CRL_WSTAMP(kern, slot) do { } while (0)
+#endif
 constexpr int FX_MB = 128;                                   // samples per block tile
 constexpr int FX_WBYTES = X2_SLAB_F16 * 2;                   // 32,768: one weight slab
 constexpr int FX_XBYTES = 2 * FX_MB * X3ROW * 2;             // 20,480: one activation slab, [piece][sample][X3ROW halves]
@@ -35,11 +43,15 @@ struct FusedFwdArgs {
 };
 
 // one weight slab into LDS by LDS-DMA: 32 pieces of 1 KB, four per wave; the image is the pack buffer's own fragment order
-__device__ __forceinline__ void fx_dma_wslab(const float* Wx2, int slab, unsigned char* dst, int wave, int lane) {
+// Every block of the grid streams the SAME 256 KB of weights, and blocks that started together reach the same slab together: fetched in
+// the same order, all CUs of an XCD ask one L2 channel for one line at the same moment and the transfer takes ≈2 µs instead of ≈0.5
+// (in-kernel stamps, scripts/wstamps_probe.py). `rot` (from the block index) rotates the order of the 32 pieces, so that at any moment
+// the CUs are spread over the slab's lines.
+__device__ __forceinline__ void fx_dma_wslab(const float* Wx2, int slab, unsigned char* dst, int wave, int lane, int rot = 0) {
   const char* g = reinterpret_cast<const char*>(Wx2) + (size_t)slab * FX_WBYTES;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int piece = i * 8 + wave;
+    const int piece = (i * 8 + wave + rot) & 31;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + piece * 1024 + lane * 16),
                                      (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
   }
@@ -78,11 +90,13 @@ __device__ __forceinline__ void wide_fused_fwd_body(const FusedFwdArgs& a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rg = wave & 3, sg = wave >> 2;
+  const int rot = (int)((blockIdx.x * 5u + (blockIdx.x >> 3)) & 31u);   // blocks b and b + 8 share an XCD: spread both neighbours and XCD mates
   const int m0 = blockIdx.x * FX_MB;
   // staging role of this thread: sample sm, k-octet sq of every slab
   const int sm = tid & (FX_MB - 1), sq = __builtin_amdgcn_readfirstlane(tid >> 7);
   const int gm = m0 + sm;
   const bool live = gm < a.M;
+  CRL_WSTAMP(0, 0);
   float x[DP];
   {
     const int src = live ? (a.perm ? a.perm[gm] : gm) : 0;
@@ -119,7 +133,7 @@ __device__ __forceinline__ void wide_fused_fwd_body(const FusedFwdArgs& a) {
     _Float16* Xl = reinterpret_cast<_Float16*>(xbuf);
     *reinterpret_cast<f16x8*>(Xl + sm * X3ROW + 8 * sq) = p.hi;
     *reinterpret_cast<f16x8*>(Xl + FX_MB * X3ROW + sm * X3ROW + 8 * sq) = p.lo;
-    if (WRITE_H1 && live) {
+    if (WRITE_H1) {   // (the launcher takes this kernel only for M % 128 == 0: every staging sample is live, the store count per slab is fixed)
       f32x4 o0, o1;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { o0[e] = hv[e] * (1.0f / X2_ACT_SCALE); o1[e] = hv[4 + e] * (1.0f / X2_ACT_SCALE); }
@@ -134,26 +148,38 @@ __device__ __forceinline__ void wide_fused_fwd_body(const FusedFwdArgs& a) {
     for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ai][bi][r] = 0.0f;
-  fx_dma_wslab(a.Wx2, 0, smx, wave, lane);
+  fx_dma_wslab(a.Wx2, 0, smx, wave, lane, rot);
   stage(0, smx + FX_OFF_X);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  CRL_WSTAMP(0, 1);
 #pragma unroll 1
   for (int s = 0; s < 8; ++s) {
     const int cur = s & 1, nxt = cur ^ 1;
-    if (s + 1 < 8) fx_dma_wslab(a.Wx2, s + 1, smx + nxt * FX_WBYTES, wave, lane);   // the buffer's last readers passed the barrier of slab s - 1
+    if (s == 3) CRL_WSTAMP(0, 2);
+    if (s == 4) CRL_WSTAMP(0, 4);
+    if (s + 1 < 8) fx_dma_wslab(a.Wx2, s + 1, smx + nxt * FX_WBYTES, wave, lane, rot);   // the buffer's last readers passed the barrier of slab s - 1
+    asm volatile("" ::: "memory");   // the h1 stores of the staging stay behind the weight pieces in issue order (the counted wait relies on it)
+    if (s == 3) CRL_WSTAMP(0, 7);
     // the two waves of a SIMD (w and w + 4) take their staging and their MFMA phases in opposite order, so that one's vector work
     // faces the other's matrix work
     if (sg == 0) {
       if (s + 1 < 8) stage(s + 1, smx + FX_OFF_X + nxt * FX_XBYTES);
+      if (s == 3) CRL_WSTAMP(0, 8);
       fx_compute_slab(smx + cur * FX_WBYTES, smx + FX_OFF_X + cur * FX_XBYTES, rg, sg, lane, acc);
     } else {
       fx_compute_slab(smx + cur * FX_WBYTES, smx + FX_OFF_X + cur * FX_XBYTES, rg, sg, lane, acc);
+      if (s == 3) CRL_WSTAMP(0, 8);
       if (s + 1 < 8) stage(s + 1, smx + FX_OFF_X + nxt * FX_XBYTES);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of slab s + 1 have landed
-    __syncthreads();
+    if (s == 3) CRL_WSTAMP(0, 3);                        // this wave's own work of slab 3 done (before the wait and the barrier)
+    // this wave's DMA pieces of slab s + 1 have landed; the two h1 stores of this slab's staging (issued behind them) may stay in flight:
+    // waiting for their acknowledgement too cost 0.6 us per slab (scripts/wstamps_probe.py)
+    if (WRITE_H1 && s + 1 < 8) asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   }
+  CRL_WSTAMP(0, 5);
   // epilogue: h2 = tanh(acc·unscale + b2), head partials, h2 out in whole 128-B lines (tile_tanh_head), heads folded over the 4 row groups
   float* scr = reinterpret_cast<float*>(smx) + wave * (32 * 36);
   const int hs = a.A;
@@ -175,6 +201,7 @@ __device__ __forceinline__ void wide_fused_fwd_body(const FusedFwdArgs& a) {
     for (int q = 0; q < 4; ++q) z += hp_all[q * (FX_MB * hs) + m * hs + aa];
     if (m0 + m < a.M) a.Z[(size_t)a.ldz * (m0 + m) + aa] = z + a.b3[aa];
   }
+  CRL_WSTAMP(0, 6);
 }
 
 template <int DP, bool WRITE_H1>
@@ -265,6 +292,7 @@ __device__ __forceinline__ void wide_fused_bwd_body(const FusedBwdArgs& a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rg = wave & 3, sg = wave >> 2, j = lane & 31, hf = lane >> 5;
   const int sm = tid >> 2, sq = tid & 3;                       // staging role: sample, unit octet of every slab
+  const int rot = (int)((blockIdx.x * 5u + (blockIdx.x >> 3) + 16u * blockIdx.y) & 31u);
   float* W3l = reinterpret_cast<float*>(smx + FB_OFF_W3);
   for (int i = tid; i < a.A * 256; i += 512) W3l[i] = a.W3t[i];   // W3t is [k + 256·a]: rows of one output contiguous
   // epilogue role: this lane's two hidden units and their rows of W1 (×2·log2 e) / b1
@@ -279,24 +307,33 @@ __device__ __forceinline__ void wide_fused_bwd_body(const FusedBwdArgs& a) {
   const float wunscale = a.wsc[1];
   const int ntiles = a.M / FX_MB;                              // the launcher takes this path only for M % 128 == 0
   __syncthreads();
+  // tile set-up values of the staging role — head cotangent of the sample, its observation quarter — are loaded a tile ahead
+  float dz[NA], xq[DP / 4];
+  auto setup_load = [&](int t, float (&dzo)[NA], float (&xo)[DP / 4]) {
+    const int gmn = t * FX_MB + sm;
+#pragma unroll
+    for (int q = 0; q < NA; ++q) dzo[q] = q < a.A ? a.dZ[(size_t)a.ldd * gmn + q] : 0.0f;
+    const int src = a.perm ? a.perm[gmn] : gmn;
+#pragma unroll
+    for (int c = 0; c < DP / 4; ++c) { const int cc = sq * (DP / 4) + c; xo[c] = cc < a.D ? a.obs[(size_t)src * a.D + cc] : 0.0f; }
+  };
+  unsigned char* Hb = smx + FB_OFF_H;
+  auto tile_dma = [&](int t) {   // the first transfers of a tile: h2 slabs 0 and 1, weight slab 0
+    fb_dma_hslab(a.H2, t * FX_MB, 0, Hb, wave, lane);
+    fb_dma_hslab(a.H2, t * FX_MB, 1, Hb + FB_HBYTES, wave, lane);
+    fx_dma_wslab(a.Wx2b, 0, smx, wave, lane, rot);
+  };
+  if ((int)blockIdx.x < ntiles) { tile_dma(blockIdx.x); setup_load(blockIdx.x, dz, xq); }
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int m0 = t * FX_MB, gm = m0 + sm;
-    // ---- tile set-up: head cotangent of the staging sample, its fp16 scale, its observation quarter
-    float dz[NA];
+    const bool first = t == (int)(blockIdx.x + 8 * gridDim.x);   // (diagnostic builds stamp the block's ninth tile: warm caches)
+    if (first) CRL_WSTAMP(1, 0);
     float bound = 0.0f;
 #pragma unroll
-    for (int q = 0; q < NA; ++q) {
-      dz[q] = q < a.A ? a.dZ[(size_t)a.ldd * gm + q] : 0.0f;
+    for (int q = 0; q < NA; ++q)
       if (q < a.A) bound = __builtin_fmaf(__builtin_fabsf(dz[q]), a.wmax[q], bound);
-    }
     float s1, i1;
     pow2_scale(bound, s1, i1);
-    float xq[DP / 4];
-    {
-      const int src = a.perm ? a.perm[gm] : gm;
-#pragma unroll
-      for (int c = 0; c < DP / 4; ++c) { const int cc = sq * (DP / 4) + c; xq[c] = cc < a.D ? a.obs[(size_t)src * a.D + cc] : 0.0f; }
-    }
     f32x16 acc[2][2];
 #pragma unroll
     for (int bi = 0; bi < 2; ++bi)
@@ -333,44 +370,54 @@ __device__ __forceinline__ void wide_fused_bwd_body(const FusedBwdArgs& a) {
       *reinterpret_cast<f16x8*>(Xl + sm * X3ROW + 8 * sq) = p.hi;
       *reinterpret_cast<f16x8*>(Xl + FX_MB * X3ROW + sm * X3ROW + 8 * sq) = p.lo;
     };
-    unsigned char* Hb = smx + FB_OFF_H;
-    fb_dma_hslab(a.H2, m0, 0, Hb, wave, lane);
-    fb_dma_hslab(a.H2, m0, 1, Hb + FB_HBYTES, wave, lane);
-    fx_dma_wslab(a.Wx2b, 0, smx, wave, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this tile's first transfers (issued before the previous tile's epilogue) have landed
     __builtin_amdgcn_s_barrier();
     stage(0, Hb, smx + FX_OFF_X);
     fb_dma_hslab(a.H2, m0, 2, Hb + 2 * FB_HBYTES, wave, lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (first) CRL_WSTAMP(1, 1);
 #pragma unroll 1
     for (int s = 0; s < 8; ++s) {
       const int cur = s & 1, nxt = cur ^ 1;
+      if (first && s == 3) CRL_WSTAMP(1, 2);
+      if (first && s == 4) CRL_WSTAMP(1, 4);
       const int h1i = (s + 1) % 3, h3i = s % 3;                 // buffers of the h2 slabs s + 1 (staged now) and s + 3 (requested now)
-      if (s < 7) fx_dma_wslab(a.Wx2b, s + 1, smx + nxt * FX_WBYTES, wave, lane);
+      if (s < 7) fx_dma_wslab(a.Wx2b, s + 1, smx + nxt * FX_WBYTES, wave, lane, rot);
       asm volatile("" ::: "memory");   // the δ2 stores below stay behind the weight pieces in issue order (the counted wait relies on it)
+      if (first && s == 3) CRL_WSTAMP(1, 7);
       if (sg == 0) {
         if (s < 7) stage(s + 1, Hb + h1i * FB_HBYTES, smx + FX_OFF_X + nxt * FX_XBYTES);
+        if (first && s == 3) CRL_WSTAMP(1, 8);
         if (s + 3 < 8) fb_dma_hslab(a.H2, m0, s + 3, Hb + h3i * FB_HBYTES, wave, lane);
+        if (first && s == 3) CRL_WSTAMP(1, 9);
         fb_compute_slab(smx + cur * FX_WBYTES, smx + FX_OFF_X + cur * FX_XBYTES, rg, sg, lane, acc);
       } else {
         fb_compute_slab(smx + cur * FX_WBYTES, smx + FX_OFF_X + cur * FX_XBYTES, rg, sg, lane, acc);
+        if (first && s == 3) CRL_WSTAMP(1, 8);
         if (s < 7) stage(s + 1, Hb + h1i * FB_HBYTES, smx + FX_OFF_X + nxt * FX_XBYTES);
+        if (first && s == 3) CRL_WSTAMP(1, 9);
         if (s + 3 < 8) fb_dma_hslab(a.H2, m0, s + 3, Hb + h3i * FB_HBYTES, wave, lane);
       }
       // the weight slab s + 1 (and every older transfer, h2 slab s + 2 among them) has landed; the h2 slab s + 3 and the two δ2 stores
       // of this iteration's staging — issued after the weight pieces in both orders — may stay in flight
+      if (first && s == 3) CRL_WSTAMP(1, 3);
       if (s < 5) asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
       else if (s < 7) asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
+    if (first) CRL_WSTAMP(1, 5);
     // ---- epilogue: δ1ᵀ = acc·unscale ⊙ (1 − h1²) with h1 recomputed; dW1 / db1 accumulate per lane (lane = unit, registers = samples)
     float* xs = reinterpret_cast<float*>(smx + FX_OFF_X + FX_XBYTES);      // [128][DP], in the second activation buffer (free until slab 1 of the next tile)
     float* invs = xs + FX_MB * DP;
 #pragma unroll
     for (int c = 0; c < DP / 4; ++c) xs[sm * DP + sq * (DP / 4) + c] = xq[c];
     if (sq == 0) invs[sm] = i1 * wunscale;
+    // the next tile's first transfers and set-up loads go out now: they land under the epilogue's vector work (every buffer they touch —
+    // h2 buffers 0 and 1, weight buffer 0 — was last read before the loop's final barrier)
+    const int tn = t + gridDim.x;
+    if (tn < ntiles) { tile_dma(tn); setup_load(tn, dz, xq); }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -379,30 +426,47 @@ __device__ __forceinline__ void wide_fused_bwd_body(const FusedBwdArgs& a) {
       for (int g = 0; g < 4; ++g) {
         const int srow0 = 64 * sg + 32 * bi + 8 * g + 4 * hf;               // four consecutive samples: registers 4g … 4g + 3
         const f32x4 iv = *reinterpret_cast<const f32x4*>(invs + srow0);
+        // eight independent chains at a time (4 samples x 2 units): the scheduler keeps a dependent chain as written, so they are
+        // written interleaved — c outermost
+        float xv[4][DP], pre[4][2];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float xv[DP];
 #pragma unroll
           for (int c4 = 0; c4 < DP / 4; ++c4) {
             const f32x4 t4 = *reinterpret_cast<const f32x4*>(xs + (srow0 + e) * DP + 4 * c4);
-            xv[4 * c4] = t4[0]; xv[4 * c4 + 1] = t4[1]; xv[4 * c4 + 2] = t4[2]; xv[4 * c4 + 3] = t4[3];
+            xv[e][4 * c4] = t4[0]; xv[e][4 * c4 + 1] = t4[1]; xv[e][4 * c4 + 2] = t4[2]; xv[e][4 * c4 + 3] = t4[3];
           }
+          pre[e][0] = b1r[0]; pre[e][1] = b1r[1];
+        }
+#pragma unroll
+        for (int c = 0; c < DP; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { pre[e][0] = __builtin_fmaf(w1r[0][c], xv[e][c], pre[e][0]); pre[e][1] = __builtin_fmaf(w1r[1][c], xv[e][c], pre[e][1]); }
+        float d1[4][2];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int ai = 0; ai < 2; ++ai) pre[e][ai] = __builtin_amdgcn_exp2f(pre[e][ai]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int ai = 0; ai < 2; ++ai) pre[e][ai] = __builtin_amdgcn_rcpf(pre[e][ai] + 1.0f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int ai = 0; ai < 2; ++ai) {
-            float pre = b1r[ai];
-#pragma unroll
-            for (int c = 0; c < DP; ++c) pre = __builtin_fmaf(w1r[ai][c], xv[c], pre);
-            const float rr = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(pre) + 1.0f);
-            const float sech2 = 4.0f * rr * (1.0f - rr);                    // 1 − tanh², tanh = 1 − 2r
-            const float d1 = acc[bi][ai][4 * g + e] * iv[e] * sech2;
-            gB1[ai] += d1;
-#pragma unroll
-            for (int c = 0; c < DP; ++c) gW1[ai][c] = __builtin_fmaf(d1, xv[c], gW1[ai][c]);
+            const float rr = pre[e][ai];
+            d1[e][ai] = acc[bi][ai][4 * g + e] * iv[e] * (4.0f * rr * (1.0f - rr));   // 1 − tanh² = 4r(1 − r), tanh = 1 − 2r
+            gB1[ai] += d1[e][ai];
           }
-        }
+#pragma unroll
+        for (int c = 0; c < DP; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { gW1[0][c] = __builtin_fmaf(d1[e][0], xv[e][c], gW1[0][c]); gW1[1][c] = __builtin_fmaf(d1[e][1], xv[e][c], gW1[1][c]); }
       }
     }
     __builtin_amdgcn_s_barrier();   // every wave has read xs / invs before the next tile's set-up may overwrite that region
+    if (first) CRL_WSTAMP(1, 6);
   }
   // ---- the block's partial: lane halves hold different samples of the same unit, the two sample groups are two waves
   float* red = reinterpret_cast<float*>(smx);                               // [wave][64 units][DP + 1]
@@ -432,5 +496,442 @@ template <int DP, int NA0>   // network 0 (actor) keeps up to NA0 head cotangent
 __global__ void __launch_bounds__(512) wide_fused_bwd_kernel(FusedBwdArgs a0, FusedBwdArgs a1) {
   if (blockIdx.y == 0) wide_fused_bwd_body<DP, NA0>(a0); else wide_fused_bwd_body<DP, 1>(a1);
 }
+
+}  // namespace crl
+
+#ifdef CRL_EXP_WSTAMPS
+extern "C" int32_t crl_debug_read_wstamps(unsigned long long* out, int32_t n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(crl::crl_dbg_wstamps), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : 1;
+}
+#endif
+
+namespace crl {
+
+// ======================================================================================================================================
+// Forward, producer / consumer form (the default; wide_fused_fwd_kernel above is kept as option wide_fuse_pc = 0).
+// In-kernel stamps of the symmetric kernel (scripts/wstamps_probe.py) showed why it stays at ~20 % of the matrix pipe: every wave stages
+// AND multiplies inside one barrier interval, so a slab costs the SUM of the two latencies (0.8 + 0.6 µs), although the weight stream
+// itself is fast (scripts/micro/wstream_rate.hip: 0.35 µs per 32 KB slab). Here the block's waves take fixed roles:
+//   waves 0-3  consumers: nothing but fragment reads and MFMAs — wave c owns rows 64c … 64c + 63 x all 128 samples (2 x 4 tiles, 128
+//              accumulator registers): 12 fragment reads per 24 MFMAs;
+//   waves 4-7  producers (the SIMD partners of the consumers): the weight slab's LDS-DMA and the next activation slab. Layer 1 runs on
+//              the matrix pipe as well: h1pre(32 units x 32 samples) = W1-fragment · x-fragment, one fp16x2 product (K = obs_dim <= 16 fits
+//              ONE k-step; x scaled per sample, W1 per network into the fp16 window), then tanh, split, 8-byte LDS stores — no scalar loads,
+//              ~150 vector instructions per slab under the consumers' 48 MFMAs;
+// so a slab costs max(producer, consumer). Persistent: a block walks tiles blockIdx.x, + gridDim.x, …; the producers prepare the next
+// tile's first slab and prefetch its observations while the consumers run the epilogue (tanh, head partials, h2 out in whole lines).
+// ======================================================================================================================================
+constexpr int PC_OFF_W1F = FX_OFF_X + 2 * FX_XBYTES;          // 106,496: W1 A-fragments, [slab 8][piece 2][lane 64][8 halves] = 16 KB
+constexpr int PC_OFF_B1 = PC_OFF_W1F + 16384;                // b1·2·log2(e) [256] f32
+constexpr int PC_LDS = PC_OFF_B1 + 1024;                     // 123,904 bytes
+constexpr int PC_AMAX = 8;
+static_assert(4 * 32 * 36 * 4 <= FX_WBYTES && 4 * FX_MB * PC_AMAX * 4 <= FX_XBYTES, "epilogue scratch aliases weight buffer 1, the head partials activation buffer 1");
+
+struct FusedFwdPCArgs {
+  const float* obs; const int32_t* perm; int D;
+  const float* W1f;                               // fp16x2 A-fragments of W1·2·log2(e)·scale1 (pack: w1f), then b1·2·log2(e) [256] f32
+  const float* w1sc;                              // {scale1, 1/scale1}
+  const float* Wx2; const float* b2; const float* wsc;
+  const float* W3t; const float* b3; int A; int ldz;
+  float* H1; float* H2; float* Z; int M;
+};
+
+template <int DP, bool WRITE_H1>
+__device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, hf = lane >> 5;
+  const int ntiles = a.M / FX_MB;
+  // W1 fragments + bias table into LDS, once
+  for (int i = tid; i < (16384 + 1024) / 16; i += 512)
+    reinterpret_cast<f32x4*>(smx + PC_OFF_W1F)[i] = reinterpret_cast<const f32x4*>(a.W1f)[i];
+  __syncthreads();
+  if (wave >= 4) {
+    // ------------------------------------------------------------------------------------------------ producer p: sample tile p
+    const int p = wave - 4;
+    const float w1un = a.w1sc[1];
+    f16x8 xhi, xlo; float xinv;
+    auto load_x = [&](int t, float (&xr)[8]) {                          // this lane's sample of tile t: its observation half (k = 8hf …)
+      const int gm = t * FX_MB + 32 * p + j;
+      const int src = a.perm ? a.perm[gm] : gm;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { const int cc = 8 * hf + c; xr[c] = (cc < a.D && cc < DP) ? a.obs[(size_t)src * a.D + cc] : 0.0f; }
+    };
+    auto make_xfrag = [&](const float (&xr)[8]) {                       // per-sample power of two into the fp16 window, split
+      float m = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) m = __builtin_fmaxf(m, __builtin_fabsf(xr[c]));
+      m = __builtin_fmaxf(m, xor32(m));
+      float s1, i1;
+      pow2_scale(m, s1, i1);
+      float v[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] = xr[c] * s1;
+      const P2 q = split2(v);
+      xhi = q.hi; xlo = q.lo; xinv = i1 * w1un;
+    };
+    auto produce = [&](int t, int s, unsigned char* wbuf, unsigned char* xbuf) {
+      // weight slab s: this producer's 8 of the 32 pieces
+      const char* g = reinterpret_cast<const char*>(a.Wx2) + (size_t)s * FX_WBYTES;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int piece = i * 4 + p;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + piece * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(wbuf + piece * 1024), 16, 0, 0);
+      }
+      asm volatile("" ::: "memory");
+      // h1 slab: units 32s …, this producer's 32 samples
+      const f16x8* wf = reinterpret_cast<const f16x8*>(smx + PC_OFF_W1F) + (s * 2) * 64 + lane;
+      P2 af; af.hi = wf[0]; af.lo = wf[64];
+      P2 bf; bf.hi = xhi; bf.lo = xlo;
+      f32x16 c;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+      c = mfma_x2(af, bf, c);
+      const float* b1l = reinterpret_cast<const float*>(smx + PC_OFF_B1) + 32 * s + 4 * hf;
+      _Float16* Xl = reinterpret_cast<_Float16*>(xbuf);
+      const int gm = t * FX_MB + 32 * p + j;
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {                                   // registers 4q4 … 4q4 + 3 = units 32s + 8q4 + 4hf + {0..3}
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(b1l + 8 * q4);
+        f32x4 hv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[e] = tanh_exp2_arg(__builtin_fmaf(c[4 * q4 + e], xinv, bv[e]), X2_ACT_SCALE);
+        uint2 hh, ll;
+        split2x4(hv, 1.0f, hh, ll);
+        *reinterpret_cast<uint2*>(Xl + (32 * p + j) * X3ROW + 8 * q4 + 4 * hf) = hh;
+        *reinterpret_cast<uint2*>(Xl + FX_MB * X3ROW + (32 * p + j) * X3ROW + 8 * q4 + 4 * hf) = ll;
+        if (WRITE_H1) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = hv[e] * (1.0f / X2_ACT_SCALE);
+          *reinterpret_cast<f32x4*>(a.H1 + (size_t)256 * gm + 32 * s + 8 * q4 + 4 * hf) = o;
+        }
+      }
+    };
+    float xr[8];
+    if ((int)blockIdx.x < ntiles) { load_x(blockIdx.x, xr); make_xfrag(xr); }
+    if ((int)blockIdx.x < ntiles) {
+      produce(blockIdx.x, 0, smx, smx + FX_OFF_X);
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+      const int tn = t + gridDim.x;
+      __builtin_amdgcn_s_barrier();                                      // B_start: slab 0 is ready, the consumers are done with the previous tile
+      const bool st_ = t == (int)(blockIdx.x + 8 * gridDim.x);
+      if (st_) CRL_WSTAMP(1, 0);
+      if (tn < ntiles) load_x(tn, xr);                                   // the next tile's observations: in flight under the whole tile
+#pragma unroll 1
+      for (int s = 0; s < 8; ++s) {
+        if (st_ && s == 3) CRL_WSTAMP(1, 5);
+        if (s < 7) {
+          produce(t, s + 1, smx + ((s + 1) & 1) * FX_WBYTES, smx + FX_OFF_X + ((s + 1) & 1) * FX_XBYTES);
+          if (st_ && s == 3) CRL_WSTAMP(1, 4);
+          // the 8 weight pieces have landed (the 4 h1 stores issued behind them may stay in flight); the LDS stores are done
+          if (WRITE_H1) asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+      }
+      if (st_) CRL_WSTAMP(1, 1);
+      if (tn < ntiles) {                                                 // the next tile's first slab, under the consumers' epilogue (buffer 0: last read in slab 6)
+        make_xfrag(xr);
+        produce(tn, 0, smx, smx + FX_OFF_X);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      if (st_) CRL_WSTAMP(1, 2);
+      __builtin_amdgcn_s_barrier();                                      // B_epi: the consumers' head partials are complete
+      if (st_) CRL_WSTAMP(1, 3);
+    }
+  } else {
+    // ------------------------------------------------------------------------------------------------ consumer c: rows 64c … 64c + 63
+    const int c = wave;
+    const float cs = a.wsc[1] * (1.0f / X2_ACT_SCALE);
+    const int hs = a.A;
+    float* scr = reinterpret_cast<float*>(smx + FX_WBYTES) + c * (32 * 36);               // in weight buffer 1
+    float* hp_all = reinterpret_cast<float*>(smx + FX_OFF_X + FX_XBYTES);                 // in activation buffer 1 (both are free from the loop's last barrier to slab 1 of the next tile)
+    float* hp = hp_all + c * (FX_MB * hs);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+      const int m0 = t * FX_MB;
+      f32x16 acc[2][4];
+#pragma unroll
+      for (int ai = 0; ai < 2; ++ai)
+#pragma unroll
+        for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[ai][bi][r] = 0.0f;
+      __builtin_amdgcn_s_barrier();                                      // B_start
+      const bool st_ = t == (int)(blockIdx.x + 8 * gridDim.x);
+      if (st_) CRL_WSTAMP(1, 0);
+#pragma unroll 1
+      for (int s = 0; s < 8; ++s) {
+        if (st_ && s == 3) CRL_WSTAMP(1, 5);
+        const f16x8* Wl = reinterpret_cast<const f16x8*>(smx + (s & 1) * FX_WBYTES);
+        const _Float16* Xl = reinterpret_cast<const _Float16*>(smx + FX_OFF_X + (s & 1) * FX_XBYTES);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          P2 af[2], bf[4];
+#pragma unroll
+          for (int ai = 0; ai < 2; ++ai) {
+            const int fr = (ks * 8 + 2 * c + ai) * 64 + lane;
+            af[ai].hi = Wl[fr]; af[ai].lo = Wl[1024 + fr];
+          }
+#pragma unroll
+          for (int bi = 0; bi < 4; ++bi) {
+            const int off = (32 * bi + j) * X3ROW + 16 * ks + 8 * hf;
+            bf[bi].hi = *reinterpret_cast<const f16x8*>(Xl + off);
+            bf[bi].lo = *reinterpret_cast<const f16x8*>(Xl + FX_MB * X3ROW + off);
+          }
+#pragma unroll
+          for (int ai = 0; ai < 2; ++ai)
+#pragma unroll
+            for (int bi = 0; bi < 4; ++bi) acc[ai][bi] = mfma_x2(af[ai], bf[bi], acc[ai][bi]);
+        }
+        if (st_ && s == 3) CRL_WSTAMP(1, 4);
+        __builtin_amdgcn_s_barrier();
+      }
+      if (st_) CRL_WSTAMP(1, 1);
+      // epilogue: h2 = tanh(acc·unscale + b2) out in whole lines, head partials of this consumer's 64 rows
+      for (int i = lane; i < FX_MB * hs; i += 64) hp[i] = 0.0f;
+      wave_lds_fence();
+#pragma unroll
+      for (int ai = 0; ai < 2; ++ai)
+#pragma unroll
+        for (int bi = 0; bi < 4; ++bi)
+          tile_tanh_head(scr, acc[ai][bi], lane, 64 * c + 32 * ai, 32 * bi, m0 + 32 * bi, a.M, a.b2, a.H2, a.W3t, a.A, hp, hs, cs, true);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (st_) CRL_WSTAMP(1, 2);
+      __builtin_amdgcn_s_barrier();                                      // B_epi
+      if (st_) CRL_WSTAMP(1, 3);
+      for (int i = tid; i < FX_MB * a.A; i += 256) {                     // the four consumers fold the partials in fixed order
+        const int m = i / a.A, aa = i - m * a.A;
+        float z = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) z += hp_all[q * (FX_MB * hs) + m * hs + aa];
+        a.Z[(size_t)a.ldz * (m0 + m) + aa] = z + a.b3[aa];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+}
+
+template <int DP, bool WRITE_H1>
+__global__ void __launch_bounds__(512) wide_fused_fwd_pc_kernel(FusedFwdPCArgs a0, FusedFwdPCArgs a1) {
+  if (blockIdx.y == 0) wide_fused_fwd_pc_body<DP, WRITE_H1>(a0); else wide_fused_fwd_pc_body<DP, WRITE_H1>(a1);
+}
+
+// fp16x2 A-fragments of W1·2·log2(e)·scale1 for the producers' layer-1 product — [slab][piece][lane][8]: element e of lane l of slab s is
+// W1[32s + (l & 31)][8 (l >> 5) + e] (zero beyond obs_dim) — followed by b1·2·log2(e) [256] as f32. scale1 (a power of two, w1sc[0]) puts
+// the largest |W1·2·log2 e| into [2^14, 2^15).
+__global__ void __launch_bounds__(256) wide_pack_w1f_kernel(const float* __restrict__ W1, const float* __restrict__ b1, int D, const float* __restrict__ w1sc,
+                                                            float* __restrict__ out) {
+  const int t = blockIdx.x * 256 + threadIdx.x;          // (slab, lane)
+  if (t < 8 * 64) {
+    const int lane = t & 63, s = t >> 6;
+    const int u = 32 * s + (lane & 31), k0 = 8 * (lane >> 5);
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (k0 + e) < D ? W1[u + 256 * (k0 + e)] * TWO_LOG2E * w1sc[0] : 0.0f;
+    const P2 p2 = split2(x);
+    f16x8* dst = reinterpret_cast<f16x8*>(out) + (s * 2) * 64 + lane;
+    dst[0] = p2.hi; dst[64] = p2.lo;
+  }
+  if (t < 256) out[4096 + t] = b1[t] * TWO_LOG2E;        // 16 KB of fragments = 4096 floats, then the bias table
+}
+// scale1 for wide_pack_w1f_kernel from the largest |W1| (same rule as wide_w2scale_kernel, with the 2·log2(e) factor folded in)
+__global__ void __launch_bounds__(256) wide_w1scale_kernel(const float* __restrict__ W1, int n, float* __restrict__ w1sc) {
+  __shared__ float sm[4];
+  float m = 0.0f;
+  for (int i = threadIdx.x; i < n; i += 256) m = __builtin_fmaxf(m, __builtin_fabsf(W1[i]) * TWO_LOG2E);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = __builtin_fmaxf(__builtin_fmaxf(sm[0], sm[1]), __builtin_fmaxf(sm[2], sm[3]));
+    float s1, i1;
+    if (!(m > 0.0f) || !(m < 3.0e38f)) { s1 = 256.0f; i1 = 1.0f / 256.0f; } else pow2_scale(m, s1, i1);
+    w1sc[0] = s1; w1sc[1] = i1;
+  }
+}
+
+}  // namespace crl
+
+namespace crl {
+
+// ======================================================================================================================================
+// Weight gradient of the hidden layer with h1 REGENERATED on the CU: dW2[n, k] = Σ_m δ2[n, m]·h1[k, m], db2[n] = Σ_m δ2[n, m] over one sample
+// chunk (ppo.jl:202 pullback of Dense(256, 256)). wide_wgrad_x2_kernel reads both [256 x M] operands from HBM (δ2 twice: two 128-column
+// blocks); here a block owns the whole 256 x 256 tile (2 x 4 MFMA tiles per wave, 128 accumulator registers), reads δ2 ONCE and never reads
+// h1: every wave produces one 32-unit tile of the h1 slab per 32 samples with ONE fp16x2 product on the matrix pipe — mfma(x-fragment,
+// W1ᵀ-fragment): rows = samples, columns = units, i.e. lane = unit, registers = 4 consecutive samples per quad, exactly the [unit][sample]
+// image the K = samples product wants — then tanh, split, 8-byte LDS stores. With it the forward pass no longer stores h1 at all:
+// 2.1 GB of HBM traffic per optimiser step less (h1 written once, read once per network).
+// ======================================================================================================================================
+struct WgradGenArgs {
+  const float* dY; const float* obs; const int32_t* perm; int D;
+  const float* W1f; const float* w1sc;
+  const float* bz; int bld; int bA; const float* wmax;
+  float* pW; float* pB; int M; int chunk;
+};
+
+template <int DP>
+__device__ __forceinline__ void wide_wgrad_gen_body(const WgradGenArgs& a) {
+  constexpr int H = 256, NT = 512;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smw[];
+  _Float16* Yp = reinterpret_cast<_Float16*>(smw);             // [2][256][X3ROW]: δ2·G pieces, [unit][sample]
+  _Float16* Xp = Yp + 2 * H * X3ROW;                           // [2][256][X3ROW]: 2^14·h1 pieces, [unit][sample]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 31, hf = lane >> 5;
+  const int wn = wave & 3, wk = wave >> 2;
+  const int c0 = blockIdx.x * a.chunk;
+  const int c1 = (c0 + a.chunk) < a.M ? (c0 + a.chunk) : a.M;
+  float G, Ginv;
+  {
+    float bmax = 0.0f;
+    for (int m = c0 + tid; m < c1; m += NT) {
+      float bound = 0.0f;
+      for (int q2 = 0; q2 < a.bA; ++q2) bound = __builtin_fmaf(__builtin_fabsf(a.bz[(size_t)a.bld * m + q2]), a.wmax[q2], bound);
+      bmax = __builtin_fmaxf(bmax, bound);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) bmax = __builtin_fmaxf(bmax, __shfl_xor(bmax, o, 64));
+    float* red = reinterpret_cast<float*>(smw);
+    if (lane == 0) red[wave] = bmax;
+    __syncthreads();
+    bmax = red[0];
+    for (int w8 = 1; w8 < NT / 64; ++w8) bmax = __builtin_fmaxf(bmax, red[w8]);
+    __syncthreads();
+    pow2_scale(bmax, G, Ginv);
+  }
+  // this wave's h1 tile: units 32·wave …; its W1ᵀ B-fragment (= the A-fragment of W1 the forward's producers use) and bias stay in registers
+  P2 w1b;
+  {
+    const f16x8* wf = reinterpret_cast<const f16x8*>(a.W1f) + (wave * 2) * 64 + lane;
+    w1b.hi = wf[0]; w1b.lo = wf[64];
+  }
+  const float b1u = a.W1f[4096 + 32 * wave + j];
+  const float w1un = a.w1sc[1];
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.0f;
+  const int sg = lane & 7, ql = lane >> 3;
+  const int rrow = 32 * wave + 4 * ql;
+  const float* ybase = a.dY + (size_t)H * c0 + rrow;
+  const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 yr[4], bacc = zero4;
+  float xo[8];                                                 // observation half (k = 8hf …) of sample m + (lane & 31)
+  auto fetch = [&](int m) {
+    const size_t off = (size_t)H * (m - c0 + 4 * sg);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) yr[e] = (m + 4 * sg + e < c1) ? *reinterpret_cast<const f32x4*>(ybase + off + (size_t)H * e) : zero4;
+    const int ms = m + j;
+    const bool ok = ms < c1;
+    const int src = ok ? (a.perm ? a.perm[ms] : ms) : 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { const int cc = 8 * hf + c; xo[c] = (ok && cc < a.D && cc < DP) ? a.obs[(size_t)src * a.D + cc] : 0.0f; }
+  };
+  if (c0 < c1) fetch(c0);
+  for (int m = c0; m < c1; m += 32) {
+    if (m != c0) __syncthreads();
+    // δ2 slab → [unit][sample] pieces (4 x 4 register transposes, as wide_wgrad_x2_kernel)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      f32x4 vy;
+      vy[0] = yr[0][e]; vy[1] = yr[1][e]; vy[2] = yr[2][e]; vy[3] = yr[3][e];
+      uint2 hh, ll;
+      split2x4(vy, G, hh, ll);
+      *reinterpret_cast<uint2*>(Yp + (0 * H + rrow + e) * X3ROW + 4 * sg) = hh;
+      *reinterpret_cast<uint2*>(Yp + (1 * H + rrow + e) * X3ROW + 4 * sg) = ll;
+    }
+    bacc += (yr[0] + yr[1]) + (yr[2] + yr[3]);
+    // h1 tile of this wave: one product on the matrix pipe, the slab's observations scaled by ONE power of two (the scale must not vary
+    // along the rows of the result: they are the registers here)
+    {
+      float mx = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) mx = __builtin_fmaxf(mx, __builtin_fabsf(xo[c]));
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, o, 64));
+      float sx, ix;
+      pow2_scale(mx, sx, ix);
+      float v[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] = xo[c] * sx;
+      const P2 xa = split2(v);
+      f32x16 c16;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c16[r] = 0.0f;
+      c16 = mfma_x2(xa, w1b, c16);                              // rows = samples (registers), columns = units (lanes)
+      const float un1 = ix * w1un;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {                             // registers 4g … 4g + 3 = samples 8g + 4hf + {0..3} of the slab
+        f32x4 hv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[e] = tanh_exp2_arg(__builtin_fmaf(c16[4 * g + e], un1, b1u), X2_ACT_SCALE);
+        uint2 hh, ll;
+        split2x4(hv, 1.0f, hh, ll);
+        *reinterpret_cast<uint2*>(Xp + (0 * H + 32 * wave + j) * X3ROW + 8 * g + 4 * hf) = hh;
+        *reinterpret_cast<uint2*>(Xp + (1 * H + 32 * wave + j) * X3ROW + 8 * g + 4 * hf) = ll;
+      }
+    }
+    __syncthreads();
+    if (m + 32 < c1) fetch(m + 32);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      P2 af[2], bf[4];
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        const int off = ((wn * 2 + x) * 32 + j) * X3ROW + 16 * ks + 8 * hf;
+        af[x].hi = *reinterpret_cast<const f16x8*>(Yp + 0 * H * X3ROW + off);
+        af[x].lo = *reinterpret_cast<const f16x8*>(Yp + 1 * H * X3ROW + off);
+      }
+#pragma unroll
+      for (int y = 0; y < 4; ++y) {
+        const int off = ((wk * 4 + y) * 32 + j) * X3ROW + 16 * ks + 8 * hf;
+        bf[y].hi = *reinterpret_cast<const f16x8*>(Xp + 0 * H * X3ROW + off);
+        bf[y].lo = *reinterpret_cast<const f16x8*>(Xp + 1 * H * X3ROW + off);
+      }
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] = mfma_x2(af[x], bf[y], acc[x][y]);
+    }
+  }
+  __syncthreads();
+  const float un = Ginv * (1.0f / X2_ACT_SCALE);
+  float* pw = a.pW + (size_t)blockIdx.x * H * H;
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      const int k = (wk * 4 + y) * 32 + j;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = (wn * 2 + x) * 32 + 8 * g + 4 * hf;
+        f32x4 o; o[0] = acc[x][y][4 * g] * un; o[1] = acc[x][y][4 * g + 1] * un; o[2] = acc[x][y][4 * g + 2] * un; o[3] = acc[x][y][4 * g + 3] * un;
+        *reinterpret_cast<f32x4*>(pw + (size_t)H * k + n) = o;
+      }
+    }
+  if (a.pB) {
+    float* scr = reinterpret_cast<float*>(smw);
+    *reinterpret_cast<f32x4*>(scr + 4 * tid) = bacc;
+    __syncthreads();
+    if (sg == 0) {
+      f32x4 sacc = bacc;
+      for (int q = 1; q < 8; ++q) sacc += *reinterpret_cast<const f32x4*>(scr + 4 * (tid + q));
+      *reinterpret_cast<f32x4*>(a.pB + (size_t)blockIdx.x * H + rrow) = sacc;
+    }
+  }
+}
+
+template <int DP>
+__global__ void __launch_bounds__(512) wide_wgrad_gen_kernel(WgradGenArgs a0, WgradGenArgs a1) {
+  if (blockIdx.y == 0) wide_wgrad_gen_body<DP>(a0); else wide_wgrad_gen_body<DP>(a1);
+}
+constexpr int WG_LDS = 2 * 2 * 256 * X3ROW * 2;   // 81,920 bytes
 
 }  // namespace crl

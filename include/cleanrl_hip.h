@@ -215,8 +215,11 @@ int32_t crl_comm_destroy(crl_ppo* h);
  *   gae_nt_loads (2)        standalone GAE kernel: 1 = nontemporal input loads (inputs not in the caches), 0 = cached, 2 = 1 for an external env with 4 M samples or more per rollout, else 0
  *   wide_rollout_persist (1)  layer-wise path, 2x256 fp16x2, obs_dim <= 16: the whole rollout as one launch (0 = three per step)
  *   update_xcd_align (1)    update kernel: tile t is worked on by blocks ≡ t (mod 8) of both roles (same XCD / L2 for a record's two readers)
- *   wide_fuse (2)           layer-wise path, 2x256 fp16x2, obs_dim <= 16: the update pass runs the tile-resident fused kernels (csrc/wide_fused.hpp):
- *                           2 = forward and backward, 1 = forward only, 0 = one launch per layer
+ *   wide_fuse (3)           layer-wise path, 2x256 fp16x2, obs_dim <= 16: the update pass runs the tile-resident fused kernels (csrc/wide_fused.hpp):
+ *                           3 = forward, backward and a weight-gradient kernel that regenerates h1 (h1 is never stored), 2 = forward and backward,
+ *                           1 = forward only, 0 = one launch per layer
+ *   wide_fuse_pc (1)        the fused forward in its producer / consumer form (four MFMA-only waves, four staging waves, persistent blocks); 0 = the
+ *                           symmetric first version
  *   fuse_optim (1)          single GPU, speculative step: gradient reduction + ClipNorm + Adam as ONE launch (0 = two launches)
  * Read-only through crl_ppo_get_option: gemm_fallback_seen (1 once any launch of the fused 4/2/64 path took the bf16x3 fallback; the
  * layer-wise path needs none: it scales its fp16x2 weight pieces by the largest |w| of the layer at every optimiser step).

@@ -1,0 +1,21 @@
+"""Timeline of the producer / consumer forward kernel (ninth tile of every block; build: bash scripts/build_variant.sh wstamps -DCRL_EXP_WSTAMPS wide)."""
+import ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import cleanrl_jl_amd as crl   # noqa: E402
+L = crl._lib
+agent = crl.Agent(crl.PPOConfig(num_envs=16384, num_steps=128, total_timesteps=16384 * 128 * 100), obs_dim=8, n_act=4, hidden=256, env_kind=L.ENV_SYNTHETIC,
+                  options={"wide_fuse": 1})   # forward only: the backward kernel shares the stamp slots
+h = agent.handle; h.env_reset(); h.iterate(1, want_stats=False); h.sync()
+lib = L.load(); buf = np.zeros(2 * 256 * 8 * 16, np.uint64)
+lib.crl_debug_read_wstamps.argtypes = [C.c_void_p, C.c_int32]
+assert lib.crl_debug_read_wstamps(buf.ctypes.data_as(C.c_void_p), buf.size) == 0
+st = buf.reshape(2, 256, 8, 16)[1, :128, :, :6].astype(np.int64)
+ok = (st[:, :, 0] > 0).all(axis=1); st = st[ok]
+us = (st - st[:, :, :1].min(axis=1, keepdims=True)) / 100.0
+print(len(st), "blocks; us since B_start of the ninth tile")
+for g, nm in ((slice(0, 4), "consumers"), (slice(4, 8), "producers")):
+    u = us[:, g, :]
+    print("  %-10s B_start %5.2f | top of slab 3 %5.2f | own slab-3 work done %5.2f | loop end %5.2f | before B_epi %5.2f | after B_epi %5.2f" %
+          (nm, np.median(u[..., 0]), np.median(u[..., 5]), np.median(u[..., 4]), np.median(u[..., 1]), np.median(u[..., 2]), np.median(u[..., 3])))
+agent.close()
