@@ -40,6 +40,7 @@ static const OptDesc kOpts[OPT_COUNT] = {
     {"wide_rollout_persist", 1, 0, 1},
     {"fuse_optim", 1, 0, 1},
     {"update_xcd_align", 1, 0, 1},
+    {"wide_wgrad_full", 1, 0, 1},
     {"wide_fuse_pc", 1, 0, 1},
     {"wide_fuse", 3, 0, 3},
 };
@@ -60,6 +61,7 @@ static int opt_set(crl_ppo* h, const char* key, int64_t value) {
   if (id == OPT_GAE_TILE && value != 0 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64) { set_error("crl_ppo_set_option: gae_tile is 0 (automatic), 4 (streaming kernel), 8, 16, 32 or 64"); return 1; }
   h->opt[id] = value;
   if (id == OPT_GUARD_WINDOW) h->window_len = (int)value;
+  if (id == OPT_WIDE_GEMM) wide_mark_params_changed(h);   // the packed weight copies depend on the flavour
   return 0;
 }
 // CRL_OPTIONS="key=value,key=value": the one environment hook left, for shell-driven experiments (scripts/, bench.py --opt goes

@@ -259,8 +259,9 @@ static int ensure_pack(crl_ppo* h) {
     hipLaunchKernelGGL(wide_pack_kernel, dim3((w->pk[n].x3f + 255) / 256), dim3(256), 0, h->stream, h->params, w->pack, w->H, w->D,
                        w->D8, NO, O8, n ? (int)h->Pa : 0, w->pk_base[n], w->pk[n]);
     if (w->H == 256) {
-      hipLaunchKernelGGL(wide_pack_x3_kernel, dim3(2 * 8 * 2 * 8 * 64 / 256), dim3(256), 0, h->stream, h->params, w->pack,
-                         (n ? (int)h->Pa : 0) + w->H * w->D + w->H, w->pk_base[n], w->pk[n]);
+      if (!wide_x2(h))   // the bf16x3 fragments are read by the wide_gemm = 1 flavour only
+        hipLaunchKernelGGL(wide_pack_x3_kernel, dim3(2 * 8 * 2 * 8 * 64 / 256), dim3(256), 0, h->stream, h->params, w->pack,
+                           (n ? (int)h->Pa : 0) + w->H * w->D + w->H, w->pk_base[n], w->pk[n]);
       hipLaunchKernelGGL(wide_w2scale_kernel, dim3(1), dim3(1024), 0, h->stream, h->params + (n ? (int)h->Pa : 0) + w->H * w->D + w->H,
                          w->H * w->H, w->wsc + 2 * n);
       hipLaunchKernelGGL(wide_pack_x2_kernel, dim3(2 * 8 * 2 * 8 * 64 / 256), dim3(256), 0, h->stream, h->params, w->pack,
@@ -1054,6 +1055,8 @@ struct WgradArgs {
   const float* dZ; int ldd; int Ad; const float* W3t;
   // x2 kernel: the head cotangent (bz, ld bld, bA live rows) and wmax bound |δ2| per sample — the block's scale comes from them
   const float* bz; int bld; int bA; const float* wmax;
+  // GEN flavour (wide_wgrad_x2_kernel<4, true>): X is not read — h1 is regenerated from the observations (wide_fused.hpp, wide_wgrad_gen_kernel)
+  const float* obs = nullptr; const int32_t* perm = nullptr; int D = 0; const float* W1f = nullptr; const float* w1sc = nullptr;
 };
 
 template <int TW>
@@ -1298,7 +1301,7 @@ __global__ void __launch_bounds__(128 * WNB) wide_wgrad_x3_kernel(WgradArgs a) {
 // the scale is the block's own: G = 2^(14 − ⌈log2 max_m bound_m⌉) over the chunk's samples, bound_m = Σ_a |δ3[a, m]|·wmax[a]
 // (≥ every |δ2[·, m]|; a few KB of reads, no pass over δ2). X = h1 takes the static 2^14.
 // ------------------------------------------------------------------------------------------------------
-template <int WNB>
+template <int WNB, bool GEN = false>
 __global__ void __launch_bounds__(128 * WNB) wide_wgrad_x2_kernel(WgradArgs a) {
   constexpr int BN = 64 * WNB, BK = 128, NT = 128 * WNB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smw[];
@@ -1341,17 +1344,35 @@ __global__ void __launch_bounds__(128 * WNB) wide_wgrad_x2_kernel(WgradArgs a) {
   const int rrow = 32 * wave + 4 * ql;
   const bool stage_x = wave < BK / 32;
   const float* ybase = a.dY + (size_t)a.H * c0 + n0 + rrow;
-  const float* xbase = a.X + (size_t)a.H * c0 + kk0 + rrow;
+  const float* xbase = GEN ? nullptr : a.X + (size_t)a.H * c0 + kk0 + rrow;
   const bool do_bias = (tkb == 0) && a.pB;
   const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
   f32x4 yr[4], xr[4], bacc = zero4;
+  // GEN: waves 0-3 regenerate their 32-unit tile of the h1 slab with one fp16x2 product (see wide_wgrad_gen_kernel): W1ᵀ fragment + bias in registers
+  P2 w1b; float b1u = 0.0f, w1un = 0.0f, xo[8];
+  int src_nx = 0;
+  if (GEN && stage_x) {
+    src_nx = (c0 + j < c1) ? (a.perm ? a.perm[c0 + j] : c0 + j) : 0;
+    const f16x8* wf = reinterpret_cast<const f16x8*>(a.W1f) + ((kk0 / 32 + wave) * 2) * 64 + lane;
+    w1b.hi = wf[0]; w1b.lo = wf[64];
+    b1u = a.W1f[4096 + kk0 + 32 * wave + j]; w1un = a.w1sc[1];
+  }
   auto fetch = [&](int m) {
     const size_t off = (size_t)a.H * (m - c0 + 4 * sg);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const bool ok = m + 4 * sg + e < c1;
       yr[e] = ok ? *reinterpret_cast<const f32x4*>(ybase + off + (size_t)a.H * e) : zero4;
-      xr[e] = (ok && stage_x) ? *reinterpret_cast<const f32x4*>(xbase + off + (size_t)a.H * e) : zero4;
+      if (!GEN) xr[e] = (ok && stage_x) ? *reinterpret_cast<const f32x4*>(xbase + off + (size_t)a.H * e) : zero4;
+    }
+    if (GEN && stage_x) {
+      // the observation row index of this slab's sample was loaded a slab earlier (a dependent perm → obs chain inside one fetch stalls the
+      // wave for a memory round trip before its MFMAs: 497 instead of ≈300 us per launch)
+      const bool ok = m + j < c1;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { const int cc = 8 * hf + c; xo[c] = (ok && cc < a.D) ? a.obs[(size_t)src_nx * a.D + cc] : 0.0f; }
+      const int mn = m + 32 + j;
+      src_nx = mn < c1 ? (a.perm ? a.perm[mn] : mn) : 0;
     }
   };
   if (c0 < c1) fetch(c0);
@@ -1365,12 +1386,40 @@ __global__ void __launch_bounds__(128 * WNB) wide_wgrad_x2_kernel(WgradArgs a) {
       split2x4(vy, G, hh, ll);
       *reinterpret_cast<uint2*>(Yp + (0 * BN + rrow + e) * X3ROW + 4 * sg) = hh;
       *reinterpret_cast<uint2*>(Yp + (1 * BN + rrow + e) * X3ROW + 4 * sg) = ll;
-      if (stage_x) {
+      if (!GEN && stage_x) {
         f32x4 vx;
         vx[0] = xr[0][e]; vx[1] = xr[1][e]; vx[2] = xr[2][e]; vx[3] = xr[3][e];
         split2x4(vx, X2_ACT_SCALE, hh, ll);
         *reinterpret_cast<uint2*>(Xp + (0 * BK + rrow + e) * X3ROW + 4 * sg) = hh;
         *reinterpret_cast<uint2*>(Xp + (1 * BK + rrow + e) * X3ROW + 4 * sg) = ll;
+      }
+    }
+    if (GEN && stage_x) {
+      float mx = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) mx = __builtin_fmaxf(mx, __builtin_fabsf(xo[c]));
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, o, 64));
+      float sx, ix;
+      pow2_scale(mx, sx, ix);
+      float v[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] = xo[c] * sx;
+      const P2 xa = split2(v);
+      f32x16 c16;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c16[r] = 0.0f;
+      c16 = mfma_x2(xa, w1b, c16);                              // rows = samples (registers), columns = units (lanes)
+      const float un1 = ix * w1un;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 hv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[e] = tanh_exp2_arg(__builtin_fmaf(c16[4 * g + e], un1, b1u), X2_ACT_SCALE);
+        uint2 hh, ll;
+        split2x4(hv, 1.0f, hh, ll);
+        *reinterpret_cast<uint2*>(Xp + (0 * BK + 32 * wave + j) * X3ROW + 8 * g + 4 * hf) = hh;
+        *reinterpret_cast<uint2*>(Xp + (1 * BK + 32 * wave + j) * X3ROW + 8 * g + 4 * hf) = ll;
       }
     }
     if (do_bias) bacc += (yr[0] + yr[1]) + (yr[2] + yr[3]);
@@ -2191,6 +2240,11 @@ static int wide_backward_fused(crl_ppo* h, const int32_t* perm, int M) {
   else hipLaunchKernelGGL((wide_fused_bwd_kernel<16, 8>), dim3(nb, 2), dim3(512), lds, h->stream, a[0], a[1]);
   CRL_HIP_CHECK(hipGetLastError());
   w->fb_blocks = nb;
+  // The dW3 sweeps over h2 depend on the loss kernel only, like the fused backward: they run on the second stream beside it (small blocks
+  // that fit next to the backward's one block per CU) and join before the weight-gradient launch.
+  const bool side = opt(h, OPT_SHUFFLE_OVERLAP) != 0;
+  hipStream_t sk = side ? h->stream2 : h->stream;
+  if (side) CRL_HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));   // ev_fork was recorded behind the loss kernel (wide_grad_passes)
   for (int net = 0; net < 2; ++net) {
     const int NO = net ? 1 : w->A;
     const float* pk = w->pack + w->pk_base[net];
@@ -2198,7 +2252,7 @@ static int wide_backward_fused(crl_ppo* h, const int32_t* perm, int M) {
     SkinnyArgs s;   // dW3[a, k] = Σ δ3[a]·h2[k]
     s.Big = w->h2[net]; s.H = 256; s.Small = dOut; s.lds = ldd; s.idx = nullptr; s.M = M; s.chunk = w->chunks;
     s.pW = w->pW3[net]; s.os_row = NO; s.os_s = 1; s.St = NO; s.wsize = 256 * NO; s.pB = nullptr; s.D2out = nullptr; s.W3t = pk + w->pk[net].w3t;
-    if (skinny_launch(h->stream, w->Ss, s)) return 1;
+    if (skinny_launch(sk, w->Ss, s)) return 1;
     if (!wide_h1_free(h)) {
       WgradArgs g;    // dW2 = δ2·h1ᵀ, db2 = Σ δ2 from the stored h1
       g.dY = net ? w->dB : w->dA; g.X = w->h1[net]; g.H = 256; g.M = M; g.chunk = w->chunk2; g.pW = w->pW2[net]; g.pB = w->pB2[net];
@@ -2207,7 +2261,20 @@ static int wide_backward_fused(crl_ppo* h, const int32_t* perm, int M) {
       CRL_HIP_CHECK(hipGetLastError());
     }
   }
-  if (wide_h1_free(h)) {   // both networks in one launch, h1 regenerated on the CU (wide_wgrad_gen_kernel)
+  if (side) { CRL_HIP_CHECK(hipEventRecord(h->ev_join, h->stream2)); CRL_HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_join, 0)); }
+  if (wide_h1_free(h) && !opt(h, OPT_WIDE_WGRAD_FULL)) {
+    // h1 regenerated inside wide_wgrad_x2_kernel's own structure (256 x 128 tiles, two blocks per CU: the stream of δ2 hides under the other block)
+    for (int net = 0; net < 2; ++net) {
+      const float* pk = w->pack + w->pk_base[net];
+      WgradArgs g;
+      g.dY = net ? w->dB : w->dA; g.X = nullptr; g.H = 256; g.M = M; g.chunk = w->chunk2; g.pW = w->pW2[net]; g.pB = w->pB2[net];
+      g.dZ = nullptr; g.ldd = net ? 8 : w->A8; g.Ad = net ? 1 : w->A; g.W3t = pk + w->pk[net].w3t;
+      g.bz = net ? w->dv8 : w->z; g.bld = net ? 8 : w->A8; g.bA = net ? 1 : w->A; g.wmax = pk + w->pk[net].wmax;
+      g.obs = h->obs; g.perm = perm; g.D = w->D; g.W1f = pk + w->pk[net].w1f; g.w1sc = w->wsc + 4 + 2 * net;
+      hipLaunchKernelGGL((wide_wgrad_x2_kernel<4, true>), dim3(w->S2, 2), dim3(512), 2 * (256 + 128) * X3ROW * 2, h->stream, g);
+      CRL_HIP_CHECK(hipGetLastError());
+    }
+  } else if (wide_h1_free(h)) {   // both networks in one launch, 256 x 256 tile per block (wide_wgrad_gen_kernel)
     WgradGenArgs g[2];
     for (int net = 0; net < 2; ++net) {
       const float* pk = w->pack + w->pk_base[net];
@@ -2252,7 +2319,10 @@ static int wide_grad_passes(crl_ppo* h, int mb, const int32_t* perm, double Mglo
     CRL_HIP_CHECK(hipGetLastError());
   }
   w->fb_blocks = 0;
-  if (wide_fused_ok(h) && M % FX_MB == 0 && w->A <= FB_AMAX && opt(h, OPT_WIDE_FUSE) >= 2) return wide_backward_fused(h, perm, M);
+  if (wide_fused_ok(h) && M % FX_MB == 0 && w->A <= FB_AMAX && opt(h, OPT_WIDE_FUSE) >= 2) {
+    if (opt(h, OPT_SHUFFLE_OVERLAP)) CRL_HIP_CHECK(hipEventRecord(h->ev_fork, h->stream));   // behind the loss kernel: the side stream starts here
+    return wide_backward_fused(h, perm, M);
+  }
   if (wide_backward(h, 0, w->z, w->A8, perm)) return 1;
   if (wide_backward(h, 1, w->dv8, 8, perm)) return 1;
   return 0;

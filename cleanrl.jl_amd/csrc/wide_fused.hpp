@@ -824,15 +824,16 @@ __device__ __forceinline__ void wide_wgrad_gen_body(const WgradGenArgs& a) {
   const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
   f32x4 yr[4], bacc = zero4;
   float xo[8];                                                 // observation half (k = 8hf …) of sample m + (lane & 31)
+  int src_nx = (c0 + j < c1) ? (a.perm ? a.perm[c0 + j] : c0 + j) : 0;
   auto fetch = [&](int m) {
     const size_t off = (size_t)H * (m - c0 + 4 * sg);
 #pragma unroll
     for (int e = 0; e < 4; ++e) yr[e] = (m + 4 * sg + e < c1) ? *reinterpret_cast<const f32x4*>(ybase + off + (size_t)H * e) : zero4;
-    const int ms = m + j;
-    const bool ok = ms < c1;
-    const int src = ok ? (a.perm ? a.perm[ms] : ms) : 0;
+    const bool ok = m + j < c1;                                 // (the row index was loaded a slab earlier: no dependent chain inside the fetch)
 #pragma unroll
-    for (int c = 0; c < 8; ++c) { const int cc = 8 * hf + c; xo[c] = (ok && cc < a.D && cc < DP) ? a.obs[(size_t)src * a.D + cc] : 0.0f; }
+    for (int c = 0; c < 8; ++c) { const int cc = 8 * hf + c; xo[c] = (ok && cc < a.D && cc < DP) ? a.obs[(size_t)src_nx * a.D + cc] : 0.0f; }
+    const int mn = m + 32 + j;
+    src_nx = mn < c1 ? (a.perm ? a.perm[mn] : mn) : 0;
   };
   if (c0 < c1) fetch(c0);
   for (int m = c0; m < c1; m += 32) {

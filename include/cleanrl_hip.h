@@ -218,6 +218,7 @@ int32_t crl_comm_destroy(crl_ppo* h);
  *   wide_fuse (3)           layer-wise path, 2x256 fp16x2, obs_dim <= 16: the update pass runs the tile-resident fused kernels (csrc/wide_fused.hpp):
  *                           3 = forward, backward and a weight-gradient kernel that regenerates h1 (h1 is never stored), 2 = forward and backward,
  *                           1 = forward only, 0 = one launch per layer
+ *   wide_wgrad_full (1)     the h1-regenerating weight-gradient kernel: 1 = one 256x256 tile per block, δ2 read once (default); 0 = 256x128 output tiles
  *   wide_fuse_pc (1)        the fused forward in its producer / consumer form (four MFMA-only waves, four staging waves, persistent blocks); 0 = the
  *                           symmetric first version
  *   fuse_optim (1)          single GPU, speculative step: gradient reduction + ClipNorm + Adam as ONE launch (0 = two launches)
