@@ -40,6 +40,7 @@ static const OptDesc kOpts[OPT_COUNT] = {
     {"wide_rollout_persist", 1, 0, 1},
     {"fuse_optim", 1, 0, 1},
     {"update_xcd_align", 1, 0, 1},
+    {"update_prio_small", 0, 0, 3},
     {"wide_wgrad_full", 1, 0, 1},
     {"wide_fuse_pc", 1, 0, 1},
     {"wide_fuse", 3, 0, 3},

@@ -66,6 +66,7 @@ enum OptId {
   OPT_WIDE_ROLLOUT_PERSIST,   // layer-wise path, 2x256 fp16x2: the whole rollout as one launch (0 = three launches per step)
   OPT_FUSE_OPTIM,             // 1 = single-GPU speculative steps run reduce + ClipNorm + Adam as one launch (reduce_optim_kernel)
   OPT_UPDATE_XCD_ALIGN,       // 1 = update kernel: a tile's actor and critic blocks on the same XCD (the record's second reader hits L2)
+  OPT_UPDATE_PRIO_SMALL,      // update kernel, launches with < 16 tiles per wave: wave-priority rule (0 none, 1 feedback, 2 static for waves 4-7, 3 alternating)
   OPT_WIDE_WGRAD_FULL,        // h1-free weight gradient: 0 = 256x128 tiles, two blocks per CU (default), 1 = 256x256 tile per block (δ2 read once)
   OPT_WIDE_FUSE_PC,           // fused forward: 1 = producer / consumer waves, persistent (default), 0 = the symmetric first version
   OPT_WIDE_FUSE,              // layer-wise path, 2x256 fp16x2: 1 = tile-resident fused passes of wide_fused.hpp (default), 0 = one launch per layer

@@ -240,9 +240,13 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
   const float invG = X2 ? sgpr(1.0f / Gdw) : 1.0f;
   float d2run = 0.0f;
   // (only where a wave has 16 tiles or more: with the 4-8 tiles per wave of a 4096 / 8192-env shard the same rule measured 4-5 % SLOWER)
-  const bool balance = X2 && ntiles >= 16 * tstride;
+  const bool balance = X2 && (ntiles >= 16 * tstride || a.prio_mode == 1);
+  const int small_prio = (X2 && ntiles < 16 * tstride) ? a.prio_mode : 0;
+  if (small_prio == 2 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+  int tile_parity = 0;
   for (; tile < ntiles; tile += tstride) {
     int partner_tile = 0;
+    if (small_prio == 3) { if (((tile_parity++) & 1) == (wave >> 2)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
     if (balance) {
       // The SIMD's arbiter favours the older of its two waves (w over w + 4): left alone, waves 0-3 finish their tiles a quarter of
       // the launch early (measured with timestamps: 395 of 531 µs) and waves 4-7 run the rest alone, at half the SIMD's issue rate.
@@ -1049,6 +1053,7 @@ static int run_update(crl_ppo* h, int mb, int mode, hipEvent_t ev0 = nullptr, hi
     main_pass_blocks(h, &a.nblk[0], &a.nblk[1]);
     a.xcd_align = (a.nblk[0] % 8 == 0 && a.nblk[1] % 8 == 0 && opt(h, OPT_UPDATE_XCD_ALIGN)) ? 1 : 0;
     a.stagger = (int)opt(h, OPT_UPDATE_STAGGER);
+    a.prio_mode = (int)opt(h, OPT_UPDATE_PRIO_SMALL);
     // LDS for the larger of the two layouts: the fp16x2 kernel runs a role as bf16x3 when its weights leave the fp16 window
     const size_t smem = sizeof(float) * (X2_KERNEL_LDS_FLOATS + 8 * PF_SLOT_FLOATS);
     static_assert(NetImageX3<4, 2, true>::SIZE >= NetImageX2<4, 2>::SIZE, "the bf16x3 image is the larger one");

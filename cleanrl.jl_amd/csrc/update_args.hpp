@@ -20,6 +20,7 @@ struct UpdateArgs {
   int pmax;               // capacity (blocks per role) of the partial buffers
   int stagger;            // x3 kernel: start delay of waves 4-7 (units of 1024 clocks)
   int xcd_align = 0;      // 1 (both block counts multiples of 8): tile t is worked on by blocks with index ≡ t (mod 8) in BOTH roles — same XCD, same L2
+  int prio_mode = 0;      // small launches (< 16 tiles per wave, where the feedback rule is off): 0 = nothing, 1 = the feedback rule anyway, 2 = static priority 1 for waves 4-7, 3 = priority alternating tile by tile
   double Mglobal;         // minibatch size over all ranks (the 1/M of every mean)
 };
 

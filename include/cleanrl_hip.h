@@ -215,6 +215,9 @@ int32_t crl_comm_destroy(crl_ppo* h);
  *   gae_nt_loads (2)        standalone GAE kernel: 1 = nontemporal input loads (inputs not in the caches), 0 = cached, 2 = 1 for an external env with 4 M samples or more per rollout, else 0
  *   wide_rollout_persist (1)  layer-wise path, 2x256 fp16x2, obs_dim <= 16: the whole rollout as one launch (0 = three per step)
  *   update_xcd_align (1)    update kernel: tile t is worked on by blocks ≡ t (mod 8) of both roles (same XCD / L2 for a record's two readers)
+ *   update_prio_small (0)   update kernel, launches with fewer than 16 tiles per wave (shards of 8192 envs and below): wave-priority rule of a
+ *                           wave pair on one SIMD — 0 none (default), 1 the large-launch feedback rule, 2 static (younger wave first), 3 alternate
+ *                           per tile.  Measured: 3 is -1..-2 % at 8192 envs and +1 % at 4096, the others neutral or worse
  *   wide_fuse (3)           layer-wise path, 2x256 fp16x2, obs_dim <= 16: the update pass runs the tile-resident fused kernels (csrc/wide_fused.hpp):
  *                           3 = forward, backward and a weight-gradient kernel that regenerates h1 (h1 is never stored), 2 = forward and backward,
  *                           1 = forward only, 0 = one launch per layer

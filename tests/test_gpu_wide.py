@@ -136,6 +136,42 @@ def test_wide_update_gradient_matches_oracle(crl, D, A, Hd, nt, k, ret_scale, cl
     agent.close(); st.close()
 
 
+@pytest.mark.parametrize("opts", [
+    {"wide_fuse": 0}, {"wide_fuse": 1}, {"wide_fuse": 2}, {"wide_fuse": 3},
+    {"wide_fuse": 3, "wide_fuse_pc": 0}, {"wide_fuse": 2, "wide_fuse_pc": 0}, {"wide_fuse": 3, "wide_wgrad_full": 0},
+    {"wide_fuse": 3, "shuffle_overlap": 0}], ids=lambda o: ",".join(f"{a}={b}" for a, b in o.items()))
+@pytest.mark.parametrize("D,A,nt", [(8, 4, 24), (16, 8, 16), (3, 2, 12)])
+def test_every_2x256_kernel_flavour_matches_the_oracle(crl, opts, D, A, nt):
+    """The 2x256 shape has four selectable pipelines (option wide_fuse: 0 layer-wise GEMMs, 1 tile-resident forward, 2 + tile-
+    resident backward, 3 + h1 never stored) and the flavours under them (producer/consumer forward, the two weight-gradient
+    kernels, dW3 on the side stream).  Every one of them must give the oracle's loss scalars and gradient on the same
+    buffers — the default is only the fastest of equals.  Shapes: C3's, the largest the fused kernels take (obs 16, 8
+    actions) and an odd small one (obs 3, 2 actions)."""
+    k, Hd = 128, 256
+    rng = np.random.default_rng(nt + D)
+    cfg = ocfg(nt, k, D, A, Hd)
+    params = O.orthogonal_params(cfg, 5) + (0.05 * rng.standard_normal(O.lib().orc_param_count(cfg))).astype(np.float32)
+    agent = make_wide(crl, nt, k, D, A, Hd, params=params)
+    h = agent.handle
+    for name, v in opts.items():
+        h.set_option(name, v)
+    st = O.State(cfg); st.params[:] = params
+    inject(crl, agent, st, rng, D, A, 3.0)
+    h.adv_stats()
+    M = nt * k // 4
+    assert M % 128 == 0
+    off = O.param_offsets(cfg)
+    for mb in (0, 3):
+        gs = h.update_minibatch(mb, 2.5e-4, apply_update=False)
+        g_gpu = h.read(crl._lib.F_GRADS)
+        g_orc, so = O.loss_grad(cfg, params, st.obs.reshape(D, -1, order="F"), st.action, st.logprob, st.value, st.adv, st.ret,
+                                st.perm[mb * M:(mb + 1) * M])
+        for key in ("loss", "pg_loss", "v_loss", "entropy_loss"):
+            assert loss_close(key, gs[key], so[key], RTOL), (key, gs[key], so[key])
+        _grad_close(g_gpu, g_orc, off)
+    agent.close(); st.close()
+
+
 def test_wide_fp16x2_weight_scale_follows_the_weights(crl):
     """The 256-wide fp16x2 products stage W2 with a power of two taken from the largest |w| of the network at every optimiser step
     (wide_w2scale_kernel), so a weight of 300 — outside the fixed 2^8 window of rounds 1-2, where it raised an error — and a network
