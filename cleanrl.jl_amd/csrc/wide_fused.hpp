@@ -19,9 +19,11 @@ namespace crl {
 // diagnostic build only (bash scripts/build_variant.sh wstamps -DCRL_EXP_WSTAMPS wide): wall-clock stamps (100 MHz) of the first tile of
 // every block of the fused kernels — [kernel 0 fwd / 1 bwd][block][wave][slot], read back by scripts/wstamps_probe.py
 __device__ unsigned long long crl_dbg_wstamps[2 * 256 * 8 * 16];
+#define CRL_WSTAMP_CYC(kern, slot) do { const unsigned bx_ = (kern) ? blockIdx.x : blockIdx.x - 2048u; if ((threadIdx.x & 63) == 0 && bx_ < 256u && blockIdx.y == 0) crl_dbg_wstamps[(((kern) * 256 + bx_) * 8 + (threadIdx.x >> 6)) * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
 #define CRL_WSTAMP(kern, slot) do { const unsigned bx_ = (kern) ? blockIdx.x : blockIdx.x - 2048u; if ((threadIdx.x & 63) == 0 && bx_ < 256u && blockIdx.y == 0) crl_dbg_wstamps[(((kern) * 256 + bx_) * 8 + (threadIdx.x >> 6)) * 16 + (slot)] = wall_clock64(); } while (0)
 #else
 #define CRL_WSTAMP(kern, slot) do { } while (0)
+#define CRL_WSTAMP_CYC(kern, slot) do { } while (0)
 #endif
 constexpr int FX_MB = 128;                                   // samples per block tile
 constexpr int FX_WBYTES = X2_SLAB_F16 * 2;                   // 32,768: one weight slab
@@ -47,13 +49,22 @@ struct FusedFwdArgs {
 // the same order, all CUs of an XCD ask one L2 channel for one line at the same moment and the transfer takes ≈2 µs instead of ≈0.5
 // (in-kernel stamps, scripts/wstamps_probe.py). `rot` (from the block index) rotates the order of the 32 pieces, so that at any moment
 // the CUs are spread over the slab's lines.
+// One LDS-DMA piece — 64 lanes x 16 B from (wave-uniform base + per-lane byte offset) to the 1 KB at the wave-uniform LDS address — in the
+// SGPR-base + VGPR-offset form, spelled out. __builtin_amdgcn_global_load_lds compiles to a 64-bit VGPR address that is recomputed per
+// piece, and each of those vector writes waits until the previous fetch has read the register pair: 8 pieces took the producers of
+// wide_fused_fwd_pc_kernel 1.04 µs to ISSUE beside their partner's MFMAs, 0.32 µs in this form (profiles/r04_c3_stamps.txt).
+__device__ __forceinline__ void lds_dma16(const void* sbase, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)p; }
+
 __device__ __forceinline__ void fx_dma_wslab(const float* Wx2, int slab, unsigned char* dst, int wave, int lane, int rot = 0) {
   const char* g = reinterpret_cast<const char*>(Wx2) + (size_t)slab * FX_WBYTES;
+  const unsigned l0 = lds_addr_of(dst), voff = lane * 16;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int piece = (i * 8 + wave + rot) & 31;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + piece * 1024 + lane * 16),
-                                     (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+    lds_dma16(g + piece * 1024, voff, l0 + piece * 1024);
   }
 }
 
@@ -251,12 +262,11 @@ struct FusedBwdArgs {
 
 // one h2 slab (units 32s …, samples m0 …) into LDS as [sample][32 units]: 16 pieces of 1 KB (8 samples x 128 B), two per wave
 __device__ __forceinline__ void fb_dma_hslab(const float* H2, int m0, int s, unsigned char* dst, int wave, int lane) {
+  const unsigned l0 = lds_addr_of(dst), voff = (lane >> 3) * 1024 + (lane & 7) * 16;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int piece = i * 8 + wave;                       // samples 8·piece … 8·piece + 7
-    const int smp = 8 * piece + (lane >> 3);
-    const char* g = reinterpret_cast<const char*>(H2 + (size_t)256 * (m0 + smp) + 32 * s) + (lane & 7) * 16;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+    lds_dma16(H2 + (size_t)256 * (m0 + 8 * piece) + 32 * s, voff, l0 + piece * 1024);
   }
 }
 
@@ -523,8 +533,13 @@ namespace crl {
 // ======================================================================================================================================
 constexpr int PC_OFF_W1F = FX_OFF_X + 2 * FX_XBYTES;          // 106,496: W1 A-fragments, [slab 8][piece 2][lane 64][8 halves] = 16 KB
 constexpr int PC_OFF_B1 = PC_OFF_W1F + 16384;                // b1·2·log2(e) [256] f32
-constexpr int PC_LDS = PC_OFF_B1 + 1024;                     // 123,904 bytes
+#ifndef PC_PRODUCER_PRIO
+#define PC_PRODUCER_PRIO 0   // measured: 0, 2 and 3 within noise (45.5-46.2 ms per C3 iteration on one box)
+#endif
 constexpr int PC_AMAX = 8;
+constexpr int PC_OFF_W3 = PC_OFF_B1 + 1024;                  // W3ᵀ [A <= 8][256] f32 and b2 [256] f32: the consumers' epilogue reads them from LDS
+constexpr int PC_OFF_B2 = PC_OFF_W3 + PC_AMAX * 1024;
+constexpr int PC_LDS = PC_OFF_B2 + 1024;                     // 133,120 bytes
 static_assert(4 * 32 * 36 * 4 <= FX_WBYTES && 4 * FX_MB * PC_AMAX * 4 <= FX_XBYTES, "epilogue scratch aliases weight buffer 1, the head partials activation buffer 1");
 
 struct FusedFwdPCArgs {
@@ -545,8 +560,11 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
   // W1 fragments + bias table into LDS, once
   for (int i = tid; i < (16384 + 1024) / 16; i += 512)
     reinterpret_cast<f32x4*>(smx + PC_OFF_W1F)[i] = reinterpret_cast<const f32x4*>(a.W1f)[i];
+  for (int i = tid; i < a.A * 256; i += 512) reinterpret_cast<float*>(smx + PC_OFF_W3)[i] = a.W3t[i];
+  if (tid < 256) reinterpret_cast<float*>(smx + PC_OFF_B2)[tid] = a.b2[tid];
   __syncthreads();
   if (wave >= 4) {
+    if (PC_PRODUCER_PRIO) __builtin_amdgcn_s_setprio(PC_PRODUCER_PRIO);   // few instructions, all on the slab's critical path: they go first
     // ------------------------------------------------------------------------------------------------ producer p: sample tile p
     const int p = wave - 4;
     const float w1un = a.w1sc[1];
@@ -570,16 +588,14 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
       const P2 q = split2(v);
       xhi = q.hi; xlo = q.lo; xinv = i1 * w1un;
     };
-    auto produce = [&](int t, int s, unsigned char* wbuf, unsigned char* xbuf) {
+    auto produce = [&](int t, int s, unsigned char* wbuf, unsigned char* xbuf, bool stamp = false) {
       // weight slab s: this producer's 8 of the 32 pieces
-      const char* g = reinterpret_cast<const char*>(a.Wx2) + (size_t)s * FX_WBYTES;
+      const char* g = reinterpret_cast<const char*>(a.Wx2) + (size_t)s * FX_WBYTES + p * 1024;
+      const unsigned lds0 = lds_addr_of(wbuf) + p * 1024, voff = lane * 16;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int piece = i * 4 + p;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + piece * 1024 + lane * 16),
-                                         (__attribute__((address_space(3))) void*)(wbuf + piece * 1024), 16, 0, 0);
-      }
+      for (int i = 0; i < 8; ++i) lds_dma16(g + i * 4096, voff, lds0 + i * 4096);
       asm volatile("" ::: "memory");
+      if (stamp) CRL_WSTAMP(1, 6);
       // h1 slab: units 32s …, this producer's 32 samples
       const f16x8* wf = reinterpret_cast<const f16x8*>(smx + PC_OFF_W1F) + (s * 2) * 64 + lane;
       P2 af; af.hi = wf[0]; af.lo = wf[64];
@@ -588,6 +604,9 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) c[r] = 0.0f;
       c = mfma_x2(af, bf, c);
+#ifdef CRL_EXP_WSTAMPS
+      if (stamp) { asm volatile("v_mov_b32 %0, %0" : "+v"(c[0])); asm volatile("s_nop 0" ::: "memory"); CRL_WSTAMP(1, 7); }
+#endif
       const float* b1l = reinterpret_cast<const float*>(smx + PC_OFF_B1) + 32 * s + 4 * hf;
       _Float16* Xl = reinterpret_cast<_Float16*>(xbuf);
       const int gm = t * FX_MB + 32 * p + j;
@@ -623,9 +642,9 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
       if (tn < ntiles) load_x(tn, xr);                                   // the next tile's observations: in flight under the whole tile
 #pragma unroll 1
       for (int s = 0; s < 8; ++s) {
-        if (st_ && s == 3) CRL_WSTAMP(1, 5);
+        if (st_) CRL_WSTAMP(1, 8 + s);
         if (s < 7) {
-          produce(t, s + 1, smx + ((s + 1) & 1) * FX_WBYTES, smx + FX_OFF_X + ((s + 1) & 1) * FX_XBYTES);
+          produce(t, s + 1, smx + ((s + 1) & 1) * FX_WBYTES, smx + FX_OFF_X + ((s + 1) & 1) * FX_XBYTES, st_ && s == 3);
           if (st_ && s == 3) CRL_WSTAMP(1, 4);
           // the 8 weight pieces have landed (the 4 h1 stores issued behind them may stay in flight); the LDS stores are done
           if (WRITE_H1) asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
@@ -662,10 +681,10 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
           for (int r = 0; r < 16; ++r) acc[ai][bi][r] = 0.0f;
       __builtin_amdgcn_s_barrier();                                      // B_start
       const bool st_ = t == (int)(blockIdx.x + 8 * gridDim.x);
-      if (st_) CRL_WSTAMP(1, 0);
+      if (st_) { CRL_WSTAMP(1, 0); CRL_WSTAMP_CYC(1, 5); }
 #pragma unroll 1
       for (int s = 0; s < 8; ++s) {
-        if (st_ && s == 3) CRL_WSTAMP(1, 5);
+        if (st_) CRL_WSTAMP(1, 8 + s);
         const f16x8* Wl = reinterpret_cast<const f16x8*>(smx + (s & 1) * FX_WBYTES);
         const _Float16* Xl = reinterpret_cast<const _Float16*>(smx + FX_OFF_X + (s & 1) * FX_XBYTES);
 #pragma unroll
@@ -690,15 +709,59 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
         if (st_ && s == 3) CRL_WSTAMP(1, 4);
         __builtin_amdgcn_s_barrier();
       }
-      if (st_) CRL_WSTAMP(1, 1);
-      // epilogue: h2 = tanh(acc·unscale + b2) out in whole lines, head partials of this consumer's 64 rows
-      for (int i = lane; i < FX_MB * hs; i += 64) hp[i] = 0.0f;
-      wave_lds_fence();
+      if (st_) { CRL_WSTAMP(1, 1); CRL_WSTAMP_CYC(1, 6); }
+      // epilogue: h2 = tanh(acc·unscale + b2) out in whole lines, head partials of this consumer's 64 rows. b2 and W3 come from LDS and a
+      // row group's 16 head weights per action are read ONCE for its four sample tiles (the first version read them per tile from global
+      // memory: 32 dependent round trips, 11.8 of the tile's 24 µs — profiles/r04_c3_stamps.txt)
+      float hacc[4][PC_AMAX];
 #pragma unroll
-      for (int ai = 0; ai < 2; ++ai)
+      for (int bi = 0; bi < 4; ++bi)
 #pragma unroll
-        for (int bi = 0; bi < 4; ++bi)
-          tile_tanh_head(scr, acc[ai][bi], lane, 64 * c + 32 * ai, 32 * bi, m0 + 32 * bi, a.M, a.b2, a.H2, a.W3t, a.A, hp, hs, cs, true);
+        for (int aa = 0; aa < PC_AMAX; ++aa) hacc[bi][aa] = 0.0f;
+#pragma unroll
+      for (int ai = 0; ai < 2; ++ai) {
+        const int n0 = 64 * c + 32 * ai;
+        const float* b2l = reinterpret_cast<const float*>(smx + PC_OFF_B2) + n0 + 4 * hf;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(b2l + 8 * g);
+#pragma unroll
+          for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[ai][bi][4 * g + e] = tanh_exp2(__builtin_fmaf(acc[ai][bi][4 * g + e], cs, bv[e]), TWO_LOG2E, 1.0f);
+        }
+#pragma unroll
+        for (int bi = 0; bi < 4; ++bi) tile_out<EPI_STORE>(scr, acc[ai][bi], lane, n0, m0 + 32 * bi, a.M, nullptr, nullptr, 0, a.H2, 256);
+#pragma unroll
+        for (int aa = 0; aa < PC_AMAX; ++aa) {
+          if (aa < a.A) {
+            const float* w3l = reinterpret_cast<const float*>(smx + PC_OFF_W3) + 256 * aa + n0 + 4 * hf;
+            f32x4 w[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) w[g] = *reinterpret_cast<const f32x4*>(w3l + 8 * g);
+#pragma unroll
+            for (int bi = 0; bi < 4; ++bi) {
+              float pp = hacc[bi][aa];
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pp = __builtin_fmaf(w[g][e], acc[ai][bi][4 * g + e], pp);
+              hacc[bi][aa] = pp;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int aa = 0; aa < PC_AMAX; ++aa) {
+        if (aa < a.A) {
+#pragma unroll
+          for (int bi = 0; bi < 4; ++bi) {
+            float pp = hacc[bi][aa];
+            pp += xor32(pp);
+            if (hf == 0) hp[(32 * bi + j) * hs + aa] = pp;
+          }
+        }
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (st_) CRL_WSTAMP(1, 2);
       __builtin_amdgcn_s_barrier();                                      // B_epi

@@ -10,12 +10,18 @@ h = agent.handle; h.env_reset(); h.iterate(1, want_stats=False); h.sync()
 lib = L.load(); buf = np.zeros(2 * 256 * 8 * 16, np.uint64)
 lib.crl_debug_read_wstamps.argtypes = [C.c_void_p, C.c_int32]
 assert lib.crl_debug_read_wstamps(buf.ctypes.data_as(C.c_void_p), buf.size) == 0
-st = buf.reshape(2, 256, 8, 16)[1, :128, :, :6].astype(np.int64)
+st = buf.reshape(2, 256, 8, 16)[1, :128, :, :16].astype(np.int64)
 ok = (st[:, :, 0] > 0).all(axis=1); st = st[ok]
 us = (st - st[:, :, :1].min(axis=1, keepdims=True)) / 100.0
 print(len(st), "blocks; us since B_start of the ninth tile")
 for g, nm in ((slice(0, 4), "consumers"), (slice(4, 8), "producers")):
     u = us[:, g, :]
     print("  %-10s B_start %5.2f | top of slab 3 %5.2f | own slab-3 work done %5.2f | loop end %5.2f | before B_epi %5.2f | after B_epi %5.2f" %
-          (nm, np.median(u[..., 0]), np.median(u[..., 5]), np.median(u[..., 4]), np.median(u[..., 1]), np.median(u[..., 2]), np.median(u[..., 3])))
+          (nm, np.median(u[..., 0]), np.median(u[..., 11]), np.median(u[..., 4]), np.median(u[..., 1]), np.median(u[..., 2]), np.median(u[..., 3])))
 agent.close()
+p = us[:, 4:8, :]
+print("  producer slab 3: top %.2f | DMA issued +%.2f | layer-1 MFMA result +%.2f | tanh/split/LDS stores +%.2f" % (
+    np.median(p[..., 11]), np.median(p[..., 6] - p[..., 11]), np.median(p[..., 7] - p[..., 6]), np.median(p[..., 4] - p[..., 7])))
+print("  top of slab 0..7 and loop end:", " ".join("%.2f" % np.median(p[..., 8 + s]) for s in range(8)), "%.2f" % np.median(p[..., 1]))
+raw = buf.reshape(2, 256, 8, 16)[1, :128][ok].astype(np.int64)[:, :4, :]
+print("  shader clock during the slab loop (s_memtime / s_memrealtime, consumer waves): %.0f MHz" % np.median((raw[..., 6] - raw[..., 5]) / ((raw[..., 1] - raw[..., 0]) / 100.0)))
