@@ -19,10 +19,12 @@ namespace crl {
 // diagnostic build only (bash scripts/build_variant.sh wstamps -DCRL_EXP_WSTAMPS wide): wall-clock stamps (100 MHz) of the first tile of
 // every block of the fused kernels — [kernel 0 fwd / 1 bwd][block][wave][slot], read back by scripts/wstamps_probe.py
 __device__ unsigned long long crl_dbg_wstamps[2 * 256 * 8 * 16];
+#define CRL_BSTAMP(slot) do { if (lane == 0) bst[wave * 16 + (slot)] = wall_clock64(); } while (0)
 #define CRL_WSTAMP_CYC(kern, slot) do { const unsigned bx_ = (kern) ? blockIdx.x : blockIdx.x - 2048u; if ((threadIdx.x & 63) == 0 && bx_ < 256u && blockIdx.y == 0) crl_dbg_wstamps[(((kern) * 256 + bx_) * 8 + (threadIdx.x >> 6)) * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
 #define CRL_WSTAMP(kern, slot) do { const unsigned bx_ = (kern) ? blockIdx.x : blockIdx.x - 2048u; if ((threadIdx.x & 63) == 0 && bx_ < 256u && blockIdx.y == 0) crl_dbg_wstamps[(((kern) * 256 + bx_) * 8 + (threadIdx.x >> 6)) * 16 + (slot)] = wall_clock64(); } while (0)
 #else
 #define CRL_WSTAMP(kern, slot) do { } while (0)
+#define CRL_BSTAMP(slot) do { } while (0)
 #define CRL_WSTAMP_CYC(kern, slot) do { } while (0)
 #endif
 constexpr int FX_MB = 128;                                   // samples per block tile
@@ -297,9 +299,15 @@ __device__ __forceinline__ void fb_compute_slab(const unsigned char* wbuf, const
 }
 
 template <int DP, int NA>   // NA: head outputs kept in registers (a.A <= NA)
+#ifndef CRL_ABL_B
+#define CRL_ABL_B 0   // timing ablations of the backward kernel (scripts/ablate_bwd.sh): 1 no epilogue arithmetic, 2 no products, 3 no staging, 4 no δ2 store — results are garbage
+#endif
 __device__ __forceinline__ void wide_fused_bwd_body(const FusedBwdArgs& a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef CRL_EXP_WSTAMPS
+  unsigned long long* bst = reinterpret_cast<unsigned long long*>(smx + 160 * 1024 - 1024);   // stamps stay in LDS until the end: a global store per stamp would sit in the counted vmcnt waits
+#endif
   const int rg = wave & 3, sg = wave >> 2, j = lane & 31, hf = lane >> 5;
   const int sm = tid >> 2, sq = tid & 3;                       // staging role: sample, unit octet of every slab
   const int rot = (int)((blockIdx.x * 5u + (blockIdx.x >> 3) + 16u * blockIdx.y) & 31u);
@@ -337,7 +345,7 @@ __device__ __forceinline__ void wide_fused_bwd_body(const FusedBwdArgs& a) {
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int m0 = t * FX_MB, gm = m0 + sm;
     const bool first = t == (int)(blockIdx.x + 8 * gridDim.x);   // (diagnostic builds stamp the block's ninth tile: warm caches)
-    if (first) CRL_WSTAMP(1, 0);
+    if (first) CRL_BSTAMP(0);
     float bound = 0.0f;
 #pragma unroll
     for (int q = 0; q < NA; ++q)
@@ -371,7 +379,7 @@ __device__ __forceinline__ void wide_fused_bwd_body(const FusedBwdArgs& a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { o0[e] = d[e] * (1.0f - h0[e] * h0[e]); o1[e] = d[4 + e] * (1.0f - h1v[e] * h1v[e]); }
       float* dst = a.D2 + (size_t)256 * gm + 32 * s + 8 * sq;
-      *reinterpret_cast<f32x4*>(dst) = o0; *reinterpret_cast<f32x4*>(dst + 4) = o1;
+      if (CRL_ABL_B != 4) { *reinterpret_cast<f32x4*>(dst) = o0; *reinterpret_cast<f32x4*>(dst + 4) = o1; }
       float v[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] = o0[e] * s1; v[4 + e] = o1[e] * s1; }
@@ -382,42 +390,43 @@ __device__ __forceinline__ void wide_fused_bwd_body(const FusedBwdArgs& a) {
     };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this tile's first transfers (issued before the previous tile's epilogue) have landed
     __builtin_amdgcn_s_barrier();
+    if (first) CRL_BSTAMP(10);
     stage(0, Hb, smx + FX_OFF_X);
     fb_dma_hslab(a.H2, m0, 2, Hb + 2 * FB_HBYTES, wave, lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (first) CRL_WSTAMP(1, 1);
+    if (first) CRL_BSTAMP(1);
 #pragma unroll 1
     for (int s = 0; s < 8; ++s) {
       const int cur = s & 1, nxt = cur ^ 1;
-      if (first && s == 3) CRL_WSTAMP(1, 2);
-      if (first && s == 4) CRL_WSTAMP(1, 4);
+      if (first && s == 3) CRL_BSTAMP(2);
+      if (first && s == 4) CRL_BSTAMP(4);
       const int h1i = (s + 1) % 3, h3i = s % 3;                 // buffers of the h2 slabs s + 1 (staged now) and s + 3 (requested now)
       if (s < 7) fx_dma_wslab(a.Wx2b, s + 1, smx + nxt * FX_WBYTES, wave, lane, rot);
       asm volatile("" ::: "memory");   // the δ2 stores below stay behind the weight pieces in issue order (the counted wait relies on it)
-      if (first && s == 3) CRL_WSTAMP(1, 7);
+      if (first && s == 3) CRL_BSTAMP(7);
       if (sg == 0) {
-        if (s < 7) stage(s + 1, Hb + h1i * FB_HBYTES, smx + FX_OFF_X + nxt * FX_XBYTES);
-        if (first && s == 3) CRL_WSTAMP(1, 8);
+        if (s < 7 && CRL_ABL_B != 3) stage(s + 1, Hb + h1i * FB_HBYTES, smx + FX_OFF_X + nxt * FX_XBYTES);
+        if (first && s == 3) CRL_BSTAMP(8);
         if (s + 3 < 8) fb_dma_hslab(a.H2, m0, s + 3, Hb + h3i * FB_HBYTES, wave, lane);
-        if (first && s == 3) CRL_WSTAMP(1, 9);
-        fb_compute_slab(smx + cur * FX_WBYTES, smx + FX_OFF_X + cur * FX_XBYTES, rg, sg, lane, acc);
+        if (first && s == 3) CRL_BSTAMP(9);
+        if (CRL_ABL_B != 2) fb_compute_slab(smx + cur * FX_WBYTES, smx + FX_OFF_X + cur * FX_XBYTES, rg, sg, lane, acc);
       } else {
-        fb_compute_slab(smx + cur * FX_WBYTES, smx + FX_OFF_X + cur * FX_XBYTES, rg, sg, lane, acc);
-        if (first && s == 3) CRL_WSTAMP(1, 8);
-        if (s < 7) stage(s + 1, Hb + h1i * FB_HBYTES, smx + FX_OFF_X + nxt * FX_XBYTES);
-        if (first && s == 3) CRL_WSTAMP(1, 9);
+        if (CRL_ABL_B != 2) fb_compute_slab(smx + cur * FX_WBYTES, smx + FX_OFF_X + cur * FX_XBYTES, rg, sg, lane, acc);
+        if (first && s == 3) CRL_BSTAMP(8);
+        if (s < 7 && CRL_ABL_B != 3) stage(s + 1, Hb + h1i * FB_HBYTES, smx + FX_OFF_X + nxt * FX_XBYTES);
+        if (first && s == 3) CRL_BSTAMP(9);
         if (s + 3 < 8) fb_dma_hslab(a.H2, m0, s + 3, Hb + h3i * FB_HBYTES, wave, lane);
       }
       // the weight slab s + 1 (and every older transfer, h2 slab s + 2 among them) has landed; the h2 slab s + 3 and the two δ2 stores
       // of this iteration's staging — issued after the weight pieces in both orders — may stay in flight
-      if (first && s == 3) CRL_WSTAMP(1, 3);
+      if (first && s == 3) CRL_BSTAMP(3);
       if (s < 5) asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
       else if (s < 7) asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
-    if (first) CRL_WSTAMP(1, 5);
+    if (first) CRL_BSTAMP(5);
     // ---- epilogue: δ1ᵀ = acc·unscale ⊙ (1 − h1²) with h1 recomputed; dW1 / db1 accumulate per lane (lane = unit, registers = samples)
     float* xs = reinterpret_cast<float*>(smx + FX_OFF_X + FX_XBYTES);      // [128][DP], in the second activation buffer (free until slab 1 of the next tile)
     float* invs = xs + FX_MB * DP;
@@ -430,8 +439,9 @@ __device__ __forceinline__ void wide_fused_bwd_body(const FusedBwdArgs& a) {
     if (tn < ntiles) { tile_dma(tn); setup_load(tn, dz, xq); }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (first) CRL_BSTAMP(11);
 #pragma unroll
-    for (int bi = 0; bi < 2; ++bi) {
+    for (int bi = 0; bi < (CRL_ABL_B == 1 ? 0 : 2); ++bi) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int srow0 = 64 * sg + 32 * bi + 8 * g + 4 * hf;               // four consecutive samples: registers 4g … 4g + 3
@@ -476,8 +486,13 @@ __device__ __forceinline__ void wide_fused_bwd_body(const FusedBwdArgs& a) {
       }
     }
     __builtin_amdgcn_s_barrier();   // every wave has read xs / invs before the next tile's set-up may overwrite that region
-    if (first) CRL_WSTAMP(1, 6);
+    if (first) CRL_BSTAMP(6);
   }
+#ifdef CRL_EXP_WSTAMPS
+  if (lane == 0 && blockIdx.y == 0 && blockIdx.x < 256)
+    for (int q = 0; q < 16; ++q) crl_dbg_wstamps[((256 + blockIdx.x) * 8 + wave) * 16 + q] = bst[wave * 16 + q];
+  __syncthreads();
+#endif
   // ---- the block's partial: lane halves hold different samples of the same unit, the two sample groups are two waves
   float* red = reinterpret_cast<float*>(smx);                               // [wave][64 units][DP + 1]
 #pragma unroll

@@ -20,7 +20,7 @@ lib = L.load()
 buf = np.zeros(2 * 256 * 8 * 16, np.uint64)
 lib.crl_debug_read_wstamps.argtypes = [C.c_void_p, C.c_int32]
 assert lib.crl_debug_read_wstamps(buf.ctypes.data_as(C.c_void_p), buf.size) == 0
-st = buf.reshape(2, 256, 8, 16)[..., :11].astype(np.int64)
+st = buf.reshape(2, 256, 8, 16)[..., :12].astype(np.int64)
 for k, name in enumerate(("forward", "backward")):
     s = st[k]
     ok = (s[:, :, 0] > 0).all(axis=1)
@@ -36,4 +36,8 @@ for k, name in enumerate(("forward", "backward")):
               f"→ (bwd) second marker {np.median(u[..., 9] - u[..., 8]):.2f} | → own work done {np.median(u[..., 3] - np.maximum(u[..., 8], u[..., 9])):.2f}")
     d = np.median(us[..., 5] - us[..., 1]); print(f"   slab loop {d:.2f} us ({d / 8:.2f} per slab); slab 3 own work {np.median(us[..., 3] - us[..., 2]):.2f}, wait+barrier {np.median(us[..., 4] - us[..., 3]):.2f}; "
                                                   f"prologue {np.median(us[..., 1]):.2f}, epilogue {np.median(us[..., 6] - us[..., 5]):.2f}")
+s = st[1]; s = s[(s[:, :, 0] > 0).all(axis=1)]
+us = (s - s[:, :, :1].min(axis=1, keepdims=True)) / 100.0
+print("backward tile (ninth of the block; LDS-resident stamps): top %.2f | first transfers landed + barrier %.2f | slab 0 staged + barrier %.2f | loop end %.2f | "
+      "epilogue set-up + barrier %.2f | tile end %.2f" % tuple(np.median(us[..., i]) for i in (0, 10, 1, 5, 11, 6)))
 agent.close()
