@@ -45,10 +45,6 @@ for nt in 8192 16384 32768; do
 done
 timeout 300 $B --workload c2 --steps 40 --no-cpu-baseline > $O/bench_c2_n1.json 2>/dev/null
 timeout 600 $B --workload c3 --steps 5 --warmup 2 > $O/bench_c3_n1.json 2>/dev/null
-# multi-rank functional runs on this one GPU (peer all-reduce) — labelled shared_gpu, not scaling points
-for n in 2 4 8; do
-  timeout 600 python3 $R/bench.py --gpus $n --comm peer --share-gpu --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | grep '^{' > $O/bench_shared_gpu_n$n.json
-done
 timeout 900 python3 $R/scripts/parity_margins.py > $O/parity_margins.json 2>/dev/null
 timeout 300 python3 $R/scripts/bench_gae.py 0 0 > $O/gae_sizes.txt 2>/dev/null
 echo done
