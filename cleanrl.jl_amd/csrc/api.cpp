@@ -37,7 +37,7 @@ static const OptDesc kOpts[OPT_COUNT] = {
     {"gae_seg", 0, 0, 16},
     {"gae_tile", 0, 0, 64},
     {"gae_nt_loads", 2, 0, 2},
-    {"wide_rollout_persist", 1, 0, 1},
+    {"wide_rollout_persist", 2, 0, 2},
     {"fuse_optim", 1, 0, 1},
     {"update_xcd_align", 1, 0, 1},
     {"update_prio_small", 0, 0, 3},

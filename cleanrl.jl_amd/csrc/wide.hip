@@ -1805,6 +1805,241 @@ __global__ void __launch_bounds__(512, 4) wide_rollout_persist_kernel(WRollArgs 
   if (tid < 64) wide_step_stats(r.s.ep_stats, st_n, st_ret, st_len, st_max);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The same rollout in the producer / consumer form of the fused forward pass (wide_fused.hpp), option wide_rollout_persist = 2 (default
+// when num_envs is a multiple of 64). wide_rollout_persist_kernel walks 16 weight slabs per step through registers with two barriers
+// each and a fetch distance of one short MFMA phase: 52 µs per step at C3, almost all of it L2 latency. Here a block owns 64 envs and
+//   waves 0-3  multiply: rows 64c … 64c + 63 x 64 envs (2 x 2 accumulator tiles), then tanh + head partials; wave 0 also steps the envs;
+//   waves 4-5  make the next h1 slab (layer 1 as ONE fp16x2 product per 32 x 32 tile, tanh, split) for 32 envs each;
+//   waves 6-7  bring the next 32 KB weight slab by LDS-DMA (16 pieces each);
+// one barrier per slab, actor then critic, the critic's first slab prepared under the actor's epilogue. Nothing but the logits / values
+// (for wide_step_env) and the rollout buffer leaves the CU. The actor keeps the reference's rational tanh_fast in both layers; its layer 1
+// is now an fp16x2 product like its layer 2 (action indices equal the oracle's away from CDF knots — the margin rule of the parity tests).
+// ------------------------------------------------------------------------------------------------------
+constexpr int RP_MB = 64;
+constexpr int RP_XBYTES = 2 * RP_MB * X3ROW * 2;             // 10,240: one activation slab, [piece][env][X3ROW halves]
+constexpr int RP_OFF_X = 2 * FX_WBYTES;                       // 65,536
+constexpr int RP_W1F_BYTES = 16384 + 1024;                    // per network: W1 fragments + bias table (pack: w1f)
+constexpr int RP_OFF_W1F = RP_OFF_X + 2 * RP_XBYTES;          // 86,016
+constexpr int RP_OFF_W3 = RP_OFF_W1F + 2 * RP_W1F_BYTES;      // 120,832: actor W3ᵀ [A <= 8][256] f32, then the critic's [256]
+constexpr int RP_OFF_B2 = RP_OFF_W3 + 9 * 1024;               // b2 of the actor, of the critic
+constexpr int RP_OFF_HP = RP_OFF_B2 + 2 * 1024;               // head partials [4 row groups][64 envs][8] f32
+constexpr int RP_LDS = RP_OFF_HP + 4 * RP_MB * 8 * 4;         // 140,288 bytes
+constexpr float INV_TWO_LOG2E = 0.34657359027997264f;
+struct RollPCNet {
+  const float* W1f; const float* w1sc; const float* Wx2; const float* b2; const float* wsc; const float* W3t; const float* b3;
+  float* Z; int A; int ldz; int rat;                          // rat: 1 = tanh_fast (rational), 0 = the exp2 form
+};
+struct RollPCArgs { RollPCNet n[2]; WStepArgs s; int D; };
+
+template <int DP>
+__global__ void __launch_bounds__(512) wide_rollout_pc_kernel(RollPCArgs r) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, hf = lane >> 5;
+  const int m0 = blockIdx.x * RP_MB;
+  for (int net = 0; net < 2; ++net) {
+    for (int i = tid; i < RP_W1F_BYTES / 16; i += 512)
+      reinterpret_cast<f32x4*>(smx + RP_OFF_W1F + net * RP_W1F_BYTES)[i] = reinterpret_cast<const f32x4*>(r.n[net].W1f)[i];
+    for (int i = tid; i < r.n[net].A * 256; i += 512) reinterpret_cast<float*>(smx + RP_OFF_W3 + net * 8192)[i] = r.n[net].W3t[i];
+    if (tid < 256) reinterpret_cast<float*>(smx + RP_OFF_B2 + net * 1024)[tid] = r.n[net].b2[tid];
+  }
+  __syncthreads();
+  const int nsteps = r.s.c.k;
+  if (wave >= 4) {
+    // ------------------------------------------------------------------------------------------------ producers
+    const int p = wave - 4;
+    f16x8 xhi, xlo; float xi1 = 0.0f;
+    auto produce = [&](int net, int s, unsigned char* wbuf, unsigned char* xbuf) {
+      if (p >= 2) {                                                      // weight slab s: 16 of its 32 pieces
+        const char* g = reinterpret_cast<const char*>(r.n[net].Wx2) + (size_t)s * FX_WBYTES + (p - 2) * 16384;
+        const unsigned lds0 = lds_addr_of(wbuf) + (p - 2) * 16384, voff = lane * 16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) lds_dma16(g + i * 1024, voff, lds0 + i * 1024);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {                                                           // h1 slab: units 32s …, envs 32p …
+        const unsigned char* tab = smx + RP_OFF_W1F + net * RP_W1F_BYTES;
+        const f16x8* wf = reinterpret_cast<const f16x8*>(tab) + (s * 2) * 64 + lane;
+        P2 af; af.hi = wf[0]; af.lo = wf[64];
+        P2 bf; bf.hi = xhi; bf.lo = xlo;
+        f32x16 c;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) c[q] = 0.0f;
+        c = mfma_x2(af, bf, c);
+        const float xinv = xi1 * r.n[net].w1sc[1];
+        const float* b1l = reinterpret_cast<const float*>(tab + 16384) + 32 * s + 4 * hf;
+        _Float16* Xl = reinterpret_cast<_Float16*>(xbuf);
+        const bool rat = r.n[net].rat != 0;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {                                 // registers 4q4 … 4q4 + 3 = units 32s + 8q4 + 4hf + {0..3}
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(b1l + 8 * q4);
+          f32x4 hv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t = __builtin_fmaf(c[4 * q4 + e], xinv, bv[e]);   // 2·log2(e)·(W1·x + b1)
+            hv[e] = rat ? tanh_fast(t * INV_TWO_LOG2E) * X2_ACT_SCALE : tanh_exp2_arg(t, X2_ACT_SCALE);
+          }
+          uint2 hh, ll;
+          split2x4(hv, 1.0f, hh, ll);
+          *reinterpret_cast<uint2*>(Xl + (32 * p + j) * X3ROW + 8 * q4 + 4 * hf) = hh;
+          *reinterpret_cast<uint2*>(Xl + RP_MB * X3ROW + (32 * p + j) * X3ROW + 8 * q4 + 4 * hf) = ll;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    };
+#pragma unroll 1
+    for (int step = 0; step < nsteps; ++step) {
+      __builtin_amdgcn_s_barrier();                                      // B_obs: the envs have been stepped
+      if (p < 2) {
+        const int gm = m0 + 32 * p + j;
+        float xr[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int cc = 8 * hf + q; xr[q] = (cc < r.D && cc < DP) ? r.s.cur_obs[(size_t)gm * r.D + cc] : 0.0f; }
+        float m = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m = __builtin_fmaxf(m, __builtin_fabsf(xr[q]));
+        m = __builtin_fmaxf(m, xor32(m));
+        float s1;
+        pow2_scale(m, s1, xi1);
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = xr[q] * s1;
+        const P2 q2 = split2(v);
+        xhi = q2.hi; xlo = q2.lo;
+      }
+      produce(0, 0, smx, smx + RP_OFF_X);
+#pragma unroll 1
+      for (int net = 0; net < 2; ++net) {
+        __builtin_amdgcn_s_barrier();                                    // B_start
+#pragma unroll 1
+        for (int s = 0; s < 8; ++s) {
+          if (s < 7) produce(net, s + 1, smx + ((s + 1) & 1) * FX_WBYTES, smx + RP_OFF_X + ((s + 1) & 1) * RP_XBYTES);
+          __builtin_amdgcn_s_barrier();
+        }
+        if (net == 0) produce(1, 0, smx, smx + RP_OFF_X);                // the critic's first slab, under the actor's epilogue
+        __builtin_amdgcn_s_barrier();                                    // B_epi
+      }
+      __builtin_amdgcn_s_barrier();                                      // B_fold
+    }
+  } else {
+    // ------------------------------------------------------------------------------------------------ consumer c: rows 64c … 64c + 63
+    const int c = wave;
+    double st_n = 0.0, st_ret = 0.0, st_len = 0.0, st_max = 0.0;
+    float* hp_all = reinterpret_cast<float*>(smx + RP_OFF_HP);
+#pragma unroll 1
+    for (int step = 0; step < nsteps; ++step) {
+      __builtin_amdgcn_s_barrier();                                      // B_obs
+#pragma unroll 1
+      for (int net = 0; net < 2; ++net) {
+        const RollPCNet& nn = r.n[net];
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int ai = 0; ai < 2; ++ai)
+#pragma unroll
+          for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[ai][bi][q] = 0.0f;
+        __builtin_amdgcn_s_barrier();                                    // B_start
+#pragma unroll 1
+        for (int s = 0; s < 8; ++s) {
+          const f16x8* Wl = reinterpret_cast<const f16x8*>(smx + (s & 1) * FX_WBYTES);
+          const _Float16* Xl = reinterpret_cast<const _Float16*>(smx + RP_OFF_X + (s & 1) * RP_XBYTES);
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            P2 af[2], bf[2];
+#pragma unroll
+            for (int ai = 0; ai < 2; ++ai) {
+              const int fr = (ks * 8 + 2 * c + ai) * 64 + lane;
+              af[ai].hi = Wl[fr]; af[ai].lo = Wl[1024 + fr];
+            }
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi) {
+              const int off = (32 * bi + j) * X3ROW + 16 * ks + 8 * hf;
+              bf[bi].hi = *reinterpret_cast<const f16x8*>(Xl + off);
+              bf[bi].lo = *reinterpret_cast<const f16x8*>(Xl + RP_MB * X3ROW + off);
+            }
+#pragma unroll
+            for (int ai = 0; ai < 2; ++ai)
+#pragma unroll
+              for (int bi = 0; bi < 2; ++bi) acc[ai][bi] = mfma_x2(af[ai], bf[bi], acc[ai][bi]);
+          }
+          __builtin_amdgcn_s_barrier();
+        }
+        // epilogue: h2 = tanh(acc·unscale + b2) stays in registers; head partials of this row group
+        const float cs = nn.wsc[1] * (1.0f / X2_ACT_SCALE);
+        const bool rat = nn.rat != 0;
+        const int hs = nn.A;
+        float hacc[2][PC_AMAX];
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+          for (int aa = 0; aa < PC_AMAX; ++aa) hacc[bi][aa] = 0.0f;
+#pragma unroll
+        for (int ai = 0; ai < 2; ++ai) {
+          const int n0 = 64 * c + 32 * ai;
+          const float* b2l = reinterpret_cast<const float*>(smx + RP_OFF_B2 + net * 1024) + n0 + 4 * hf;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(b2l + 8 * g);
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float x = __builtin_fmaf(acc[ai][bi][4 * g + e], cs, bv[e]);
+                acc[ai][bi][4 * g + e] = rat ? tanh_fast(x) : tanh_exp2(x, TWO_LOG2E, 1.0f);
+              }
+          }
+#pragma unroll
+          for (int aa = 0; aa < PC_AMAX; ++aa) {
+            if (aa < nn.A) {
+              const float* w3l = reinterpret_cast<const float*>(smx + RP_OFF_W3 + net * 8192) + 256 * aa + n0 + 4 * hf;
+              f32x4 w[4];
+#pragma unroll
+              for (int g = 0; g < 4; ++g) w[g] = *reinterpret_cast<const f32x4*>(w3l + 8 * g);
+#pragma unroll
+              for (int bi = 0; bi < 2; ++bi) {
+                float pp = hacc[bi][aa];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) pp = __builtin_fmaf(w[g][e], acc[ai][bi][4 * g + e], pp);
+                hacc[bi][aa] = pp;
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int aa = 0; aa < PC_AMAX; ++aa) {
+          if (aa < nn.A) {
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi) {
+              float pp = hacc[bi][aa];
+              pp += xor32(pp);
+              if (hf == 0) hp_all[c * (RP_MB * hs) + (32 * bi + j) * hs + aa] = pp;
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                    // B_epi
+        for (int i = tid; i < RP_MB * nn.A; i += 256) {                  // the four row groups' partials, fixed order
+          const int m = i / nn.A, aa = i - m * nn.A;
+          float z = 0.0f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) z += hp_all[q * (RP_MB * hs) + m * hs + aa];
+          nn.Z[(size_t)nn.ldz * (m0 + m) + aa] = z + nn.b3[aa];
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                      // B_fold: logits and values of the 64 envs are out
+      if (wave == 0) {
+        wide_step_env(r.s, m0 + lane, step, st_n, st_ret, st_len, st_max);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+    if (wave == 0) wide_step_stats(r.s.ep_stats, st_n, st_ret, st_len, st_max);
+  }
+}
+
 // env construction for the synthetic env (oracle: orc_env_init, gstep = ~0)
 __global__ void __launch_bounds__(256) wide_synth_reset_kernel(DevCfg c, float* env_state, int32_t* env_t, float* cur_obs,
                                                               uint8_t* next_done, float* ep_return, int32_t* ep_length, double* ep_stats) {
@@ -2077,6 +2312,27 @@ int wide_rollout(crl_ppo* h) {
   a.ring = h->ep_ring; a.ring_count = h->ep_ring_count; a.ring_cap = h->ep_ring_cap;
   if (h->ep_ring_cap > 0) CRL_HIP_CHECK(hipMemsetAsync(h->ep_ring_count, 0, sizeof(uint32_t), h->stream));
   ProfScope ps(h, CRL_K_ROLLOUT);
+  if (w->H == 256 && wide_x2(h) && w->D <= 16 && w->A <= PC_AMAX && opt(h, OPT_WIDE_ROLLOUT_PERSIST) >= 2 && h->dc.nt % RP_MB == 0) {
+    // one launch for all steps, producer / consumer form (wide_rollout_pc_kernel)
+    RollPCArgs r;
+    const bool fast_ok = !opt(h, OPT_WIDE_TANH_RATIONAL);
+    for (int net = 0; net < 2; ++net) {
+      const int NO = net ? 1 : w->A;
+      const NetOff o = net_off(256, w->D, NO);
+      const float* P = h->params + (net ? h->Pa : 0);
+      const float* pk = w->pack + w->pk_base[net];
+      RollPCNet& n = r.n[net];
+      n.W1f = pk + w->pk[net].w1f; n.w1sc = w->wsc + 4 + 2 * net; n.Wx2 = pk + w->pk[net].x2f; n.b2 = P + o.b2; n.wsc = w->wsc + 2 * net;
+      n.W3t = pk + w->pk[net].w3t; n.b3 = P + o.b3; n.Z = net ? w->v : w->z; n.A = NO; n.ldz = net ? 1 : w->A8;
+      n.rat = (net == 1 && fast_ok) ? 0 : 1;            // the actor keeps tanh_fast: its logits decide bit-compared action indices
+    }
+    r.s = a; r.D = w->D;
+    const int nb = h->dc.nt / RP_MB;
+    if (w->D8 == 8) hipLaunchKernelGGL(wide_rollout_pc_kernel<8>, dim3(nb), dim3(512), RP_LDS, h->stream, r);
+    else hipLaunchKernelGGL(wide_rollout_pc_kernel<16>, dim3(nb), dim3(512), RP_LDS, h->stream, r);
+    CRL_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   if (w->H == 256 && wide_x2(h) && w->D <= 16 && opt(h, OPT_WIDE_ROLLOUT_PERSIST)) {   // one launch for all steps (wide_rollout_persist_kernel)
     WRollArgs r;
     const bool fast_ok = !opt(h, OPT_WIDE_TANH_RATIONAL);

@@ -213,7 +213,9 @@ int32_t crl_comm_destroy(crl_ppo* h);
  *   gae_seg, gae_tile       standalone GAE kernel: steps per segment / envs per block, 0 = automatic; gae_tile = 4 = the streaming kernel
  *                           (four envs per thread, 16-byte accesses, serial Float64 recurrence: what batches of 67 M samples or more take by themselves)
  *   gae_nt_loads (2)        standalone GAE kernel: 1 = nontemporal input loads (inputs not in the caches), 0 = cached, 2 = 1 for an external env with 4 M samples or more per rollout, else 0
- *   wide_rollout_persist (1)  layer-wise path, 2x256 fp16x2, obs_dim <= 16: the whole rollout as one launch (0 = three per step)
+ *   wide_rollout_persist (2)  layer-wise path, 2x256 fp16x2, obs_dim <= 16: the whole rollout as one launch — 2 = producer / consumer form (64 envs per
+ *                           block, weight slabs by LDS-DMA, layer 1 on the matrix pipe; num_envs % 64 == 0, n_act <= 8, else 1), 1 = the first
+ *                           one-launch kernel (32 envs per block), 0 = three launches per step
  *   update_xcd_align (1)    update kernel: tile t is worked on by blocks ≡ t (mod 8) of both roles (same XCD / L2 for a record's two readers)
  *   update_prio_small (0)   update kernel, launches with fewer than 16 tiles per wave (shards of 8192 envs and below): wave-priority rule of a
  *                           wave pair on one SIMD — 0 none (default), 1 the large-launch feedback rule, 2 static (younger wave first), 3 alternate

@@ -69,7 +69,7 @@ def test_wide_policy_act_and_logprob_match_oracle(crl, D, A, Hd, n):
     agent.close()
 
 
-@pytest.mark.parametrize("D,A,Hd,nt,k", [(8, 4, 256, 70, 16), (6, 3, 128, 8, 32), (4, 2, 64, 33, 8)])
+@pytest.mark.parametrize("D,A,Hd,nt,k", [(8, 4, 256, 70, 16), (6, 3, 128, 8, 32), (4, 2, 64, 33, 8), (8, 4, 256, 192, 24), (16, 8, 256, 64, 16), (3, 2, 256, 128, 8)])
 def test_wide_rollout_matches_oracle(crl, D, A, Hd, nt, k):
     cfg = ocfg(nt, k, D, A, Hd)
     params = spread_params(cfg, 5)
@@ -258,9 +258,10 @@ def test_wide_full_iteration_matches_oracle(crl, D, A, Hd, nt, k):
     agent.close(); st.close()
 
 
-@pytest.mark.parametrize("persist", [1, 0])
+@pytest.mark.parametrize("persist", [2, 1, 0])
 def test_c3_shaped_iteration_at_1024_envs_matches_oracle(crl, persist):
-    """(wide_rollout_persist = 1: the rollout as one launch, wide_rollout_persist_kernel; 0: three launches per step.)
+    """(wide_rollout_persist = 2: the rollout as one launch in producer / consumer form, wide_rollout_pc_kernel — the default when num_envs
+    is a multiple of 64; 1: one launch, wide_rollout_persist_kernel; 0: three launches per step.)
     BASELINE configs[2]'s shape (obs 8 / act 4 / 2x256, synthetic env) at num_envs = 1024 — 32 tiles per launch, so the multi-tile
     paths of the layer-wise kernels run (chunked weight gradients, several blocks per GEMM) — for one whole iteration against the
     oracle at the north_star bar: actions and permutation bit-equal, advantages / losses within 1e-5 relative, parameters within 1e-5
