@@ -2500,8 +2500,8 @@ static int wide_backward_fused(crl_ppo* h, const int32_t* perm, int M) {
   else hipLaunchKernelGGL((wide_fused_bwd_kernel<16, 8>), dim3(nb, 2), dim3(512), lds, h->stream, a[0], a[1]);
   CRL_HIP_CHECK(hipGetLastError());
   w->fb_blocks = nb;
-  // The dW3 sweeps over h2 depend on the loss kernel only, like the fused backward: they run on the second stream beside it (small blocks
-  // that fit next to the backward's one block per CU) and join before the weight-gradient launch.
+  // The dW3 sweeps over h2 depend on the loss kernel only, like the fused backward: they run on the second stream beside it and join at
+  // the end of this function.
   const bool side = opt(h, OPT_SHUFFLE_OVERLAP) != 0;
   hipStream_t sk = side ? h->stream2 : h->stream;
   if (side) CRL_HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));   // ev_fork was recorded behind the loss kernel (wide_grad_passes)
@@ -2521,7 +2521,6 @@ static int wide_backward_fused(crl_ppo* h, const int32_t* perm, int M) {
       CRL_HIP_CHECK(hipGetLastError());
     }
   }
-  if (side) { CRL_HIP_CHECK(hipEventRecord(h->ev_join, h->stream2)); CRL_HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_join, 0)); }
   if (wide_h1_free(h) && !opt(h, OPT_WIDE_WGRAD_FULL)) {
     // h1 regenerated inside wide_wgrad_x2_kernel's own structure (256 x 128 tiles, two blocks per CU: the stream of δ2 hides under the other block)
     for (int net = 0; net < 2; ++net) {
@@ -2546,6 +2545,10 @@ static int wide_backward_fused(crl_ppo* h, const int32_t* perm, int M) {
     else hipLaunchKernelGGL((wide_wgrad_gen_kernel<16>), dim3(w->S2, 2), dim3(512), WG_LDS, h->stream, g[0], g[1]);
     CRL_HIP_CHECK(hipGetLastError());
   }
+  // The dW3 partials are first read by the reduction that follows this function: the join sits behind the weight-gradient launches, so the
+  // sweeps' blocks may fill the tails of BOTH big kernels (each of those owns every CU's registers while its blocks run; joined before the
+  // weight gradient, the two sweeps took 2 x 480 µs on their stream against the backward's 764: the main stream waited for them)
+  if (side) { CRL_HIP_CHECK(hipEventRecord(h->ev_join, h->stream2)); CRL_HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_join, 0)); }
   return 0;
 }
 
