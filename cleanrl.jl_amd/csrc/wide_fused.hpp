@@ -603,7 +603,22 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
       const P2 q = split2(v);
       xhi = q.hi; xlo = q.lo; xinv = i1 * w1un;
     };
-    auto produce = [&](int t, int s, unsigned char* wbuf, unsigned char* xbuf, bool stamp = false) {
+    // Layer 1 of the whole tile — 8 slabs x one fp16x2 product — is issued in ONE burst when the tile's observations are at hand: at that
+    // point (the consumers' epilogue of the previous tile) the matrix pipe is idle, and the slab loop no longer waits 0.36-0.40 µs per slab
+    // for three chained MFMAs queued behind the consumer's 48 (profiles/r04_c3_stamps.txt). 128 registers the producers have to spare.
+    f32x16 hpre[8];
+    auto layer1 = [&]() {
+      P2 bf; bf.hi = xhi; bf.lo = xlo;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const f16x8* wf = reinterpret_cast<const f16x8*>(smx + PC_OFF_W1F) + (s * 2) * 64 + lane;
+        P2 af; af.hi = wf[0]; af.lo = wf[64];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hpre[s][r] = 0.0f;
+        hpre[s] = mfma_x2(af, bf, hpre[s]);
+      }
+    };
+    auto produce = [&](int t, int s, const f32x16& c, unsigned char* wbuf, unsigned char* xbuf, bool stamp = false) {
       // weight slab s: this producer's 8 of the 32 pieces
       const char* g = reinterpret_cast<const char*>(a.Wx2) + (size_t)s * FX_WBYTES + p * 1024;
       const unsigned lds0 = lds_addr_of(wbuf) + p * 1024, voff = lane * 16;
@@ -612,16 +627,6 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
       asm volatile("" ::: "memory");
       if (stamp) CRL_WSTAMP(1, 6);
       // h1 slab: units 32s …, this producer's 32 samples
-      const f16x8* wf = reinterpret_cast<const f16x8*>(smx + PC_OFF_W1F) + (s * 2) * 64 + lane;
-      P2 af; af.hi = wf[0]; af.lo = wf[64];
-      P2 bf; bf.hi = xhi; bf.lo = xlo;
-      f32x16 c;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) c[r] = 0.0f;
-      c = mfma_x2(af, bf, c);
-#ifdef CRL_EXP_WSTAMPS
-      if (stamp) { asm volatile("v_mov_b32 %0, %0" : "+v"(c[0])); asm volatile("s_nop 0" ::: "memory"); CRL_WSTAMP(1, 7); }
-#endif
       const float* b1l = reinterpret_cast<const float*>(smx + PC_OFF_B1) + 32 * s + 4 * hf;
       _Float16* Xl = reinterpret_cast<_Float16*>(xbuf);
       const int gm = t * FX_MB + 32 * p + j;
@@ -644,9 +649,9 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
       }
     };
     float xr[8];
-    if ((int)blockIdx.x < ntiles) { load_x(blockIdx.x, xr); make_xfrag(xr); }
+    if ((int)blockIdx.x < ntiles) { load_x(blockIdx.x, xr); make_xfrag(xr); layer1(); }
     if ((int)blockIdx.x < ntiles) {
-      produce(blockIdx.x, 0, smx, smx + FX_OFF_X);
+      produce(blockIdx.x, 0, hpre[0], smx, smx + FX_OFF_X);
       asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     }
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -655,11 +660,11 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
       const bool st_ = t == (int)(blockIdx.x + 8 * gridDim.x);
       if (st_) CRL_WSTAMP(1, 0);
       if (tn < ntiles) load_x(tn, xr);                                   // the next tile's observations: in flight under the whole tile
-#pragma unroll 1
+#pragma unroll
       for (int s = 0; s < 8; ++s) {
         if (st_) CRL_WSTAMP(1, 8 + s);
         if (s < 7) {
-          produce(t, s + 1, smx + ((s + 1) & 1) * FX_WBYTES, smx + FX_OFF_X + ((s + 1) & 1) * FX_XBYTES, st_ && s == 3);
+          produce(t, s + 1, hpre[(s + 1) & 7], smx + ((s + 1) & 1) * FX_WBYTES, smx + FX_OFF_X + ((s + 1) & 1) * FX_XBYTES, st_ && s == 3);
           if (st_ && s == 3) CRL_WSTAMP(1, 4);
           // the 8 weight pieces have landed (the 4 h1 stores issued behind them may stay in flight); the LDS stores are done
           if (WRITE_H1) asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
@@ -668,9 +673,10 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
         __builtin_amdgcn_s_barrier();
       }
       if (st_) CRL_WSTAMP(1, 1);
-      if (tn < ntiles) {                                                 // the next tile's first slab, under the consumers' epilogue (buffer 0: last read in slab 6)
+      if (tn < ntiles) {                                                 // the next tile's layer 1 and first slab, under the consumers' epilogue (buffer 0: last read in slab 6)
         make_xfrag(xr);
-        produce(tn, 0, smx, smx + FX_OFF_X);
+        layer1();
+        produce(tn, 0, hpre[0], smx, smx + FX_OFF_X);
         asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
       }
       if (st_) CRL_WSTAMP(1, 2);
