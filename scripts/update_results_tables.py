@@ -27,7 +27,7 @@ p = os.path.join(ROOT, "BASELINE.md")
 s = open(p).read()
 a = s.index("| **C4 shape on ONE GPU: nt=65536, k=128** (`bench.py`, N=1; `" + tag + "_bench_n1.json`)")
 b = s.index("| C4 on 8 GPUs | 8 |")
-new = f'''| **C4 shape on ONE GPU: nt=65536, k=128** (`bench.py`, N=1; `{tag}_bench_n1.json`) | 1 | **{g3(n1['value'])}** ({g3(bd['value'])} with `--kernel-breakdown`) | {n1['ms_per_step']:.2f} | {r['avg_launch_ms']:.3f} ms/launch (HIP events; rocprofv3 agrees within its own overhead); `roofline`: **bound valu-issue, {r['valu_instructions_per_launch']/1e6:.1f} M vector instructions per launch (SQ_INSTS_VALU) ÷ {r['avg_launch_ms']:.3f} ms = {r['achieved']:.0f} G/s = {r['frac']:.3f} of 1228.8 G/s** ({r['frac_of_measured_two_wave_ceiling']:.3f} of what two waves per SIMD were measured to sustain on independent FMAs; by the hardware's own busy counters some pipe of a SIMD is busy {valu + mfma - both:.2f} of the time: vector {valu:.2f}, matrix {mfma:.2f}, both {both:.2f}); matrix pipe {r['matrix_pipe']['frac']:.3f} of 2.5 PFLOP/s; f32-equivalent {r['f32_equivalent']['tflops']:.0f} TFLOP/s; **HBM traffic {r['traffic']/1e6:.1f} MB per launch vs 75.5 MB algorithmic** (271.9 MB before a tile's two readers shared an XCD; the rest is the 64-byte record format, which carries 36 bytes) | same-box A/Bs of the round: wave balancing −4.6 % per launch, record prefetch −1.1 %, shuffle rewrite −0.09 ms per iteration, one-launch optimiser step −0.07 ms |
+new = f'''| **C4 shape on ONE GPU: nt=65536, k=128** (`bench.py`, N=1; `{tag}_bench_n1.json`) | 1 | **{g3(n1['value'])}** ({g3(bd['value'])} with `--kernel-breakdown`) | {n1['ms_per_step']:.2f} | {r['avg_launch_ms']:.3f} ms/launch (HIP events; rocprofv3 agrees within its own overhead); `roofline`: **bound valu-issue, {r['valu_instructions_per_launch']/1e6:.1f} M vector instructions per launch (SQ_INSTS_VALU) ÷ {r['avg_launch_ms']:.3f} ms = {r['achieved']:.0f} G/s = {r['frac']:.3f} of 1228.8 G/s** ({r['frac_of_measured_two_wave_ceiling']:.3f} of what two waves per SIMD were measured to sustain on independent FMAs; by the hardware's own busy counters some pipe of a SIMD is busy {valu + mfma - both:.2f} of the time: vector {valu:.2f}, matrix {mfma:.2f}, both {both:.2f}); matrix pipe {r['matrix_pipe']['frac']:.3f} of 2.5 PFLOP/s; f32-equivalent {r['f32_equivalent']['tflops']:.0f} TFLOP/s; **HBM traffic {r['traffic']/1e6:.1f} MB per launch vs 75.5 MB algorithmic** (271.9 MB before a tile's two readers shared an XCD; the rest is the 64-byte record format, which carries 36 bytes) | unchanged kernels this round (the bounded grid barrier and the option table are the only edits of `update.hip`); `update_prio_small` sweep in DESIGN.md §3 |
 | same, `--shuffle bijection` | 1 | {g3(bij[0])} | {bij[1]:.2f} | same | slower than the exact shuffle: its advantage sums gather through the permutation |
 | same, `--minibatches 1` | 1 | {g3(mb1[0])} | {mb1[1]:.2f} | {mb1[2]:.2f} ms/launch (M = 8,388,608) | north_star's one gradient message per epoch |
 | same, `--opt gemm=1` (bf16x3 products — the flavour a launch falls back to by itself when a weight leaves the fp16 window) | 1 | {g3(x3[0])} | {x3[1]:.2f} | {x3[2]:.3f} ms/launch | |
@@ -35,14 +35,29 @@ new = f'''| **C4 shape on ONE GPU: nt=65536, k=128** (`bench.py`, N=1; `{tag}_be
 | nt=16384 (share at N=4) | 1 | {g3(e16[0])} | {e16[1]:.2f} | {e16[2]*1e3:.0f} µs/launch | |
 | nt=8192 (share at N=8) | 1 | {g3(e8[0])} (×8 ideal {g3(e8[0]*8)} before the 16 + 1 all-reduces) | {e8[1]:.2f} | {e8[2]*1e3:.0f} µs/launch | breakdown (ms, events around every kernel): update {k8['update']:.2f} · rollout {k8['rollout']:.2f} · reduce + optimiser (one launch) {k8['reduce']+k8['optim']:.2f} · shuffle {k8['shuffle']:.2f} · pack {k8['pack']:.2f} · advantage sums {k8['adv_stats']:.2f}; with a communicator the two-launch path runs (0.33) |
 | **C2: nt=4096** (`bench.py --workload c2`, also a `--suite` sub-record) | 1 | **{g3(c2[0])}** | {c2[1]:.2f} | {c2[2]*1e3:.0f} µs/launch (four tiles per wave, launch floor ≈17 µs) | BASELINE configs[1] |
-| **C3: obs 8 / act 4 / 2×256, nt=16384** (`bench.py --workload c3`) | 1 | **{g3(c3d['value'])}** | {c3d['ms_per_step']:.1f} (63.0 at the start of the round on the same pool) | layer-wise GEMMs: {c3r['avg_launch_ms']:.2f} ms per minibatch = {c3r['achieved']:.0f} TFLOP/s issued to the f16 pipe = {c3r['frac']:.3f} of 2.5 PFLOP/s ({c3r['f32_equivalent']['tflops']:.0f} TFLOP/s f32-equivalent); counters and what bounds it: DESIGN.md §3b | full-iteration oracle parity at 1024 envs at 1e-5 (`tests/test_gpu_wide.py`) |
+| **C3: obs 8 / act 4 / 2×256, nt=16384** (`bench.py --workload c3`) | 1 | **{g3(c3d['value'])}** | {c3d['ms_per_step']:.1f} (59.1 for the round-3 pipeline; the bench line is from the box of the round's measurement set, same-box A/Bs in DESIGN.md §3b) | layer-wise GEMMs: {c3r['avg_launch_ms']:.2f} ms per minibatch = {c3r['achieved']:.0f} TFLOP/s issued to the f16 pipe = {c3r['frac']:.3f} of 2.5 PFLOP/s ({c3r['f32_equivalent']['tflops']:.0f} TFLOP/s f32-equivalent); counters and what bounds it: DESIGN.md §3b | full-iteration oracle parity at 1024 envs at 1e-5 (`tests/test_gpu_wide.py`) |
 '''
 s = s[:a] + new + s[b:]
 rf, pf = L("bench_n1_rccl_forced.json")["value"], L("bench_n1_peer_forced.json")["value"]
 s = re.sub(r"\(`" + tag + r"_bench_n1_rccl_forced.json` [0-9.e]+, `" + tag + r"_bench_n1_peer_forced.json` [0-9.e]+\)",
-           f"(`{tag}_bench_n1_rccl_forced.json` {g3(rf)}, `{tag}_bench_n1_peer_forced.json` {g3(pf)})", s)
+           f"(`{tag}_bench_n1_rccl_forced.json` {g3(rf)}, `{tag}_bench_n1_peer_forced.json` {g3(pf)})", s, count=1)
 s = re.sub(r"update [0-9.]+ \(16 × [0-9.]+\) · rollout with the GAE tail [0-9.]+ and pack [0-9.]+ ∥ the four\nepochs' shuffles [0-9.]+",
-           f"update {k['update']:.2f} (16 × {k['update']/16:.3f}) · rollout with the GAE tail {k['rollout']:.2f} and pack {k['pack']:.2f} ∥ the four\nepochs' shuffles {k['shuffle']:.2f}", s)
+           f"update {k['update']:.2f} (16 × {k['update']/16:.3f}) · rollout with the GAE tail {k['rollout']:.2f} and pack {k['pack']:.2f} ∥ the four\nepochs' shuffles {k['shuffle']:.2f}", s, count=1)
+# GAE table (profiles/<tag>_gae_sizes.txt), first table of the file = the current round's
+rows = [json.loads(x) for x in open(P("gae_sizes.txt")) if x.startswith("{")]
+tab = "".join(f"| {d['nt']} | {d['cold_us']:.1f} ({d['cold_frac']:.2f}) | {d['cold_nt_us']:.1f} ({d['cold_nt_frac']:.2f}) | {d['warm_us']:.1f} ({d['warm_frac']:.2f}) | {d['copy_us']:.1f} | "
+              f"{d['cold_over_copy']:.2f} · {d['cold_nt_over_copy']:.2f} |\n" for d in rows)
+s = re.sub(r"(\| num_envs \(× 128 steps\) \|[^\n]*\n\|---[^\n]*\n)(?:\| [0-9]+ \|[^\n]*\n)+", lambda m: m.group(1) + tab, s, count=1)
+cb = n1["cpu_baseline"]; bt = cb.get("batched") or {}; bc = (n1.get("roofline_gae") or {}).get("beyond_cache") or {}
+sf, rb = n1.get("strict_f32") or {}, n1.get("with_stats_readback") or {}
+line = (f"CPU baseline (`cpu_baseline` of the line): {g3(cb['value'])} env-steps/s — the OpenMP parity oracle (`kind: \"port\"`, scalar strided C in the reference's operation order) on the "
+        f"{cb['cores']} cores the box's cgroup allows; `batched` {g3(bt.get('value', 0))} — the same loop with network passes batched over 64-sample blocks and vectorised (`oracle/ppo_cpu_batched.c`, "
+        f"`-O3 -march=native`, built on the box); {g3(cb['single_thread']['value'])} single-threaded at C1. The reference itself (Julia / Flux on BLAS) cannot run here.\n"
+        f"Also in the default line: `strict_f32` (bf16x3 products, 24-bit operands) {g3(sf.get('value', 0))} env-steps/s, {sf.get('ms_per_step', 0):.2f} ms; `with_stats_readback` (loss records and episode "
+        f"statistics read back after every update, as `ppo()` does) {g3(rb.get('value', 0))}, {rb.get('ms_per_step', 0):.2f} ms; `roofline.frac_rocprof` {r.get('frac_rocprof') or 0:.3f} "
+        f"(the same fraction on rocprofv3's clock); `roofline_gae.beyond_cache`: the streaming scan on {bc.get('bytes_per_launch', 0)/1e9:.2f} GB at {bc.get('frac', 0):.2f} of 8 TB/s = "
+        f"{bc.get('over_copy', 0):.2f} of a hand-written float4 copy of the same bytes.")
+s = re.sub(r"CPU baseline[^\n]*\n[^\n]*single-threaded at C1\.[^\n]*(?:\nAlso in the default line:[^\n]*)?", lambda m: line, s, count=1)
 open(p, "w").write(s)
 
 p = os.path.join(ROOT, "README.md")
@@ -52,9 +67,5 @@ t = re.sub(r"[0-9.]+e7 env-steps/s at 16384 envs × 2×256", f"{c3d['value']/1e7
 t = re.sub(r"BASELINE's 4096-env CartPole config runs at [0-9.]+e8", f"BASELINE's 4096-env CartPole config runs at {c2[0]/1e8:.1f}e8", t)
 open(p, "w").write(t)
 
-p = os.path.join(ROOT, "DESIGN.md")
-t = open(p).read()
-t = re.sub(r"\| [0-9.]+e8 \([0-9.]+ ms\), BASELINE.md §5;", f"| {n1['value']/1e8:.2f}e8 ({n1['ms_per_step']:.2f} ms), BASELINE.md §5;", t)
-t = re.sub(r"\| \*\*[0-9.]+ ms\*\*: 128 samples per block", f"| **{c3d['ms_per_step']:.1f} ms**: 128 samples per block", t)
-open(p, "w").write(t)
+# (DESIGN.md's round tables are written by hand: they quote same-box A/B figures, not the measurement set's)
 print(f"{tag}: {g3(n1['value'])} env-steps/s, {n1['ms_per_step']:.2f} ms, update {r['avg_launch_ms']:.4f} ms/launch, pipes busy {valu + mfma - both:.2f}")
