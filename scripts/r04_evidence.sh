@@ -12,7 +12,8 @@ hdr() { echo "# $1"; echo "# csrc sha256/12 = $HASH, $(date -u +%Y-%m-%dT%H:%MZ)
 { hdr "in-kernel timelines of the fused 2x256 kernels (variant build -DCRL_EXP_WSTAMPS; s_memrealtime stamps, 100 MHz)"
   export CRL_LIB_PATH=$R/cleanrl.jl_amd/variants/wstamps/libcleanrl_hip.so
   echo "== producer/consumer forward (scripts/wstamps_pc.py)"; timeout 200 python scripts/wstamps_pc.py
-  echo "== backward (scripts/wstamps_probe.py)"; timeout 200 python scripts/wstamps_probe.py
+  echo "== backward (scripts/wstamps_probe.py) — NOTE: this kernel has no registers to spare: the stamped build spills and runs ~2x slower than production (46 vs 23 us per tile);"
+  echo "   the proportions are indicative only, the reliable breakdown is scripts/ablate_bwd.sh (timing ablations of the production build)"; timeout 200 python scripts/wstamps_probe.py
   unset CRL_LIB_PATH; } > $O/r04_c3_stamps.txt 2>&1
 { hdr "in-kernel timeline of update_x2_kernel (variant build -DCRL_EXP_STAMPS) at the headline and shard sizes"
   export CRL_LIB_PATH=$R/cleanrl.jl_amd/variants/stamps/libcleanrl_hip.so

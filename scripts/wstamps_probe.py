@@ -25,6 +25,8 @@ for k, name in enumerate(("forward", "backward")):
     s = st[k]
     ok = (s[:, :, 0] > 0).all(axis=1)
     s = s[ok]
+    if len(s) == 0:
+        continue   # (the symmetric forward kernel is not the default any more: no stamps of it)
     us = (s - s[:, :, :1].min(axis=1, keepdims=True)) / 100.0     # per block: from its first wave's entry
     print(f"{name}: {len(s)} blocks (first tile of each); median over blocks, us since the block's first wave entered the tile")
     for g, nm in ((slice(0, 4), "waves 0-3 (sg 0: stage then compute)"), (slice(4, 8), "waves 4-7 (sg 1: compute then stage)")):
