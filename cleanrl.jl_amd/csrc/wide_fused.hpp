@@ -630,20 +630,38 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
       const float* b1l = reinterpret_cast<const float*>(smx + PC_OFF_B1) + 32 * s + 4 * hf;
       _Float16* Xl = reinterpret_cast<_Float16*>(xbuf);
       const int gm = t * FX_MB + 32 * p + j;
+      // sixteen independent chains, written stage by stage: per group of four (bias load, tanh, split, store) the compiler keeps the groups
+      // in order — it cannot tell the LDS stores from the next group's bias load — and a lone wave beside a multiplying partner then waits out
+      // every link of a 9-deep chain that is only 4 wide
+      f32x4 bv[4];
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {                                   // registers 4q4 … 4q4 + 3 = units 32s + 8q4 + 4hf + {0..3}
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(b1l + 8 * q4);
-        f32x4 hv;
+      for (int q4 = 0; q4 < 4; ++q4) bv[q4] = *reinterpret_cast<const f32x4*>(b1l + 8 * q4);   // registers 4q4 … 4q4 + 3 = units 32s + 8q4 + 4hf + {0..3}
+      float tt[16];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) hv[e] = tanh_exp2_arg(__builtin_fmaf(c[4 * q4 + e], xinv, bv[e]), X2_ACT_SCALE);
-        uint2 hh, ll;
-        split2x4(hv, 1.0f, hh, ll);
-        *reinterpret_cast<uint2*>(Xl + (32 * p + j) * X3ROW + 8 * q4 + 4 * hf) = hh;
-        *reinterpret_cast<uint2*>(Xl + FX_MB * X3ROW + (32 * p + j) * X3ROW + 8 * q4 + 4 * hf) = ll;
-        if (WRITE_H1) {
+      for (int i = 0; i < 16; ++i) tt[i] = __builtin_fmaf(c[i], xinv, bv[i >> 2][i & 3]);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) tt[i] = __builtin_amdgcn_exp2f(tt[i]);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) tt[i] = __builtin_amdgcn_rcpf(tt[i] + 1.0f);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) tt[i] = __builtin_fmaf(-2.0f * X2_ACT_SCALE, tt[i], X2_ACT_SCALE);   // tanh_exp2_arg, stage by stage
+      uint2 hh[4], ll[4];
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        f32x4 hv; hv[0] = tt[4 * q4]; hv[1] = tt[4 * q4 + 1]; hv[2] = tt[4 * q4 + 2]; hv[3] = tt[4 * q4 + 3];
+        split2x4(hv, 1.0f, hh[q4], ll[q4]);
+      }
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        *reinterpret_cast<uint2*>(Xl + (32 * p + j) * X3ROW + 8 * q4 + 4 * hf) = hh[q4];
+        *reinterpret_cast<uint2*>(Xl + FX_MB * X3ROW + (32 * p + j) * X3ROW + 8 * q4 + 4 * hf) = ll[q4];
+      }
+      if (WRITE_H1) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
           f32x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = hv[e] * (1.0f / X2_ACT_SCALE);
+          for (int e = 0; e < 4; ++e) o[e] = tt[4 * q4 + e] * (1.0f / X2_ACT_SCALE);
           *reinterpret_cast<f32x4*>(a.H1 + (size_t)256 * gm + 32 * s + 8 * q4 + 4 * hf) = o;
         }
       }
