@@ -756,7 +756,13 @@ static int dense_x3_launch(hipStream_t st, const DenseX3Args& a) {
 __device__ __forceinline__ void split2x4(const f32x4 v, float s, uint2& h, uint2& l) {
   f32x2 a, b; a[0] = v[0] * s; a[1] = v[1] * s; b[0] = v[2] * s; b[1] = v[3] * s;
   const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
-  f32x2 ra, rb; ra[0] = a[0] - (float)ha[0]; ra[1] = a[1] - (float)ha[1]; rb[0] = b[0] - (float)hb[0]; rb[1] = b[1] - (float)hb[1];
+  // x − float(hi) as ONE v_fma_mix_f32 per value (as split2 of mlp_x2.hpp: the compiler's own form is v_cvt_f32_f16 + v_sub_f32)
+  f32x2 ra, rb;
+  const uint32_t hab = __builtin_bit_cast(uint32_t, ha), hbb = __builtin_bit_cast(uint32_t, hb);
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra[0]) : "v"(hab), "v"(a[0]));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(ra[1]) : "v"(hab), "v"(a[1]));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(rb[0]) : "v"(hbb), "v"(b[0]));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb[1]) : "v"(hbb), "v"(b[1]));
   const f16x2 la = __builtin_convertvector(ra, f16x2), lb = __builtin_convertvector(rb, f16x2);
   h = make_uint2(__builtin_bit_cast(uint32_t, ha), __builtin_bit_cast(uint32_t, hb));
   l = make_uint2(__builtin_bit_cast(uint32_t, la), __builtin_bit_cast(uint32_t, lb));
