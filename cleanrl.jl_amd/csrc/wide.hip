@@ -1816,8 +1816,8 @@ __global__ void __launch_bounds__(512, 4) wide_rollout_persist_kernel(WRollArgs 
 // when num_envs is a multiple of 64). wide_rollout_persist_kernel walks 16 weight slabs per step through registers with two barriers
 // each and a fetch distance of one short MFMA phase: 52 µs per step at C3, almost all of it L2 latency. Here a block owns 64 envs and
 //   waves 0-3  multiply: rows 64c … 64c + 63 x 64 envs (2 x 2 accumulator tiles), then tanh + head partials; wave 0 also steps the envs;
-//   waves 4-5  make the next h1 slab (layer 1 as ONE fp16x2 product per 32 x 32 tile, tanh, split) for 32 envs each;
-//   waves 6-7  bring the next 32 KB weight slab by LDS-DMA (16 pieces each);
+//   waves 4-7  bring the next 32 KB weight slab by LDS-DMA (8 pieces each) and make the next h1 slab (layer 1 as ONE fp16x2 product per
+//              32 x 32 tile — computed by both waves of a pair, each of which then finishes half of it: tanh, split, LDS stores);
 // one barrier per slab, actor then critic, the critic's first slab prepared under the actor's epilogue. Nothing but the logits / values
 // (for wide_step_env) and the rollout buffer leaves the CU. The actor keeps the reference's rational tanh_fast in both layers; its layer 1
 // is now an fp16x2 product like its layer 2 (action indices equal the oracle's away from CDF knots — the margin rule of the parity tests).
@@ -1856,14 +1856,17 @@ __global__ void __launch_bounds__(512) wide_rollout_pc_kernel(RollPCArgs r) {
     // ------------------------------------------------------------------------------------------------ producers
     const int p = wave - 4;
     f16x8 xhi, xlo; float xi1 = 0.0f;
+    // every producer: 8 of the slab's 32 weight pieces, and HALF of an h1 tile (envs 32·(p & 1) …, registers 8·(p >> 1) … of the 32 x 32
+    // product, which both waves of a pair compute — three MFMAs are cheaper than the 8 rational tanh they spare each wave)
+    const int pt = p & 1, ph = p >> 1;
     auto produce = [&](int net, int s, unsigned char* wbuf, unsigned char* xbuf) {
-      if (p >= 2) {                                                      // weight slab s: 16 of its 32 pieces
-        const char* g = reinterpret_cast<const char*>(r.n[net].Wx2) + (size_t)s * FX_WBYTES + (p - 2) * 16384;
-        const unsigned lds0 = lds_addr_of(wbuf) + (p - 2) * 16384, voff = lane * 16;
+      {
+        const char* g = reinterpret_cast<const char*>(r.n[net].Wx2) + (size_t)s * FX_WBYTES + p * 8192;
+        const unsigned lds0 = lds_addr_of(wbuf) + p * 8192, voff = lane * 16;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) lds_dma16(g + i * 1024, voff, lds0 + i * 1024);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      } else {                                                           // h1 slab: units 32s …, envs 32p …
+        for (int i = 0; i < 8; ++i) lds_dma16(g + i * 1024, voff, lds0 + i * 1024);
+      }
+      {
         const unsigned char* tab = smx + RP_OFF_W1F + net * RP_W1F_BYTES;
         const f16x8* wf = reinterpret_cast<const f16x8*>(tab) + (s * 2) * 64 + lane;
         P2 af; af.hi = wf[0]; af.lo = wf[64];
@@ -1877,27 +1880,29 @@ __global__ void __launch_bounds__(512) wide_rollout_pc_kernel(RollPCArgs r) {
         _Float16* Xl = reinterpret_cast<_Float16*>(xbuf);
         const bool rat = r.n[net].rat != 0;
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {                                 // registers 4q4 … 4q4 + 3 = units 32s + 8q4 + 4hf + {0..3}
+        for (int qq = 0; qq < 2; ++qq) {                                 // registers 4q4 … 4q4 + 3 = units 32s + 8q4 + 4hf + {0..3}
+          const int q4 = 2 * ph + qq;
           const f32x4 bv = *reinterpret_cast<const f32x4*>(b1l + 8 * q4);
           f32x4 hv;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float t = __builtin_fmaf(c[4 * q4 + e], xinv, bv[e]);   // 2·log2(e)·(W1·x + b1)
+            const float cv = ph ? c[8 + 4 * qq + e] : c[4 * qq + e];
+            const float t = __builtin_fmaf(cv, xinv, bv[e]);               // 2·log2(e)·(W1·x + b1)
             hv[e] = rat ? tanh_fast(t * INV_TWO_LOG2E) * X2_ACT_SCALE : tanh_exp2_arg(t, X2_ACT_SCALE);
           }
           uint2 hh, ll;
           split2x4(hv, 1.0f, hh, ll);
-          *reinterpret_cast<uint2*>(Xl + (32 * p + j) * X3ROW + 8 * q4 + 4 * hf) = hh;
-          *reinterpret_cast<uint2*>(Xl + RP_MB * X3ROW + (32 * p + j) * X3ROW + 8 * q4 + 4 * hf) = ll;
+          *reinterpret_cast<uint2*>(Xl + (32 * pt + j) * X3ROW + 8 * q4 + 4 * hf) = hh;
+          *reinterpret_cast<uint2*>(Xl + RP_MB * X3ROW + (32 * pt + j) * X3ROW + 8 * q4 + 4 * hf) = ll;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     };
 #pragma unroll 1
     for (int step = 0; step < nsteps; ++step) {
       __builtin_amdgcn_s_barrier();                                      // B_obs: the envs have been stepped
-      if (p < 2) {
-        const int gm = m0 + 32 * p + j;
+      {
+        const int gm = m0 + 32 * pt + j;
         float xr[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) { const int cc = 8 * hf + q; xr[q] = (cc < r.D && cc < DP) ? r.s.cur_obs[(size_t)gm * r.D + cc] : 0.0f; }
