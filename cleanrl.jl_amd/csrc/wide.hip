@@ -1859,7 +1859,22 @@ __global__ void __launch_bounds__(512) wide_rollout_pc_kernel(RollPCArgs r) {
     // every producer: 8 of the slab's 32 weight pieces, and HALF of an h1 tile (envs 32·(p & 1) …, registers 8·(p >> 1) … of the 32 x 32
     // product, which both waves of a pair compute — three MFMAs are cheaper than the 8 rational tanh they spare each wave)
     const int pt = p & 1, ph = p >> 1;
-    auto produce = [&](int net, int s, unsigned char* wbuf, unsigned char* xbuf) {
+    // layer 1 of a network for the whole step (8 slabs) in one burst while the matrix pipe is idle — the env step for the actor, the actor's
+    // epilogue for the critic — as in wide_fused_fwd_pc_kernel
+    f32x16 hpre[8];
+    auto layer1 = [&](int net) {
+      const unsigned char* tab = smx + RP_OFF_W1F + net * RP_W1F_BYTES;
+      P2 bf; bf.hi = xhi; bf.lo = xlo;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const f16x8* wf = reinterpret_cast<const f16x8*>(tab) + (s * 2) * 64 + lane;
+        P2 af; af.hi = wf[0]; af.lo = wf[64];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) hpre[s][q] = 0.0f;
+        hpre[s] = mfma_x2(af, bf, hpre[s]);
+      }
+    };
+    auto produce = [&](int net, int s, const f32x16& c, unsigned char* wbuf, unsigned char* xbuf) {
       {
         const char* g = reinterpret_cast<const char*>(r.n[net].Wx2) + (size_t)s * FX_WBYTES + p * 8192;
         const unsigned lds0 = lds_addr_of(wbuf) + p * 8192, voff = lane * 16;
@@ -1868,13 +1883,6 @@ __global__ void __launch_bounds__(512) wide_rollout_pc_kernel(RollPCArgs r) {
       }
       {
         const unsigned char* tab = smx + RP_OFF_W1F + net * RP_W1F_BYTES;
-        const f16x8* wf = reinterpret_cast<const f16x8*>(tab) + (s * 2) * 64 + lane;
-        P2 af; af.hi = wf[0]; af.lo = wf[64];
-        P2 bf; bf.hi = xhi; bf.lo = xlo;
-        f32x16 c;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) c[q] = 0.0f;
-        c = mfma_x2(af, bf, c);
         const float xinv = xi1 * r.n[net].w1sc[1];
         const float* b1l = reinterpret_cast<const float*>(tab + 16384) + 32 * s + 4 * hf;
         _Float16* Xl = reinterpret_cast<_Float16*>(xbuf);
@@ -1918,16 +1926,17 @@ __global__ void __launch_bounds__(512) wide_rollout_pc_kernel(RollPCArgs r) {
         const P2 q2 = split2(v);
         xhi = q2.hi; xlo = q2.lo;
       }
-      produce(0, 0, smx, smx + RP_OFF_X);
+      layer1(0);
+      produce(0, 0, hpre[0], smx, smx + RP_OFF_X);
 #pragma unroll 1
       for (int net = 0; net < 2; ++net) {
         __builtin_amdgcn_s_barrier();                                    // B_start
-#pragma unroll 1
+#pragma unroll
         for (int s = 0; s < 8; ++s) {
-          if (s < 7) produce(net, s + 1, smx + ((s + 1) & 1) * FX_WBYTES, smx + RP_OFF_X + ((s + 1) & 1) * RP_XBYTES);
+          if (s < 7) produce(net, s + 1, hpre[(s + 1) & 7], smx + ((s + 1) & 1) * FX_WBYTES, smx + RP_OFF_X + ((s + 1) & 1) * RP_XBYTES);
           __builtin_amdgcn_s_barrier();
         }
-        if (net == 0) produce(1, 0, smx, smx + RP_OFF_X);                // the critic's first slab, under the actor's epilogue
+        if (net == 0) { layer1(1); produce(1, 0, hpre[0], smx, smx + RP_OFF_X); }   // the critic's layer 1 and first slab, under the actor's epilogue
         __builtin_amdgcn_s_barrier();                                    // B_epi
       }
       __builtin_amdgcn_s_barrier();                                      // B_fold
