@@ -150,14 +150,14 @@ void wide_mark_params_changed(crl_ppo* h) {
 // Weight packing: W1 → [H × D8] (zero columns beyond obs_dim), W3 → [32 × H] (zero rows beyond n_out),
 // W2ᵀ [H × H], W3ᵀ → [H × O8]. W2 itself is used in place (it already is H × H column-major).
 // ------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) wide_pack_kernel(const float* __restrict__ params, float* __restrict__ pack, int H, int D,
-                                                       int D8, int NO, int O8, int pbase, int kbase, WideNetPack pk) {
+__device__ __forceinline__ void wide_pack_body(int bx, int nbx, const float* __restrict__ params, float* __restrict__ pack, int H, int D,
+                                               int D8, int NO, int O8, int pbase, int kbase, WideNetPack pk) {
   const float* W1 = params + pbase;
   const float* W2 = W1 + H * D + H;
   const float* W3 = W2 + H * H + H;
   float* o = pack + kbase;
   const int total = pk.x3f;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+  for (int i = bx * blockDim.x + threadIdx.x; i < total; i += nbx * blockDim.x) {
     float val;
     if (i < pk.w3) { const int n = i % H, k = i / H; val = k < D ? W1[n + H * k] : 0.0f; }
     else if (i < pk.w2t) { const int q = i - pk.w3; const int a = q & 31, k = q >> 5; val = a < NO ? W3[a + NO * k] : 0.0f; }
@@ -165,6 +165,10 @@ __global__ void __launch_bounds__(256) wide_pack_kernel(const float* __restrict_
     else { const int q = i - pk.w3t; const int k = q % H, a = q / H; val = a < NO ? W3[a + NO * k] : 0.0f; }
     o[i] = val;
   }
+}
+__global__ void __launch_bounds__(256) wide_pack_kernel(const float* __restrict__ params, float* __restrict__ pack, int H, int D,
+                                                       int D8, int NO, int O8, int pbase, int kbase, WideNetPack pk) {
+  wide_pack_body(blockIdx.x, gridDim.x, params, pack, H, D, D8, NO, O8, pbase, kbase, pk);
 }
 
 // bf16x3 A-fragments of W2 (dir 0: rows = outputs) and W2ᵀ (dir 1: rows = inputs) for wide_dense_x3_kernel:
@@ -191,16 +195,16 @@ __global__ void __launch_bounds__(256) wide_pack_x3_kernel(const float* __restri
 // The power of two the 256-wide fp16x2 weight pieces are staged with: largest |w|·scale lands in [2^14, 2^15), so W2 fits the fp16
 // window whatever its magnitude (the fused 64-wide kernels use a fixed 2^8 and fall back to bf16x3 for |w| >= 255; round 2 raised an
 // error here instead). A power of two is exact, and the GEMM epilogues take it back out of the f32 accumulator (DenseX3Args::wsc).
-__global__ void __launch_bounds__(1024) wide_w2scale_kernel(const float* __restrict__ W2, int n, float* __restrict__ wsc) {
+__device__ __forceinline__ void wide_w2scale_body(const float* __restrict__ W2, int n, float* __restrict__ wsc) {
   __shared__ float sm[16];
   float m = 0.0f;
-  for (int i = threadIdx.x; i < n; i += 1024) m = __builtin_fmaxf(m, __builtin_fabsf(W2[i]));
+  for (int i = threadIdx.x; i < n; i += blockDim.x) m = __builtin_fmaxf(m, __builtin_fabsf(W2[i]));
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < 16; ++w) m = __builtin_fmaxf(m, sm[w]);
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = __builtin_fmaxf(m, sm[w]);
     int e = (int)((__float_as_uint(m) >> 23) & 0xFFu);          // biased exponent: m in [2^(e-127), 2^(e-126))
     if (!(m > 0.0f) || e >= 255) e = 127 + 6;                   // all zero / non-finite weights: 2^8 as in the fused kernels
     e = e < 40 ? 40 : (e > 220 ? 220 : e);
@@ -208,11 +212,12 @@ __global__ void __launch_bounds__(1024) wide_w2scale_kernel(const float* __restr
     wsc[1] = __uint_as_float((unsigned)(e - 14) << 23);               // its inverse
   }
 }
+__global__ void __launch_bounds__(1024) wide_w2scale_kernel(const float* __restrict__ W2, int n, float* __restrict__ wsc) { wide_w2scale_body(W2, n, wsc); }
 // fp16x2 A-fragments of W2·scale / W2ᵀ·scale (same fragment order as wide_pack_x3_kernel, two pieces)
-__global__ void __launch_bounds__(256) wide_pack_x2_kernel(const float* __restrict__ params, float* __restrict__ pack, int pbase,
-                                                          int kbase, WideNetPack pk, const float* __restrict__ wsc) {
+__device__ __forceinline__ void wide_pack_x2_body(int bx, const float* __restrict__ params, float* __restrict__ pack, int pbase,
+                                                  int kbase, WideNetPack pk, const float* __restrict__ wsc) {
   constexpr int H = 256;
-  const int t = blockIdx.x * 256 + threadIdx.x;          // (dir, s, kstep, ntile, lane)
+  const int t = bx * 256 + threadIdx.x;          // (dir, s, kstep, ntile, lane)
   if (t >= 2 * 8 * 2 * 8 * 64) return;
   const int lane = t & 63, ntile = (t >> 6) & 7, kstep = (t >> 9) & 1, sl = (t >> 10) & 7, dir = t >> 13;
   const int n = 32 * ntile + (lane & 31), k0 = 32 * sl + 16 * kstep + 8 * (lane >> 5);
@@ -230,9 +235,13 @@ __global__ void __launch_bounds__(256) wide_pack_x2_kernel(const float* __restri
   reinterpret_cast<f16x8*>(dst)[0 * 1024 + fr] = p2.hi;
   reinterpret_cast<f16x8*>(dst)[1 * 1024 + fr] = p2.lo;
 }
+__global__ void __launch_bounds__(256) wide_pack_x2_kernel(const float* __restrict__ params, float* __restrict__ pack, int pbase,
+                                                          int kbase, WideNetPack pk, const float* __restrict__ wsc) {
+  wide_pack_x2_body(blockIdx.x, params, pack, pbase, kbase, pk, wsc);
+}
 // wmax[a] = max_k |W3[a, k]|: with it Σ_a |δ3[a, m]|·wmax[a] bounds every |δ2[k, m]| of a sample — the per-sample (backward-
 // data) and per-chunk (weight-gradient) fp16x2 scales come from this bound, no pass over δ2 needed
-__global__ void __launch_bounds__(64) wide_wmax_kernel(const float* __restrict__ W3, int NO, int H, float* __restrict__ wmax) {
+__device__ __forceinline__ void wide_wmax_body(const float* __restrict__ W3, int NO, int H, float* __restrict__ wmax) {   // one wave
   for (int a = 0; a < AMAX; ++a) {
     float m = 0.0f;
     if (a < NO) for (int k = threadIdx.x; k < H; k += 64) m = __builtin_fmaxf(m, __builtin_fabsf(W3[a + NO * k]));
@@ -241,6 +250,7 @@ __global__ void __launch_bounds__(64) wide_wmax_kernel(const float* __restrict__
     if (threadIdx.x == 0) wmax[a] = m;
   }
 }
+__global__ void __launch_bounds__(64) wide_wmax_kernel(const float* __restrict__ W3, int NO, int H, float* __restrict__ wmax) { wide_wmax_body(W3, NO, H, wmax); }
 
 // option "wide_gemm": 2 (default) = 256-wide GEMMs as fp16x2 (three f16 MFMAs per product), 1 = bf16x3 (six; the fallback
 // flavour without range limits), 0 = every GEMM on v_mfma_f32_32x32x2_f32
@@ -251,9 +261,32 @@ bool wide_x2_active(const crl_ppo* h) { return h->wide && h->cfg.hidden == 256 &
 __global__ void wide_pack_w1s_kernel(const float* __restrict__ W1, const float* __restrict__ b1, int H, int D, int DP, float* __restrict__ out);
 __global__ void wide_pack_w1f_kernel(const float* __restrict__ W1, const float* __restrict__ b1, int D, const float* __restrict__ w1sc, float* __restrict__ out);
 __global__ void wide_w1scale_kernel(const float* __restrict__ W1, int n, float* __restrict__ w1sc);
+// The 2x256 fp16x2 shape repacks seven images per network after every optimiser step; as fourteen launches of a few microseconds each that
+// was 1.4 ms per C3 iteration. Two launches now (blockIdx.y = network, blockIdx.x selects the job): the scales and everything that does not
+// need them, then the two packs that do.
+struct PrepNet { int pbase; int kbase; WideNetPack pk; int NO; int O8; };
+struct PrepArgs { const float* params; float* pack; float* wsc; PrepNet n[2]; int H, D, D8; int nb_pack, nb_w1s; };
+__global__ void wide_prep_a_kernel(PrepArgs a);
+__global__ void wide_prep_b_kernel(PrepArgs a);
 static int ensure_pack(crl_ppo* h) {
   WideWs* w = static_cast<WideWs*>(h->wide_ws);
   if (!w->pack_dirty) return 0;
+  if (w->H == 256 && wide_x2(h) && w->D <= 16) {
+    PrepArgs a;
+    a.params = h->params; a.pack = w->pack; a.wsc = w->wsc; a.H = w->H; a.D = w->D; a.D8 = w->D8;
+    int nbp = 0;
+    for (int n = 0; n < 2; ++n) {
+      a.n[n].pbase = n ? (int)h->Pa : 0; a.n[n].kbase = w->pk_base[n]; a.n[n].pk = w->pk[n]; a.n[n].NO = n ? 1 : w->A; a.n[n].O8 = n ? 8 : w->A8;
+      const int nb = (w->pk[n].x3f + 255) / 256;
+      if (nb > nbp) nbp = nb;
+    }
+    a.nb_pack = nbp; a.nb_w1s = (w->H * w->D8 + w->H + 255) / 256;
+    hipLaunchKernelGGL(wide_prep_a_kernel, dim3(a.nb_pack + a.nb_w1s + 3, 2), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL(wide_prep_b_kernel, dim3(64 + 2, 2), dim3(256), 0, h->stream, a);
+    CRL_HIP_CHECK(hipGetLastError());
+    w->pack_dirty = false;
+    return 0;
+  }
   for (int n = 0; n < 2; ++n) {
     const int NO = n ? 1 : w->A, O8 = n ? 8 : w->A8;
     hipLaunchKernelGGL(wide_pack_kernel, dim3((w->pk[n].x3f + 255) / 256), dim3(256), 0, h->stream, h->params, w->pack, w->H, w->D,

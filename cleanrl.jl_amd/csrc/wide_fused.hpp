@@ -223,11 +223,15 @@ __global__ void __launch_bounds__(512) wide_fused_fwd_kernel(FusedFwdArgs a0, Fu
 }
 
 // W1·2·log2(e) as [256][DP] rows (zero beyond obs_dim) followed by b1·2·log2(e): what the staging threads read through scalar loads
-__global__ void __launch_bounds__(256) wide_pack_w1s_kernel(const float* __restrict__ W1, const float* __restrict__ b1, int H, int D, int DP,
-                                                            float* __restrict__ out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void wide_pack_w1s_body(int bx, const float* __restrict__ W1, const float* __restrict__ b1, int H, int D, int DP,
+                                                   float* __restrict__ out) {
+  const int i = bx * 256 + threadIdx.x;
   if (i < H * DP) { const int u = i / DP, c = i - u * DP; out[i] = c < D ? W1[u + H * c] * TWO_LOG2E : 0.0f; }
   else if (i < H * DP + H) out[i] = b1[i - H * DP] * TWO_LOG2E;
+}
+__global__ void __launch_bounds__(256) wide_pack_w1s_kernel(const float* __restrict__ W1, const float* __restrict__ b1, int H, int D, int DP,
+                                                            float* __restrict__ out) {
+  wide_pack_w1s_body(blockIdx.x, W1, b1, H, D, DP, out);
 }
 
 }  // namespace crl
@@ -825,9 +829,9 @@ __global__ void __launch_bounds__(512) wide_fused_fwd_pc_kernel(FusedFwdPCArgs a
 // fp16x2 A-fragments of W1·2·log2(e)·scale1 for the producers' layer-1 product — [slab][piece][lane][8]: element e of lane l of slab s is
 // W1[32s + (l & 31)][8 (l >> 5) + e] (zero beyond obs_dim) — followed by b1·2·log2(e) [256] as f32. scale1 (a power of two, w1sc[0]) puts
 // the largest |W1·2·log2 e| into [2^14, 2^15).
-__global__ void __launch_bounds__(256) wide_pack_w1f_kernel(const float* __restrict__ W1, const float* __restrict__ b1, int D, const float* __restrict__ w1sc,
+__device__ __forceinline__ void wide_pack_w1f_body(int bx, const float* __restrict__ W1, const float* __restrict__ b1, int D, const float* __restrict__ w1sc,
                                                             float* __restrict__ out) {
-  const int t = blockIdx.x * 256 + threadIdx.x;          // (slab, lane)
+  const int t = bx * 256 + threadIdx.x;          // (slab, lane)
   if (t < 8 * 64) {
     const int lane = t & 63, s = t >> 6;
     const int u = 32 * s + (lane & 31), k0 = 8 * (lane >> 5);
@@ -840,8 +844,12 @@ __global__ void __launch_bounds__(256) wide_pack_w1f_kernel(const float* __restr
   }
   if (t < 256) out[4096 + t] = b1[t] * TWO_LOG2E;        // 16 KB of fragments = 4096 floats, then the bias table
 }
+__global__ void __launch_bounds__(256) wide_pack_w1f_kernel(const float* __restrict__ W1, const float* __restrict__ b1, int D, const float* __restrict__ w1sc,
+                                                            float* __restrict__ out) {
+  wide_pack_w1f_body(blockIdx.x, W1, b1, D, w1sc, out);
+}
 // scale1 for wide_pack_w1f_kernel from the largest |W1| (same rule as wide_w2scale_kernel, with the 2·log2(e) factor folded in)
-__global__ void __launch_bounds__(256) wide_w1scale_kernel(const float* __restrict__ W1, int n, float* __restrict__ w1sc) {
+__device__ __forceinline__ void wide_w1scale_body(const float* __restrict__ W1, int n, float* __restrict__ w1sc) {
   __shared__ float sm[4];
   float m = 0.0f;
   for (int i = threadIdx.x; i < n; i += 256) m = __builtin_fmaxf(m, __builtin_fabsf(W1[i]) * TWO_LOG2E);
@@ -855,6 +863,29 @@ __global__ void __launch_bounds__(256) wide_w1scale_kernel(const float* __restri
     if (!(m > 0.0f) || !(m < 3.0e38f)) { s1 = 256.0f; i1 = 1.0f / 256.0f; } else pow2_scale(m, s1, i1);
     w1sc[0] = s1; w1sc[1] = i1;
   }
+}
+__global__ void __launch_bounds__(256) wide_w1scale_kernel(const float* __restrict__ W1, int n, float* __restrict__ w1sc) { wide_w1scale_body(W1, n, w1sc); }
+
+// the two merged repack launches of ensure_pack (wide.hip)
+__global__ void __launch_bounds__(256) wide_prep_a_kernel(PrepArgs a) {
+  const PrepNet& q = a.n[blockIdx.y];
+  const int net = blockIdx.y, bx = blockIdx.x, H = a.H;
+  const float* W1 = a.params + q.pbase;
+  const float* W2 = W1 + H * a.D + H;
+  const float* W3 = W2 + H * H + H;
+  float* pk = a.pack + q.kbase;
+  if (bx < a.nb_pack) wide_pack_body(bx, a.nb_pack, a.params, a.pack, H, a.D, a.D8, q.NO, q.O8, q.pbase, q.kbase, q.pk);
+  else if (bx < a.nb_pack + a.nb_w1s) wide_pack_w1s_body(bx - a.nb_pack, W1, W1 + H * a.D, H, a.D, a.D8, pk + q.pk.w1s);
+  else if (bx == a.nb_pack + a.nb_w1s) wide_w2scale_body(W2, H * H, a.wsc + 2 * net);
+  else if (bx == a.nb_pack + a.nb_w1s + 1) wide_w1scale_body(W1, H * a.D, a.wsc + 4 + 2 * net);
+  else if (threadIdx.x < 64) wide_wmax_body(W3, q.NO, H, pk + q.pk.wmax);
+}
+__global__ void __launch_bounds__(256) wide_prep_b_kernel(PrepArgs a) {
+  const PrepNet& q = a.n[blockIdx.y];
+  const int net = blockIdx.y, bx = blockIdx.x, H = a.H;
+  const float* W1 = a.params + q.pbase;
+  if (bx < 64) wide_pack_x2_body(bx, a.params, a.pack, q.pbase + H * a.D + H, q.kbase, q.pk, a.wsc + 2 * net);
+  else wide_pack_w1f_body(bx - 64, W1, W1 + H * a.D, a.D, a.wsc + 4 + 2 * net, a.pack + q.kbase + q.pk.w1f);
 }
 
 }  // namespace crl
