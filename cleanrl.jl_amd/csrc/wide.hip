@@ -198,7 +198,22 @@ __global__ void __launch_bounds__(256) wide_pack_x3_kernel(const float* __restri
 __device__ __forceinline__ void wide_w2scale_body(const float* __restrict__ W2, int n, float* __restrict__ wsc) {
   __shared__ float sm[16];
   float m = 0.0f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) m = __builtin_fmaxf(m, __builtin_fabsf(W2[i]));
+  {   // 16-byte loads, eight in flight per thread (n = 65536: one block of 256 threads walks it in 8 rounds)
+    const f32x4* W4 = reinterpret_cast<const f32x4*>(W2);
+    const int n4 = (reinterpret_cast<size_t>(W2) & 15) ? 0 : (n >> 2), nt = blockDim.x;   // (the critic's W2 starts n_act floats further: scalar loads then)
+    int i = threadIdx.x;
+    for (; i + 7 * nt < n4; i += 8 * nt) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = W4[i + u * nt];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m = __builtin_fmaxf(m, __builtin_fabsf(v[u][e]));
+    }
+    for (; i < n4; i += nt) { const f32x4 v = W4[i]; for (int e = 0; e < 4; ++e) m = __builtin_fmaxf(m, __builtin_fabsf(v[e])); }
+    for (int q = 4 * n4 + threadIdx.x; q < n; q += nt) m = __builtin_fmaxf(m, __builtin_fabsf(W2[q]));
+  }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
