@@ -69,6 +69,7 @@ struct WideWs {
   float *pW1[2] = {nullptr, nullptr}, *pB1[2] = {nullptr, nullptr};
   float* pW3[2] = {nullptr, nullptr};
   double* lpart = nullptr;       // [nlb][WLS]
+  float* wrec = nullptr;         // [B][8]: action (bits), logprob, value, advantage | return, 0, 0, 0 — what the loss kernel reads of a sample, one 32-byte piece
   double* vpart = nullptr;       // [1024]
   double* u_dev = nullptr;       // [0] u (reserved), [1] = double(count) under DP
   int cus = 256;                 // compute units of the device (grid of the persistent fused backward)
@@ -93,7 +94,7 @@ void wide_destroy(crl_ppo* h) {
   WideWs* w = static_cast<WideWs*>(h->wide_ws);
   if (!w) return;
   void* ptrs[] = {w->pack, w->h1[0], w->h1[1], w->h2[0], w->h2[1], w->z, w->v, w->dv8, w->dA, w->dB, w->pW2[0], w->pW2[1],
-                  w->pB2[0], w->pB2[1], w->pW1[0], w->pW1[1], w->pB1[0], w->pB1[1], w->pW3[0], w->pW3[1], w->lpart, w->vpart,
+                  w->pB2[0], w->pB2[1], w->pW1[0], w->pW1[1], w->pB1[0], w->pB1[1], w->pW3[0], w->pW3[1], w->lpart, w->wrec, w->vpart,
                   w->u_dev, w->wsc};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete w;
@@ -135,6 +136,7 @@ int wide_create(crl_ppo* h) {
     rc |= walloc(&w->pW3[n], (size_t)w->Ss * H * NO);
   }
   rc |= walloc(reinterpret_cast<float**>(&w->lpart), (size_t)w->nlb * WLS * 2);
+  rc |= walloc(&w->wrec, (size_t)h->dc.B * 8);
   rc |= walloc(reinterpret_cast<float**>(&w->vpart), 1024 * 2);
   rc |= walloc(reinterpret_cast<float**>(&w->u_dev), 4 * 2);
   if (rc) { wide_destroy(h); return 1; }
@@ -2172,9 +2174,22 @@ __global__ void wide_vcount_to_double_kernel(double* vfix) {
 // ------------------------------------------------------------------------------------------------------
 // Loss terms and output cotangents of one minibatch (ppo.jl:213-244; arithmetic identical to update.hip's tile loop)
 // ------------------------------------------------------------------------------------------------------
+// The loss kernel's view of a sample — five fields of five arrays, fetched through the epoch's permutation — as ONE 32-byte piece, packed
+// when a buffer field changed (h->recs_dirty, the flag the fused path's 64-byte records use): five scattered 4-byte reads dragged five
+// sectors per sample, 64 µs of the 0.52 M-sample launch.
+__global__ void __launch_bounds__(256) wide_pack_rec_kernel(int B, const int32_t* __restrict__ action, const float* __restrict__ logprob,
+                                                           const float* __restrict__ value, const float* __restrict__ adv,
+                                                           const float* __restrict__ ret, float* __restrict__ rec) {
+  for (int b = blockIdx.x * 256 + threadIdx.x; b < B; b += gridDim.x * 256) {
+    f32x4 r0, r1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    r0[0] = __int_as_float(action[b]); r0[1] = logprob[b]; r0[2] = value[b]; r0[3] = adv[b]; r1[0] = ret[b];
+    reinterpret_cast<f32x4*>(rec)[2 * (size_t)b] = r0;
+    reinterpret_cast<f32x4*>(rec)[2 * (size_t)b + 1] = r1;
+  }
+}
 struct WLossArgs {
   DevCfg c; const int32_t* perm; float* Z; int A8; const float* V; float* dv8;
-  const int32_t* actions; const float* logprobs; const float* values; const float* advantages; const float* returns;
+  const float* rec;
   const double* adv_ms; int mb; const double* vfix; double Mglobal; double* lpart;
 };
 
@@ -2195,7 +2210,8 @@ __global__ void __launch_bounds__(256) wide_loss_kernel(WLossArgs a) {
     float z[AMAX], pr[AMAX], lp[AMAX];
     load_logits(a.Z, a.A8, A, (size_t)pos, z);
     softmax_rt(z, A, pr, lp);
-    const int act = a.actions[smp];
+    const f32x4 r0 = reinterpret_cast<const f32x4*>(a.rec)[2 * (size_t)smp], r1 = reinterpret_cast<const f32x4*>(a.rec)[2 * (size_t)smp + 1];
+    const int act = __float_as_int(r0[0]);
     const float nlp = pick_rt(lp, A, act);
     double Hs = 0.0;
 #pragma unroll
@@ -2203,8 +2219,8 @@ __global__ void __launch_bounds__(256) wide_loss_kernel(WLossArgs a) {
     const float mean_f = (float)a.adv_ms[2 * a.mb];
     const double inv_denom = 1.0 / ((double)(float)a.adv_ms[2 * a.mb + 1] + 1e-8);
     const float eps = c.clip, lo = 1.0f - c.clip, hi = 1.0f + c.clip;
-    const double Ahat = (double)(a.advantages[smp] - mean_f) * inv_denom;
-    const float ratio = expf(nlp - a.logprobs[smp]);
+    const double Ahat = (double)(r0[3] - mean_f) * inv_denom;
+    const float ratio = expf(nlp - r0[1]);
     const float rc = fminf(fmaxf(ratio, lo), hi);
     const double pg1 = -Ahat * (double)ratio, pg2 = -Ahat * (double)rc;
     double dnlp, pg;
@@ -2216,7 +2232,7 @@ __global__ void __launch_bounds__(256) wide_loss_kernel(WLossArgs a) {
     for (int i = 0; i < AMAX; ++i)
       if (i < A) dout[i] = (float)(dnlp * ((i == act ? 1.0 : 0.0) - (double)pr[i]) + entk * (double)pr[i] * ((double)lp[i] + Hs));
     // value loss (ppo.jl:214,231-240)
-    const float v = a.V[pos], R = a.returns[smp], ov = a.values[smp];
+    const float v = a.V[pos], R = r1[0], ov = r0[2];
     const double vk = (double)c.v_coef * 0.5 * invM;
     double dv, term;
     if (c.clip_vloss) {
@@ -2644,7 +2660,12 @@ static int wide_grad_passes(crl_ppo* h, int mb, const int32_t* perm, double Mglo
   {
     WLossArgs a;
     a.c = h->dc; a.perm = perm; a.Z = w->z; a.A8 = w->A8; a.V = w->v; a.dv8 = w->dv8;
-    a.actions = h->action; a.logprobs = h->logprob; a.values = h->value; a.advantages = h->adv; a.returns = h->ret;
+    if (h->recs_dirty) {   // a buffer field changed since the records were packed (rollout, GAE, a host write)
+      int nbr = (h->dc.B + 255) / 256; if (nbr > 4096) nbr = 4096;
+      hipLaunchKernelGGL(wide_pack_rec_kernel, dim3(nbr), dim3(256), 0, h->stream, h->dc.B, h->action, h->logprob, h->value, h->adv, h->ret, w->wrec);
+      h->recs_dirty = false;
+    }
+    a.rec = w->wrec;
     a.adv_ms = h->adv_ms; a.mb = mb; a.vfix = h->vfix; a.Mglobal = Mglobal; a.lpart = w->lpart;
     hipLaunchKernelGGL(wide_loss_kernel, dim3(w->nlb), dim3(256), 0, h->stream, a);
     CRL_HIP_CHECK(hipGetLastError());
