@@ -675,11 +675,12 @@ static int guard_copy(crl_ppo* h, bool save) {
       // the sticky fp16x2 weight-gradient scale and the running largest |δ2| (mlp_x2.hpp): a replay starts from the scales the window
       // started with, so it is bit-identical to a run that never speculated
       {h->dscale, e + l.dscale, 16}};
+  const void* src[16]; void* dst[16]; size_t bytes[16]; int n = 0;
   for (const Pair& p : pairs) {
     if (!p.live) continue;   // the episode ring is optional
-    CRL_HIP_CHECK(hipMemcpyAsync(save ? p.snap : p.live, save ? p.live : p.snap, p.bytes, hipMemcpyDeviceToDevice, h->stream));
+    src[n] = save ? p.live : p.snap; dst[n] = save ? p.snap : p.live; bytes[n] = p.bytes; ++n;
   }
-  return 0;
+  return launch_guard_copy(h, src, dst, bytes, n);   // one launch (thirteen hipMemcpyAsync calls took 0.6 ms)
 }
 
 static double anneal_eta(const crl_ppo* h) {

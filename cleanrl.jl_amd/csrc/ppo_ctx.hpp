@@ -234,6 +234,7 @@ int launch_adv_stats_sums(crl_ppo* h);
 int launch_adv_bucket_sums(crl_ppo* h, int slot0, int nslots, double* part, int nblk);   // shuffle.hip; 1 = not applicable
 int launch_adv_stats_finish(crl_ppo* h, int slot0 = -1, int nslots = 1);
 int launch_pack_records(crl_ppo* h);
+int launch_guard_copy(crl_ppo* h, const void* const* src, void* const* dst, const size_t* bytes, int n);   // records.hip: the guard snapshot as one launch
 int launch_slot_adv_sums(crl_ppo* h, int slot0, int nslots);   // records.hip: Σadv, Σadv² of every minibatch of the slots
 int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot, bool inline_fix = true, bool with_optim = false, double eta = 0.0);
 int launch_update_exact_dp(crl_ppo* h, int mb, crl_ppo_stats* stats_slot);

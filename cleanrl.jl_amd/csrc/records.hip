@@ -91,4 +91,32 @@ int launch_slot_adv_sums(crl_ppo* h, int slot0, int nslots) {
   return 0;
 }
 
+// The speculation guard's snapshot (api.cpp: guard_copy) — thirteen small device buffers saved or restored at the start of every guard
+// window — as ONE launch: as thirteen hipMemcpyAsync calls they took ≈ 0.6 ms (blit launches 7-40 µs apart), once per window of 8
+// iterations in crl_ppo_iterate and once per iteration in a loop that reads the statistics back after every update.
+struct GuardCopyArgs { const void* src[16]; void* dst[16]; unsigned long long bytes[16]; int n; };
+__global__ void __launch_bounds__(256) guard_copy_kernel(GuardCopyArgs a) {
+  const int p = blockIdx.y;
+  if (p >= a.n) return;
+  const unsigned long long nb = a.bytes[p];
+  const unsigned char* s = static_cast<const unsigned char*>(a.src[p]);
+  unsigned char* d = static_cast<unsigned char*>(a.dst[p]);
+  const bool al = (((size_t)s | (size_t)d) & 15) == 0;
+  const unsigned long long n16 = al ? nb / 16 : 0;
+  for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < n16; i += gridDim.x * 256ull)
+    reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+  for (unsigned long long i = n16 * 16 + blockIdx.x * 256ull + threadIdx.x; i < nb; i += gridDim.x * 256ull) d[i] = s[i];
+}
+int launch_guard_copy(crl_ppo* h, const void* const* src, void* const* dst, const size_t* bytes, int n) {
+  if (n > 16) { set_error("internal: guard snapshot has more than 16 regions"); return 1; }
+  GuardCopyArgs a;
+  size_t mx = 0;
+  for (int i = 0; i < n; ++i) { a.src[i] = src[i]; a.dst[i] = dst[i]; a.bytes[i] = bytes[i]; if (bytes[i] > mx) mx = bytes[i]; }
+  a.n = n;
+  int bx = (int)((mx / 16 + 255) / 256); if (bx < 1) bx = 1; if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(guard_copy_kernel, dim3(bx, n), dim3(256), 0, h->stream, a);
+  CRL_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 }  // namespace crl
