@@ -2548,10 +2548,6 @@ static int wide_forward_fused(crl_ppo* h, const int32_t* perm, int M) {
     return 0;
   }
   const dim3 grid((M + FX_MB - 1) / FX_MB, 2);
-#ifdef CRL_EXP_NOH1   // timing experiment only (h1 is not stored: the weight gradients that follow are garbage)
-  if (w->D8 == 8) hipLaunchKernelGGL((wide_fused_fwd_kernel<8, false>), grid, dim3(512), FX_LDS, h->stream, a[0], a[1]);
-  else
-#endif
   if (w->D8 == 8) hipLaunchKernelGGL((wide_fused_fwd_kernel<8, true>), grid, dim3(512), FX_LDS, h->stream, a[0], a[1]);
   else hipLaunchKernelGGL((wide_fused_fwd_kernel<16, true>), grid, dim3(512), FX_LDS, h->stream, a[0], a[1]);
   CRL_HIP_CHECK(hipGetLastError());
