@@ -960,3 +960,14 @@ def test_streaming_gae_kernel_is_bit_equal_to_the_oracle(crl, nt, k):
         with pytest.raises(crl.CrlError, match="num_envs % 4"):
             a2 = make_agent(crl, nt=6, k=8, num_minibatches=1, options={"gae_tile": 4})
             a2.handle.compute_gae()
+
+
+def test_gae_bench_entry_point_times_the_scan_and_its_copy(crl):
+    """crl_gae_bench (bench.py roofline_gae.beyond_cache): the standalone scan on synthetic device-resident inputs next to a float4 copy of the
+    same byte count; every flavour returns `reps` positive launch times, and a shape the streaming kernel cannot take is an error, not a
+    silent fall-back."""
+    for tile, seg, ntl in ((4, 0, 0), (4, 16, 1), (64, 16, 0), (0, 0, 1)):
+        g, c = crl._lib.gae_bench(4096, 128, seg=seg, tile=tile, nt_loads=ntl, flush_mb=0, reps=3)
+        assert len(g) == 3 and len(c) == 3 and min(g) > 0 and min(c) > 0 and max(g) < 50.0
+    with pytest.raises(crl.CrlError):
+        crl._lib.gae_bench(4098, 128, seg=0, tile=4, nt_loads=0, flush_mb=0, reps=1)
