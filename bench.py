@@ -53,7 +53,7 @@ PEAK_HBM_GBPS = 8000.0
 SIMDS, CLOCK_HZ = 1024, 2.4e9         # 256 CUs x 4 SIMD-32; max clock
 PEAK_VALU_GSLOTS = SIMDS * CLOCK_HZ / 2 / 1e9   # one wave64 VALU instruction per 2 cycles per SIMD: 1228.8 G slots/s
 MEASURED_VALU_GSLOTS_2WAVES = SIMDS / 1.25      # scripts/micro/valu_rate.hip: two waves per SIMD retire one v_fma_f32 per 1.25 ns (819 G/s)
-PROFILE_TAG = "r04"                   # profiles/<tag>_* hold the rocprofv3 summaries of this round
+PROFILE_TAG = "r05"                   # profiles/<tag>_* hold the rocprofv3 summaries of this round
 DTYPE = "f32 (64x64 products as fp16x2 split operands: 22 significant bits, 3 f16 MFMAs per product, f32 accumulate)"
 
 
@@ -699,6 +699,27 @@ def main():
                                           "note": "the loop as ppo() / train() drive it: after every update the 16 loss records and the episode statistics are "
                                                   "read back (cleanrl.jl_amd/ppo.py, julia/CleanRLHip.jl; ppo.jl:147-165,246-248), which settles the speculation "
                                                   "guard window every iteration instead of every 8"}
+        if plain and not parse_opts(args.opt):
+            # the other BASELINE configurations, driver-observed: configs[1] (C2), configs[2] (C3) and the per-GPU share of configs[3]
+            # (one 8192-env shard of the 8-GPU job, on this one GPU without the exchange); compact records, full ones: --workload / --total-envs
+            cfgs = {}
+            for key, wl, envs, steps in (("c2", "c2", 0, 40), ("c3", "c3", 0, 5), ("shard_8192", "cartpole", 8192, 40)):
+                try:
+                    a2 = argparse.Namespace(**vars(args)); a2.total_envs = envs; a2.kernel_breakdown = False
+                    rec = run_workload(a2, wl, 1, 0, 0, dist, torch, crl, crl_dist, steps=steps, warmup=3, with_gae=False)
+                    rf = rec["roofline"]
+                    cfgs[key] = {"workload": rec["config"]["workload"], "value": rec["value"], "unit": "env-steps/s", "ms_per_step": rec["ms_per_step"],
+                                 "steps": steps, "warmup": 3, "dtype": rec["dtype"],
+                                 "roofline": {"bound": rf["bound"], "frac": rf["frac"], "achieved": rf["achieved"], "peak": rf["peak"], "unit": rf["unit"],
+                                              "avg_launch_ms": rf["avg_launch_ms"], "launches": rf["launches"],
+                                              **({"matrix_pipe_frac": rf["matrix_pipe"]["frac"]} if "matrix_pipe" in rf else {})}}
+                except Exception as e:   # noqa: BLE001 — a side record must not take the headline down
+                    cfgs[key] = {"error": str(e)}
+                log(f"bench.py: {key}: {json.dumps(cfgs[key])}")
+            cfgs["note"] = ("BASELINE configs[1], configs[2] and one 8192-env shard of configs[3] on this GPU (no exchange: what a rank of the 8-GPU job "
+                            "computes between all-reduces); c3's roofline is the f16 matrix pipe's issued TFLOP/s over the optimiser step's launches, the "
+                            "others the update kernel's vector-instruction issue rate like the headline")
+            out["configs"] = cfgs
         if world == 1 and not args.no_cpu_baseline and args.workload == "cartpole":
             out["cpu_baseline"] = cpu_baseline()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -53,7 +53,7 @@ EXPORTS = [
     "crl_shuffle", "crl_adv_stats", "crl_ppo_update_minibatch", "crl_ppo_iterate", "crl_ppo_iteration",
     "crl_comm_unique_id", "crl_comm_init", "crl_comm_init_external", "crl_comm_peer_export", "crl_comm_peer_attach", "crl_adv_stats_local", "crl_adv_stats_finish",
     "crl_prof_enable", "crl_prof_read", "crl_prof_reset", "crl_ppo_exact_reruns", "crl_episode_ring_enable",
-    "crl_episode_ring_read", "crl_comm_destroy", "crl_ppo_set_option", "crl_ppo_get_option", "crl_ppo_option_name", "crl_ppo_option_count", "crl_gae_bench",
+    "crl_episode_ring_read", "crl_comm_destroy", "crl_ppo_set_option", "crl_ppo_get_option", "crl_ppo_option_name", "crl_ppo_option_count", "crl_gae_bench", "crl_gae_opt",
     "crl_a2c_create", "crl_a2c_destroy", "crl_a2c_param_count", "crl_a2c_write_params", "crl_a2c_read_params",
     "crl_a2c_read_env", "crl_a2c_read_buffer", "crl_a2c_run_until_update", "crl_a2c_discounted_future_rewards",
     "crl_dqn_create", "crl_dqn_destroy", "crl_dqn_write_params", "crl_dqn_read_params", "crl_dqn_status_read", "crl_dqn_run",
@@ -133,6 +133,7 @@ def load():
     L.crl_policy_act.argtypes = [vp, fp, dp, C.c_int32, ip, fp, fp]
     L.crl_logprob_actions.argtypes = [vp, fp, ip, C.c_int32, fp, fp]
     L.crl_gae.argtypes = [C.c_int32, fp, fp, u8p, fp, u8p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, fp, fp]
+    L.crl_gae_opt.argtypes = L.crl_gae.argtypes + [C.c_int32] * 3
     L.crl_rollout_store.argtypes = [vp, C.c_int32, fp, ip, fp, fp, u8p, fp]
     L.crl_env_reset.argtypes = [vp]
     L.crl_rollout_run.argtypes = [vp]
@@ -407,17 +408,22 @@ def comm_unique_id() -> bytes:
     return bytes(buf)
 
 
-def gae_host(value, reward, terminal, next_value, next_done, gamma, lam, mode=GAE_COMPAT, device=0):
-    """crl_gae on host arrays: value/reward/terminal are (nt,k) Fortran-ordered."""
+def gae_host(value, reward, terminal, next_value, next_done, gamma, lam, mode=GAE_COMPAT, device=0, seg=0, tile=0, nt_loads=2):
+    """crl_gae / crl_gae_opt on host arrays: value/reward/terminal are (nt,k) Fortran-ordered; seg / tile / nt_loads select the kernel
+    flavour like the handle options gae_seg / gae_tile / gae_nt_loads (defaults: the library decides)."""
     value = np.asfortranarray(value, np.float32); reward = np.asfortranarray(reward, np.float32)
     terminal = np.asfortranarray(terminal, np.uint8)
     nt, k = value.shape
     nv = None if next_value is None else np.ascontiguousarray(next_value, np.float32)
     nd = None if next_done is None else np.ascontiguousarray(next_done, np.uint8)
     adv = np.zeros((nt, k), np.float32, order="F"); ret = np.zeros((nt, k), np.float32, order="F")
-    check(load().crl_gae(device, _ptr(value, C.c_float), _ptr(reward, C.c_float), _ptr(terminal, C.c_uint8),
-                         _ptr(nv, C.c_float) if nv is not None else None, _ptr(nd, C.c_uint8) if nd is not None else None,
-                         nt, k, gamma, lam, mode, _ptr(adv, C.c_float), _ptr(ret, C.c_float)))
+    args = (device, _ptr(value, C.c_float), _ptr(reward, C.c_float), _ptr(terminal, C.c_uint8),
+            _ptr(nv, C.c_float) if nv is not None else None, _ptr(nd, C.c_uint8) if nd is not None else None,
+            nt, k, gamma, lam, mode, _ptr(adv, C.c_float), _ptr(ret, C.c_float))
+    if (seg, tile, nt_loads) == (0, 0, 2):
+        check(load().crl_gae(*args))
+    else:
+        check(load().crl_gae_opt(*args, seg, tile, nt_loads))
     return adv, ret
 
 

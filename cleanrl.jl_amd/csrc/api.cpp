@@ -188,7 +188,7 @@ using namespace crl;
   CRL_HIP_CHECK(hipSetDevice((h)->device));
 
 static int settle(crl_ppo* h);
-static int check_bfy(crl_ppo* h);
+static int check_bfy(crl_ppo* h, bool host_syncs = true);
 // Every entry point that reads or mutates handle state first closes an open speculation guard window (see settle below): a
 // host-driven step, an env reset or a field write issued inside a window would otherwise be undone by a later restore + replay.
 // crl_ppo_iterate itself and the pure getters are the only entry points that do not.
@@ -448,7 +448,15 @@ int32_t crl_logprob_actions(crl_ppo* h, const float* obs, const int32_t* actions
 int32_t crl_gae(int32_t device, const float* value, const float* reward, const uint8_t* terminal, const float* next_value,
                 const uint8_t* next_done, int32_t nt, int32_t k, float gamma, float lambda, int32_t mode, float* adv,
                 float* ret) {
+  return crl_gae_opt(device, value, reward, terminal, next_value, next_done, nt, k, gamma, lambda, mode, adv, ret, 0, 0, 2);
+}
+
+int32_t crl_gae_opt(int32_t device, const float* value, const float* reward, const uint8_t* terminal, const float* next_value,
+                    const uint8_t* next_done, int32_t nt, int32_t k, float gamma, float lambda, int32_t mode, float* adv,
+                    float* ret, int32_t gae_seg, int32_t gae_tile, int32_t gae_nt_loads) {
   if (nt < 0 || k < 0) { set_error("crl_gae: negative size"); return 1; }
+  if ((gae_seg != 0 && gae_seg != 8 && gae_seg != 16) || (gae_tile != 0 && gae_tile != 4 && gae_tile != 8 && gae_tile != 16 && gae_tile != 32 && gae_tile != 64) ||
+      gae_nt_loads < 0 || gae_nt_loads > 2) { set_error("crl_gae_opt: gae_seg is 0 / 8 / 16, gae_tile 0 / 4 / 8 / 16 / 32 / 64, gae_nt_loads 0 / 1 / 2 (automatic)"); return 1; }
   if (nt == 0 || k == 0) return 0;  // gae of an empty rollout is empty
   if (!value || !reward || !terminal || !adv) { set_error("crl_gae: null argument"); return 1; }
   if (mode == CRL_GAE_FIXED && (!next_value || !next_done)) { set_error("crl_gae: fixed mode needs next_value/next_done"); return 1; }
@@ -469,7 +477,8 @@ int32_t crl_gae(int32_t device, const float* value, const float* reward, const u
   if (!rc)
     rc = launch_gae(nullptr, (const float*)(buf + o_v), (const float*)(buf + o_r), (const uint8_t*)(buf + o_t),
                     next_value ? (const float*)(buf + o_nv) : nullptr, next_done ? (const uint8_t*)(buf + o_nd) : nullptr, nt, k,
-                    gamma, lambda, mode, (float*)(buf + o_a), (float*)(buf + o_ret), nullptr, nullptr, 0, 0, /*nt_loads=*/B >= ((size_t)1 << 22) ? 1 : 0);   // inputs arrived by copies; streaming loads pay from ~4 M samples
+                    gamma, lambda, mode, (float*)(buf + o_a), (float*)(buf + o_ret), nullptr, nullptr, gae_seg, gae_tile,
+                    gae_nt_loads == 2 ? (B >= ((size_t)1 << 22) ? 1 : 0) : gae_nt_loads);   // automatic: inputs arrived by copies; streaming loads pay from ~4 M samples
   if (!rc && (e = hipDeviceSynchronize()) != hipSuccess) fail(e, "gae kernel");
   if (!rc && (e = hipMemcpy(adv, buf + o_a, B * 4, hipMemcpyDeviceToHost)) != hipSuccess) fail(e, "copy adv");
   if (!rc && ret && (e = hipMemcpy(ret, buf + o_ret, B * 4, hipMemcpyDeviceToHost)) != hipSuccess) fail(e, "copy ret");
@@ -574,9 +583,11 @@ int32_t crl_compute_gae(crl_ppo* h) {
   return compute_gae(h);
 }
 
-static int check_bfy(crl_ppo* h) {
+// host_syncs: the caller synchronises with the stream anyway (crl_sync, statistics read-back); crl_shuffle does so only in the blocked
+// Fisher-Yates mode (its overflow word), so the optimiser step's time-out word is not fetched from its other modes
+static int check_bfy(crl_ppo* h, bool host_syncs) {
   if (peer_check(h)) return 1;
-  if (fused_optim_check(h)) return 1;
+  if ((host_syncs || h->cfg.shuffle_mode == CRL_SHUFFLE_BLOCKED_FY) && fused_optim_check(h)) return 1;
   if (h->cfg.shuffle_mode != CRL_SHUFFLE_BLOCKED_FY) return 0;
   uint32_t err = 0;
   for (int z = 0; z < h->cfg.update_epochs && !err; ++z) {
@@ -591,7 +602,7 @@ int32_t crl_shuffle(crl_ppo* h, uint64_t epoch_id) {
   CRL_GUARD_SETTLED(h);
   h->slot_fresh &= ~(1u << h->cur_slot);
   if (launch_shuffle(h, epoch_id)) return 1;
-  return check_bfy(h);
+  return check_bfy(h, /*host_syncs=*/false);
 }
 
 // local Σadv, Σadv² of the current slot's minibatches → adv_sums

@@ -930,6 +930,7 @@ __global__ void __launch_bounds__(64 * RG) reduce_optim_kernel(const float* __re
 #error "reduce_optim_kernel's fence-free meeting point relies on gfx942 / gfx950 behaviour (sc1 atomics are write-through and counted in vmcnt): port the ordering (release on the ticket add, acquire after the wait) before building for another target"
 #endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the partials have arrived before the ticket moves
+  unsigned timed_out = 0;
   if (o == 0) {
     __hip_atomic_fetch_add(oa.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // bounded: if a block of the grid is not resident (a partitioned device, CUs held by another tenant — crl_ppo_create checks the
@@ -939,9 +940,12 @@ __global__ void __launch_bounds__(64 * RG) reduce_optim_kernel(const float* __re
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(oa.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - oa.target > 0x7FFFFFFFu) {
       __builtin_amdgcn_s_sleep(1);
-      if (wall_clock64() - t0 > oa.timeout) { __hip_atomic_store(oa.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if (wall_clock64() - t0 > oa.timeout) { __hip_atomic_store(oa.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); timed_out = 1; break; }
     }
   }
+  // a block that gave up must not step its slice from incomplete norms: parameters, Adam state and the β powers keep their pre-step
+  // values and the sticky word reports the failure at the next host synchronisation
+  if (__builtin_amdgcn_readfirstlane(timed_out)) return;
   __builtin_amdgcn_wave_barrier();
   asm volatile("" ::: "memory");
   for (int a = a_lo; a <= a_hi; ++a) {

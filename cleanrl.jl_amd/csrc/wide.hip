@@ -74,6 +74,7 @@ struct WideWs {
   double* u_dev = nullptr;       // [0] u (reserved), [1] = double(count) under DP
   int cus = 256;                 // compute units of the device (grid of the persistent fused backward)
   int fb_blocks = 0;             // > 0: the last backward ran fused (wide_fused.hpp) and left this many dW1 / db1 partials per network
+  int lds_max = 160 * 1024;      // LDS a block may ask for on this device: the fused kernels need 133-160 KB and are not chosen below that
 };
 
 static int walloc(float** p, size_t n) {
@@ -110,6 +111,9 @@ int wide_create(crl_ppo* h) {
   const int M = h->dc.M, nt = h->dc.nt;
   w->Mw = M > nt ? M : nt;
   { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cu > 0) w->cus = cu; }
+  // gfx950 has 160 KB of LDS per workgroup; the #error guard of update.hip also admits gfx942 (64 KB), where the tile-resident kernels
+  // cannot launch: there the layer-wise kernels (wide_fuse = 0, wide_rollout_persist = 1) run instead of a launch failure
+  { int lds = 0; if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, h->device) == hipSuccess && lds > 0) w->lds_max = lds; }
   w->pk[0] = pack_layout(w->H, w->D8, w->A8);
   w->pk[1] = pack_layout(w->H, w->D8, 8);
   w->pk_base[0] = 0; w->pk_base[1] = w->pk[0].size;
@@ -2396,7 +2400,7 @@ int wide_rollout(crl_ppo* h) {
   a.ring = h->ep_ring; a.ring_count = h->ep_ring_count; a.ring_cap = h->ep_ring_cap;
   if (h->ep_ring_cap > 0) CRL_HIP_CHECK(hipMemsetAsync(h->ep_ring_count, 0, sizeof(uint32_t), h->stream));
   ProfScope ps(h, CRL_K_ROLLOUT);
-  if (w->H == 256 && wide_x2(h) && w->D <= 16 && w->A <= PC_AMAX && opt(h, OPT_WIDE_ROLLOUT_PERSIST) >= 2 && h->dc.nt % RP_MB == 0) {
+  if (w->H == 256 && wide_x2(h) && w->D <= 16 && w->A <= PC_AMAX && opt(h, OPT_WIDE_ROLLOUT_PERSIST) >= 2 && h->dc.nt % RP_MB == 0 && w->lds_max >= RP_LDS) {
     // one launch for all steps, producer / consumer form (wide_rollout_pc_kernel)
     RollPCArgs r;
     const bool fast_ok = !opt(h, OPT_WIDE_TANH_RATIONAL);
@@ -2509,7 +2513,8 @@ static int wide_backward(crl_ppo* h, int net, const float* dOut, int ldd, const 
 // exp2-based activation (what wide_forward(…, fast_act = true) computes layer by layer). Option wide_fuse = 0 keeps the layer-wise launches.
 static bool wide_fused_ok(const crl_ppo* h) {
   const WideWs* w = static_cast<const WideWs*>(h->wide_ws);
-  return w->H == 256 && wide_x2(h) && w->D8 <= 16 && w->A <= AMAX && opt(h, OPT_WIDE_FUSE) != 0 && !opt(h, OPT_WIDE_TANH_RATIONAL);
+  return w->H == 256 && wide_x2(h) && w->D8 <= 16 && w->A <= AMAX && opt(h, OPT_WIDE_FUSE) != 0 && !opt(h, OPT_WIDE_TANH_RATIONAL) &&
+         w->lds_max >= FB_OFF_W3 + FB_AMAX * 1024;    // the largest request of the fused forward / backward / weight-gradient kernels
 }
 // h1 is never stored: the fused backward does not read it and the weight gradient regenerates it (option wide_fuse = 3, the default)
 static bool wide_h1_free(const crl_ppo* h) {

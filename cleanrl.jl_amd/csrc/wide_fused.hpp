@@ -56,7 +56,10 @@ struct FusedFwdArgs {
 // piece, and each of those vector writes waits until the previous fetch has read the register pair: 8 pieces took the producers of
 // wide_fused_fwd_pc_kernel 1.04 µs to ISSUE beside their partner's MFMAs, 0.32 µs in this form (profiles/r04_c3_stamps.txt).
 __device__ __forceinline__ void lds_dma16(const void* sbase, unsigned voff, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+  // M0 = LDS destination; the compiler reserves M0 (it cannot be named as a clobber), so it is saved and restored inside the statement
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
 }
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)p; }
 

@@ -107,7 +107,7 @@ def logprob_actions(obs, actor: Policy, actions):
     return actor.agent.handle.logprob_actions(obs, actions - 1)
 
 
-def gae(values, rewards, terminals, gamma, lam, *, mode=L.GAE_COMPAT, device=0):
+def gae(values, rewards, terminals, gamma, lam, *, mode=L.GAE_COMPAT, device=0, seg=0, tile=0, nt_loads=2):
     """ppo.jl:48-73 for one env: values [0,k], rewards [1,k], terminals [0,k] → advantages.
     In compat mode the last slot is 0.0 (the reference leaves it uninitialised, ppo.jl:62,66)."""
     values = np.asarray(values, np.float32); rewards = np.asarray(rewards, np.float32)
@@ -117,7 +117,7 @@ def gae(values, rewards, terminals, gamma, lam, *, mode=L.GAE_COMPAT, device=0):
         raise ValueError("gae: values and terminals need length(rewards)+1 entries")
     if k == 0:
         return np.zeros(0, np.float32)
-    adv, _ = L.gae_host(values[None, :k], rewards[None, :], terminals[None, :k], values[k:], terminals[k:], gamma, lam, mode, device)
+    adv, _ = L.gae_host(values[None, :k], rewards[None, :], terminals[None, :k], values[k:], terminals[k:], gamma, lam, mode, device, seg, tile, nt_loads)
     return adv[0]
 
 

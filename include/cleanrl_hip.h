@@ -129,6 +129,12 @@ int32_t crl_logprob_actions(crl_ppo* h, const float* obs, const int32_t* actions
 int32_t crl_gae(int32_t device, const float* value, const float* reward, const uint8_t* terminal,
                 const float* next_value, const uint8_t* next_done, int32_t nt, int32_t k, float gamma, float lambda,
                 int32_t mode, float* adv, float* ret);
+/* The same stateless call with the kernel-flavour switches a handle carries as options (gae_seg / gae_tile / gae_nt_loads of
+ * crl_ppo_set_option): gae_tile = 4 forces the streaming kernel (serial Float64 recurrence, four envs per thread), 0 lets the size
+ * decide; gae_nt_loads = 2 is crl_gae's own rule (nontemporal loads from 4 M samples). ppo.jl:48-73,173-181. */
+int32_t crl_gae_opt(int32_t device, const float* value, const float* reward, const uint8_t* terminal,
+                    const float* next_value, const uint8_t* next_done, int32_t nt, int32_t k, float gamma, float lambda,
+                    int32_t mode, float* adv, float* ret, int32_t gae_seg, int32_t gae_tile, int32_t gae_nt_loads);
 
 /* Buffer.add!(rb, transition) — replay_buffer.jl:23-37 / ppo.jl:133-140, external-env path: slot = step (0-based). */
 int32_t crl_rollout_store(crl_ppo* h, int32_t step, const float* obs, const int32_t* action, const float* logprob,

@@ -112,14 +112,14 @@ end
 # ppo.jl:48-73 — one env; values [0,k], rewards [1,k], terminals [0,k]. The last slot is 0 (upstream: uninitialised).
 # `device` names the GPU the stateless scan runs on (an Agent's own is agent.device).
 function gae(values::AbstractVector{Float32}, rewards::AbstractVector{Float32}, terminals::AbstractVector{Bool},
-             γ::Float32, λ::Float32; mode::Integer=0, device::Integer=0)
+             γ::Float32, λ::Float32; mode::Integer=0, device::Integer=0, seg::Integer=0, tile::Integer=0, nt_loads::Integer=2)
   k = length(rewards)
   v = Vector{Float32}(values[1:k]); r = Vector{Float32}(rewards); t = UInt8.(terminals[1:k])   # BitArray → bytes
   nv = Float32[values[k+1]]; nd = UInt8[terminals[k+1]]
   adv = Vector{Float32}(undef, k)
-  GC.@preserve v r t nv nd adv check(ccall((:crl_gae, libcrl), Int32,
+  GC.@preserve v r t nv nd adv check(ccall((:crl_gae_opt, libcrl), Int32,
     (Int32, Ptr{Float32}, Ptr{Float32}, Ptr{UInt8}, Ptr{Float32}, Ptr{UInt8}, Int32, Int32, Float32, Float32, Int32,
-     Ptr{Float32}, Ptr{Float32}), device, v, r, t, nv, nd, 1, k, γ, λ, mode, adv, C_NULL))
+     Ptr{Float32}, Ptr{Float32}, Int32, Int32, Int32), device, v, r, t, nv, nd, 1, k, γ, λ, mode, adv, C_NULL, seg, tile, nt_loads))
   adv
 end
 
@@ -163,8 +163,14 @@ end
 # finish ~10^5 episodes per rollout). Multi-GPU: pass comm = (id, world_size, rank) and a config whose num_envs is the shard.
 # Shapes other than the reference's CartPole 4 / 2 / 64 are keywords forwarded to Agent (obs_dim, n_act, hidden, env_kind, gae_mode,
 # stale_obs): ppo(cfg; obs_dim = 8, n_act = 4, hidden = 256) is BASELINE config 3 on the synthetic env.
+# ppo.jl:77 installs the global logger before anything else (`Logger.make_logger("ppo-2-test"; to_terminal=false)`, logger.jl:7-29): `make_logger`
+# is that function — by default the `Logger` module of the package this file is included into (src/CleanRL.jl includes utils/logger.jl before
+# the algorithms), `nothing` when there is none (standalone use: the caller's own global logger receives the @info records).
+_default_make_logger() = isdefined(parentmodule(@__MODULE__), :Logger) ? getfield(parentmodule(@__MODULE__), :Logger).make_logger : nothing
 function ppo(config::PPOConfig=PPOConfig(); device::Integer=0, params::Union{Nothing,Vector{Float32}}=nothing, episode_records::Integer=4096,
-             comm::Union{Nothing,Tuple{Vector{UInt8},Int,Int}}=nothing, shape...)
+             comm::Union{Nothing,Tuple{Vector{UInt8},Int,Int}}=nothing, run_name::AbstractString="ppo-2-test", make_logger=_default_make_logger(),
+             shape...)
+  make_logger === nothing || make_logger(run_name; to_terminal=false)      # ppo.jl:77
   world, rank = comm === nothing ? (1, 0) : (comm[2], comm[3])
   agent = Agent(config; device, env_id_offset=rank * config.num_envs, shape...)
   params === nothing || length(params) == param_count(agent) || error("params has $(length(params)) entries, the networks have $(param_count(agent))")

@@ -261,12 +261,13 @@ def test_shuffle_bijection_is_a_permutation(crl, nt, k):
     agent.close()
 
 
-@pytest.mark.parametrize("n_iters,fuse_optim", [(1, 1), (3, 1), (3, 0)])
-def test_full_iteration_matches_oracle(crl, n_iters, fuse_optim):
+@pytest.mark.parametrize("n_iters,fuse_optim,gemm", [(1, 1, 2), (3, 1, 2), (3, 0, 2), (3, 1, 1)])
+def test_full_iteration_matches_oracle(crl, n_iters, fuse_optim, gemm):
     """C1 (BASELINE configs[0]): num_envs=8, num_steps=128 — whole ppo.jl:117-253 loop body, exact Fisher–Yates; with the gradient
-    reduction + ClipNorm + Adam as one launch (the default inside crl_ppo_iterate on one GPU) and as two."""
+    reduction + ClipNorm + Adam as one launch (the default inside crl_ppo_iterate on one GPU) and as two; gemm = 1 is the bf16x3
+    flavour (24-bit operands) behind bench.py's `strict_f32` figure — rollout_split_kernel + update_x3_kernel."""
     nt, k = 8, 128
-    agent = make_agent(crl, nt=nt, k=k, shuffle_mode=0, options={"fuse_optim": fuse_optim})
+    agent = make_agent(crl, nt=nt, k=k, shuffle_mode=0, options={"fuse_optim": fuse_optim, "gemm": gemm})
     params = agent.get_params()
     cfgo, st = _oracle_state(nt, k, params)
     h = agent.handle
@@ -478,13 +479,15 @@ def _knot_margin(cfgo, params, st, e, t, seed=0x5EED):
     return float(margin[0])
 
 
-def test_c2_size_rollout_and_update_match_oracle(crl):
-    """BASELINE configs[1] (C2): num_envs=4096, num_steps=128, 2x64 — the oracle still finishes in seconds here, so the
+@pytest.mark.parametrize("gemm", [2, 1])
+def test_c2_size_rollout_and_update_match_oracle(crl, gemm):
+    """gemm = 2: the fp16x2 default; gemm = 1: bf16x3 everywhere (bench.py `strict_f32`).
+    BASELINE configs[1] (C2): num_envs=4096, num_steps=128, 2x64 — the oracle still finishes in seconds here, so the
     whole rollout, GAE and one minibatch gradient (M = 131,072 samples) are compared directly, not through properties.
     An action may differ from the oracle's ONLY where the uniform draw sits within 1e-6 of a CDF knot: every first
     difference of an env is checked against that margin and fails the test otherwise; envs without one must match exactly."""
     nt, k = 4096, 128
-    agent = make_agent(crl, nt=nt, k=k)
+    agent = make_agent(crl, nt=nt, k=k, options={"gemm": gemm})
     params = agent.get_params()
     cfgo, st = _oracle_state(nt, k, params)
     h = agent.handle; F = crl._lib
@@ -518,12 +521,13 @@ def test_c2_size_rollout_and_update_match_oracle(crl):
     agent.close(); st.close()
 
 
-def test_c4_size_minibatch_gradient_matches_oracle(crl):
-    """BASELINE full size, directly: ONE minibatch of the headline configuration (num_envs=65536, num_steps=128: M = 2,097,152
+@pytest.mark.parametrize("gemm", [2, 1])
+def test_c4_size_minibatch_gradient_matches_oracle(crl, gemm):
+    """gemm = 1: update_x3_kernel at M = 2,097,152 — the launch bench.py's `strict_f32` record times. BASELINE full size, directly: ONE minibatch of the headline configuration (num_envs=65536, num_steps=128: M = 2,097,152
     samples) through the HIP update path and through orc_loss_grad (OpenMP) on the same buffer — the four loss scalars and all
     twelve gradient arrays. (The rollout that fills the buffer is the GPU's; its parity is the C2 test's business.)"""
     nt, k = 65536, 128
-    agent = make_agent(crl, nt=nt, k=k)
+    agent = make_agent(crl, nt=nt, k=k, options={"gemm": gemm})
     params = agent.get_params()
     cfgo = O.make_config(num_envs=nt, num_steps=k)
     h = agent.handle; F = crl._lib
@@ -960,6 +964,61 @@ def test_streaming_gae_kernel_is_bit_equal_to_the_oracle(crl, nt, k):
         with pytest.raises(crl.CrlError, match="num_envs % 4"):
             a2 = make_agent(crl, nt=6, k=8, num_minibatches=1, options={"gae_tile": 4})
             a2.handle.compute_gae()
+
+
+def _gae_inputs(nt, k, seed):
+    rng = np.random.default_rng(seed)
+    value = np.asfortranarray((rng.standard_normal((nt, k), dtype=np.float32) * 10))
+    reward = np.asfortranarray((rng.random((nt, k), dtype=np.float32) > 0.02).astype(np.float32))
+    term = np.asfortranarray((rng.random((nt, k), dtype=np.float32) < 0.02).astype(np.uint8))
+    nv = (rng.standard_normal(nt) * 10).astype(np.float32); nd = (rng.random(nt) < 0.3).astype(np.uint8)
+    return value, reward, term, nv, nd
+
+
+@pytest.mark.parametrize("nt_loads", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("nt,k", [(8192, 128), (65536, 128), (1028, 37), (65540, 9)])
+def test_streaming_gae_kernel_many_blocks_both_modes_both_load_flavours(crl, nt, k, mode, nt_loads):
+    """gae_stream_kernel with MANY blocks (8 … 65 of 256 threads; `blockIdx.x * 256` indexing, a ragged last block at 1028 / 65540 envs, the
+    two-register-set prefetch over 16 chunks at k = 128 and a partial first chunk at k = 37 / 9), the cached and the nontemporal load
+    flavour, compat mode AND fixed mode with a random bootstrap (next_value / next_done through the 16-byte / 4-byte loads that seed
+    vnext / dnext): crl_gae_opt(gae_tile = 4) on host arrays must equal orc_gae bit for bit — it runs the reference's serial Float64
+    recurrence (ppo.jl:63-69) in the reference's order."""
+    value, reward, term, nv, nd = _gae_inputs(nt, k, nt * 7 + k + mode)
+    adv_o, ret_o = O.gae_batch(value, reward, term, nv, nd, 0.99, 0.95, mode)
+    adv_g, ret_g = crl._lib.gae_host(value, reward, term, nv, nd, 0.99, 0.95, mode, tile=4, nt_loads=nt_loads)
+    assert np.array_equal(adv_g, adv_o) and np.array_equal(ret_g, ret_o)
+    if mode == 1:     # the bootstrap is live: a different next_value must move the last column
+        adv_2, _ = crl._lib.gae_host(value, reward, term, nv + 1.0, np.zeros_like(nd), 0.99, 0.95, mode, tile=4, nt_loads=nt_loads)
+        assert (adv_2[:, -1] != adv_g[:, -1]).mean() > 0.9
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_automatic_gae_kernel_choice_past_the_infinity_cache_is_bit_equal(crl, mode):
+    """(524288, 128) = 2^26 samples, 1.14 GB per launch — the shape bench.py's roofline_gae.beyond_cache times: crl_gae takes the streaming
+    kernel BY ITSELF here (gae.hip launch_gae: tile = 0, nt·k >= 2^26, nt >= 262144) with nontemporal loads (crl_gae's own rule from 4 M
+    samples): 512 blocks, every CU two of them. Bit-equal to orc_gae; the explicit cached-load flavour as well."""
+    nt, k = 524288, 128
+    value, reward, term, nv, nd = _gae_inputs(nt, k, 99 + mode)
+    adv_o, ret_o = O.gae_batch(value, reward, term, nv, nd, 0.99, 0.95, mode)
+    adv_g, ret_g = crl._lib.gae_host(value, reward, term, nv, nd, 0.99, 0.95, mode)
+    assert np.array_equal(adv_g, adv_o) and np.array_equal(ret_g, ret_o)
+    del adv_g, ret_g
+    adv_g, ret_g = crl._lib.gae_host(value, reward, term, nv, nd, 0.99, 0.95, mode, tile=0, nt_loads=0)
+    assert np.array_equal(adv_g, adv_o) and np.array_equal(ret_g, ret_o)
+    # the segmented kernel forced on the same inputs composes affine maps: last-bit differences only (<= 1e-6 of the outputs)
+    adv_s, _ = crl._lib.gae_host(value, reward, term, nv, nd, 0.99, 0.95, mode, tile=64, nt_loads=1)
+    assert np.sum(adv_s != adv_o) <= adv_o.size * 1e-6 and rel_err(adv_s, adv_o) < 1e-6
+
+
+def test_gae_opt_rejects_bad_flavours(crl):
+    value, reward, term, nv, nd = _gae_inputs(8, 4, 1)
+    for kw in (dict(seg=5), dict(tile=3), dict(nt_loads=3)):
+        with pytest.raises(crl.CrlError, match="gae_seg is 0"):
+            crl._lib.gae_host(value, reward, term, nv, nd, 0.99, 0.95, 0, **{**dict(seg=0, tile=8, nt_loads=0), **kw})
+    value, reward, term, nv, nd = _gae_inputs(6, 4, 1)
+    with pytest.raises(crl.CrlError, match="num_envs % 4"):
+        crl._lib.gae_host(value, reward, term, nv, nd, 0.99, 0.95, 0, tile=4)
 
 
 def test_gae_bench_entry_point_times_the_scan_and_its_copy(crl):

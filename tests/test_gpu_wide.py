@@ -323,6 +323,42 @@ def test_c3_full_size_properties(crl):
     agent.close(); st.close()
 
 
+def test_c3_full_size_rollout_slices_match_the_oracle(crl):
+    """BASELINE configs[2] at full size: the whole 16384-env x 128-step rollout of the full-grid `wide_rollout_pc_kernel` (256 blocks of 64
+    envs, one per CU — the default for this shape) against the oracle on three 64-env slices — the first block, one in the middle of the
+    grid and the last — for ALL 128 steps: the oracle rolls envs [o, o + 64) out under `env_id_offset = o` (global env ids key every
+    random stream, so a slice is independent of the other envs). Actions exact under the knot-margin rule (a draw within 1e-6 of a CDF
+    knot may flip; the synthetic env's observations do not depend on the action, so nothing else moves), observations / rewards /
+    terminals bit-equal, logprob / value / advantages / returns 1e-5."""
+    nt, k, D, A, Hd = 16384, 128, 8, 4, 256
+    cfg_full = ocfg(nt, k, D, A, Hd)
+    params = spread_params(cfg_full, 17)
+    agent = make_wide(crl, nt, k, D, A, Hd, params=params)
+    h = agent.handle; F = crl._lib
+    assert h.get_option("wide_rollout_persist") == 2 and h.get_option("wide_fuse") == 3, "defaults must select wide_rollout_pc_kernel"
+    h.env_reset(); h.rollout_run(); h.compute_gae()
+    act, obs, rew, term = h.read(F.F_ACTION), h.read(F.F_OBS), h.read(F.F_REWARD), h.read(F.F_TERMINAL)
+    lp, val, adv, ret = h.read(F.F_LOGPROB), h.read(F.F_VALUE), h.read(F.F_ADVANTAGE), h.read(F.F_RETURN)
+    nd = h.read(F.F_NEXT_DONE)
+    for o in (0, 8160, 16320):
+        sl = slice(o, o + 64)
+        cfg = ocfg(64, k, D, A, Hd, env_id_offset=o)
+        st = O.State(cfg); st.params[:] = params; st.env_init(); st.rollout(); st.compute_gae()
+        diff = act[sl] != st.action
+        for e, t in zip(*np.nonzero(diff)):
+            u = O.lib().orc_u53(cfg.seed, int(o + e), int(t), 0)
+            _, _, _, m = O.get_action(cfg, params, st.obs[:, e, t].reshape(-1, 1), np.array([u]))
+            assert m[0] <= 1e-6, f"slice {o} env {e} step {t}: action differs although the draw is {m[0]:.3e} away from the CDF knot"
+        assert diff.mean() < 1e-4
+        assert np.array_equal(obs[:, sl], st.obs) and np.array_equal(rew[sl], st.reward) and np.array_equal(term[sl], st.terminal)
+        assert np.array_equal(nd[sl], st.next_done)
+        same = ~diff
+        assert rel_err_s(lp[sl][same], st.logprob[same]) < RTOL and rel_err(val[sl], st.value) < RTOL
+        assert rel_err(adv[sl], st.adv) < RTOL and rel_err(ret[sl], st.ret) < RTOL
+        st.close()
+    agent.close()
+
+
 def test_c3_size_minibatch_gradient_matches_oracle(crl):
     """BASELINE configs[2] at full size, directly: ONE minibatch (num_envs=16384, num_steps=128, obs 8 / act 4 / 2x256: M = 524,288
     samples, 4.3e11 flop) through the layer-wise HIP path and through orc_loss_grad (OpenMP) on the same buffer — four loss

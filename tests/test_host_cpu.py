@@ -190,6 +190,13 @@ def test_julia_shell_structs_and_symbols_follow_the_header(crl):
     assert "Matrix{Float32}(undef, actor.n_act, n)" in jl
     assert re.search(r"function ppo\(config::PPOConfig=PPOConfig\(\);.*?shape\.\.\.\)", jl, re.S) and "Agent(config; device, env_id_offset=rank * config.num_envs, shape...)" in jl
     assert "crl_ppo_param_count" in called
+    # ppo.jl:77: the logger is installed first; the runner (README.md:24, config_parser.jl:18-40) goes argparse_struct -> ppo
+    body = re.search(r"function ppo\(config::PPOConfig=PPOConfig\(\);(.*?)\n  agent\nend", jl, re.S).group(1)
+    assert 'run_name::AbstractString="ppo-2-test"' in body and "make_logger=_default_make_logger()" in body
+    assert body.index("make_logger(run_name; to_terminal=false)") < body.index("agent = Agent(")
+    run = open(os.path.join(ROOT, "julia", "run_ppo.jl")).read()
+    assert "ConfigParser.argparse_struct(CleanRLHip.PPOConfig())" in run and "CleanRLHip.ppo(config; make_logger = CleanRL.Logger.make_logger)" in run
+    assert 'include(joinpath(@__DIR__, "CleanRLHip.jl"))' in run
 
 
 def _pb_fields(buf):

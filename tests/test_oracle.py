@@ -434,9 +434,12 @@ def test_batched_cpu_iteration_tracks_the_oracle():
     same = (a.action == b.action).all(axis=1)
     assert same.mean() >= 0.9, "knot hits aside, the sampled actions agree"
     assert np.array_equal(a.terminal[same], b.terminal[same]) and np.allclose(a.value[same], b.value[same], rtol=1e-5, atol=1e-6)
-    if same.all():
-        for x, y in zip(sa, sb):
-            for key in ("loss", "pg_loss", "v_loss", "entropy_loss"):
-                assert abs(x[key] - y[key]) <= 2e-5 * abs(x[key]) + 2e-6, (key, x[key], y[key])
-        assert np.max(np.abs(a.params - b.params)) < 5e-5
+    assert np.allclose(a.logprob[same], b.logprob[same], rtol=1e-5, atol=1e-6) and np.allclose(a.adv[same], b.adv[same], rtol=1e-4, atol=1e-4)
+    # both sides are deterministic CPU code on fixed seeds: for THIS seed no draw sits on a CDF knot, so the update pass sees identical
+    # minibatches and the loss records / parameters are compared unconditionally (a knot hit would fail here, not skip the comparison)
+    assert same.all(), "seed 11 / orthogonal seed 3 has no knot hit between the scalar and the batched port"
+    for x, y in zip(sa, sb):
+        for key in ("loss", "pg_loss", "v_loss", "entropy_loss"):
+            assert abs(x[key] - y[key]) <= 2e-5 * abs(x[key]) + 2e-6, (key, x[key], y[key])
+    assert np.max(np.abs(a.params - b.params)) < 5e-5
     a.close(); b.close()
