@@ -371,7 +371,7 @@ def gae_beyond_cache(crl, sizes=(262144, 524288), reps=8):
     for nt in sizes:
         nbytes = GAE_BYTES_PER_STEP * nt * NUM_STEPS + GAE_BYTES_PER_ENV * nt
         row = {"num_envs": nt, "bytes_per_launch": nbytes}
-        for name, ntl, tile, seg in (("cached_loads", 0, 0, 0), ("nt_loads", 1, 0, 0), ("segmented_kernel", 1, 64, 16)):
+        for name, ntl, tile, seg in (("cached_loads", 0, 0, 0), ("nt_loads", 1, 0, 0), ("two_envs_window8", 1, 2, 8), ("segmented_kernel", 1, 64, 16)):
             g, c = crl._lib.gae_bench(nt, NUM_STEPS, nt_loads=ntl, tile=tile, seg=seg, reps=reps)
             gm, cm = med(list(g)), med(list(c))
             row[name] = {"avg_launch_ms": gm, "achieved": nbytes / (gm * 1e-3) / 1e9, "frac": nbytes / (gm * 1e-3) / 1e9 / PEAK_HBM_GBPS,
@@ -384,8 +384,8 @@ def gae_beyond_cache(crl, sizes=(262144, 524288), reps=8):
     big = out[str(sizes[-1])]
     return {"num_envs": big["num_envs"], "bytes_per_launch": big["bytes_per_launch"], "flavour": big["best"], "unit": "GB/s", "peak": PEAK_HBM_GBPS,
             **big[big["best"]], "copy": big["copy"], "sizes": out,
-            "kernel": "gae_stream_kernel (four envs per thread, 16-byte accesses, serial Float64 recurrence) — what batches of 67 M samples or more take (the 262144-env rows run the segmented kernel); "
-                      "segmented_kernel = gae_kernel<64, 16> on the same inputs",
+            "kernel": "gae_stream_kernel<4, 4> (four envs per thread, a rolling window of four steps' loads in flight, serial Float64 recurrence, nontemporal both ways; <2, 4> at 262144 "
+                      "envs) — what batches of 33 M samples or more take by themselves (both sizes here); two_envs_window8 = gae_stream_kernel<2, 8>, segmented_kernel = gae_kernel<64, 16> on the same inputs",
             "note": "crl_gae_bench: the standalone scan on 0.57 / 1.14 GB of synthetic inputs (past the 256 MiB Infinity Cache), median of "
                     f"{reps} launches; frac = algorithmic bytes ÷ time ÷ 8 TB/s; over_copy = copy time ÷ scan time"}
 

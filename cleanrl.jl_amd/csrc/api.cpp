@@ -45,6 +45,8 @@ static const OptDesc kOpts[OPT_COUNT] = {
     {"wide_fuse_pc", 1, 0, 1},
     {"wide_fuse", 3, 0, 3},
 };
+static bool gae_seg_ok(int64_t v) { return v == 0 || v == 4 || v == 8 || v == 16; }
+static bool gae_tile_ok(int64_t v) { return v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64; }
 static int opt_find(const char* key) {
   if (!key) return -1;
   for (int i = 0; i < OPT_COUNT; ++i) if (std::strcmp(kOpts[i].name, key) == 0) return i;
@@ -58,8 +60,8 @@ static int opt_set(crl_ppo* h, const char* key, int64_t value) {
               std::to_string(kOpts[id].hi) + "]");
     return 1;
   }
-  if (id == OPT_GAE_SEG && value != 0 && value != 8 && value != 16) { set_error("crl_ppo_set_option: gae_seg is 0 (automatic), 8 or 16"); return 1; }
-  if (id == OPT_GAE_TILE && value != 0 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64) { set_error("crl_ppo_set_option: gae_tile is 0 (automatic), 4 (streaming kernel), 8, 16, 32 or 64"); return 1; }
+  if (id == OPT_GAE_SEG && !gae_seg_ok(value)) { set_error("crl_ppo_set_option: gae_seg is 0 (automatic), 8 or 16 (4: streaming kernel only)"); return 1; }
+  if (id == OPT_GAE_TILE && !gae_tile_ok(value)) { set_error("crl_ppo_set_option: gae_tile is 0 (automatic), 1 / 2 / 4 (streaming kernel, envs per thread), 8, 16, 32 or 64"); return 1; }
   h->opt[id] = value;
   if (id == OPT_GUARD_WINDOW) h->window_len = (int)value;
   if (id == OPT_WIDE_GEMM) wide_mark_params_changed(h);   // the packed weight copies depend on the flavour
@@ -455,8 +457,10 @@ int32_t crl_gae_opt(int32_t device, const float* value, const float* reward, con
                     const uint8_t* next_done, int32_t nt, int32_t k, float gamma, float lambda, int32_t mode, float* adv,
                     float* ret, int32_t gae_seg, int32_t gae_tile, int32_t gae_nt_loads) {
   if (nt < 0 || k < 0) { set_error("crl_gae: negative size"); return 1; }
-  if ((gae_seg != 0 && gae_seg != 8 && gae_seg != 16) || (gae_tile != 0 && gae_tile != 4 && gae_tile != 8 && gae_tile != 16 && gae_tile != 32 && gae_tile != 64) ||
-      gae_nt_loads < 0 || gae_nt_loads > 2) { set_error("crl_gae_opt: gae_seg is 0 / 8 / 16, gae_tile 0 / 4 / 8 / 16 / 32 / 64, gae_nt_loads 0 / 1 / 2 (automatic)"); return 1; }
+  if (!gae_seg_ok(gae_seg) || !gae_tile_ok(gae_tile) || (gae_seg == 4 && gae_tile > 4) || gae_nt_loads < 0 || gae_nt_loads > 2) {
+    set_error("crl_gae_opt: gae_seg is 0 / 8 / 16 (4 with the streaming kernel), gae_tile 0 / 1 / 2 / 4 (streaming kernel) / 8 / 16 / 32 / 64, gae_nt_loads 0 / 1 / 2 (automatic)");
+    return 1;
+  }
   if (nt == 0 || k == 0) return 0;  // gae of an empty rollout is empty
   if (!value || !reward || !terminal || !adv) { set_error("crl_gae: null argument"); return 1; }
   if (mode == CRL_GAE_FIXED && (!next_value || !next_done)) { set_error("crl_gae: fixed mode needs next_value/next_done"); return 1; }

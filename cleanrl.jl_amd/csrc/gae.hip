@@ -115,79 +115,78 @@ __global__ void __launch_bounds__(512) gae_kernel(const float* __restrict__ valu
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // Streaming flavour for batches past the Infinity Cache (crl_gae on big host arrays, crl_gae_bench: 0.57 / 1.14 GB per launch).
-// One thread owns FOUR consecutive envs for the whole rollout and walks it backwards in chunks of 8 steps, the carry in registers:
-// no segments, no LDS, and every access is 16 bytes per lane (value, reward, advantage, return: 1 KB rows per wave-instruction) or 4
-// (the four done bytes of a step) — 40 memory instructions per 544 bytes instead of 41 per 136. The next chunk's 24 loads are issued
-// before the current chunk is computed (two register sets). The arithmetic is the reference's serial Float64 recurrence in its own
-// order (ppo.jl:63-69), so the result is bit-identical to orc_gae (the segmented kernel composes affine maps: ≤ 1e-6 of its outputs
-// differ in the last bit). Needs nt % 4 == 0; pays only when there are enough envs to fill the chip (one thread per four envs): taken by itself from 2^26 samples.
+// One thread owns E consecutive envs (E = 4: 16-byte accesses, 2: 8-byte, 1: 4-byte) for the whole rollout and walks it backwards with
+// the carry in registers: no segments, no LDS, the reference's serial Float64 recurrence in its own order (ppo.jl:63-69) — bit-identical
+// to orc_gae (the segmented kernel composes affine maps: <= 1e-6 of its outputs differ in the last bit).
+// ROLLING WINDOW (round 5): the inputs of the next D steps are always in flight — slot i of a D-entry register ring is refilled with
+// step t - D right after step t has been computed from it — so loads, arithmetic and stores interleave step by step. Round 4's kernel
+// moved chunks of eight steps through two register sets (206 VGPRs, two waves per SIMD) and every wave alternated between a burst of 24
+// loads and a burst of 16 stores: 0.63-0.66 of 8 TB/s at 524288 envs and 0.43 at 262144. The rolling form (E = 2, D = 8: 72 VGPRs) runs
+// 0.72-0.73 at both sizes next to a copy ceiling of 6.4-6.5 TB/s = 0.81 (scripts/micro/stream_rate.hip, profiles/r05_gae_stream_micro.txt).
 // ------------------------------------------------------------------------------------------------------------------------------
 typedef float gf4 __attribute__((ext_vector_type(4)));
-struct GaeChunk { gf4 v[8], r[8]; uint32_t t[8]; };
-template <bool NTL>
-__device__ __forceinline__ void gae_chunk_load(GaeChunk& c, const float* value, const float* reward, const uint8_t* terminal, size_t e, int nt, int t0, int k) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int t = t0 + i;
-    if (t < k) {
-      const size_t idx = e + (size_t)nt * t;
-      const gf4* pv = reinterpret_cast<const gf4*>(value + idx);
-      const gf4* pr = reinterpret_cast<const gf4*>(reward + idx);
-      const uint32_t* pt = reinterpret_cast<const uint32_t*>(terminal + idx);
-      c.v[i] = NTL ? __builtin_nontemporal_load(pv) : *pv;
-      c.r[i] = NTL ? __builtin_nontemporal_load(pr) : *pr;
-      c.t[i] = NTL ? __builtin_nontemporal_load(pt) : *pt;
-    }
-  }
-}
-template <bool NTL>
+typedef float gf2 __attribute__((ext_vector_type(2)));
+typedef float gf1 __attribute__((ext_vector_type(1)));
+template <int E> struct GaeVec;
+template <> struct GaeVec<4> { typedef gf4 V; typedef uint32_t Dn; };
+template <> struct GaeVec<2> { typedef gf2 V; typedef uint16_t Dn; };
+template <> struct GaeVec<1> { typedef gf1 V; typedef uint8_t Dn; };
+template <int E, int D, bool NTL>
 __global__ void __launch_bounds__(256) gae_stream_kernel(const float* __restrict__ value, const float* __restrict__ reward,
                                                          const uint8_t* __restrict__ terminal, const float* __restrict__ next_value,
                                                          const uint8_t* __restrict__ next_done, int nt, int k, float gamma, float gl, int mode,
                                                          float* __restrict__ adv, float* __restrict__ ret) {
 #pragma clang fp contract(off)
-  const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  typedef typename GaeVec<E>::V V; typedef typename GaeVec<E>::Dn Dn;
+  const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * E;
   if (e >= (size_t)nt) return;
-  double A[4] = {0.0, 0.0, 0.0, 0.0};
-  gf4 vnext = {0.0f, 0.0f, 0.0f, 0.0f};        // value of step t + 1 (bootstrap behind the last step, ppo.jl:174)
-  uint32_t dnext = 0;                           // the done bytes that gate step t: terminal[t + 1] (next_done behind the last step, ppo.jl:176)
-  if (next_value) vnext = *reinterpret_cast<const gf4*>(next_value + e);
-  if (next_done) dnext = *reinterpret_cast<const uint32_t*>(next_done + e);
-  auto compute = [&](const GaeChunk& c, int t0) {
+  double A[E];
+  V vnext;                                      // value of step t + 1 (bootstrap behind the last step, ppo.jl:174)
+  Dn dnext = 0;                                 // the done bytes that gate step t: terminal[t + 1] (next_done behind the last step, ppo.jl:176)
 #pragma unroll
-    for (int i = 7; i >= 0; --i) {
-      const int t = t0 + i;
-      if (t < k) {
-        gf4 a32, r32;
+  for (int j = 0; j < E; ++j) { A[j] = 0.0; vnext[j] = 0.0f; }
+  if (next_value) vnext = *reinterpret_cast<const V*>(next_value + e);
+  if (next_done) dnext = *reinterpret_cast<const Dn*>(next_done + e);
+  V sv[D], sr[D]; Dn st[D];
+  auto load = [&](int slot, int t) {
+    if (t >= 0) {
+      const size_t idx = e + (size_t)nt * t;
+      const V* pv = reinterpret_cast<const V*>(value + idx); const V* pr = reinterpret_cast<const V*>(reward + idx);
+      const Dn* pt = reinterpret_cast<const Dn*>(terminal + idx);
+      sv[slot] = NTL ? __builtin_nontemporal_load(pv) : *pv; sr[slot] = NTL ? __builtin_nontemporal_load(pr) : *pr;
+      st[slot] = NTL ? __builtin_nontemporal_load(pt) : *pt;
+    }
+  };
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const double nonterm = 1.0 - (double)(((dnext >> (8 * j)) & 0xFFu) ? 1 : 0);
-          double delta = (double)c.r[i][j] + ((double)gamma * nonterm) * (double)vnext[j] - (double)c.v[i][j];
+  for (int i = 0; i < D; ++i) load(i, k - 1 - i);            // slot of step t = (k - 1 - t) % D
+  for (int tb = k - 1; tb >= 0; tb -= D) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      const int t = tb - i;
+      if (t >= 0) {
+        V a32, r32;
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+          const double nonterm = 1.0 - (double)((((uint32_t)dnext >> (8 * j)) & 0xFFu) ? 1 : 0);
+          double delta = (double)sr[i][j] + ((double)gamma * nonterm) * (double)vnext[j] - (double)sv[i][j];
           double cc = (double)gl * nonterm;
           if (mode == CRL_GAE_COMPAT && t == k - 1) { delta = 0.0; cc = 0.0; }   // ppo.jl:66: the loop starts at k-1; slot k is defined as 0
           A[j] = delta + (cc * A[j]);
           a32[j] = (float)A[j];
-          r32[j] = a32[j] + c.v[i][j];
+          r32[j] = a32[j] + sv[i][j];
         }
         const size_t idx = e + (size_t)nt * t;
-        *reinterpret_cast<gf4*>(adv + idx) = a32;
-        if (ret) *reinterpret_cast<gf4*>(ret + idx) = r32;
-        vnext = c.v[i]; dnext = c.t[i];
+        if (NTL) {      // the streaming flavour streams both ways: outputs this large are not re-read from a cache either
+          __builtin_nontemporal_store(a32, reinterpret_cast<V*>(adv + idx));
+          if (ret) __builtin_nontemporal_store(r32, reinterpret_cast<V*>(ret + idx));
+        } else {
+          *reinterpret_cast<V*>(adv + idx) = a32;
+          if (ret) *reinterpret_cast<V*>(ret + idx) = r32;
+        }
+        vnext = sv[i]; dnext = st[i];
+        load(i, t - D);
       }
     }
-  };
-  GaeChunk ca, cb;
-  int t0 = ((k - 1) / 8) * 8;
-  gae_chunk_load<NTL>(ca, value, reward, terminal, e, nt, t0, k);
-  while (true) {
-    if (t0 >= 8) gae_chunk_load<NTL>(cb, value, reward, terminal, e, nt, t0 - 8, k);
-    compute(ca, t0);
-    t0 -= 8;
-    if (t0 < 0) break;
-    if (t0 >= 8) gae_chunk_load<NTL>(ca, value, reward, terminal, e, nt, t0 - 8, k);
-    compute(cb, t0);
-    t0 -= 8;
-    if (t0 < 0) break;
   }
 }
 
@@ -196,23 +195,39 @@ int launch_gae(hipStream_t st, const float* value, const float* reward, const ui
                float* adv, float* ret, hipEvent_t ev_start, hipEvent_t ev_stop, int seg, int tile, int nt_loads) {
   if (nt <= 0 || k <= 0) { set_error("gae: empty input"); return 1; }
   const float gl = gamma * lambda;  // Float32 product, as `γ * λ` with both T=Float32 (ppo.jl:68)
-  // tile = 4 selects the streaming kernel (four envs per thread); tile = 0 takes it by itself for batches past the Infinity Cache
-  const bool can_stream = (nt % 4) == 0 && ((uintptr_t)value % 16) == 0 && ((uintptr_t)reward % 16) == 0 && ((uintptr_t)adv % 16) == 0 &&
-                          (!ret || ((uintptr_t)ret % 16) == 0) && ((uintptr_t)terminal % 4) == 0 && (!next_value || ((uintptr_t)next_value % 16) == 0) &&
-                          (!next_done || ((uintptr_t)next_done % 4) == 0);
-  if (tile == 4 && !can_stream) { set_error("gae: the streaming kernel (gae_tile = 4) needs num_envs % 4 == 0 and 16-byte aligned buffers"); return 1; }
-  // measured (profiles/r04_gae_beyond_cache.txt): at 524288 envs x 128 (1.14 GB) the streaming kernel runs at the float4 copy's own speed
-  // (216-226 us, 0.63-0.66 of 8 TB/s; the segmented kernel 282-342 us); at 262144 envs its 1024 waves are too few (160-176 us against 128-135)
-  if (tile == 4 || (tile == 0 && can_stream && (size_t)nt * (size_t)k >= ((size_t)1 << 26) && nt >= 262144)) {
-    const dim3 grid((unsigned)((nt / 4 + 255) / 256)), block(256);
-    if (nt_loads) hipExtLaunchKernelGGL((gae_stream_kernel<true>), grid, block, 0, st, ev_start, ev_stop, 0, value, reward, terminal, next_value, next_done, nt, k, gamma, gl, mode, adv, ret);
-    else hipExtLaunchKernelGGL((gae_stream_kernel<false>), grid, block, 0, st, ev_start, ev_stop, 0, value, reward, terminal, next_value, next_done, nt, k, gamma, gl, mode, adv, ret);
+  // tile = 4 / 2 / 1 selects the streaming kernel with that many envs per thread (seg = its window depth: 0 -> 8, 4, 8 or 16); tile = 0 takes
+  // it by itself (two envs per thread, depth 8) for batches past the Infinity Cache
+  auto aligned = [&](int E) {
+    const uintptr_t fa = (uintptr_t)(4 * E) - 1, da = (uintptr_t)E - 1;
+    return (nt % E) == 0 && ((uintptr_t)value & fa) == 0 && ((uintptr_t)reward & fa) == 0 && ((uintptr_t)adv & fa) == 0 && (!ret || ((uintptr_t)ret & fa) == 0) &&
+           ((uintptr_t)terminal & da) == 0 && (!next_value || ((uintptr_t)next_value & fa) == 0) && (!next_done || ((uintptr_t)next_done & da) == 0);
+  };
+  const bool forced = tile == 4 || tile == 2 || tile == 1;
+  if (forced && !aligned(tile)) { set_error("gae: the streaming kernel (gae_tile = 4 / 2) needs num_envs % gae_tile == 0 and buffers aligned to gae_tile floats"); return 1; }
+  // measured (profiles/r05_gae_beyond_cache.txt; launch-to-launch spread about 2 %): at 524288 envs x 128 four envs per thread with a window of 4
+  // steps 0.73 of 8 TB/s (two envs / window 8: 0.72; the segmented kernel 0.44-0.50), at 262144 envs two envs per thread / window 4 0.70 (four envs: 0.68;
+  // segmented 0.49-0.53); at 65536 envs (143 MB: 256-512 waves of this kernel) the segmented kernel stays ahead (0.44 against 0.24 with caches flushed)
+  const size_t samples = (size_t)nt * (size_t)k;
+  const int auto_E = samples >= ((size_t)1 << 26) ? 4 : 2;
+  const bool automatic = tile == 0 && aligned(auto_E) && samples >= ((size_t)1 << 25) && nt >= 262144;
+  if (forced || automatic) {
+    const int E = forced ? tile : auto_E, Dw = (seg == 4 || seg == 8 || seg == 16) ? seg : (forced ? 8 : 4);
+    const dim3 grid((unsigned)((nt / E + 255) / 256)), block(256);
+#define CRL_GAE_STREAM(e_, d_)                                                                                                                                   \
+    if (E == e_ && Dw == d_) {                                                                                                                                   \
+      if (nt_loads) hipExtLaunchKernelGGL((gae_stream_kernel<e_, d_, true>), grid, block, 0, st, ev_start, ev_stop, 0, value, reward, terminal, next_value, next_done, nt, k, gamma, gl, mode, adv, ret); \
+      else hipExtLaunchKernelGGL((gae_stream_kernel<e_, d_, false>), grid, block, 0, st, ev_start, ev_stop, 0, value, reward, terminal, next_value, next_done, nt, k, gamma, gl, mode, adv, ret);      \
+    } else
+    CRL_GAE_STREAM(4, 4) CRL_GAE_STREAM(4, 8) CRL_GAE_STREAM(4, 16) CRL_GAE_STREAM(2, 4) CRL_GAE_STREAM(2, 8) CRL_GAE_STREAM(2, 16)
+    CRL_GAE_STREAM(1, 4) CRL_GAE_STREAM(1, 8) CRL_GAE_STREAM(1, 16)
+    { set_error("gae: unsupported streaming configuration"); return 1; }
+#undef CRL_GAE_STREAM
     CRL_HIP_CHECK(hipGetLastError());
     return 0;
   }
   // segment length L and env tile EB: S = ceil(k/L) segments, block = S*EB <= 512 threads.
   // Short segments + narrow tiles give the most loads in flight; long rollouts fall back to longer segments.
-  const int env_L = seg, env_EB = tile, env_nts = 0;   // options gae_seg / gae_tile (0 = automatic)
+  const int env_L = seg == 4 ? 0 : seg, env_EB = tile, env_nts = 0;   // options gae_seg / gae_tile (0 = automatic)
   // (a 4-envs-per-thread variant with 16-B loads was measured SLOWER: 38.9 vs 32.1 us at nt=65536 — 182 VGPRs leave only
   //  2 waves/SIMD; profiles/r01_g_gae_wide_vs_scalar.txt)
   int L = env_L ? env_L : (k <= 256 ? 8 : 16);
@@ -249,17 +264,13 @@ __global__ void __launch_bounds__(256) gae_bench_fill_kernel(float* value, float
     terminal[i] = (((x >> 8) & 0xFFu) < 5u) ? 1 : 0;                 // Bernoulli(≈0.02)
   }
 }
-// the ceiling: a plain streaming copy, 16 B per lane, four pieces in flight per thread, nontemporal both ways
+// the ceiling: a plain streaming copy, ONE 16-byte piece per thread, nontemporal both ways. scripts/micro/stream_rate.hip swept the grid size
+// (512 ... 16384 blocks), 1 / 2 / 4 / 8 pieces in flight per thread, a grid-stride against a block-contiguous walk and cached against
+// nontemporal accesses at 0.14 / 0.57 / 1.14 GB: one piece per thread (6.4-6.5 TB/s at 0.57 and 1.14 GB) and eight pieces of a
+// block-contiguous share at 16384 blocks (6.4-6.6) lead; round 4's grid-stride walk with four pieces at <= 8192 blocks ran 5.0-5.3.
 __global__ void __launch_bounds__(256) gae_bench_copy_kernel(const f32x4v* __restrict__ src, f32x4v* __restrict__ dst, size_t n4) {
-  const size_t stride = (size_t)gridDim.x * 256;
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  for (; i + 3 * stride < n4; i += 4 * stride) {
-    const f32x4v a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride),
-                 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
-    __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + stride);
-    __builtin_nontemporal_store(c, dst + i + 2 * stride); __builtin_nontemporal_store(d, dst + i + 3 * stride);
-  }
-  for (; i < n4; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
 }  // namespace crl
@@ -303,9 +314,7 @@ extern "C" int32_t crl_gae_bench(int32_t device, int32_t nt, int32_t k, int32_t 
       CRL_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
       if (r >= 0) gae_ms[r] = ms;
       if (flush) CRL_HIP_CHECK(hipMemsetAsync(flush, (r + 1) & 0xFF, (size_t)flush_mb << 20, st));
-      size_t blocks = (n4 + 256 * 4 - 1) / (256 * 4);
-      if (blocks > 8192) blocks = 8192;
-      if (blocks < 1) blocks = 1;
+      const size_t blocks = (n4 + 255) / 256;
       hipExtLaunchKernelGGL(gae_bench_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, st, e0, e1, 0, csrc, cdst, n4);
       CRL_HIP_CHECK(hipGetLastError());
       CRL_HIP_CHECK(hipEventSynchronize(e1));

@@ -13,8 +13,8 @@ sizes = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [6553
 med = lambda v: sorted(v)[len(v) // 2]   # noqa: E731
 for nt in sizes:
     nbytes = 17 * nt * 128 + 5 * nt
-    for tile in (4, 64):
-        for seg in (0, 16):
+    for tile, seg in ((4, 4), (4, 8), (4, 16), (2, 4), (2, 8), (2, 16), (1, 8), (1, 16), (64, 0), (64, 16), (0, 0)):
+        if True:
             for ntl in (0, 1):
                 try:
                     g, c = crl._lib.gae_bench(nt, 128, seg=seg, tile=tile, nt_loads=ntl, flush_mb=(1024 if nbytes < (300 << 20) else 0), reps=8)

@@ -961,7 +961,7 @@ def test_streaming_gae_kernel_is_bit_equal_to_the_oracle(crl, nt, k):
     assert rel_err(h.read(F.F_ADVANTAGE), adv_o) < 1e-6
     agent.close()
     if nt == 4:
-        with pytest.raises(crl.CrlError, match="num_envs % 4"):
+        with pytest.raises(crl.CrlError, match="num_envs % gae_tile"):
             a2 = make_agent(crl, nt=6, k=8, num_minibatches=1, options={"gae_tile": 4})
             a2.handle.compute_gae()
 
@@ -977,27 +977,29 @@ def _gae_inputs(nt, k, seed):
 
 @pytest.mark.parametrize("nt_loads", [0, 1])
 @pytest.mark.parametrize("mode", [0, 1])
-@pytest.mark.parametrize("nt,k", [(8192, 128), (65536, 128), (1028, 37), (65540, 9)])
-def test_streaming_gae_kernel_many_blocks_both_modes_both_load_flavours(crl, nt, k, mode, nt_loads):
-    """gae_stream_kernel with MANY blocks (8 … 65 of 256 threads; `blockIdx.x * 256` indexing, a ragged last block at 1028 / 65540 envs, the
-    two-register-set prefetch over 16 chunks at k = 128 and a partial first chunk at k = 37 / 9), the cached and the nontemporal load
-    flavour, compat mode AND fixed mode with a random bootstrap (next_value / next_done through the 16-byte / 4-byte loads that seed
-    vnext / dnext): crl_gae_opt(gae_tile = 4) on host arrays must equal orc_gae bit for bit — it runs the reference's serial Float64
-    recurrence (ppo.jl:63-69) in the reference's order."""
+@pytest.mark.parametrize("nt,k,tile,seg", [(8192, 128, 4, 0), (65536, 128, 4, 0), (65536, 128, 2, 0), (65536, 128, 2, 16), (65536, 128, 1, 4), (1028, 37, 4, 16),
+                                           (1028, 37, 2, 8), (65540, 9, 4, 8), (65542, 9, 2, 16), (65541, 3, 1, 8)])
+def test_streaming_gae_kernel_many_blocks_both_modes_both_load_flavours(crl, nt, k, tile, seg, mode, nt_loads):
+    """gae_stream_kernel with MANY blocks (`blockIdx.x * 256` indexing, ragged last blocks at 1028 / 65540 / 65541 / 65542 envs), every
+    envs-per-thread width (gae_tile = 4 / 2 / 1: 16- / 8- / 4-byte accesses) and window depth (gae_seg = 4 / 8 / 16; k = 37 / 9 / 3 leave the
+    rolling window partly empty or never full), the cached and the nontemporal flavour, compat mode AND fixed mode with a random
+    bootstrap (next_value / next_done through the vector loads that seed vnext / dnext): crl_gae_opt on host arrays must equal orc_gae bit
+    for bit — the kernel runs the reference's serial Float64 recurrence (ppo.jl:63-69) in the reference's order."""
     value, reward, term, nv, nd = _gae_inputs(nt, k, nt * 7 + k + mode)
     adv_o, ret_o = O.gae_batch(value, reward, term, nv, nd, 0.99, 0.95, mode)
-    adv_g, ret_g = crl._lib.gae_host(value, reward, term, nv, nd, 0.99, 0.95, mode, tile=4, nt_loads=nt_loads)
+    adv_g, ret_g = crl._lib.gae_host(value, reward, term, nv, nd, 0.99, 0.95, mode, tile=tile, seg=seg, nt_loads=nt_loads)
     assert np.array_equal(adv_g, adv_o) and np.array_equal(ret_g, ret_o)
     if mode == 1:     # the bootstrap is live: a different next_value must move the last column
-        adv_2, _ = crl._lib.gae_host(value, reward, term, nv + 1.0, np.zeros_like(nd), 0.99, 0.95, mode, tile=4, nt_loads=nt_loads)
+        adv_2, _ = crl._lib.gae_host(value, reward, term, nv + 1.0, np.zeros_like(nd), 0.99, 0.95, mode, tile=tile, seg=seg, nt_loads=nt_loads)
         assert (adv_2[:, -1] != adv_g[:, -1]).mean() > 0.9
 
 
 @pytest.mark.parametrize("mode", [0, 1])
 def test_automatic_gae_kernel_choice_past_the_infinity_cache_is_bit_equal(crl, mode):
     """(524288, 128) = 2^26 samples, 1.14 GB per launch — the shape bench.py's roofline_gae.beyond_cache times: crl_gae takes the streaming
-    kernel BY ITSELF here (gae.hip launch_gae: tile = 0, nt·k >= 2^26, nt >= 262144) with nontemporal loads (crl_gae's own rule from 4 M
-    samples): 512 blocks, every CU two of them. Bit-equal to orc_gae; the explicit cached-load flavour as well."""
+    kernel BY ITSELF here (gae.hip launch_gae: tile = 0, nt·k >= 2^25, nt >= 262144: two envs per thread, window of 8) with nontemporal
+    accesses (crl_gae's own rule from 4 M samples): 1024 blocks, every CU four of them. Bit-equal to orc_gae; the explicit cached flavour as
+    well. (262144 x 128, the other beyond_cache row, goes the same way in test_gae_matches_oracle's last case.)"""
     nt, k = 524288, 128
     value, reward, term, nv, nd = _gae_inputs(nt, k, 99 + mode)
     adv_o, ret_o = O.gae_batch(value, reward, term, nv, nd, 0.99, 0.95, mode)
@@ -1017,7 +1019,7 @@ def test_gae_opt_rejects_bad_flavours(crl):
         with pytest.raises(crl.CrlError, match="gae_seg is 0"):
             crl._lib.gae_host(value, reward, term, nv, nd, 0.99, 0.95, 0, **{**dict(seg=0, tile=8, nt_loads=0), **kw})
     value, reward, term, nv, nd = _gae_inputs(6, 4, 1)
-    with pytest.raises(crl.CrlError, match="num_envs % 4"):
+    with pytest.raises(crl.CrlError, match="num_envs % gae_tile"):
         crl._lib.gae_host(value, reward, term, nv, nd, 0.99, 0.95, 0, tile=4)
 
 
@@ -1025,7 +1027,7 @@ def test_gae_bench_entry_point_times_the_scan_and_its_copy(crl):
     """crl_gae_bench (bench.py roofline_gae.beyond_cache): the standalone scan on synthetic device-resident inputs next to a float4 copy of the
     same byte count; every flavour returns `reps` positive launch times, and a shape the streaming kernel cannot take is an error, not a
     silent fall-back."""
-    for tile, seg, ntl in ((4, 0, 0), (4, 16, 1), (64, 16, 0), (0, 0, 1)):
+    for tile, seg, ntl in ((4, 0, 0), (4, 16, 1), (2, 4, 1), (1, 8, 0), (64, 16, 0), (0, 0, 1)):
         g, c = crl._lib.gae_bench(4096, 128, seg=seg, tile=tile, nt_loads=ntl, flush_mb=0, reps=3)
         assert len(g) == 3 and len(c) == 3 and min(g) > 0 and min(c) > 0 and max(g) < 50.0
     with pytest.raises(crl.CrlError):
