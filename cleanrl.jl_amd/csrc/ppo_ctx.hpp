@@ -70,6 +70,7 @@ enum OptId {
   OPT_WIDE_WGRAD_FULL,        // h1-free weight gradient: 0 = 256x128 tiles, two blocks per CU (default), 1 = 256x256 tile per block (δ2 read once)
   OPT_WIDE_FUSE_PC,           // fused forward: 1 = producer / consumer waves, persistent (default), 0 = the symmetric first version
   OPT_WIDE_FUSE,              // layer-wise path, 2x256 fp16x2: 1 = tile-resident fused passes of wide_fused.hpp (default), 0 = one launch per layer
+  OPT_WIDE_FWD_WBUFS,         // fused forward (producer / consumer): weight buffers in LDS — 2 = the producers fetch the next slab (default), 3 = the consumers fetch the slab after next (n_act <= 6; measured equal)
   OPT_COUNT
 };
 

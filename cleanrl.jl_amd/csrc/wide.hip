@@ -1928,8 +1928,8 @@ __global__ void __launch_bounds__(512) wide_rollout_pc_kernel(RollPCArgs r) {
         hpre[s] = mfma_x2(af, bf, hpre[s]);
       }
     };
-    auto produce = [&](int net, int s, const f32x16& c, unsigned char* wbuf, unsigned char* xbuf) {
-      {
+    auto produce = [&](int net, int s, const f32x16& c, unsigned char* wbuf, unsigned char* xbuf, bool with_dma) {
+      if (with_dma) {      // a network's FIRST weight slab only; inside the slab loop the consumers fetch the next one behind their own MFMAs
         const char* g = reinterpret_cast<const char*>(r.n[net].Wx2) + (size_t)s * FX_WBYTES + p * 8192;
         const unsigned lds0 = lds_addr_of(wbuf) + p * 8192, voff = lane * 16;
 #pragma unroll
@@ -1981,16 +1981,16 @@ __global__ void __launch_bounds__(512) wide_rollout_pc_kernel(RollPCArgs r) {
         xhi = q2.hi; xlo = q2.lo;
       }
       layer1(0);
-      produce(0, 0, hpre[0], smx, smx + RP_OFF_X);
+      produce(0, 0, hpre[0], smx, smx + RP_OFF_X, true);
 #pragma unroll 1
       for (int net = 0; net < 2; ++net) {
         __builtin_amdgcn_s_barrier();                                    // B_start
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-          if (s < 7) produce(net, s + 1, hpre[(s + 1) & 7], smx + ((s + 1) & 1) * FX_WBYTES, smx + RP_OFF_X + ((s + 1) & 1) * RP_XBYTES);
+          if (s < 7) produce(net, s + 1, hpre[(s + 1) & 7], smx + ((s + 1) & 1) * FX_WBYTES, smx + RP_OFF_X + ((s + 1) & 1) * RP_XBYTES, false);
           __builtin_amdgcn_s_barrier();
         }
-        if (net == 0) { layer1(1); produce(1, 0, hpre[0], smx, smx + RP_OFF_X); }   // the critic's layer 1 and first slab, under the actor's epilogue
+        if (net == 0) { layer1(1); produce(1, 0, hpre[0], smx, smx + RP_OFF_X, true); }   // the critic's layer 1 and first slab, under the actor's epilogue
         __builtin_amdgcn_s_barrier();                                    // B_epi
       }
       __builtin_amdgcn_s_barrier();                                      // B_fold
@@ -2018,6 +2018,10 @@ __global__ void __launch_bounds__(512) wide_rollout_pc_kernel(RollPCArgs r) {
         for (int s = 0; s < 8; ++s) {
           const f16x8* Wl = reinterpret_cast<const f16x8*>(smx + (s & 1) * FX_WBYTES);
           const _Float16* Xl = reinterpret_cast<const _Float16*>(smx + RP_OFF_X + (s & 1) * RP_XBYTES);
+          // the next weight slab: this consumer's 8 of the 32 pieces, one behind every product (as in wide_fused_fwd_pc_kernel)
+          const bool dma = s + 1 < 8;
+          const char* wg = reinterpret_cast<const char*>(nn.Wx2) + (size_t)(s + 1) * FX_WBYTES + c * 8192;
+          const unsigned wl0 = lds_addr_of(smx + ((s + 1) & 1) * FX_WBYTES) + c * 8192, wvo = lane * 16;
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
             P2 af[2], bf[2];
@@ -2035,8 +2039,12 @@ __global__ void __launch_bounds__(512) wide_rollout_pc_kernel(RollPCArgs r) {
 #pragma unroll
             for (int ai = 0; ai < 2; ++ai)
 #pragma unroll
-              for (int bi = 0; bi < 2; ++bi) acc[ai][bi] = mfma_x2(af[ai], bf[bi], acc[ai][bi]);
+              for (int bi = 0; bi < 2; ++bi) {
+                acc[ai][bi] = mfma_x2(af[ai], bf[bi], acc[ai][bi]);
+                if (dma) { const int pc = ks * 4 + ai * 2 + bi; lds_dma16(wg + pc * 1024, wvo, wl0 + pc * 1024); }
+              }
           }
+          if (dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
         }
         // epilogue: h2 = tanh(acc·unscale + b2) stays in registers; head partials of this row group
@@ -2544,11 +2552,17 @@ static int wide_forward_fused(crl_ppo* h, const int32_t* perm, int M) {
       q[net].ldz = a[net].ldz; q[net].H1 = a[net].H1; q[net].H2 = a[net].H2; q[net].Z = a[net].Z; q[net].M = M;
     }
     int nb = w->cus / 2; const int ntiles = M / FX_MB; if (nb > ntiles) nb = ntiles; if (nb < 1) nb = 1;
-    if (wide_h1_free(h)) {
-      if (w->D8 == 8) hipLaunchKernelGGL((wide_fused_fwd_pc_kernel<8, false>), dim3(nb, 2), dim3(512), PC_LDS, h->stream, q[0], q[1]);
-      else hipLaunchKernelGGL((wide_fused_fwd_pc_kernel<16, false>), dim3(nb, 2), dim3(512), PC_LDS, h->stream, q[0], q[1]);
-    } else if (w->D8 == 8) hipLaunchKernelGGL((wide_fused_fwd_pc_kernel<8, true>), dim3(nb, 2), dim3(512), PC_LDS, h->stream, q[0], q[1]);
-    else hipLaunchKernelGGL((wide_fused_fwd_pc_kernel<16, true>), dim3(nb, 2), dim3(512), PC_LDS, h->stream, q[0], q[1]);
+    // three weight buffers (the slab after next in flight) where the W3ᵀ table leaves room for them, option wide_fwd_wbufs = 2 keeps two
+    const bool three = w->A <= pc_amax(3) && opt(h, OPT_WIDE_FWD_WBUFS) >= 3 && w->lds_max >= pc_lds(3);
+#define CRL_FWD_PC(dp, wh1)                                                                                                                      \
+    do {                                                                                                                                           \
+      if (three) hipLaunchKernelGGL((wide_fused_fwd_pc_kernel<dp, wh1, 3>), dim3(nb, 2), dim3(512), pc_lds(3), h->stream, q[0], q[1]);             \
+      else hipLaunchKernelGGL((wide_fused_fwd_pc_kernel<dp, wh1, 2>), dim3(nb, 2), dim3(512), pc_lds(2), h->stream, q[0], q[1]);                   \
+    } while (0)
+    if (wide_h1_free(h)) { if (w->D8 == 8) CRL_FWD_PC(8, false); else CRL_FWD_PC(16, false); }
+    else if (w->D8 == 8) CRL_FWD_PC(8, true);
+    else CRL_FWD_PC(16, true);
+#undef CRL_FWD_PC
     CRL_HIP_CHECK(hipGetLastError());
     return 0;
   }

@@ -553,7 +553,23 @@ namespace crl {
 // so a slab costs max(producer, consumer). Persistent: a block walks tiles blockIdx.x, + gridDim.x, …; the producers prepare the next
 // tile's first slab and prefetch its observations while the consumers run the epilogue (tanh, head partials, h2 out in whole lines).
 // ======================================================================================================================================
-constexpr int PC_OFF_W1F = FX_OFF_X + 2 * FX_XBYTES;          // 106,496: W1 A-fragments, [slab 8][piece 2][lane 64][8 halves] = 16 KB
+// LDS layout, by the number of weight buffers NWB: [NWB weight slabs 32 KB][2 activation slabs 20 KB][W1 fragments 16 KB][b1 1 KB][W3ᵀ][b2 1 KB].
+// NWB = 3 (round 5, option wide_fwd_wbufs = 3, n_act <= 6): the CONSUMERS fetch the weight slab after next behind their own MFMAs — two slabs of lead
+// for the LDS-DMA, nothing but h1 left to the producers. Built on the reading that the loop (1.44 µs per slab against 0.77 µs of MFMAs) waits for the
+// DMA's latency; the stamps of both flavours (profiles/r05_c3_fwd_stamps.txt) say otherwise: with two buffers a producer spends 0.56 µs issuing its 8
+// pieces and 0.88 µs on h1 beside a consumer whose 48 MFMAs take 1.04 µs; with three the consumer's 48 MFMAs + 8 pieces take 1.28 µs and the producer's h1
+// work 1.40 µs — the same 1.5 µs per slab. Both waves of a SIMD draw on ONE vector-issue port: an MFMA holds it 8 of its 32 cycles, a VALU instruction 4-8,
+// and an LDS-DMA piece 100-140 cycles (MI355X_MICROARCH.md: 60 among bare MFMAs, 100-185 in a busy phase) — a slab's 32 pieces cost each SIMD ≈ 0.4 µs of
+// issue time whoever issues them. Kept as an option; NWB = 2 stays the default.
+constexpr int pc_off_x(int nwb) { return nwb * FX_WBYTES; }
+constexpr int pc_off_w1f(int nwb) { return pc_off_x(nwb) + 2 * FX_XBYTES; }
+constexpr int pc_off_b1(int nwb) { return pc_off_w1f(nwb) + 16384; }
+constexpr int pc_off_w3(int nwb) { return pc_off_b1(nwb) + 1024; }
+constexpr int pc_amax(int nwb) { return nwb == 3 ? 6 : 8; }                  // head rows the W3ᵀ table holds (160 KB of LDS: 3 buffers leave room for 6)
+constexpr int pc_off_b2(int nwb) { return pc_off_w3(nwb) + pc_amax(nwb) * 1024; }
+constexpr int pc_lds(int nwb) { return pc_off_b2(nwb) + 1024; }
+static_assert(pc_lds(3) <= 160 * 1024 && pc_lds(2) == 133120, "producer / consumer forward: LDS budget");
+constexpr int PC_OFF_W1F = FX_OFF_X + 2 * FX_XBYTES;          // (two-buffer layout) 106,496: W1 A-fragments, [slab 8][piece 2][lane 64][8 halves] = 16 KB
 constexpr int PC_OFF_B1 = PC_OFF_W1F + 16384;                // b1·2·log2(e) [256] f32
 #ifndef PC_PRODUCER_PRIO
 #define PC_PRODUCER_PRIO 0   // measured: 0, 2 and 3 within noise (45.5-46.2 ms per C3 iteration on one box)
@@ -573,17 +589,19 @@ struct FusedFwdPCArgs {
   float* H1; float* H2; float* Z; int M;
 };
 
-template <int DP, bool WRITE_H1>
+template <int DP, bool WRITE_H1, int NWB>
 __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
+  constexpr int OFF_X = pc_off_x(NWB), OFF_W1F = pc_off_w1f(NWB), OFF_B1 = pc_off_b1(NWB), OFF_W3 = pc_off_w3(NWB), OFF_B2 = pc_off_b2(NWB);
+  constexpr int SCRB = NWB == 3 ? 2 : 1;      // weight buffer the consumers' epilogue scratch aliases: free from the loop's last barrier on (3 buffers: last read in slab 5)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, hf = lane >> 5;
   const int ntiles = a.M / FX_MB;
   // W1 fragments + bias table into LDS, once
   for (int i = tid; i < (16384 + 1024) / 16; i += 512)
-    reinterpret_cast<f32x4*>(smx + PC_OFF_W1F)[i] = reinterpret_cast<const f32x4*>(a.W1f)[i];
-  for (int i = tid; i < a.A * 256; i += 512) reinterpret_cast<float*>(smx + PC_OFF_W3)[i] = a.W3t[i];
-  if (tid < 256) reinterpret_cast<float*>(smx + PC_OFF_B2)[tid] = a.b2[tid];
+    reinterpret_cast<f32x4*>(smx + OFF_W1F)[i] = reinterpret_cast<const f32x4*>(a.W1f)[i];
+  for (int i = tid; i < a.A * 256; i += 512) reinterpret_cast<float*>(smx + OFF_W3)[i] = a.W3t[i];
+  if (tid < 256) reinterpret_cast<float*>(smx + OFF_B2)[tid] = a.b2[tid];
   __syncthreads();
   if (wave >= 4) {
     if (PC_PRODUCER_PRIO) __builtin_amdgcn_s_setprio(PC_PRODUCER_PRIO);   // few instructions, all on the slab's critical path: they go first
@@ -618,23 +636,27 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
       P2 bf; bf.hi = xhi; bf.lo = xlo;
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        const f16x8* wf = reinterpret_cast<const f16x8*>(smx + PC_OFF_W1F) + (s * 2) * 64 + lane;
+        const f16x8* wf = reinterpret_cast<const f16x8*>(smx + OFF_W1F) + (s * 2) * 64 + lane;
         P2 af; af.hi = wf[0]; af.lo = wf[64];
 #pragma unroll
         for (int r = 0; r < 16; ++r) hpre[s][r] = 0.0f;
         hpre[s] = mfma_x2(af, bf, hpre[s]);
       }
     };
-    auto produce = [&](int t, int s, const f32x16& c, unsigned char* wbuf, unsigned char* xbuf, bool stamp = false) {
-      // weight slab s: this producer's 8 of the 32 pieces
+    auto dma_w = [&](int s, unsigned char* wbuf) {                     // weight slab s: this producer's 8 of the 32 pieces
       const char* g = reinterpret_cast<const char*>(a.Wx2) + (size_t)s * FX_WBYTES + p * 1024;
       const unsigned lds0 = lds_addr_of(wbuf) + p * 1024, voff = lane * 16;
 #pragma unroll
       for (int i = 0; i < 8; ++i) lds_dma16(g + i * 4096, voff, lds0 + i * 4096);
+    };
+    auto produce = [&](int t, int s, const f32x16& c, unsigned char* wbuf, unsigned char* xbuf, bool with_dma, bool stamp = false) {
+      // with_dma: the producers fetch the weight slab as well — always with two weight buffers; with three only a tile's first two slabs (under
+      // the consumers' epilogue): inside the slab loop the consumers fetch the slab after next themselves, in the shadow of their own MFMAs
+      if (with_dma) dma_w(s, wbuf);
       asm volatile("" ::: "memory");
       if (stamp) CRL_WSTAMP(1, 6);
       // h1 slab: units 32s …, this producer's 32 samples
-      const float* b1l = reinterpret_cast<const float*>(smx + PC_OFF_B1) + 32 * s + 4 * hf;
+      const float* b1l = reinterpret_cast<const float*>(smx + OFF_B1) + 32 * s + 4 * hf;
       _Float16* Xl = reinterpret_cast<_Float16*>(xbuf);
       const int gm = t * FX_MB + 32 * p + j;
       // sixteen independent chains, written stage by stage: per group of four (bias load, tanh, split, store) the compiler keeps the groups
@@ -676,7 +698,8 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
     float xr[8];
     if ((int)blockIdx.x < ntiles) { load_x(blockIdx.x, xr); make_xfrag(xr); layer1(); }
     if ((int)blockIdx.x < ntiles) {
-      produce(blockIdx.x, 0, hpre[0], smx, smx + FX_OFF_X);
+      produce(blockIdx.x, 0, hpre[0], smx, smx + OFF_X, true);
+      if (NWB == 3) dma_w(1, smx + FX_WBYTES);
       asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     }
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -689,11 +712,13 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
       for (int s = 0; s < 8; ++s) {
         if (st_) CRL_WSTAMP(1, 8 + s);
         if (s < 7) {
-          produce(t, s + 1, hpre[(s + 1) & 7], smx + ((s + 1) & 1) * FX_WBYTES, smx + FX_OFF_X + ((s + 1) & 1) * FX_XBYTES, st_ && s == 3);
+          produce(t, s + 1, hpre[(s + 1) & 7], smx + ((s + 1) & 1) * FX_WBYTES, smx + OFF_X + ((s + 1) & 1) * FX_XBYTES, NWB == 2, st_ && s == 3);
           if (st_ && s == 3) CRL_WSTAMP(1, 4);
-          // the 8 weight pieces have landed (the 4 h1 stores issued behind them may stay in flight); the LDS stores are done
-          if (WRITE_H1) asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+          if (NWB == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS stores are done (h1 stores to HBM, if any, may stay in flight)
+          // two buffers: the 8 weight pieces have landed (the 4 h1 stores issued behind them may stay in flight)
+          else if (WRITE_H1) asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+          if (st_ && s == 3) CRL_WSTAMP(1, 7);
         }
         __builtin_amdgcn_s_barrier();
       }
@@ -701,7 +726,8 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
       if (tn < ntiles) {                                                 // the next tile's layer 1 and first slab, under the consumers' epilogue (buffer 0: last read in slab 6)
         make_xfrag(xr);
         layer1();
-        produce(tn, 0, hpre[0], smx, smx + FX_OFF_X);
+        produce(tn, 0, hpre[0], smx, smx + OFF_X, true);
+        if (NWB == 3) dma_w(1, smx + FX_WBYTES);                         // buffer 1: last read in slab 7, before the loop's last barrier
         asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
       }
       if (st_) CRL_WSTAMP(1, 2);
@@ -713,8 +739,8 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
     const int c = wave;
     const float cs = a.wsc[1] * (1.0f / X2_ACT_SCALE);
     const int hs = a.A;
-    float* scr = reinterpret_cast<float*>(smx + FX_WBYTES) + c * (32 * 36);               // in weight buffer 1
-    float* hp_all = reinterpret_cast<float*>(smx + FX_OFF_X + FX_XBYTES);                 // in activation buffer 1 (both are free from the loop's last barrier to slab 1 of the next tile)
+    float* scr = reinterpret_cast<float*>(smx + SCRB * FX_WBYTES) + c * (32 * 36);        // in weight buffer SCRB
+    float* hp_all = reinterpret_cast<float*>(smx + OFF_X + FX_XBYTES);                 // in activation buffer 1 (both are free from the loop's last barrier to slab 1 of the next tile)
     float* hp = hp_all + c * (FX_MB * hs);
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
       const int m0 = t * FX_MB;
@@ -731,8 +757,14 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
 #pragma unroll 1
       for (int s = 0; s < 8; ++s) {
         if (st_) CRL_WSTAMP(1, 8 + s);
-        const f16x8* Wl = reinterpret_cast<const f16x8*>(smx + (s & 1) * FX_WBYTES);
-        const _Float16* Xl = reinterpret_cast<const _Float16*>(smx + FX_OFF_X + (s & 1) * FX_XBYTES);
+        const int wb = NWB == 3 ? s % 3 : (s & 1);
+        const f16x8* Wl = reinterpret_cast<const f16x8*>(smx + wb * FX_WBYTES);
+        const _Float16* Xl = reinterpret_cast<const _Float16*>(smx + OFF_X + (s & 1) * FX_XBYTES);
+        // three buffers: the weight slab AFTER NEXT — this consumer's 8 of its 32 pieces, one behind each of the slab's first eight products
+        // (buffer (s + 2) % 3 was last read in slab s - 1, before the previous barrier)
+        const bool dma = NWB == 3 && s + 2 < 8;
+        const char* wg = reinterpret_cast<const char*>(a.Wx2) + (size_t)(s + 2) * FX_WBYTES + c * 1024;
+        const unsigned wl0 = lds_addr_of(smx + ((s + 2) % 3) * FX_WBYTES) + c * 1024, wvo = lane * 16;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           P2 af[2], bf[4];
@@ -750,24 +782,31 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
 #pragma unroll
           for (int ai = 0; ai < 2; ++ai)
 #pragma unroll
-            for (int bi = 0; bi < 4; ++bi) acc[ai][bi] = mfma_x2(af[ai], bf[bi], acc[ai][bi]);
+            for (int bi = 0; bi < 4; ++bi) {
+              acc[ai][bi] = mfma_x2(af[ai], bf[bi], acc[ai][bi]);
+              if (dma && ks == 0) { const int pc = ai * 4 + bi; lds_dma16(wg + pc * 4096, wvo, wl0 + pc * 4096); }
+            }
         }
         if (st_ && s == 3) CRL_WSTAMP(1, 4);
+        // the pieces of slab s + 1 (issued a slab ago; a tile's first two slabs come from the producers) have landed before anybody passes the
+        // barrier; the eight of slab s + 2 just issued stay in flight
+        if (NWB == 3) { if (dma) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        if (st_ && s == 3) CRL_WSTAMP(1, 7);
         __builtin_amdgcn_s_barrier();
       }
       if (st_) { CRL_WSTAMP(1, 1); CRL_WSTAMP_CYC(1, 6); }
       // epilogue: h2 = tanh(acc·unscale + b2) out in whole lines, head partials of this consumer's 64 rows. b2 and W3 come from LDS and a
       // row group's 16 head weights per action are read ONCE for its four sample tiles (the first version read them per tile from global
       // memory: 32 dependent round trips, 11.8 of the tile's 24 µs — profiles/r04_c3_stamps.txt)
-      float hacc[4][PC_AMAX];
+      float hacc[4][pc_amax(NWB)];
 #pragma unroll
       for (int bi = 0; bi < 4; ++bi)
 #pragma unroll
-        for (int aa = 0; aa < PC_AMAX; ++aa) hacc[bi][aa] = 0.0f;
+        for (int aa = 0; aa < pc_amax(NWB); ++aa) hacc[bi][aa] = 0.0f;
 #pragma unroll
       for (int ai = 0; ai < 2; ++ai) {
         const int n0 = 64 * c + 32 * ai;
-        const float* b2l = reinterpret_cast<const float*>(smx + PC_OFF_B2) + n0 + 4 * hf;
+        const float* b2l = reinterpret_cast<const float*>(smx + OFF_B2) + n0 + 4 * hf;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x4 bv = *reinterpret_cast<const f32x4*>(b2l + 8 * g);
@@ -779,9 +818,9 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
 #pragma unroll
         for (int bi = 0; bi < 4; ++bi) tile_out<EPI_STORE>(scr, acc[ai][bi], lane, n0, m0 + 32 * bi, a.M, nullptr, nullptr, 0, a.H2, 256);
 #pragma unroll
-        for (int aa = 0; aa < PC_AMAX; ++aa) {
+        for (int aa = 0; aa < pc_amax(NWB); ++aa) {
           if (aa < a.A) {
-            const float* w3l = reinterpret_cast<const float*>(smx + PC_OFF_W3) + 256 * aa + n0 + 4 * hf;
+            const float* w3l = reinterpret_cast<const float*>(smx + OFF_W3) + 256 * aa + n0 + 4 * hf;
             f32x4 w[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) w[g] = *reinterpret_cast<const f32x4*>(w3l + 8 * g);
@@ -798,7 +837,7 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
         }
       }
 #pragma unroll
-      for (int aa = 0; aa < PC_AMAX; ++aa) {
+      for (int aa = 0; aa < pc_amax(NWB); ++aa) {
         if (aa < a.A) {
 #pragma unroll
           for (int bi = 0; bi < 4; ++bi) {
@@ -824,9 +863,9 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
   }
 }
 
-template <int DP, bool WRITE_H1>
+template <int DP, bool WRITE_H1, int NWB>
 __global__ void __launch_bounds__(512) wide_fused_fwd_pc_kernel(FusedFwdPCArgs a0, FusedFwdPCArgs a1) {
-  if (blockIdx.y == 0) wide_fused_fwd_pc_body<DP, WRITE_H1>(a0); else wide_fused_fwd_pc_body<DP, WRITE_H1>(a1);
+  if (blockIdx.y == 0) wide_fused_fwd_pc_body<DP, WRITE_H1, NWB>(a0); else wide_fused_fwd_pc_body<DP, WRITE_H1, NWB>(a1);
 }
 
 // fp16x2 A-fragments of W1·2·log2(e)·scale1 for the producers' layer-1 product — [slab][piece][lane][8]: element e of lane l of slab s is

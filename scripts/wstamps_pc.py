@@ -20,8 +20,11 @@ for g, nm in ((slice(0, 4), "consumers"), (slice(4, 8), "producers")):
           (nm, np.median(u[..., 0]), np.median(u[..., 11]), np.median(u[..., 4]), np.median(u[..., 1]), np.median(u[..., 2]), np.median(u[..., 3])))
 agent.close()
 p = us[:, 4:8, :]
-print("  producer slab 3: top %.2f | DMA issued +%.2f | layer-1 MFMA result +%.2f | tanh/split/LDS stores +%.2f" % (
-    np.median(p[..., 11]), np.median(p[..., 6] - p[..., 11]), np.median(p[..., 7] - p[..., 6]), np.median(p[..., 4] - p[..., 7])))
+c = us[:, 0:4, :]
+print("  slab 3, producers: top %.2f | bias loads / DMA issue +%.2f | tanh, split, LDS stores issued +%.2f | waits done +%.2f | next top +%.2f" % (
+    np.median(p[..., 11]), np.median(p[..., 6] - p[..., 11]), np.median(p[..., 4] - p[..., 6]), np.median(p[..., 7] - p[..., 4]), np.median(p[..., 12] - p[..., 7])))
+print("  slab 3, consumers: top %.2f | 48 MFMAs (+ 8 DMA pieces) issued +%.2f | vmcnt wait done +%.2f | next top +%.2f" % (
+    np.median(c[..., 11]), np.median(c[..., 4] - c[..., 11]), np.median(c[..., 7] - c[..., 4]), np.median(c[..., 12] - c[..., 7])))
 print("  top of slab 0..7 and loop end:", " ".join("%.2f" % np.median(p[..., 8 + s]) for s in range(8)), "%.2f" % np.median(p[..., 1]))
 raw = buf.reshape(2, 256, 8, 16)[1, :128][ok].astype(np.int64)[:, :4, :]
 print("  shader clock during the slab loop (s_memtime / s_memrealtime, consumer waves): %.0f MHz" % np.median((raw[..., 6] - raw[..., 5]) / ((raw[..., 1] - raw[..., 0]) / 100.0)))
