@@ -44,7 +44,7 @@ static const OptDesc kOpts[OPT_COUNT] = {
     {"wide_wgrad_full", 1, 0, 1},
     {"wide_fuse_pc", 1, 0, 1},
     {"wide_fuse", 3, 0, 3},
-    {"wide_fwd_wbufs", 2, 2, 3},
+    {"wide_fwd_wbufs", 2, 0, 3},
 };
 static bool gae_seg_ok(int64_t v) { return v == 0 || v == 4 || v == 8 || v == 16; }
 static bool gae_tile_ok(int64_t v) { return v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64; }
@@ -62,6 +62,7 @@ static int opt_set(crl_ppo* h, const char* key, int64_t value) {
     return 1;
   }
   if (id == OPT_GAE_SEG && !gae_seg_ok(value)) { set_error("crl_ppo_set_option: gae_seg is 0 (automatic), 8 or 16 (4: streaming kernel only)"); return 1; }
+  if (id == OPT_WIDE_FWD_WBUFS && value == 1) { set_error("crl_ppo_set_option: wide_fwd_wbufs is 0 (weight fragments to registers), 2 or 3 (LDS buffers)"); return 1; }
   if (id == OPT_GAE_TILE && !gae_tile_ok(value)) { set_error("crl_ppo_set_option: gae_tile is 0 (automatic), 1 / 2 / 4 (streaming kernel, envs per thread), 8, 16, 32 or 64"); return 1; }
   h->opt[id] = value;
   if (id == OPT_GUARD_WINDOW) h->window_len = (int)value;

@@ -227,7 +227,7 @@ int launch_gae(hipStream_t st, const float* value, const float* reward, const ui
   }
   // segment length L and env tile EB: S = ceil(k/L) segments, block = S*EB <= 512 threads.
   // Short segments + narrow tiles give the most loads in flight; long rollouts fall back to longer segments.
-  const int env_L = seg == 4 ? 0 : seg, env_EB = tile, env_nts = 0;   // options gae_seg / gae_tile (0 = automatic)
+  const int env_L = seg == 4 ? 0 : seg, env_EB = tile, env_nts = 0;   // nontemporal STORES measured in round 5 (65536 / 32768 / 131072 envs, caches flushed): no difference for this kernel   // options gae_seg / gae_tile (0 = automatic)
   // (a 4-envs-per-thread variant with 16-B loads was measured SLOWER: 38.9 vs 32.1 us at nt=65536 — 182 VGPRs leave only
   //  2 waves/SIMD; profiles/r01_g_gae_wide_vs_scalar.txt)
   int L = env_L ? env_L : (k <= 256 ? 8 : 16);

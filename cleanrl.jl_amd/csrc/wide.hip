@@ -1430,7 +1430,8 @@ __global__ void __launch_bounds__(128 * WNB) wide_wgrad_x2_kernel(WgradArgs a) {
       // wave for a memory round trip before its MFMAs: 497 instead of ≈300 us per launch)
       const bool ok = m + j < c1;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) { const int cc = 8 * hf + c; xo[c] = (ok && cc < a.D) ? a.obs[(size_t)src_nx * a.D + cc] : 0.0f; }
+      for (int c = 0; c < 8; ++c) xo[c] = 0.0f;
+      load_obs8(a.obs, (size_t)src_nx, a.D, 8 * hf, ok, xo);
       const int mn = m + 32 + j;
       src_nx = mn < c1 ? (a.perm ? a.perm[mn] : mn) : 0;
     }
@@ -2554,9 +2555,11 @@ static int wide_forward_fused(crl_ppo* h, const int32_t* perm, int M) {
     int nb = w->cus / 2; const int ntiles = M / FX_MB; if (nb > ntiles) nb = ntiles; if (nb < 1) nb = 1;
     // three weight buffers (the slab after next in flight) where the W3ᵀ table leaves room for them, option wide_fwd_wbufs = 2 keeps two
     const bool three = w->A <= pc_amax(3) && opt(h, OPT_WIDE_FWD_WBUFS) >= 3 && w->lds_max >= pc_lds(3);
+    const bool regs = opt(h, OPT_WIDE_FWD_WBUFS) == 0;      // weight fragments straight into the consumers' registers
 #define CRL_FWD_PC(dp, wh1)                                                                                                                      \
     do {                                                                                                                                           \
-      if (three) hipLaunchKernelGGL((wide_fused_fwd_pc_kernel<dp, wh1, 3>), dim3(nb, 2), dim3(512), pc_lds(3), h->stream, q[0], q[1]);             \
+      if (regs) hipLaunchKernelGGL((wide_fused_fwd_pc_kernel<dp, wh1, 0>), dim3(nb, 2), dim3(512), pc_lds(0), h->stream, q[0], q[1]);              \
+      else if (three) hipLaunchKernelGGL((wide_fused_fwd_pc_kernel<dp, wh1, 3>), dim3(nb, 2), dim3(512), pc_lds(3), h->stream, q[0], q[1]);        \
       else hipLaunchKernelGGL((wide_fused_fwd_pc_kernel<dp, wh1, 2>), dim3(nb, 2), dim3(512), pc_lds(2), h->stream, q[0], q[1]);                   \
     } while (0)
     if (wide_h1_free(h)) { if (w->D8 == 8) CRL_FWD_PC(8, false); else CRL_FWD_PC(16, false); }

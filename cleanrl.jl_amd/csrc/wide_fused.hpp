@@ -22,7 +22,9 @@ __device__ unsigned long long crl_dbg_wstamps[2 * 256 * 8 * 16];
 #define CRL_BSTAMP(slot) do { if (lane == 0) bst[wave * 16 + (slot)] = wall_clock64(); } while (0)
 #define CRL_WSTAMP_CYC(kern, slot) do { const unsigned bx_ = (kern) ? blockIdx.x : blockIdx.x - 2048u; if ((threadIdx.x & 63) == 0 && bx_ < 256u && blockIdx.y == 0) crl_dbg_wstamps[(((kern) * 256 + bx_) * 8 + (threadIdx.x >> 6)) * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
 #define CRL_WSTAMP(kern, slot) do { const unsigned bx_ = (kern) ? blockIdx.x : blockIdx.x - 2048u; if ((threadIdx.x & 63) == 0 && bx_ < 256u && blockIdx.y == 0) crl_dbg_wstamps[(((kern) * 256 + bx_) * 8 + (threadIdx.x >> 6)) * 16 + (slot)] = wall_clock64(); } while (0)
+#define CRL_GSTAMP(slot) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 256u && blockIdx.y == 0) crl_dbg_wstamps[((blockIdx.x) * 8 + (threadIdx.x >> 6)) * 16 + (slot)] = wall_clock64(); } while (0)
 #else
+#define CRL_GSTAMP(slot) do { } while (0)
 #define CRL_WSTAMP(kern, slot) do { } while (0)
 #define CRL_BSTAMP(slot) do { } while (0)
 #define CRL_WSTAMP_CYC(kern, slot) do { } while (0)
@@ -60,6 +62,21 @@ __device__ __forceinline__ void lds_dma16(const void* sbase, unsigned voff, unsi
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+// Eight consecutive observation floats (elements k0 … k0 + 7, zero beyond obs_dim) of one gathered row. With obs_dim % 4 == 0 the row is 16-byte
+// aligned and the eight floats are TWO 16-byte loads; element by element the same gather is eight instructions of 32 different cache lines each, and
+// the CU's address unit takes a cycle per line: in wide_wgrad_gen_kernel, which gathers per 32-sample slab, that was 2.1 of a slab's 5.0 µs
+// (in-kernel stamps, profiles/r05_c3_wgrad_stamps.txt).
+__device__ __forceinline__ void load_obs8(const float* __restrict__ obs, size_t row, int D, int k0, bool ok, float (&x)[8]) {
+  if ((D & 3) == 0) {
+    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+    const f32x4* p = reinterpret_cast<const f32x4*>(obs + row * (size_t)D + k0);
+    const f32x4 a = (ok && k0 < D) ? p[0] : z, b = (ok && k0 + 4 < D) ? p[1] : z;
+    x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
+  } else {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) x[c] = (ok && k0 + c < D) ? obs[row * (size_t)D + k0 + c] : 0.0f;
+  }
 }
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)p; }
 
@@ -334,13 +351,18 @@ __device__ __forceinline__ void wide_fused_bwd_body(const FusedBwdArgs& a) {
   __syncthreads();
   // tile set-up values of the staging role — head cotangent of the sample, its observation quarter — are loaded a tile ahead
   float dz[NA], xq[DP / 4];
+  // The observation row of a tile's sample is addressed through the permutation: that index is loaded a TILE ahead (srcn), so that no load of
+  // setup_load depends on another one of the same call. Round 4 loaded index and row back to back: the wait between them was an s_waitcnt vmcnt(0)
+  // right behind the next tile's first eight LDS-DMA pieces — every tile sat out their HBM round trip before its epilogue (ISA audit, round 5).
+  int srcn = 0;
+  auto perm_of = [&](int t) { int g = t * FX_MB + sm; g = g < a.M ? g : a.M - 1; return a.perm ? a.perm[g] : g; };
   auto setup_load = [&](int t, float (&dzo)[NA], float (&xo)[DP / 4]) {
     const int gmn = t * FX_MB + sm;
 #pragma unroll
-    for (int q = 0; q < NA; ++q) dzo[q] = q < a.A ? a.dZ[(size_t)a.ldd * gmn + q] : 0.0f;
-    const int src = a.perm ? a.perm[gmn] : gmn;
+    for (int c = 0; c < DP / 4; ++c) { int cc = sq * (DP / 4) + c; cc = cc < a.D ? cc : a.D - 1; xo[c] = a.obs[(size_t)srcn * a.D + cc]; }   // (beyond obs_dim: zeroed below)
 #pragma unroll
-    for (int c = 0; c < DP / 4; ++c) { const int cc = sq * (DP / 4) + c; xo[c] = cc < a.D ? a.obs[(size_t)src * a.D + cc] : 0.0f; }
+    for (int q = 0; q < NA; ++q) dzo[q] = q < a.A ? a.dZ[(size_t)a.ldd * gmn + q] : 0.0f;
+    srcn = perm_of(t + gridDim.x);
   };
   unsigned char* Hb = smx + FB_OFF_H;
   auto tile_dma = [&](int t) {   // the first transfers of a tile: h2 slabs 0 and 1, weight slab 0
@@ -348,7 +370,7 @@ __device__ __forceinline__ void wide_fused_bwd_body(const FusedBwdArgs& a) {
     fb_dma_hslab(a.H2, t * FX_MB, 1, Hb + FB_HBYTES, wave, lane);
     fx_dma_wslab(a.Wx2b, 0, smx, wave, lane, rot);
   };
-  if ((int)blockIdx.x < ntiles) { tile_dma(blockIdx.x); setup_load(blockIdx.x, dz, xq); }
+  if ((int)blockIdx.x < ntiles) { srcn = perm_of(blockIdx.x); tile_dma(blockIdx.x); setup_load(blockIdx.x, dz, xq); }
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int m0 = t * FX_MB, gm = m0 + sm;
     const bool first = t == (int)(blockIdx.x + 8 * gridDim.x);   // (diagnostic builds stamp the block's ninth tile: warm caches)
@@ -438,7 +460,7 @@ __device__ __forceinline__ void wide_fused_bwd_body(const FusedBwdArgs& a) {
     float* xs = reinterpret_cast<float*>(smx + FX_OFF_X + FX_XBYTES);      // [128][DP], in the second activation buffer (free until slab 1 of the next tile)
     float* invs = xs + FX_MB * DP;
 #pragma unroll
-    for (int c = 0; c < DP / 4; ++c) xs[sm * DP + sq * (DP / 4) + c] = xq[c];
+    for (int c = 0; c < DP / 4; ++c) xs[sm * DP + sq * (DP / 4) + c] = (sq * (DP / 4) + c < a.D) ? xq[c] : 0.0f;
     if (sq == 0) invs[sm] = i1 * wunscale;
     // the next tile's first transfers and set-up loads go out now: they land under the epilogue's vector work (every buffer they touch —
     // h2 buffers 0 and 1, weight buffer 0 — was last read before the loop's final barrier)
@@ -561,7 +583,10 @@ namespace crl {
 // work 1.40 µs — the same 1.5 µs per slab. Both waves of a SIMD draw on ONE vector-issue port: an MFMA holds it 8 of its 32 cycles, a VALU instruction 4-8,
 // and an LDS-DMA piece 100-140 cycles (MI355X_MICROARCH.md: 60 among bare MFMAs, 100-185 in a busy phase) — a slab's 32 pieces cost each SIMD ≈ 0.4 µs of
 // issue time whoever issues them. Kept as an option; NWB = 2 stays the default.
-constexpr int pc_off_x(int nwb) { return nwb * FX_WBYTES; }
+// NWB = 0 (round 5, option wide_fwd_wbufs = 0): NO weight slab in LDS. In this kernel a consumer is the only reader of its 64 rows of the weight slab, so
+// staging them in LDS buys no sharing: each consumer loads its eight A-fragments of the next slab (8 x global_load_dwordx4, 32 VGPRs) straight from L2 while it
+// multiplies the current one; the producers only make h1. The epilogue scratch gets 18 KB of its own in place of the weight buffers.
+constexpr int pc_off_x(int nwb) { return nwb == 0 ? 4 * 32 * 36 * 4 : nwb * FX_WBYTES; }
 constexpr int pc_off_w1f(int nwb) { return pc_off_x(nwb) + 2 * FX_XBYTES; }
 constexpr int pc_off_b1(int nwb) { return pc_off_w1f(nwb) + 16384; }
 constexpr int pc_off_w3(int nwb) { return pc_off_b1(nwb) + 1024; }
@@ -593,7 +618,7 @@ template <int DP, bool WRITE_H1, int NWB>
 __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
   constexpr int OFF_X = pc_off_x(NWB), OFF_W1F = pc_off_w1f(NWB), OFF_B1 = pc_off_b1(NWB), OFF_W3 = pc_off_w3(NWB), OFF_B2 = pc_off_b2(NWB);
-  constexpr int SCRB = NWB == 3 ? 2 : 1;      // weight buffer the consumers' epilogue scratch aliases: free from the loop's last barrier on (3 buffers: last read in slab 5)
+  constexpr int SCRB = NWB == 3 ? 2 : NWB == 2 ? 1 : 0;   // weight buffer the consumers' epilogue scratch aliases: free from the loop's last barrier on (3 buffers: last read in slab 5); NWB = 0: the region in front of the activation slabs
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, hf = lane >> 5;
   const int ntiles = a.M / FX_MB;
@@ -609,13 +634,25 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
     const int p = wave - 4;
     const float w1un = a.w1sc[1];
     f16x8 xhi, xlo; float xinv;
-    auto load_x = [&](int t, float (&xr)[8]) {                          // this lane's sample of tile t: its observation half (k = 8hf …)
-      const int gm = t * FX_MB + 32 * p + j;
-      const int src = a.perm ? a.perm[gm] : gm;
+    // this lane's sample of tile t: its observation half (k = 8hf …). The row index comes through the permutation and is loaded a tile AHEAD (srcn):
+    // index and row back to back put an s_waitcnt vmcnt(0) — a memory round trip — at the top of every tile's first slab
+    int srcn = 0;
+    auto perm_of = [&](int t) { int g = t * FX_MB + 32 * p + j; g = g < a.M ? g : a.M - 1; return a.perm ? a.perm[g] : g; };
+    const int k0x = (8 * hf < a.D && 8 * hf < DP) ? 8 * hf : 0;
+    auto load_x = [&](int t, float (&xr)[8]) {
+      if ((a.D & 3) == 0) {
+        const f32x4* q = reinterpret_cast<const f32x4*>(a.obs + (size_t)srcn * (size_t)a.D + k0x);
+        const f32x4 q0 = q[0], q1 = q[k0x + 4 < a.D ? 1 : 0];
+        xr[0] = q0[0]; xr[1] = q0[1]; xr[2] = q0[2]; xr[3] = q0[3]; xr[4] = q1[0]; xr[5] = q1[1]; xr[6] = q1[2]; xr[7] = q1[3];
+      } else {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) { const int cc = 8 * hf + c; xr[c] = (cc < a.D && cc < DP) ? a.obs[(size_t)src * a.D + cc] : 0.0f; }
+        for (int c = 0; c < 8; ++c) { const int cc = k0x + c < a.D ? k0x + c : a.D - 1; xr[c] = a.obs[(size_t)srcn * (size_t)a.D + cc]; }
+      }
+      srcn = perm_of(t + gridDim.x);
     };
-    auto make_xfrag = [&](const float (&xr)[8]) {                       // per-sample power of two into the fp16 window, split
+    auto make_xfrag = [&](float (&xr)[8]) {                             // per-sample power of two into the fp16 window, split
+#pragma unroll
+      for (int c = 0; c < 8; ++c) if (8 * hf + c >= a.D || 8 * hf >= DP) xr[c] = 0.0f;    // beyond obs_dim (load_x read a clamped element there)
       float m = 0.0f;
 #pragma unroll
       for (int c = 0; c < 8; ++c) m = __builtin_fmaxf(m, __builtin_fabsf(xr[c]));
@@ -652,7 +689,7 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
     auto produce = [&](int t, int s, const f32x16& c, unsigned char* wbuf, unsigned char* xbuf, bool with_dma, bool stamp = false) {
       // with_dma: the producers fetch the weight slab as well — always with two weight buffers; with three only a tile's first two slabs (under
       // the consumers' epilogue): inside the slab loop the consumers fetch the slab after next themselves, in the shadow of their own MFMAs
-      if (with_dma) dma_w(s, wbuf);
+      if (with_dma && NWB != 0) dma_w(s, wbuf);
       asm volatile("" ::: "memory");
       if (stamp) CRL_WSTAMP(1, 6);
       // h1 slab: units 32s …, this producer's 32 samples
@@ -696,7 +733,7 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
       }
     };
     float xr[8];
-    if ((int)blockIdx.x < ntiles) { load_x(blockIdx.x, xr); make_xfrag(xr); layer1(); }
+    if ((int)blockIdx.x < ntiles) { srcn = perm_of(blockIdx.x); load_x(blockIdx.x, xr); make_xfrag(xr); layer1(); }
     if ((int)blockIdx.x < ntiles) {
       produce(blockIdx.x, 0, hpre[0], smx, smx + OFF_X, true);
       if (NWB == 3) dma_w(1, smx + FX_WBYTES);
@@ -714,7 +751,7 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
         if (s < 7) {
           produce(t, s + 1, hpre[(s + 1) & 7], smx + ((s + 1) & 1) * FX_WBYTES, smx + OFF_X + ((s + 1) & 1) * FX_XBYTES, NWB == 2, st_ && s == 3);
           if (st_ && s == 3) CRL_WSTAMP(1, 4);
-          if (NWB == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS stores are done (h1 stores to HBM, if any, may stay in flight)
+          if (NWB == 3 || NWB == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS stores are done (h1 stores to HBM, if any, may stay in flight)
           // two buffers: the 8 weight pieces have landed (the 4 h1 stores issued behind them may stay in flight)
           else if (WRITE_H1) asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
@@ -742,8 +779,34 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
     float* scr = reinterpret_cast<float*>(smx + SCRB * FX_WBYTES) + c * (32 * 36);        // in weight buffer SCRB
     float* hp_all = reinterpret_cast<float*>(smx + OFF_X + FX_XBYTES);                 // in activation buffer 1 (both are free from the loop's last barrier to slab 1 of the next tile)
     float* hp = hp_all + c * (FX_MB * hs);
+    // NWB = 0: weight fragments from global memory, HALF a slab (one k-step: 24 MFMAs) ahead in registers, [ai][piece]: two sets of 16 VGPRs that
+    // alternate (a whole slab ahead — 64 VGPRs — spilled). The pack buffer holds a slab as [piece][k-step][row tile][lane][8 halves] (FX_WBYTES per slab).
+    const f16x8* wg0 = reinterpret_cast<const f16x8*>(a.Wx2) + (2 * c) * 64 + lane;
+    auto wload = [&](int s, int ks, f16x8 (&w)[2][2]) {
+      const f16x8* g = wg0 + (size_t)s * (FX_WBYTES / 16) + ks * 512;
+#pragma unroll
+      for (int ai = 0; ai < 2; ++ai) { w[ai][0] = g[ai * 64]; w[ai][1] = g[1024 + ai * 64]; }
+    };
+    auto kstep = [&](int s, int ks, const f16x8 (&w)[2][2], f32x16 (&acc)[2][4]) {
+      const _Float16* Xl = reinterpret_cast<const _Float16*>(smx + OFF_X + (s & 1) * FX_XBYTES);
+      P2 bf[4];
+#pragma unroll
+      for (int bi = 0; bi < 4; ++bi) {
+        const int off = (32 * bi + j) * X3ROW + 16 * ks + 8 * hf;
+        bf[bi].hi = *reinterpret_cast<const f16x8*>(Xl + off);
+        bf[bi].lo = *reinterpret_cast<const f16x8*>(Xl + FX_MB * X3ROW + off);
+      }
+#pragma unroll
+      for (int ai = 0; ai < 2; ++ai) {
+        P2 af; af.hi = w[ai][0]; af.lo = w[ai][1];
+#pragma unroll
+        for (int bi = 0; bi < 4; ++bi) acc[ai][bi] = mfma_x2(af, bf[bi], acc[ai][bi]);
+      }
+    };
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
       const int m0 = t * FX_MB;
+      f16x8 wa[2][2];
+      if (NWB == 0) wload(0, 0, wa);                                     // in flight across the barrier
       f32x16 acc[2][4];
 #pragma unroll
       for (int ai = 0; ai < 2; ++ai)
@@ -754,6 +817,21 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
       __builtin_amdgcn_s_barrier();                                      // B_start
       const bool st_ = t == (int)(blockIdx.x + 8 * gridDim.x);
       if (st_) { CRL_WSTAMP(1, 0); CRL_WSTAMP_CYC(1, 5); }
+      if constexpr (NWB == 0) {
+        f16x8 wb2[2][2];
+#pragma unroll 1
+        for (int s = 0; s < 8; ++s) {
+          if (st_) CRL_WSTAMP(1, 8 + s);
+          wload(s, 1, wb2);
+          __builtin_amdgcn_sched_barrier(0);
+          kstep(s, 0, wa, acc);
+          if (s + 1 < 8) wload(s + 1, 0, wa);
+          __builtin_amdgcn_sched_barrier(0);
+          kstep(s, 1, wb2, acc);
+          if (st_ && s == 3) CRL_WSTAMP(1, 4);
+          __builtin_amdgcn_s_barrier();
+        }
+      } else
 #pragma unroll 1
       for (int s = 0; s < 8; ++s) {
         if (st_) CRL_WSTAMP(1, 8 + s);
@@ -995,24 +1073,46 @@ __device__ __forceinline__ void wide_wgrad_gen_body(const WgradGenArgs& a) {
       for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.0f;
   const int sg = lane & 7, ql = lane >> 3;
   const int rrow = 32 * wave + 4 * ql;
-  const float* ybase = a.dY + (size_t)H * c0 + rrow;
   const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
   f32x4 yr[4], bacc = zero4;
   float xo[8];                                                 // observation half (k = 8hf …) of sample m + (lane & 31)
   int src_nx = (c0 + j < c1) ? (a.perm ? a.perm[c0 + j] : c0 + j) : 0;
+  // The next slab's loads. NO lane-dependent branch may surround a load here: behind an `if (row < c1) load` the compiler loses count of the loads in
+  // flight and falls back to s_waitcnt vmcnt(0) — round 4's fetch had one before its observation loads and one behind its index load, i.e. every slab
+  // waited out the HBM round trip of the δ2 loads it had just issued: 2.1 of a slab's 5.0 µs (in-kernel stamps, profiles/r05_c3_wgrad_stamps.txt). So
+  // every lane loads from a clamped, valid address and what lies beyond the chunk / beyond obs_dim is zeroed where it is USED (a slab later). Order: the
+  // observation rows first — their address is the index the PREVIOUS fetch loaded last, complete long ago —, then δ2, then the next index.
+  const int k0x = (8 * hf < a.D && 8 * hf < DP) ? 8 * hf : 0;
+  const bool ragged = ((c1 - c0) & 31) != 0;                   // (uniform) the chunk's last slab is partial
   auto fetch = [&](int m) {
-    const size_t off = (size_t)H * (m - c0 + 4 * sg);
+    if ((a.D & 3) == 0) {
+      const f32x4* p = reinterpret_cast<const f32x4*>(a.obs + (size_t)src_nx * (size_t)a.D + k0x);
+      const f32x4 q0 = p[0], q1 = p[k0x + 4 < a.D ? 1 : 0];
+      xo[0] = q0[0]; xo[1] = q0[1]; xo[2] = q0[2]; xo[3] = q0[3]; xo[4] = q1[0]; xo[5] = q1[1]; xo[6] = q1[2]; xo[7] = q1[3];
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) yr[e] = (m + 4 * sg + e < c1) ? *reinterpret_cast<const f32x4*>(ybase + off + (size_t)H * e) : zero4;
-    const bool ok = m + j < c1;                                 // (the row index was loaded a slab earlier: no dependent chain inside the fetch)
+      for (int c = 0; c < 8; ++c) { const int cc = k0x + c < a.D ? k0x + c : a.D - 1; xo[c] = a.obs[(size_t)src_nx * (size_t)a.D + cc]; }
+    }
 #pragma unroll
-    for (int c = 0; c < 8; ++c) { const int cc = 8 * hf + c; xo[c] = (ok && cc < a.D && cc < DP) ? a.obs[(size_t)src_nx * a.D + cc] : 0.0f; }
-    const int mn = m + 32 + j;
-    src_nx = mn < c1 ? (a.perm ? a.perm[mn] : mn) : 0;
+    for (int e = 0; e < 4; ++e) {
+      int mm = m + 4 * sg + e; mm = mm < c1 ? mm : c1 - 1;
+      yr[e] = *reinterpret_cast<const f32x4*>(a.dY + (size_t)H * mm + rrow);
+    }
+    int mn = m + 32 + j; mn = mn < c1 ? mn : c1 - 1;
+    src_nx = a.perm ? a.perm[mn] : mn;
   };
   if (c0 < c1) fetch(c0);
   for (int m = c0; m < c1; m += 32) {
+    const bool gst = m == c0 + 32 * 40;          // (diagnostic builds stamp the chunk's 41st slab)
+    if (gst) CRL_GSTAMP(0);
     if (m != c0) __syncthreads();
+    if (gst) CRL_GSTAMP(1);
+    if (ragged) {                                              // rows beyond the chunk were loaded from its last row: they count as zero
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (m + 4 * sg + e >= c1) yr[e] = zero4;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) if (8 * hf + c >= a.D || 8 * hf >= DP) xo[c] = 0.0f;   // beyond obs_dim (a sample beyond the chunk has δ2 = 0: its h1 does not matter)
     // δ2 slab → [unit][sample] pieces (4 x 4 register transposes, as wide_wgrad_x2_kernel)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -1024,6 +1124,7 @@ __device__ __forceinline__ void wide_wgrad_gen_body(const WgradGenArgs& a) {
       *reinterpret_cast<uint2*>(Yp + (1 * H + rrow + e) * X3ROW + 4 * sg) = ll;
     }
     bacc += (yr[0] + yr[1]) + (yr[2] + yr[3]);
+    if (gst) CRL_GSTAMP(2);
     // h1 tile of this wave: one product on the matrix pipe, the slab's observations scaled by ONE power of two (the scale must not vary
     // along the rows of the result: they are the registers here)
     {
@@ -1054,8 +1155,11 @@ __device__ __forceinline__ void wide_wgrad_gen_body(const WgradGenArgs& a) {
         *reinterpret_cast<uint2*>(Xp + (1 * H + 32 * wave + j) * X3ROW + 8 * g + 4 * hf) = ll;
       }
     }
+    if (gst) CRL_GSTAMP(3);
     __syncthreads();
+    if (gst) CRL_GSTAMP(4);
     if (m + 32 < c1) fetch(m + 32);
+    if (gst) CRL_GSTAMP(5);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       P2 af[2], bf[4];
@@ -1075,7 +1179,9 @@ __device__ __forceinline__ void wide_wgrad_gen_body(const WgradGenArgs& a) {
       for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 4; ++y) acc[x][y] = mfma_x2(af[x], bf[y], acc[x][y]);
+      if (gst && ks == 0) CRL_GSTAMP(6);
     }
+    if (gst) CRL_GSTAMP(7);
   }
   __syncthreads();
   const float un = Ginv * (1.0f / X2_ACT_SCALE);
