@@ -32,8 +32,17 @@ namespace crl {
 // at the phase boundaries of the update kernel and of reduce_optim_kernel, read back by scripts/stamps_probe.py
 __device__ unsigned long long crl_dbg_stamps[512 * 8 * 8];
 #define CRL_STAMP(slot) do { if ((threadIdx.x & 63) == 0) crl_dbg_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (slot)] = wall_clock64(); } while (0)
+// phase stamps of ONE tile per wave (its 21st): low words of the 100 MHz clock, kept in scalar registers until the tile ends
+__device__ unsigned crl_dbg_tstamps[512 * 8 * 16];
+// (ten scalar registers for all ten stamps push the kernel into spills: a build takes five of them — CRL_TS_SET 0: points 0-4 and 9, 1: points 0 and 5-9)
+#ifndef CRL_TS_SET
+#define CRL_TS_SET 0
+#endif
+constexpr int crl_ts_slot(int k) { return k == 0 ? 0 : k == 9 ? 5 : (CRL_TS_SET == 0 ? (k <= 4 ? k : -1) : (k >= 5 ? k - 4 : -1)); }
+#define CRL_TS(k) do { if constexpr (crl_ts_slot(k) >= 0) { if (ts_on) ts[crl_ts_slot(k)] = (unsigned)__builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define CRL_STAMP(slot) do { } while (0)
+#define CRL_TS(k) do { } while (0)
 #endif
 constexpr int TSTRIDE = 36;
 // phase boundary: orders the wave's LDS traffic AND stops the scheduler from moving register-only work across it (hoisted
@@ -244,7 +253,15 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
   const int small_prio = (X2 && ntiles < 16 * tstride) ? a.prio_mode : 0;
   if (small_prio == 2 && wave >= 4) __builtin_amdgcn_s_setprio(1);
   int tile_parity = 0;
+#ifdef CRL_EXP_STAMPS
+  int tcount = 0;
+#endif
   for (; tile < ntiles; tile += tstride) {
+#ifdef CRL_EXP_STAMPS
+    const bool ts_on = (tcount++ == 20);
+    unsigned ts[6];
+#endif
+    CRL_TS(0);
     int partner_tile = 0;
     if (small_prio == 3) { if (((tile_parity++) & 1) == (wave >> 2)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
     if (balance) {
@@ -280,6 +297,7 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
       const int d = __builtin_amdgcn_readfirstlane(tile - partner_tile), half = tstride >> 1;
       if (d < -half) __builtin_amdgcn_s_setprio(3); else if (d < half && (wave >> 2)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
     }
+    CRL_TS(1);
     float x[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) x[i] = cur.x[i];
@@ -297,6 +315,7 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
     if constexpr (X2) mlp_forward_x2<D, NOUT>(img, x, h1, h2, out, lane);   // h1 = 2^14·tanh(…) from here on
     else if constexpr (X3) mlp_forward_x3<D, NOUT, true, ABL>(img, x, h1, h2, out, lane);
     else mlp_forward<D, NOUT, true>(img, x, h1, h2, out, lane);
+    CRL_TS(2);
 
     if constexpr ((ABL & 32) != 0) {
 #pragma unroll
@@ -354,6 +373,7 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
       for (int i = 0; i < NOUT; ++i) dout[i] = 0.0f;
     }
 
+    CRL_TS(3);
     // ---- backward ------------------------------------------------------------------------------------
     // (1) h2ᵀ, the output cotangents and x into the wave-private scratch
     store_transposed(T, h2, j, hf);
@@ -394,6 +414,7 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
 #pragma unroll
       for (int i = 0; i < NOUT; ++i) { acc_end(K_W3 + i, ow3[i] + accw[i]); acc_end(K_B3 + i, ob3[i] + (hf == 0 ? dout[i] : 0.0f)); }
     }
+    CRL_TS(4);
     // (3) δ2 = (W3ᵀ·δ3) ⊙ (1 − h2²) in C-fragment registers (h2 dies here)
     f32x16 d2[2];
     {
@@ -419,6 +440,7 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
 #pragma unroll
         for (int r = 0; r < 16; ++r) d2[mt][r] *= (1.0f - h2[mt][r] * h2[mt][r]);
     }
+    CRL_TS(5);
     // (4) dh1 = W2ᵀ·δ2 (A-fragments of W2ᵀ from LDS, B = δ2 registers); δ1 = dh1 ⊙ (1 − h1²)
     f32x16 d1[2];
     float d2max = 0.0f;   // fp16x2: this sample's largest |δ2|
@@ -477,6 +499,7 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
       }
     }
     CRL_PHASE();
+    CRL_TS(6);
     // (7) runs before (5)/(6): δ1 dies here, so the weight-gradient phase below holds 32 fewer live registers (no spills)
     if constexpr (!(ABL & 8)) {
     // (7) δ1ᵀ → scratch; lane = row: db1, dW1[lane][c] += Σ_s δ1[lane][s]·x[s][c]
@@ -509,6 +532,7 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
     }
     CRL_PHASE();
     } else { acc_end(K_B1, acc_begin(K_B1) + d1[0][0] + d1[1][5]); }
+    CRL_TS(7);
     if constexpr (!(ABL & 2)) {
     // (5) δ2ᵀ → scratch; db2; B-fragments (δ2 rows on lanes, samples along k: smp(s,hf) = s + 16hf) (δ2 dies here)
     store_transposed(T, d2, j, hf);
@@ -540,6 +564,7 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
       }
     }
     CRL_PHASE();
+    CRL_TS(8);
     // (6) h1ᵀ → scratch (h1 dies here); A-fragments streamed; dW2ᵀ[mj][ni] += h1[mj-block]·δ2[ni-block]ᵀ over 32 samples
     store_transposed(T, h1, j, hf);
     CRL_PHASE();
@@ -612,6 +637,14 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
     }
     CRL_PHASE();
     }
+#ifdef CRL_EXP_STAMPS
+    CRL_TS(9);
+    if (ts_on && (threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int k = 0; k < 10; ++k) if (crl_ts_slot(k) >= 0) crl_dbg_tstamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + k] = ts[crl_ts_slot(k)];
+      crl_dbg_tstamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + 15] = (unsigned)ROLE + 1u;
+    }
+#endif
   }
 
   CRL_STAMP(2);
@@ -1189,6 +1222,9 @@ int launch_update_exact_dp(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
 }  // namespace crl
 
 #ifdef CRL_EXP_STAMPS
+extern "C" int32_t crl_debug_read_tstamps(unsigned* out, int32_t n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(crl::crl_dbg_tstamps), sizeof(unsigned) * (size_t)n) == hipSuccess ? 0 : 1;
+}
 extern "C" int32_t crl_debug_read_stamps(unsigned long long* out, int32_t n) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(crl::crl_dbg_stamps), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : 1;
 }

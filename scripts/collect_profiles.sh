@@ -15,4 +15,20 @@ for f in $S/prof_c3_*kernel_stats.csv; do [ -s "$f" ] && cp $f profiles/${TAG}_c
 for f in $S/prof_envs8192_*kernel_stats.csv; do [ -s "$f" ] && cp $f profiles/${TAG}_rocprof_kernel_stats_envs8192.csv; done
 cp $S/parity_margins.json profiles/${TAG}_parity_margins.json 2>/dev/null
 cp $S/gae_sizes.txt profiles/${TAG}_gae_sizes.txt 2>/dev/null
+[ -s $S/gae_beyond_cache.txt ] && { echo "# scripts/bench_gae_big.py (crl_gae_bench), from scripts/final_measure.sh"; cat $S/gae_beyond_cache.txt; } > profiles/${TAG}_gae_beyond_cache_final.txt
 ls -la profiles/${TAG}_*
+[ -s $S/generated/${TAG}_c3_pmc_summary.json ] || cp gpurun_out/${TAG}_c3pmc/generated/${TAG}_c3_pmc_summary.json profiles/ 2>/dev/null
+# profiles/ must reproduce the bench line: the summaries derived from the kernel-stats CSV are checked against the CSV that was copied beside them
+python3 - $TAG <<'PY'
+import csv, json, sys
+tag = sys.argv[1]
+j = json.load(open(f"profiles/{tag}_rocprof_update_avg.json"))
+row = next(r for r in csv.DictReader(open(f"profiles/{tag}_rocprof_kernel_stats.csv")) if "update_x2_kernel" in r["Name"])
+ok = abs(float(row["AverageNs"]) - j["avg_ns"]) < 0.5 and int(row["Calls"]) == j["calls"]
+print("rocprof_update_avg.json vs kernel_stats.csv:", "consistent" if ok else f"MISMATCH: json {j['avg_ns']} ns x {j['calls']}, csv {row['AverageNs']} ns x {row['Calls']}")
+line = json.load(open(f"profiles/{tag}_bench_n1.json"))
+fr = line["roofline"].get("avg_launch_ms_rocprof")
+if fr is not None and abs(fr * 1e6 - float(row["AverageNs"])) > 0.5:
+    ok = False; print(f"MISMATCH: bench line quotes {fr * 1e6:.1f} ns, the committed CSV {row['AverageNs']} ns")
+sys.exit(0 if ok else 3)
+PY

@@ -15,9 +15,10 @@ P="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
 KR="update_x2_kernel|adv_bucket_sums|pack_records|rollout_cartpole"
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$KR" --output-format csv -d $O/pmc_fetch -- $P > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$KR" --output-format csv -d $O/pmc_write -- $P > /dev/null 2>&1
-# the standalone GAE kernel (the loop fuses the scan into the rollout): same counters with option gae_fuse = 0
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "gae_kernel" --output-format csv -d $O/pmc_fetch_gae -- $P --opt gae_fuse=0 > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "gae_kernel" --output-format csv -d $O/pmc_write_gae -- $P --opt gae_fuse=0 > /dev/null 2>&1
+# the standalone GAE kernel (the loop fuses the scan into the rollout): same counters over scripts/pmc_gae_write.py — a handle's crl_compute_gae launches with
+# NOTHING on another stream (the TCC counters are device-wide: under `bench.py --opt gae_fuse=0` the scan was charged with the side stream's shuffle stores, round 4)
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "gae_kernel" --output-format csv -d $O/pmc_fetch_gae -- python3 $R/scripts/pmc_gae_write.py > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "gae_kernel" --output-format csv -d $O/pmc_write_gae -- python3 $R/scripts/pmc_gae_write.py > /dev/null 2>&1
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   n=$(echo $set | cut -d' ' -f1)
   timeout 300 rocprofv3 --pmc $set --kernel-include-regex "update_x2_kernel|rollout_cartpole" --output-format csv -d $O/pmc_sq_$n -- $P > /dev/null 2>&1
@@ -46,5 +47,7 @@ done
 timeout 300 $B --workload c2 --steps 40 --no-cpu-baseline > $O/bench_c2_n1.json 2>/dev/null
 timeout 600 $B --workload c3 --steps 5 --warmup 2 > $O/bench_c3_n1.json 2>/dev/null
 timeout 900 python3 $R/scripts/parity_margins.py > $O/parity_margins.json 2>/dev/null
+timeout 300 python3 $R/scripts/bench_gae_big.py > $O/gae_beyond_cache.txt 2>/dev/null
+cd $R && bash scripts/pmc_c3.sh $TAG > $O/pmc_c3.log 2>&1; cp $R/profiles/${TAG}_c3_pmc_summary.json $O/generated/ 2>/dev/null
 timeout 300 python3 $R/scripts/bench_gae.py 0 0 > $O/gae_sizes.txt 2>/dev/null
 echo done

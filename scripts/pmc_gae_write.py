@@ -19,7 +19,8 @@ h.env_reset(); h.rollout_run()
 for _ in range(5):
     h.compute_gae()
 h.sync()
-g, c = crl._lib.gae_bench(65536, 128, seg=8, tile=64, nt_loads=0, flush_mb=1024, reps=2)   # segmented kernel behind a 1 GiB fill each time
+if len(sys.argv) > 1 and sys.argv[1] == "fill":      # round 5's evidence run (profiles/r05_gae_write_size.txt): the segmented kernel behind a 1 GiB fill each time
+    g, c = crl._lib.gae_bench(65536, 128, seg=8, tile=64, nt_loads=0, flush_mb=1024, reps=2)
 h.rollout_run(); h.compute_gae(); h.sync()
 agent.close()
 print("done")
