@@ -637,9 +637,15 @@ int32_t crl_adv_stats_finish(crl_ppo* h) {
 static int update_step(crl_ppo* h, int mb, double eta, int apply, int slot, bool inline_fix = true) {
   // with a communicator attached and the optimiser following, the statistics ride in the optimiser launch (optim.hip);
   // the inline value-loss fix-up reads the flag the statistics raise, so it keeps them as their own launch
-  h->defer_stats = apply && !h->wide && has_comm(h) && !(inline_fix && h->cfg.clip_value_loss && h->world == 1);
-  // one GPU and nothing between the gradient and the optimiser (no all-reduce, no inline value-loss fix-up): one launch does both
-  const bool fused = apply && !h->wide && !has_comm(h) && !h->external_comm && !(inline_fix && h->cfg.clip_value_loss) && opt(h, OPT_FUSE_OPTIM) && h->fuse_optim_fits;
+  // nothing between the gradient and the optimiser but — under data parallelism over the peer mailboxes — the exchange, which the launch runs itself
+  // (no RCCL call, no host-side exchange, no inline value-loss fix-up): ONE launch reduces, exchanges, clips and steps (update.hip: reduce_optim_kernel)
+  // (ranks that SHARE a GPU — functional runs on a 1-GPU box — each need their whole grid resident while they wait for one another's chunks: the
+  // one-launch step is taken only while all of them fit with room to spare; otherwise the three-launch step, whose exchange kernel has no grid-wide wait)
+  const long nb_step = (long)((h->P + 4 + 63) / 64);
+  const bool local_or_peer = !has_comm(h) || (peer_active(h) && !h->comm && (long)peer_ranks_on_my_device(h) * nb_step * 10 <= h->fuse_optim_capacity * 6);
+  const bool fused = apply && !h->wide && local_or_peer && !h->external_comm && !(inline_fix && h->cfg.clip_value_loss) && opt(h, OPT_FUSE_OPTIM) &&
+                     h->fuse_optim_fits && (h->P & 63) <= 60;
+  h->defer_stats = !fused && apply && !h->wide && has_comm(h) && !(inline_fix && h->cfg.clip_value_loss && h->world == 1);
   const int rc = launch_update(h, mb, h->stats_dev + slot, inline_fix, fused, eta);
   h->defer_stats = false;
   if (rc) return 1;

@@ -25,24 +25,15 @@
 
 namespace crl {
 
-constexpr int PEER_MAX = 16;
 constexpr int PEER_CHUNK = 256;
-
-struct PeerArgs {
-  char* box[PEER_MAX];
-  int world, rank;
-  uint32_t seq;
-  int nblk;             // flag words per (parity, rank)
-  size_t slot_bytes;
-  size_t data_off;      // byte offset of the slots inside a mailbox
-  uint32_t* err;
-  long long timeout_ticks;
-};
 
 struct PeerState {
   char* box[PEER_MAX] = {};
   bool opened[PEER_MAX] = {};
-  int world = 0, rank = 0, nblk = 0;
+  int world = 0, rank = 0, nblk = 0;     // nblk: flag words per (parity, rank) — one per 64-float chunk of the largest message (the one-launch
+                                         // optimiser step exchanges 64-float chunks; peer_allreduce_kernel's 256-element chunks use the first of them)
+  int cap256 = 0;                        // 256-element chunks a slot holds
+  int on_my_device = 1;                  // ranks whose mailbox lives on THIS device (1 = one process per GPU; more = a shared GPU, functional runs)
   uint32_t seq = 0;
   size_t slot_bytes = 0, data_off = 0, box_bytes = 0;
   uint32_t* err = nullptr;
@@ -109,8 +100,9 @@ int peer_export(crl_ppo* h, int world, int rank, uint8_t handle[64]) {
   size_t msg = ((size_t)h->P + 8) * sizeof(float);
   const size_t adv = (size_t)h->cfg.update_epochs * h->cfg.num_minibatches * 2 * sizeof(double);
   if (adv > msg) msg = adv;
-  s->nblk = (int)((msg / 4 + PEER_CHUNK - 1) / PEER_CHUNK);
-  s->slot_bytes = (size_t)s->nblk * PEER_CHUNK * sizeof(double);     // a chunk is 256 ELEMENTS of either type
+  s->cap256 = (int)((msg / 4 + PEER_CHUNK - 1) / PEER_CHUNK);
+  s->nblk = (int)((msg / 4 + 63) / 64);
+  s->slot_bytes = (size_t)s->cap256 * PEER_CHUNK * sizeof(double);   // a chunk is 256 ELEMENTS of either type
   s->data_off = (((size_t)2 * world * s->nblk * sizeof(uint32_t)) + 255) & ~(size_t)255;
   s->box_bytes = s->data_off + (size_t)2 * world * s->slot_bytes;
   // The protocol needs a peer's stores over xGMI to become visible inside an already-running kernel of the home GPU: the mailbox
@@ -163,6 +155,7 @@ int peer_attach(crl_ppo* h, const uint8_t* handles) {
     s->box[p] = static_cast<char*>(ptr); s->opened[p] = true;
     // a mailbox that lives on another device must be reachable from this one over xGMI / PCIe peer access
     hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, ptr) == hipSuccess && at.device == h->device) s->on_my_device += 1;
     if (hipPointerGetAttributes(&at, ptr) == hipSuccess && at.device >= 0 && at.device != h->device) {
       int can = 0;
       if (hipDeviceCanAccessPeer(&can, h->device, at.device) == hipSuccess && !can) {
@@ -177,13 +170,14 @@ int peer_attach(crl_ppo* h, const uint8_t* handles) {
 }
 
 bool peer_active(const crl_ppo* h) { return h->peer && static_cast<const PeerState*>(h->peer)->attached; }
+int peer_ranks_on_my_device(const crl_ppo* h) { return h->peer ? static_cast<const PeerState*>(h->peer)->on_my_device : 1; }
 
 int peer_allreduce(crl_ppo* h, void* buf, size_t count, bool is_double) {
   PeerState* s = peer_of(h);
   if (!s || !s->attached) { set_error("peer all-reduce before crl_comm_peer_attach"); return 1; }
   const size_t bytes = count * (is_double ? sizeof(double) : sizeof(float));
   const int nblk = (int)((count + PEER_CHUNK - 1) / PEER_CHUNK);
-  if (nblk > s->nblk || bytes > s->slot_bytes) { set_error("peer all-reduce: message larger than the mailbox slot"); return 1; }
+  if (nblk > s->cap256 || bytes > s->slot_bytes) { set_error("peer all-reduce: message larger than the mailbox slot"); return 1; }
   if (count == 0) return 0;
   const double timeout_s = (double)opt(h, OPT_PEER_TIMEOUT_MS) * 1e-3;
   PeerArgs a;
@@ -195,6 +189,16 @@ int peer_allreduce(crl_ppo* h, void* buf, size_t count, bool is_double) {
   else
     hipLaunchKernelGGL(peer_allreduce_kernel<float>, dim3(nblk), dim3(PEER_CHUNK), 0, h->stream, a, static_cast<float*>(buf), count);
   CRL_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int peer_next_args(crl_ppo* h, PeerArgs* a, int chunks, size_t floats) {
+  PeerState* s = peer_of(h);
+  if (!s || !s->attached) { set_error("peer exchange before crl_comm_peer_attach"); return 1; }
+  if (chunks > s->nblk || floats * sizeof(float) > s->slot_bytes) { set_error("peer exchange: message larger than the mailbox slot"); return 1; }
+  for (int p = 0; p < PEER_MAX; ++p) a->box[p] = s->box[p];
+  a->world = s->world; a->rank = s->rank; a->seq = ++s->seq; a->nblk = s->nblk; a->slot_bytes = s->slot_bytes; a->data_off = s->data_off;
+  a->err = s->err; a->timeout_ticks = (long long)((double)opt(h, OPT_PEER_TIMEOUT_MS) * 1e-3 * 1e8);
   return 0;
 }
 

@@ -111,6 +111,7 @@ struct crl_ppo {
   double* optim_part = nullptr;  // per-slice Σg² of the sliced optimiser step (large networks); [12][blocks] of the fused reduce + optimiser launch
   unsigned* ticket = nullptr;    // grid meeting point of reduce_optim_kernel: [0] counts arrivals, never reset; [1] sticky time-out flag
   bool fuse_optim_fits = false;  // the whole grid of reduce_optim_kernel can be resident on this device (checked at crl_ppo_create)
+  long fuse_optim_capacity = 0;  // blocks of reduce_optim_kernel the device holds at once (occupancy x CUs, no margin)
   unsigned ticket_target = 0;    // arrivals after the launch being enqueued
   // One permutation per update epoch (ppo.jl:194): crl_ppo_iterate draws all update_epochs of them right after GAE, so the
   // advantage statistics of every minibatch of the iteration are known (and all-reduced, once) before the first optimiser
@@ -258,7 +259,23 @@ void comm_destroy(crl_ppo* h);
 int peer_export(crl_ppo* h, int world, int rank, uint8_t handle[64]);
 int peer_attach(crl_ppo* h, const uint8_t* handles);
 bool peer_active(const crl_ppo* h);
+int peer_ranks_on_my_device(const crl_ppo* h);   // > 1: ranks share this GPU (functional runs on a 1-GPU box)
 int peer_allreduce(crl_ppo* h, void* buf, size_t count, bool is_double);
+// what a kernel needs to take part in one peer exchange (peer.hip): mailbox bases, this message's sequence number, the layout
+constexpr int PEER_MAX = 16;
+struct PeerArgs {
+  char* box[PEER_MAX];
+  int world, rank;
+  uint32_t seq;
+  int nblk;             // flag words per (parity, rank)
+  size_t slot_bytes;
+  size_t data_off;      // byte offset of the slots inside a mailbox
+  uint32_t* err;
+  long long timeout_ticks;
+};
+// the next message's arguments for a kernel that runs the exchange itself (update.hip: reduce_optim_kernel<true>, 64-float chunks,
+// one flag per chunk): bumps the sequence number like peer_allreduce does; `chunks` flag words are needed
+int peer_next_args(crl_ppo* h, PeerArgs* out, int chunks, size_t floats);
 int peer_check(crl_ppo* h);
 int fused_optim_fits(crl_ppo* h, bool* fits);   // update.hip: occupancy of reduce_optim_kernel's grid on this device
 int fused_optim_check(crl_ppo* h);              // update.hip: sticky time-out word of its meeting point

@@ -6,12 +6,12 @@ namespace crl {
 
 // "Training Statistics" (ppo.jl:247) from the (all-reduced) sums msg[P..P+3]; mode 0 also raises the value-loss
 // speculation flag (u > 0), mode 1 is the re-evaluation after the exact critic pass.
-__device__ __forceinline__ void compute_stats(const float* msg, int P, const DevCfg& c, double Mglobal, const double* adv_ms,
-                                              int mb, double* vfix, crl_ppo_stats* out, int mode) {
-  const double pg = (double)msg[P] / Mglobal;
-  const double ent = (double)(float)((double)msg[P + 1] / ((double)c.A * Mglobal));
-  const double u = (double)(float)((double)msg[P + 2] / Mglobal);
-  const double vl = 0.5 * (double)(float)((double)msg[P + 3] / Mglobal);
+__device__ __forceinline__ void compute_stats4(float s0, float s1, float s2, float s3, const DevCfg& c, double Mglobal, const double* adv_ms,
+                                               int mb, double* vfix, crl_ppo_stats* out, int mode) {
+  const double pg = (double)s0 / Mglobal;
+  const double ent = (double)(float)((double)s1 / ((double)c.A * Mglobal));
+  const double u = (double)(float)((double)s2 / Mglobal);
+  const double vl = 0.5 * (double)(float)((double)s3 / Mglobal);
   if (mode == 0) {
     vfix[0] = u;
     vfix[3] = (c.clip_vloss && u > 0.0) ? 1.0 : 0.0;
@@ -23,6 +23,11 @@ __device__ __forceinline__ void compute_stats(const float* msg, int P, const Dev
   out->pg_loss = pg; out->entropy_loss = ent; out->v_loss = vl; out->u_value = u;
   out->loss = pg - (double)(c.ent_coeff * (float)ent) + (double)c.v_coef * vl;
   out->adv_mean = (double)(float)adv_ms[2 * mb]; out->adv_std = (double)(float)adv_ms[2 * mb + 1];
+}
+
+__device__ __forceinline__ void compute_stats(const float* msg, int P, const DevCfg& c, double Mglobal, const double* adv_ms,
+                                              int mb, double* vfix, crl_ppo_stats* out, int mode) {
+  compute_stats4(msg[P], msg[P + 1], msg[P + 2], msg[P + 3], c, Mglobal, adv_ms, mb, vfix, out, mode);
 }
 
 struct StatsArgs {

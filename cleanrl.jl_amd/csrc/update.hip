@@ -879,13 +879,21 @@ struct FusedOptimArgs {
   unsigned long long timeout;   // ticks of the 100 MHz wall clock a block waits at the meeting point before it gives up (2 s)
   double eta, thresh;
 };
+// PEER = true (round 5): the DATA-PARALLEL optimiser step as one launch over the peer mailboxes of peer.hip — reduce → push this block's 64 sums into
+// every rank's mailbox → flag → wait for the W flags of this chunk → add the W slots in rank order → Σg² → ticket → ClipNorm + Adam. Replaces
+// reduce_kernel + peer_allreduce_kernel + clipnorm_adam_kernel (three launches, ≈ 40 µs beside an 85 µs update launch at 8192 envs per rank). A chunk
+// is a block's 64 floats, so chunks never wait on each other across ranks; the grid-wide ticket stays local to the GPU. The four loss sums ride in the
+// last block's chunk (indices P … P + 3), the statistics record is written from the all-reduced sums by that block. Every rank adds the same slots in
+// the same order and clips by the same norms: replicas stay bit-identical.
+template <bool PEER>
 __global__ void __launch_bounds__(64 * RG) reduce_optim_kernel(const float* __restrict__ gpart, const double* __restrict__ lpart,
                                                                int nblkA, int nblkC, int pmax, int gstride, int Pa, int Pc,
-                                                               float* __restrict__ msg, StatsArgs st, FusedOptimArgs oa) {
+                                                               float* __restrict__ msg, StatsArgs st, FusedOptimArgs oa, PeerArgs pa) {
 #pragma clang fp contract(off)
   __shared__ float sm[RG][64];
   __shared__ double smd[RG][4];
   __shared__ double nrm2[12];
+  __shared__ float gsum[4];
   const int P = Pa + Pc;
   const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + o;
@@ -905,7 +913,8 @@ __global__ void __launch_bounds__(64 * RG) reduce_optim_kernel(const float* __re
   }
   sm[g][o] = s;
   double ds = 0.0;
-  const bool last = blockIdx.x == gridDim.x - 1;
+  // the block whose chunk holds the loss sums (indices P … P + 3; the launcher sizes the grid so that one block holds all four)
+  const bool last = blockIdx.x == (unsigned)(P / 64);
   if (last && o < 4) {
     const int which = o, lrole = which >> 1;
     const double* l = lpart + (size_t)lrole * pmax * 2 + (which & 1);
@@ -923,28 +932,67 @@ __global__ void __launch_bounds__(64 * RG) reduce_optim_kernel(const float* __re
   float grad = 0.0f;
   double bp0 = 0.0, bp1 = 0.0;
   float m_old = 0.0f, v_old = 0.0f, p_old = 0.0f;   // this entry's optimiser state: fetched before the meeting point, under its latency
+  if (last && g == 0 && o < 4) {
+    double t = smd[0][o];
+#pragma unroll
+    for (int q = 1; q < RG; ++q) t += smd[q][o];
+    gsum[o] = (float)t;
+  }
+  if (last) __syncthreads();
+  unsigned timed_out = 0;
   if (g == 0) {
     if (live) {
       m_old = oa.m[i]; v_old = oa.v[i]; p_old = oa.params[i];
       float t = sm[0][o];
 #pragma unroll
       for (int q = 1; q < RG; ++q) t += sm[q][o];
-      msg[i] = t;
       grad = t;
       while (arr < 11 && i >= oa.off[arr + 1]) ++arr;
       bp0 = oa.betap[2 * arr]; bp1 = oa.betap[2 * arr + 1];
     }
+    const bool lsum = last && i >= P && i < P + 4;          // this lane carries one of the four loss sums
+    float val = live ? grad : (lsum ? gsum[i - P] : 0.0f);
+    if constexpr (PEER) {
+      // ---- the exchange, one wave, one chunk (peer.hip's protocol at 64 floats per chunk)
+      const bool carry = live || lsum;
+      const int par = (int)(pa.seq & 1u), W = pa.world;
+      for (int d = 1; d <= W; ++d) {                        // my chunk into my slot of every mailbox, right-hand neighbour first
+        const int p = (pa.rank + d) % W;
+        float* dst = reinterpret_cast<float*>(pa.box[p] + pa.data_off + ((size_t)par * W + pa.rank) * pa.slot_bytes);
+        if (carry) __builtin_nontemporal_store(val, dst + i);
+      }
+      __threadfence_system();                               // every lane's stores are out before a flag of this chunk moves
+      if (o < W) {
+        uint32_t* f = reinterpret_cast<uint32_t*>(pa.box[o]) + ((size_t)par * W + pa.rank) * pa.nblk + blockIdx.x;
+        __hip_atomic_store(f, pa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint32_t* gq = reinterpret_cast<const uint32_t*>(pa.box[pa.rank]) + ((size_t)par * W + o) * pa.nblk + blockIdx.x;
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(gq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != pa.seq) {
+          __builtin_amdgcn_s_sleep(2);
+          if (wall_clock64() - t0 > pa.timeout_ticks) { atomicExch(pa.err, 1u); timed_out = 1; break; }
+        }
+      }
+      timed_out = (unsigned)(__builtin_amdgcn_ballot_w64(timed_out != 0) != 0);
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      if (carry) {
+        // slots written by other devices while this kernel runs: system-scope atomic loads, served at the memory side (peer.hip)
+        const char* mine = pa.box[pa.rank] + pa.data_off + (size_t)par * W * pa.slot_bytes;
+        float t = 0.0f;
+        for (int r = 0; r < W; ++r) {
+          const unsigned bits = __hip_atomic_load(reinterpret_cast<const unsigned*>(mine + (size_t)r * pa.slot_bytes) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          t += __uint_as_float(bits);
+        }
+        val = t;
+      }
+      if (live) grad = val;
+    }
+    if (live || lsum) msg[i] = val;                         // comm_buf keeps the (all-reduced) message: CRL_F_GRADS, the statistics of a replay
+    if (lsum) gsum[i - P] = val;
     const double gsq = live ? (double)grad * (double)grad : 0.0;
     for (int a = a_lo; a <= a_hi; ++a) {
       const double t = wave_sum((live && arr == a) ? gsq : 0.0);
       if (o == 0) __hip_atomic_store(oa.part + (size_t)a * gridDim.x + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-  }
-  if (last && g == 0 && o < 4) {
-    double t = smd[0][o];
-#pragma unroll
-    for (int q = 1; q < RG; ++q) t += smd[q][o];
-    msg[P + o] = (float)t;
   }
   if (last && st.dscale && threadIdx.x < 2) {
     unsigned* mx = reinterpret_cast<unsigned*>(st.dscale + 2);
@@ -953,7 +1001,7 @@ __global__ void __launch_bounds__(64 * RG) reduce_optim_kernel(const float* __re
   }
   if (last) {
     __syncthreads();
-    if (threadIdx.x == 0) compute_stats(msg, P, st.c, st.Mglobal, st.adv_ms, st.mb, st.vfix, st.out, 0);
+    if (threadIdx.x == 0) compute_stats4(gsum[0], gsum[1], gsum[2], gsum[3], st.c, st.Mglobal, st.adv_ms, st.mb, st.vfix, st.out, 0);
   }
   if (g != 0) return;                       // the optimiser half runs on the block's first wave
   // grid-wide meeting point. Everything that crosses blocks (the Σg² partials, the ticket) moves through agent-scope atomic
@@ -963,7 +1011,6 @@ __global__ void __launch_bounds__(64 * RG) reduce_optim_kernel(const float* __re
 #error "reduce_optim_kernel's fence-free meeting point relies on gfx942 / gfx950 behaviour (sc1 atomics are write-through and counted in vmcnt): port the ordering (release on the ticket add, acquire after the wait) before building for another target"
 #endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the partials have arrived before the ticket moves
-  unsigned timed_out = 0;
   if (o == 0) {
     __hip_atomic_fetch_add(oa.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // bounded: if a block of the grid is not resident (a partitioned device, CUs held by another tenant — crl_ppo_create checks the
@@ -976,8 +1023,8 @@ __global__ void __launch_bounds__(64 * RG) reduce_optim_kernel(const float* __re
       if (wall_clock64() - t0 > oa.timeout) { __hip_atomic_store(oa.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); timed_out = 1; break; }
     }
   }
-  // a block that gave up must not step its slice from incomplete norms: parameters, Adam state and the β powers keep their pre-step
-  // values and the sticky word reports the failure at the next host synchronisation
+  // a block that gave up (at the ticket, or waiting for a peer's chunk) must not step its slice from incomplete sums: parameters, Adam state and
+  // the β powers keep their pre-step values and the sticky words report the failure at the next host synchronisation
   if (__builtin_amdgcn_readfirstlane(timed_out)) return;
   __builtin_amdgcn_wave_barrier();
   asm volatile("" ::: "memory");
@@ -1009,12 +1056,13 @@ __global__ void __launch_bounds__(64 * RG) reduce_optim_kernel(const float* __re
 // may not fit; the handle then keeps the two-launch optimiser step (reduce_kernel + clipnorm_adam_kernel).
 int fused_optim_fits(crl_ppo* h, bool* fits) {
   int per_cu = 0;
-  CRL_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reduce_optim_kernel, 64 * RG, 0));
+  CRL_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reduce_optim_kernel<true>, 64 * RG, 0));
   hipDeviceProp_t prop;
   CRL_HIP_CHECK(hipGetDeviceProperties(&prop, h->device));
   // one block per CU of margin: the occupancy query can read one high near a register-file edge (MI355X guide, "Residency")
   const long resident = (long)(per_cu > 1 ? per_cu - 1 : per_cu) * (long)prop.multiProcessorCount;
   *fits = resident >= (long)((h->P + 63) / 64);
+  h->fuse_optim_capacity = (long)per_cu * (long)prop.multiProcessorCount;
   return 0;
 }
 // sticky time-out word of the meeting point (ticket[1]): read where the host synchronises anyway
@@ -1135,20 +1183,32 @@ int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot, bool inline_fix
     main_pass_blocks(h, &nA, &nC);
     ProfScope ps(h, CRL_K_REDUCE);
     if (with_optim) {
-      // single GPU, no fix-up between gradient and optimiser: reduce + ClipNorm + Adam in one launch (reduce_optim_kernel)
-      if (dp || (inline_fix && h->cfg.clip_value_loss)) { set_error("internal: the fused optimiser step needs a local, speculative step"); return 1; }
+      // no fix-up between gradient and optimiser: reduce (+ the peer exchange under data parallelism) + ClipNorm + Adam in one launch
+      if ((dp && !peer_active(h)) || (inline_fix && h->cfg.clip_value_loss) || (P & 63) > 60) {
+        set_error("internal: the fused optimiser step needs a speculative step that is local or exchanged through the peer mailboxes"); return 1;
+      }
       FusedOptimArgs oa;
       const int hN = h->cfg.hidden, d = h->cfg.obs_dim, A = h->cfg.n_act;
       const int sizes[12] = {hN * d, hN, hN * hN, hN, A * hN, A, hN * d, hN, hN * hN, hN, hN, 1};
       oa.off[0] = 0;
       for (int q = 0; q < 12; ++q) oa.off[q + 1] = oa.off[q] + sizes[q];
-      const unsigned nb = (unsigned)((P + 63) / 64);
+      const unsigned nb = (unsigned)((P + 4 + 63) / 64);     // the four loss sums ride behind the gradient, in the chunk of index P
       CRL_HIP_CHECK(hipGetLastError());   // an error left behind by an earlier call is reported as such, not mistaken for this launch's
+      PeerArgs pa{};
+      if (dp && peer_next_args(h, &pa, (int)nb, (size_t)P + 4)) return 1;
       h->ticket_target += nb;
       oa.params = h->params; oa.m = h->adam_m; oa.v = h->adam_v; oa.betap = h->betap; oa.part = h->optim_part; oa.ticket = h->ticket;
       oa.target = h->ticket_target; oa.eta = eta; oa.thresh = 0.5; oa.timeout = 200000000ull;
-      hipLaunchKernelGGL(reduce_optim_kernel, dim3(nb), dim3(64 * RG), 0, h->stream, h->gpart, h->lpart, nA, nC, h->update_blocks, (int)h->Pa,
-                         (int)h->Pa, (int)h->Pc, h->comm_buf, stats_args(h, mb, stats_slot, 1), oa);
+      if (dp) {
+        // a peer that never arrives ends the wait after peer_timeout_ms; the grid's own meeting point must outlast that
+        const unsigned long long pt = (unsigned long long)pa.timeout_ticks + 200000000ull;
+        oa.timeout = pt;
+        hipLaunchKernelGGL(reduce_optim_kernel<true>, dim3(nb), dim3(64 * RG), 0, h->stream, h->gpart, h->lpart, nA, nC, h->update_blocks, (int)h->Pa,
+                           (int)h->Pa, (int)h->Pc, h->comm_buf, stats_args(h, mb, stats_slot, 1), oa, pa);
+      } else {
+        hipLaunchKernelGGL(reduce_optim_kernel<false>, dim3(nb), dim3(64 * RG), 0, h->stream, h->gpart, h->lpart, nA, nC, h->update_blocks, (int)h->Pa,
+                           (int)h->Pa, (int)h->Pc, h->comm_buf, stats_args(h, mb, stats_slot, 1), oa, pa);
+      }
       const hipError_t le = hipGetLastError();
       if (le != hipSuccess) {             // a launch that never ran must not leave later ones waiting for its arrivals
         h->ticket_target -= nb;
@@ -1162,7 +1222,7 @@ int launch_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot, bool inline_fix
     }
     CRL_HIP_CHECK(hipGetLastError());
   }
-  if (dp) {
+  if (dp && !with_optim) {      // (the one-launch step has exchanged the message itself and written the statistics)
     {
       ProfScope ps(h, CRL_K_ALLREDUCE);
       if (comm_allreduce(h, h->comm_buf, (size_t)P + 4, false)) return 1;

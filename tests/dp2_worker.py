@@ -36,6 +36,7 @@ def main():
 
     def attach(hh):
         hh.set_option("peer_timeout_ms", int(os.environ.get("DP2_PEER_TIMEOUT_MS", "60000")))
+        hh.set_option("fuse_optim", int(os.environ.get("DP2_FUSE_OPTIM", "1")))   # 1: reduce + peer exchange + ClipNorm + Adam as ONE launch inside crl_ppo_iterate
         crl_dist.attach_comm(dist, hh, world, rank, kind, crl.comm_unique_id)
     NT, k = 16 * world, 128
     n, off = crl_dist.shard_envs(NT, world, rank)
@@ -116,8 +117,14 @@ def main():
         hh.iterate(2, want_stats=False)
         stats = hh.iterate(1)
         ps = gather(hh.read(L.F_PARAMS))
-        out[name] = {"replicas_equal": all(np.array_equal(ps[0], q) for q in ps), "exact_reruns": hh.exact_reruns,
-                     "loss": stats[-1]["loss"], "finite": bool(np.isfinite(ps[0]).all())}
+        losses = gather(np.array([[st[key] for key in ("loss", "pg_loss", "v_loss", "entropy_loss")] for st in stats]))
+        ms = gather(hh.read(L.F_ADAM_M)); gr = gather(hh.read(L.F_GRADS))
+        out[name] = {"replicas_equal": all(np.array_equal(ps[0], q) for q in ps) and all(np.array_equal(ms[0], q) for q in ms),
+                     "stats_equal": all(np.array_equal(losses[0], q) for q in losses) and bool(np.isfinite(losses[0]).all()),
+                     "grads_equal": all(np.array_equal(gr[0], q) for q in gr),
+                     "exact_reruns": hh.exact_reruns, "loss": stats[-1]["loss"], "finite": bool(np.isfinite(ps[0]).all()),
+                     "params_l2": float(np.linalg.norm(ps[0].astype(np.float64))), "fuse_optim": hh.get_option("fuse_optim"),
+                     "grads_l2": float(np.linalg.norm(gr[0].astype(np.float64))), "first_step": [float(x) for x in losses[0][0]], "last_step": [float(x) for x in losses[0][-1]]}
         dist.barrier()   # nobody frees a mailbox a slower rank could still be pushing into
         a.close()
     if rank == 0:

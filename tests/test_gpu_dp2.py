@@ -21,10 +21,10 @@ def _gpu_count():
     return torch.cuda.device_count()     # counting devices does not initialise the GPU on this image
 
 
-def _run_ranks(world, comm, share_gpu, port):
+def _run_ranks(world, comm, share_gpu, port, fuse_optim=1):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_SOCKET_IFNAME="lo", OMP_NUM_THREADS="4", DP2_COMM=comm,
-               DP2_SHARE_GPU="1" if share_gpu else "0", DP2_PEER_TIMEOUT_MS="60000")
+               DP2_SHARE_GPU="1" if share_gpu else "0", DP2_PEER_TIMEOUT_MS="60000", DP2_FUSE_OPTIM=str(fuse_optim))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dp2_worker.py")]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
@@ -36,6 +36,8 @@ def _run_ranks(world, comm, share_gpu, port):
     assert r["rel_l2_vs_union"] < 1e-5, r            # four Adam steps on the union batch vs on shards + all-reduce
     assert r["iterate"]["replicas_equal"] and r["iterate"]["finite"] and r["iterate"]["exact_reruns"] == 0
     assert r["forced_branch"]["replicas_equal"] and r["forced_branch"]["exact_reruns"] == 3, r
+    assert r["iterate"]["stats_equal"] and r["iterate"]["grads_equal"] and r["forced_branch"]["stats_equal"], r
+    return r
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
@@ -47,8 +49,23 @@ def test_rccl_ranks_match_union_handle_and_stay_replicated(world):
 
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_peer_allreduce_ranks_match_union_handle_and_stay_replicated(world):
-    """One GPU per rank when the box has them, otherwise all ranks on GPU 0."""
-    _run_ranks(world, "peer", _gpu_count() < world, 29600 + world)
+    """One GPU per rank when the box has them, otherwise all ranks on GPU 0. Inside crl_ppo_iterate the optimiser step of a peer-attached
+    handle is ONE launch (option fuse_optim = 1, the default: reduce -> push -> wait -> rank-order sum -> ClipNorm + Adam,
+    update.hip reduce_optim_kernel<true>)."""
+    r = _run_ranks(world, "peer", _gpu_count() < world, 29600 + world)
+    assert r["iterate"]["fuse_optim"] == 1
+
+
+def test_one_launch_and_three_launch_data_parallel_steps_agree():
+    """The same two-rank run with the optimiser step as ONE launch and as three (reduce_kernel, peer_allreduce_kernel, clipnorm_adam_kernel:
+    option fuse_optim = 0): both add the ranks' chunks in rank order, so the all-reduced gradients are the same bits; the per-array norms are
+    summed in another grouping, so parameters agree to float32 rounding (the loss records to 1e-6 relative)."""
+    share = _gpu_count() < 2
+    a = _run_ranks(2, "peer", share, 29621, fuse_optim=1)
+    b = _run_ranks(2, "peer", share, 29622, fuse_optim=0)
+    assert a["iterate"]["fuse_optim"] == 1 and b["iterate"]["fuse_optim"] == 0
+    assert abs(a["iterate"]["loss"] - b["iterate"]["loss"]) <= 1e-6 * abs(b["iterate"]["loss"]) + 5e-7, (a["iterate"], b["iterate"])
+    assert abs(a["iterate"]["params_l2"] - b["iterate"]["params_l2"]) <= 1e-6 * b["iterate"]["params_l2"]
 
 
 def test_bench_runs_multi_rank_on_a_shared_gpu():
