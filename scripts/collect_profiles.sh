@@ -3,7 +3,7 @@ TAG=${1:-final}
 S=gpurun_out/$TAG
 cp $S/generated/*.json profiles/ 2>/dev/null
 cp $S/bench_n1.json profiles/${TAG}_bench_n1.json
-for f in suite breakdown x3 bijection minibatches1 rccl_forced peer_forced envs8192 envs16384 envs32768 envs8192_breakdown; do
+for f in suite breakdown x3 bijection minibatches1 rccl_forced peer_forced envs8192 envs16384 envs32768 envs8192_breakdown envs8192_peer_forced envs8192_peer_forced_three_launch; do
   [ -s $S/bench_n1_$f.json ] && cp $S/bench_n1_$f.json profiles/${TAG}_bench_n1_$f.json
 done
 [ -s $S/suite.json ] && cp $S/suite.json profiles/${TAG}_suite.json

@@ -40,6 +40,9 @@ timeout 300 $B --shuffle bijection --no-cpu-baseline > $O/bench_n1_bijection.jso
 timeout 300 $B --minibatches 1 --no-cpu-baseline > $O/bench_n1_minibatches1.json 2> /dev/null
 timeout 300 $B --opt comm_force=1 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_n1_rccl_forced.json 2>/dev/null
 timeout 300 $B --opt comm_force=1 --comm peer --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_n1_peer_forced.json 2>/dev/null
+# the 8-GPU job's per-rank shape with the exchange in the loop (1-rank mailbox: push to self): one-launch optimiser step, then the three-launch step
+timeout 300 $B --opt comm_force=1 --comm peer --total-envs 8192 --steps 40 --warmup 5 --no-cpu-baseline --no-extras > $O/bench_n1_envs8192_peer_forced.json 2>/dev/null
+timeout 300 $B --opt comm_force=1 --opt fuse_optim=0 --comm peer --total-envs 8192 --steps 40 --warmup 5 --no-cpu-baseline --no-extras > $O/bench_n1_envs8192_peer_forced_three_launch.json 2>/dev/null
 for nt in 8192 16384 32768; do
   timeout 300 $B --total-envs $nt --no-cpu-baseline > $O/bench_n1_envs$nt.json 2>/dev/null
   timeout 300 $B --total-envs $nt --no-cpu-baseline --kernel-breakdown > $O/bench_n1_envs${nt}_breakdown.json 2>/dev/null
