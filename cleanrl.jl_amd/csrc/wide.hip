@@ -2591,11 +2591,7 @@ static int wide_backward_fused(crl_ppo* h, const int32_t* perm, int M) {
     a[net].obs = h->obs; a[net].perm = perm; a[net].D = w->D; a[net].W1s = pk + w->pk[net].w1s;
     a[net].D2 = net ? w->dB : w->dA; a[net].pW1 = w->pW1[net]; a[net].pB1 = w->pB1[net]; a[net].M = M;
   }
-#ifdef CRL_EXP_WSTAMPS
-  const size_t lds = 160 * 1024;   // (the last KB holds the in-kernel stamps: n_act <= 7)
-#else
   const size_t lds = (size_t)FB_OFF_W3 + (size_t)w->A * 1024;
-#endif
   if (w->D8 == 8 && w->A <= 4) hipLaunchKernelGGL((wide_fused_bwd_kernel<8, 4>), dim3(nb, 2), dim3(512), lds, h->stream, a[0], a[1]);
   else if (w->D8 == 8) hipLaunchKernelGGL((wide_fused_bwd_kernel<8, 8>), dim3(nb, 2), dim3(512), lds, h->stream, a[0], a[1]);
   else if (w->A <= 4) hipLaunchKernelGGL((wide_fused_bwd_kernel<16, 4>), dim3(nb, 2), dim3(512), lds, h->stream, a[0], a[1]);

@@ -19,7 +19,18 @@ namespace crl {
 // diagnostic build only (bash scripts/build_variant.sh wstamps -DCRL_EXP_WSTAMPS wide): wall-clock stamps (100 MHz) of the first tile of
 // every block of the fused kernels — [kernel 0 fwd / 1 bwd][block][wave][slot], read back by scripts/wstamps_probe.py
 __device__ unsigned long long crl_dbg_wstamps[2 * 256 * 8 * 16];
-#define CRL_BSTAMP(slot) do { if (lane == 0) bst[wave * 16 + (slot)] = wall_clock64(); } while (0)
+// backward kernel: stamps (low words of the 100 MHz clock) sit in SCALAR registers until the block ends — the LDS-resident version of round 4 cost vector
+// registers this kernel does not have and ran 2x slower than production. Six points per build: CRL_BTS_SET 0 = tile level (slots 0, 10, 1, 5, 11, 6),
+// 1 = slab 3 in detail (slots 2, 7, 8, 9, 3, 4).
+#ifndef CRL_BTS_SET
+#define CRL_BTS_SET 0
+#endif
+constexpr int crl_bts_idx(int slot) {   // (six stamps held across a whole tile spilled 876 bytes per lane: the tile-level points come three per build, sets 0 and 2)
+  return CRL_BTS_SET == 0 ? (slot == 0 ? 0 : slot == 10 ? 1 : slot == 1 ? 2 : -1)
+       : CRL_BTS_SET == 2 ? (slot == 5 ? 0 : slot == 11 ? 1 : slot == 6 ? 2 : -1)
+                          : (slot == 2 ? 0 : slot == 7 ? 1 : slot == 8 ? 2 : slot == 9 ? 3 : slot == 3 ? 4 : slot == 4 ? 5 : -1);
+}
+#define CRL_BSTAMP(slot) do { if constexpr (crl_bts_idx(slot) >= 0) bts[crl_bts_idx(slot)] = (unsigned)__builtin_amdgcn_s_memrealtime(); } while (0)
 #define CRL_WSTAMP_CYC(kern, slot) do { const unsigned bx_ = (kern) ? blockIdx.x : blockIdx.x - 2048u; if ((threadIdx.x & 63) == 0 && bx_ < 256u && blockIdx.y == 0) crl_dbg_wstamps[(((kern) * 256 + bx_) * 8 + (threadIdx.x >> 6)) * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
 #define CRL_WSTAMP(kern, slot) do { const unsigned bx_ = (kern) ? blockIdx.x : blockIdx.x - 2048u; if ((threadIdx.x & 63) == 0 && bx_ < 256u && blockIdx.y == 0) crl_dbg_wstamps[(((kern) * 256 + bx_) * 8 + (threadIdx.x >> 6)) * 16 + (slot)] = wall_clock64(); } while (0)
 #define CRL_GSTAMP(slot) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 256u && blockIdx.y == 0) crl_dbg_wstamps[((blockIdx.x) * 8 + (threadIdx.x >> 6)) * 16 + (slot)] = wall_clock64(); } while (0)
@@ -330,7 +341,7 @@ __device__ __forceinline__ void wide_fused_bwd_body(const FusedBwdArgs& a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef CRL_EXP_WSTAMPS
-  unsigned long long* bst = reinterpret_cast<unsigned long long*>(smx + 160 * 1024 - 1024);   // stamps stay in LDS until the end: a global store per stamp would sit in the counted vmcnt waits
+  unsigned bts[6] = {0u, 0u, 0u, 0u, 0u, 0u};
 #endif
   const int rg = wave & 3, sg = wave >> 2, j = lane & 31, hf = lane >> 5;
   const int sm = tid >> 2, sq = tid & 3;                       // staging role: sample, unit octet of every slab
@@ -518,9 +529,11 @@ __device__ __forceinline__ void wide_fused_bwd_body(const FusedBwdArgs& a) {
     if (first) CRL_BSTAMP(6);
   }
 #ifdef CRL_EXP_WSTAMPS
-  if (lane == 0 && blockIdx.y == 0 && blockIdx.x < 256)
-    for (int q = 0; q < 16; ++q) crl_dbg_wstamps[((256 + blockIdx.x) * 8 + wave) * 16 + q] = bst[wave * 16 + q];
-  __syncthreads();
+  if (lane == 0 && blockIdx.y == 0 && blockIdx.x < 256) {
+    constexpr int slots[3][6] = {{0, 10, 1, -1, -1, -1}, {2, 7, 8, 9, 3, 4}, {5, 11, 6, -1, -1, -1}};
+#pragma unroll
+    for (int q = 0; q < 6; ++q) if (slots[CRL_BTS_SET][q] >= 0) crl_dbg_wstamps[((256 + blockIdx.x) * 8 + wave) * 16 + slots[CRL_BTS_SET][q]] = bts[q];
+  }
 #endif
   // ---- the block's partial: lane halves hold different samples of the same unit, the two sample groups are two waves
   float* red = reinterpret_cast<float*>(smx);                               // [wave][64 units][DP + 1]
