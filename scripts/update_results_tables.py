@@ -57,7 +57,12 @@ line = (f"CPU baseline (`cpu_baseline` of the line): {g3(cb['value'])} env-steps
         f"statistics read back after every update, as `ppo()` does) {g3(rb.get('value', 0))}, {rb.get('ms_per_step', 0):.2f} ms; `roofline.frac_rocprof` {r.get('frac_rocprof') or 0:.3f} "
         f"(the same fraction on rocprofv3's clock); `roofline_gae.beyond_cache`: the streaming scan on {bc.get('bytes_per_launch', 0)/1e9:.2f} GB at {bc.get('frac', 0):.2f} of 8 TB/s = "
         f"{bc.get('over_copy', 0):.2f} of a hand-written float4 copy of the same bytes.")
-s = re.sub(r"CPU baseline[^\n]*\n[^\n]*single-threaded at C1\.[^\n]*(?:\nAlso in the default line:[^\n]*)?", lambda m: line, s, count=1)
+# the FIRST "CPU baseline (`cpu_baseline` of the line)" paragraph behind this round's table (one line, optionally followed by the "Also in the default line" line);
+# older rounds' sections further down keep their own text
+a0 = s.index("`" + tag + "_bench_n1.json`")
+m = re.search(r"CPU baseline \(`cpu_baseline` of the line\)[^\n]*(?:\nAlso in the default line:[^\n]*)?", s[a0:])
+assert m, "CPU-baseline paragraph of the round's section not found"
+s = s[:a0 + m.start()] + line + s[a0 + m.end():]
 open(p, "w").write(s)
 
 p = os.path.join(ROOT, "README.md")
