@@ -174,9 +174,10 @@ __global__ void __launch_bounds__(1024) clipnorm_adam_kernel(OptimArgs a) {
 }
 
 // The same optimiser for large parameter arrays (2×256: W2 has 65,536 entries), where one block per array makes the step a
-// 100 µs serial walk: slices of 4,096 entries per block. Three launches: per-slice Σg² partials (Float64) → every slice sums its
-// array's partials in slice order (one norm, identical in all slices), clips and applies Adam to its entries → the running β
-// powers advance. Same arithmetic per element as clipnorm_adam_kernel; only the order of the Σg² sum differs (by slices).
+// 100 µs serial walk: slices of 4,096 entries per block. Two launches: per-slice Σg² partials (Float64; the array's first slice also sets the step's β
+// powers aside) → every slice sums its array's partials in slice order (one norm, identical in all slices), clips and applies Adam to its entries with
+// the powers set aside, and the array's first slice advances the running powers (a launch of its own until round 5). Same arithmetic per element as
+// clipnorm_adam_kernel; only the order of the Σg² sum differs (by slices).
 constexpr int OPT_SLICE = 4096;
 struct OptimSliceArgs {
   int off[13]; int first_blk[13];   // first_blk[a] = index of array a's first slice; first_blk[12] = number of slices
@@ -204,6 +205,9 @@ __global__ void __launch_bounds__(1024) clipnorm_partial_kernel(OptimSliceArgs a
     double t = 0.0;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sm[w];
     a.part[blockIdx.x] = t;
+    // the β powers this step uses, set aside by the array's first block: adam_slice_kernel reads the copy and its first block of the array advances the
+    // original — no block can read a power another one has already advanced (betap_advance_kernel was a launch of its own for that reason)
+    if ((int)blockIdx.x == a.first_blk[arr]) { a.part[a.first_blk[12] + 2 * arr] = a.betap[2 * arr]; a.part[a.first_blk[12] + 2 * arr + 1] = a.betap[2 * arr + 1]; }
   }
 }
 __global__ void __launch_bounds__(1024) adam_slice_kernel(OptimSliceArgs a) {
@@ -216,7 +220,8 @@ __global__ void __launch_bounds__(1024) adam_slice_kernel(OptimSliceArgs a) {
   const bool clip = (double)nrm > a.thresh;
   const double sc = clip ? a.thresh / (double)nrm : 1.0;
   const double b1 = 0.9, b2 = 0.999, epsn = 1e-8;
-  const double bp0 = a.betap[2 * arr], bp1 = a.betap[2 * arr + 1];
+  const double bp0 = a.part[a.first_blk[12] + 2 * arr], bp1 = a.part[a.first_blk[12] + 2 * arr + 1];
+  if ((int)blockIdx.x == a.first_blk[arr] && threadIdx.x == 0) { a.betap[2 * arr] = bp0 * b1; a.betap[2 * arr + 1] = bp1 * b2; }
   for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     double g = (double)a.grads[i];
     if (clip) g = (double)(float)(g * sc);
@@ -250,7 +255,6 @@ int launch_optim(crl_ppo* h, double eta) {
     b.eta = eta; b.thresh = 0.5;
     hipLaunchKernelGGL(clipnorm_partial_kernel, dim3(nb), dim3(1024), 0, h->stream, b);
     hipLaunchKernelGGL(adam_slice_kernel, dim3(nb), dim3(1024), 0, h->stream, b);
-    hipLaunchKernelGGL(betap_advance_kernel, dim3(1), dim3(64), 0, h->stream, h->betap);
   } else {
     int blocks = 12;
     if (h->stats_pending) {

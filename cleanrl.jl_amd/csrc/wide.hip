@@ -2161,11 +2161,28 @@ __global__ void __launch_bounds__(64) wide_vsum_final_kernel(const double* __res
   s = wave_sum(s);
   if (threadIdx.x == 0) { vfix[5] = s; *reinterpret_cast<unsigned long long*>(&vfix[6]) = 0ull; }
 }
+// vpart != nullptr (one GPU): every block folds the nparts partial sums of wide_vsum_kernel itself — in wide_vsum_final_kernel's order, so all blocks and
+// the two-launch form get the same bits — and block 0 leaves Σ, u and, when u <= 0 (always, in practice: q_b >= 0), the count 0: two launches fewer per step
 __global__ void __launch_bounds__(256) wide_vcount_kernel(DevCfg c, const float* __restrict__ V, const float* __restrict__ values,
                                                          const float* __restrict__ returns, const int32_t* __restrict__ perm, int M,
-                                                         double Mglobal, double* vfix) {
-  const float u = (float)(vfix[5] / Mglobal);
-  if (blockIdx.x == 0 && threadIdx.x == 0) vfix[0] = (double)u;
+                                                         double Mglobal, double* vfix, const double* __restrict__ vpart, int nparts) {
+  __shared__ double ssum;
+  double total;
+  if (vpart) {
+    if (threadIdx.x < 64) {
+      double s = 0.0;
+      for (int i = threadIdx.x; i < nparts; i += 64) s += vpart[i];
+      s = wave_sum(s);
+      if (threadIdx.x == 0) ssum = s;
+    }
+    __syncthreads();
+    total = ssum;
+  } else total = vfix[5];
+  const float u = (float)(total / Mglobal);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    vfix[0] = (double)u;
+    if (vpart) { vfix[5] = total; if (!(u > 0.0f)) vfix[1] = 0.0; }
+  }
   if (!(u > 0.0f)) return;   // q_b ≥ 0: no sample can lose against u ≤ 0
   unsigned long long cnt = 0;
   for (int pos = blockIdx.x * 256 + threadIdx.x; pos < M; pos += gridDim.x * 256) {
@@ -2179,6 +2196,20 @@ __global__ void __launch_bounds__(256) wide_vcount_kernel(DevCfg c, const float*
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
   if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(reinterpret_cast<unsigned long long*>(&vfix[6]), cnt);
+  if (vpart) {
+    // one GPU, u > 0 (rare): the block that arrives last turns the integer count into vfix[1] and leaves both counters at zero for the next step
+    // (integer adds: the count does not depend on the order of arrival)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      unsigned long long* done = reinterpret_cast<unsigned long long*>(&vfix[7]);
+      if (atomicAdd(done, 1ull) == (unsigned long long)gridDim.x - 1ull) {
+        unsigned long long* tot = reinterpret_cast<unsigned long long*>(&vfix[6]);
+        vfix[1] = (double)atomicAdd(tot, 0ull);
+        atomicExch(tot, 0ull); atomicExch(done, 0ull);
+      }
+    }
+  }
 }
 __global__ void wide_vcount_to_double_kernel(double* vfix) {
   if (threadIdx.x == 0 && blockIdx.x == 0) vfix[1] = (double)*reinterpret_cast<unsigned long long*>(&vfix[6]);
@@ -2297,12 +2328,14 @@ __global__ void __launch_bounds__(256) wide_loss_kernel(WLossArgs a) {
 struct WRedArgs {
   const float* part[12]; int nparts[12]; int off[13];
   const double* lpart; int nlb; float* out; int P; int A;
+  int with_stats; StatsArgs st;      // one GPU: the block that folds the loss sums also writes the "Training Statistics" record (no launch of its own)
 };
 
 __global__ void __launch_bounds__(256) wide_reduce_kernel(WRedArgs a) {
   if (blockIdx.x == gridDim.x - 1) {
     // loss sums and head-bias gradients: 4 + 16 + 1 quantities over nlb block partials
     __shared__ double sm[256];
+    __shared__ float lsum4[4];
     for (int q = 0; q < 4 + AMAX + 1; ++q) {
       const bool live = q < 4 || q == 4 + AMAX || (q - 4) < a.A;
       if (!live) continue;
@@ -2316,12 +2349,14 @@ __global__ void __launch_bounds__(256) wide_reduce_kernel(WRedArgs a) {
       }
       if (threadIdx.x == 0) {
         const float f = (float)sm[0];
-        if (q < 4) a.out[a.P + q] = f;
+        if (q < 4) { a.out[a.P + q] = f; lsum4[q] = f; }
         else if (q == 4 + AMAX) a.out[a.off[11]] = f;
         else a.out[a.off[5] + (q - 4)] = f;
       }
       __syncthreads();
     }
+    if (a.with_stats && threadIdx.x == 0)
+      compute_stats4(lsum4[0], lsum4[1], lsum4[2], lsum4[3], a.st.c, a.st.Mglobal, a.st.adv_ms, a.st.mb, a.st.vfix, a.st.out, 1);
     return;
   }
   // 64 elements per block, 4 threads per element: thread (e, pg) sums partials pg, pg+4, …; folded in pg order
@@ -2663,13 +2698,21 @@ static int wide_grad_passes(crl_ppo* h, int mb, const int32_t* perm, double Mglo
   if (h->cfg.clip_value_loss) {
     int nb = (M + 255) / 256; if (nb > 1024) nb = 1024;
     hipLaunchKernelGGL(wide_vsum_kernel, dim3(nb), dim3(256), 0, h->stream, w->v, h->ret, perm, M, w->vpart);
-    hipLaunchKernelGGL(wide_vsum_final_kernel, dim3(1), dim3(64), 0, h->stream, w->vpart, nb, h->vfix);
-    CRL_HIP_CHECK(hipGetLastError());
-    if (dp && comm_allreduce(h, h->vfix + 5, 1, true)) return 1;
-    hipLaunchKernelGGL(wide_vcount_kernel, dim3(nb), dim3(256), 0, h->stream, h->dc, w->v, h->value, h->ret, perm, M, Mglobal, h->vfix);
-    hipLaunchKernelGGL(wide_vcount_to_double_kernel, dim3(1), dim3(1), 0, h->stream, h->vfix);
-    CRL_HIP_CHECK(hipGetLastError());
-    if (dp && comm_allreduce(h, h->vfix + 1, 1, true)) return 1;
+    if (!dp) {
+      // one GPU: two launches instead of four — the count kernel folds the partial sums itself and finishes the count in its last block
+      hipLaunchKernelGGL(wide_vcount_kernel, dim3(nb), dim3(256), 0, h->stream, h->dc, w->v, h->value, h->ret, perm, M, Mglobal, h->vfix,
+                         (const double*)w->vpart, nb);
+      CRL_HIP_CHECK(hipGetLastError());
+    } else {
+      hipLaunchKernelGGL(wide_vsum_final_kernel, dim3(1), dim3(64), 0, h->stream, w->vpart, nb, h->vfix);
+      CRL_HIP_CHECK(hipGetLastError());
+      if (comm_allreduce(h, h->vfix + 5, 1, true)) return 1;
+      hipLaunchKernelGGL(wide_vcount_kernel, dim3(nb), dim3(256), 0, h->stream, h->dc, w->v, h->value, h->ret, perm, M, Mglobal, h->vfix,
+                         (const double*)nullptr, 0);
+      hipLaunchKernelGGL(wide_vcount_to_double_kernel, dim3(1), dim3(1), 0, h->stream, h->vfix);
+      CRL_HIP_CHECK(hipGetLastError());
+      if (comm_allreduce(h, h->vfix + 1, 1, true)) return 1;
+    }
   }
   {
     WLossArgs a;
@@ -2727,19 +2770,23 @@ int wide_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
       r.part[b + 5] = nullptr; r.nparts[b + 5] = 0;
     }
     r.lpart = w->lpart; r.nlb = w->nlb; r.out = h->comm_buf; r.P = P; r.A = A;
+    r.with_stats = dp ? 0 : 1;
+    r.st.c = h->dc; r.st.Mglobal = Mglobal; r.st.adv_ms = h->adv_ms; r.st.mb = mb; r.st.vfix = h->vfix; r.st.out = stats_slot; r.st.fused = 0; r.st.dscale = nullptr;
     ProfScope pr(h, CRL_K_REDUCE);
     hipLaunchKernelGGL(wide_reduce_kernel, dim3((P + 63) / 64 + 1), dim3(256), 0, h->stream, r);
     CRL_HIP_CHECK(hipGetLastError());
   }
-  if (dp) {
-    ProfScope pa(h, CRL_K_ALLREDUCE);
-    if (comm_allreduce(h, h->comm_buf, (size_t)P + 4, false)) return 1;
+  if (dp) {      // the sums are global only after the all-reduce: the record keeps its own tiny launch
+    {
+      ProfScope pa(h, CRL_K_ALLREDUCE);
+      if (comm_allreduce(h, h->comm_buf, (size_t)P + 4, false)) return 1;
+    }
+    StatsArgs st;
+    st.c = h->dc; st.Mglobal = Mglobal; st.adv_ms = h->adv_ms; st.mb = mb; st.vfix = h->vfix; st.out = stats_slot; st.fused = 0;
+    st.dscale = nullptr;
+    hipLaunchKernelGGL(wide_stats_kernel, dim3(1), dim3(64), 0, h->stream, h->comm_buf, P, st);
+    CRL_HIP_CHECK(hipGetLastError());
   }
-  StatsArgs st;
-  st.c = h->dc; st.Mglobal = Mglobal; st.adv_ms = h->adv_ms; st.mb = mb; st.vfix = h->vfix; st.out = stats_slot; st.fused = 0;
-  st.dscale = nullptr;
-  hipLaunchKernelGGL(wide_stats_kernel, dim3(1), dim3(64), 0, h->stream, h->comm_buf, P, st);
-  CRL_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
