@@ -1097,7 +1097,14 @@ __device__ __forceinline__ void wide_wgrad_gen_body(const WgradGenArgs& a) {
   // observation rows first — their address is the index the PREVIOUS fetch loaded last, complete long ago —, then δ2, then the next index.
   const int k0x = (8 * hf < a.D && 8 * hf < DP) ? 8 * hf : 0;
   const bool ragged = ((c1 - c0) & 31) != 0;                   // (uniform) the chunk's last slab is partial
-  auto fetch = [&](int m) {
+  auto fetch_y = [&](int m) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int mm = m + 4 * sg + e; mm = mm < c1 ? mm : c1 - 1;
+      yr[e] = *reinterpret_cast<const f32x4*>(a.dY + (size_t)H * mm + rrow);
+    }
+  };
+  auto fetch_x = [&](int m) {
     if ((a.D & 3) == 0) {
       const f32x4* p = reinterpret_cast<const f32x4*>(a.obs + (size_t)src_nx * (size_t)a.D + k0x);
       const f32x4 q0 = p[0], q1 = p[k0x + 4 < a.D ? 1 : 0];
@@ -1106,15 +1113,16 @@ __device__ __forceinline__ void wide_wgrad_gen_body(const WgradGenArgs& a) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) { const int cc = k0x + c < a.D ? k0x + c : a.D - 1; xo[c] = a.obs[(size_t)src_nx * (size_t)a.D + cc]; }
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      int mm = m + 4 * sg + e; mm = mm < c1 ? mm : c1 - 1;
-      yr[e] = *reinterpret_cast<const f32x4*>(a.dY + (size_t)H * mm + rrow);
-    }
     int mn = m + 32 + j; mn = mn < c1 ? mn : c1 - 1;
     src_nx = a.perm ? a.perm[mn] : mn;
   };
-  if (c0 < c1) fetch(c0);
+  // The two waves of a SIMD (wave w and w + 4: wk = 0 / 1) request the next slab's δ2 at DIFFERENT points of the slab. Issuing 32 KB of loads takes a CU
+  // 0.9 µs (the "loads issued" interval of the timeline: the wave sits in the issue stage until the memory pipeline has taken its requests), and with all
+  // eight waves doing that behind barrier 2 the matrix pipe waited for it. Now waves 4-7 ask for their δ2 rows as soon as they have staged the current ones
+  // (their stall runs beside their partner's h1 arithmetic, which gets the issue port to itself meanwhile) and go straight to the MFMAs behind barrier 2,
+  // while waves 0-3 issue their loads there as before — beside their partner's MFMAs.
+  const bool early_y = wk == 1;
+  if (c0 < c1) { fetch_x(c0); fetch_y(c0); }
   for (int m = c0; m < c1; m += 32) {
     const bool gst = m == c0 + 32 * 40;          // (diagnostic builds stamp the chunk's 41st slab)
     if (gst) CRL_GSTAMP(0);
@@ -1137,6 +1145,7 @@ __device__ __forceinline__ void wide_wgrad_gen_body(const WgradGenArgs& a) {
       *reinterpret_cast<uint2*>(Yp + (1 * H + rrow + e) * X3ROW + 4 * sg) = ll;
     }
     bacc += (yr[0] + yr[1]) + (yr[2] + yr[3]);
+    if (early_y && m + 32 < c1) fetch_y(m + 32);
     if (gst) CRL_GSTAMP(2);
     // h1 tile of this wave: one product on the matrix pipe, the slab's observations scaled by ONE power of two (the scale must not vary
     // along the rows of the result: they are the registers here)
@@ -1171,7 +1180,7 @@ __device__ __forceinline__ void wide_wgrad_gen_body(const WgradGenArgs& a) {
     if (gst) CRL_GSTAMP(3);
     __syncthreads();
     if (gst) CRL_GSTAMP(4);
-    if (m + 32 < c1) fetch(m + 32);
+    if (m + 32 < c1) { fetch_x(m + 32); if (!early_y) fetch_y(m + 32); }
     if (gst) CRL_GSTAMP(5);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
