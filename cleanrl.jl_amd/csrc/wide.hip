@@ -63,6 +63,7 @@ struct WideWs {
   float* v = nullptr;            // [Mw] critic outputs
   float* dv8 = nullptr;          // [8 × Mw] critic-output cotangent in row 0 (rows 1-7 zero: K of the head GEMM is padded to 8)
   float *dA = nullptr, *dB = nullptr;  // [H × Mw] hidden-layer cotangents
+  float* d2s = nullptr;                // [2][Mw] per-sample inverse scales of the split δ2 planes (option wide_d2_split)
   // gradient partials
   int S2 = 1, chunk2 = 32, Ss = 1, chunks = 256, nlb = 1;
   float *pW2[2] = {nullptr, nullptr}, *pB2[2] = {nullptr, nullptr};
@@ -96,7 +97,7 @@ void wide_destroy(crl_ppo* h) {
   if (!w) return;
   void* ptrs[] = {w->pack, w->h1[0], w->h1[1], w->h2[0], w->h2[1], w->z, w->v, w->dv8, w->dA, w->dB, w->pW2[0], w->pW2[1],
                   w->pB2[0], w->pB2[1], w->pW1[0], w->pW1[1], w->pB1[0], w->pB1[1], w->pW3[0], w->pW3[1], w->lpart, w->wrec, w->vpart,
-                  w->u_dev, w->wsc};
+                  w->u_dev, w->wsc, w->d2s};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete w;
   h->wide_ws = nullptr;
@@ -123,7 +124,7 @@ int wide_create(crl_ppo* h) {
   rc |= walloc(&w->wsc, 8);   // [net][scale, 1/scale] of the W2 pieces, then the same of the W1 fragments (wide_fused.hpp)
   for (int n = 0; n < 2; ++n) { rc |= walloc(&w->h1[n], H * Mw); rc |= walloc(&w->h2[n], H * Mw); }
   rc |= walloc(&w->z, (size_t)w->A8 * Mw); rc |= walloc(&w->v, Mw); rc |= walloc(&w->dv8, 8 * Mw);
-  rc |= walloc(&w->dA, H * Mw); rc |= walloc(&w->dB, H * Mw);
+  rc |= walloc(&w->dA, H * Mw); rc |= walloc(&w->dB, H * Mw); rc |= walloc(&w->d2s, 2 * Mw);
   // weight-gradient splits: ≈2048-sample chunks for the MFMA kernel, 512-sample chunks for the VALU kernels
   // swept at C3 (M = 524,288; profiles/r02_c3_*): 4096-sample chunks 68.0 ms per iteration, 2048: 69.8, 8192: 75.9 — half the
   // partials to write and fold against one block per CU instead of two
@@ -2616,6 +2617,8 @@ static int wide_forward_fused(crl_ppo* h, const int32_t* perm, int M) {
 static int wide_backward_fused(crl_ppo* h, const int32_t* perm, int M) {
   WideWs* w = static_cast<WideWs*>(h->wide_ws);
   const int ntiles = M / FX_MB;
+  // δ2 as the backward's own fp16x2 pieces when its only reader is the 256x256 weight-gradient kernel (whole 32-sample slabs: M % 128 == 0 here)
+  const bool split = wide_h1_free(h) && opt(h, OPT_WIDE_WGRAD_FULL) && opt(h, OPT_WIDE_D2_SPLIT) && w->chunk2 % 32 == 0 && w->lds_max >= WS_LDS;
   int nb = w->cus / 2; if (nb > ntiles) nb = ntiles; if (nb > w->Ss) nb = w->Ss; if (nb < 1) nb = 1;
   FusedBwdArgs a[2];
   for (int net = 0; net < 2; ++net) {
@@ -2625,12 +2628,19 @@ static int wide_backward_fused(crl_ppo* h, const int32_t* perm, int M) {
     a[net].W3t = pk + w->pk[net].w3t; a[net].wmax = pk + w->pk[net].wmax; a[net].Wx2b = pk + w->pk[net].x2b; a[net].wsc = w->wsc + 2 * net;
     a[net].obs = h->obs; a[net].perm = perm; a[net].D = w->D; a[net].W1s = pk + w->pk[net].w1s;
     a[net].D2 = net ? w->dB : w->dA; a[net].pW1 = w->pW1[net]; a[net].pB1 = w->pB1[net]; a[net].M = M;
+    a[net].D2h = split ? reinterpret_cast<_Float16*>(net ? w->dB : w->dA) : nullptr; a[net].d2s = split ? w->d2s + (size_t)net * w->Mw : nullptr;
   }
   const size_t lds = (size_t)FB_OFF_W3 + (size_t)w->A * 1024;
-  if (w->D8 == 8 && w->A <= 4) hipLaunchKernelGGL((wide_fused_bwd_kernel<8, 4>), dim3(nb, 2), dim3(512), lds, h->stream, a[0], a[1]);
-  else if (w->D8 == 8) hipLaunchKernelGGL((wide_fused_bwd_kernel<8, 8>), dim3(nb, 2), dim3(512), lds, h->stream, a[0], a[1]);
-  else if (w->A <= 4) hipLaunchKernelGGL((wide_fused_bwd_kernel<16, 4>), dim3(nb, 2), dim3(512), lds, h->stream, a[0], a[1]);
-  else hipLaunchKernelGGL((wide_fused_bwd_kernel<16, 8>), dim3(nb, 2), dim3(512), lds, h->stream, a[0], a[1]);
+#define CRL_BWD(dp, na)                                                                                                                  \
+  do {                                                                                                                                   \
+    if (split) hipLaunchKernelGGL((wide_fused_bwd_kernel<dp, na, true>), dim3(nb, 2), dim3(512), lds, h->stream, a[0], a[1]);            \
+    else hipLaunchKernelGGL((wide_fused_bwd_kernel<dp, na, false>), dim3(nb, 2), dim3(512), lds, h->stream, a[0], a[1]);                 \
+  } while (0)
+  if (w->D8 == 8 && w->A <= 4) CRL_BWD(8, 4);
+  else if (w->D8 == 8) CRL_BWD(8, 8);
+  else if (w->A <= 4) CRL_BWD(16, 4);
+  else CRL_BWD(16, 8);
+#undef CRL_BWD
   CRL_HIP_CHECK(hipGetLastError());
   w->fb_blocks = nb;
   // The dW3 sweeps over h2 depend on the loss kernel only, like the fused backward: they run on the second stream beside it and join at
@@ -2666,6 +2676,17 @@ static int wide_backward_fused(crl_ppo* h, const int32_t* perm, int M) {
       hipLaunchKernelGGL((wide_wgrad_x2_kernel<4, true>), dim3(w->S2, 2), dim3(512), 2 * (256 + 128) * X3ROW * 2, h->stream, g);
       CRL_HIP_CHECK(hipGetLastError());
     }
+  } else if (split) {             // both networks in one launch, 256 x 256 tile per block, from the split planes (wide_wgrad_split_kernel)
+    WgradSplitArgs g[2];
+    for (int net = 0; net < 2; ++net) {
+      const float* pk = w->pack + w->pk_base[net];
+      g[net].Yh = reinterpret_cast<const _Float16*>(net ? w->dB : w->dA); g[net].ys = w->d2s + (size_t)net * w->Mw;
+      g[net].obs = h->obs; g[net].perm = perm; g[net].D = w->D; g[net].W1f = pk + w->pk[net].w1f; g[net].w1sc = w->wsc + 4 + 2 * net;
+      g[net].pW = w->pW2[net]; g[net].pB = w->pB2[net]; g[net].M = M; g[net].chunk = w->chunk2;
+    }
+    if (w->D8 == 8) hipLaunchKernelGGL((wide_wgrad_split_kernel<8>), dim3(w->S2, 2), dim3(512), WS_LDS, h->stream, g[0], g[1]);
+    else hipLaunchKernelGGL((wide_wgrad_split_kernel<16>), dim3(w->S2, 2), dim3(512), WS_LDS, h->stream, g[0], g[1]);
+    CRL_HIP_CHECK(hipGetLastError());
   } else if (wide_h1_free(h)) {   // both networks in one launch, 256 x 256 tile per block (wide_wgrad_gen_kernel)
     WgradGenArgs g[2];
     for (int net = 0; net < 2; ++net) {

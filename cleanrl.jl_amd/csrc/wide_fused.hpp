@@ -74,6 +74,17 @@ __device__ __forceinline__ void lds_dma16(const void* sbase, unsigned voff, unsi
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
 }
+// The same with a per-lane 64-bit global address (a gather into LDS: the piece of lane l lands at lds_addr + 16·l resp. + 4·l)
+__device__ __forceinline__ void lds_dma16_v(const void* vaddr, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(vaddr), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void lds_dma4_v(const void* vaddr, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(vaddr), "s"(lds_addr) : "memory");
+}
 // Eight consecutive observation floats (elements k0 … k0 + 7, zero beyond obs_dim) of one gathered row. With obs_dim % 4 == 0 the row is 16-byte
 // aligned and the eight floats are TWO 16-byte loads; element by element the same gather is eight instructions of 32 different cache lines each, and
 // the CU's address unit takes a cycle per line: in wide_wgrad_gen_kernel, which gathers per 32-sample slab, that was 2.1 of a slab's 5.0 µs
@@ -295,6 +306,9 @@ struct FusedBwdArgs {
   const float* W1s;
   float* D2; float* pW1; float* pB1;
   int M;
+  // split flavour (D2h != nullptr): δ2 leaves as the very fp16x2 pieces the staging thread makes for its own product — δ2·s1 = hi + lo with the SAMPLE's power
+  // of two s1 — in two [M][256] f16 planes (hi at D2h, lo at D2h + 256·M: the bytes of the f32 array), and 1/s1 per sample in d2s; D2 is not written
+  _Float16* D2h; float* d2s;
 };
 
 // one h2 slab (units 32s …, samples m0 …) into LDS as [sample][32 units]: 16 pieces of 1 KB (8 samples x 128 B), two per wave
@@ -333,7 +347,7 @@ __device__ __forceinline__ void fb_compute_slab(const unsigned char* wbuf, const
   }
 }
 
-template <int DP, int NA>   // NA: head outputs kept in registers (a.A <= NA)
+template <int DP, int NA, bool SPLIT>   // NA: head outputs kept in registers (a.A <= NA); SPLIT: δ2 leaves as f16 planes (FusedBwdArgs::D2h)
 #ifndef CRL_ABL_B
 #define CRL_ABL_B 0   // timing ablations of the backward kernel (scripts/ablate_bwd.sh): 1 no epilogue arithmetic, 2 no products, 3 no staging, 4 no δ2 store — results are garbage
 #endif
@@ -418,12 +432,18 @@ __device__ __forceinline__ void wide_fused_bwd_body(const FusedBwdArgs& a) {
       f32x4 o0, o1;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { o0[e] = d[e] * (1.0f - h0[e] * h0[e]); o1[e] = d[4 + e] * (1.0f - h1v[e] * h1v[e]); }
-      float* dst = a.D2 + (size_t)256 * gm + 32 * s + 8 * sq;
-      if (CRL_ABL_B != 4) { *reinterpret_cast<f32x4*>(dst) = o0; *reinterpret_cast<f32x4*>(dst + 4) = o1; }
+      if constexpr (!SPLIT) {
+        float* dst = a.D2 + (size_t)256 * gm + 32 * s + 8 * sq;
+        if (CRL_ABL_B != 4) { *reinterpret_cast<f32x4*>(dst) = o0; *reinterpret_cast<f32x4*>(dst + 4) = o1; }
+      }
       float v[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] = o0[e] * s1; v[4 + e] = o1[e] * s1; }
       const P2 p = split2(v);
+      if constexpr (SPLIT) {                                   // two 16-byte stores either way: the loop's counted waits do not change
+        _Float16* dh = a.D2h + (size_t)256 * gm + 32 * s + 8 * sq;
+        *reinterpret_cast<f16x8*>(dh) = p.hi; *reinterpret_cast<f16x8*>(dh + (size_t)256 * a.M) = p.lo;
+      }
       _Float16* Xl = reinterpret_cast<_Float16*>(xbuf);
       *reinterpret_cast<f16x8*>(Xl + sm * X3ROW + 8 * sq) = p.hi;
       *reinterpret_cast<f16x8*>(Xl + FX_MB * X3ROW + sm * X3ROW + 8 * sq) = p.lo;
@@ -473,6 +493,7 @@ __device__ __forceinline__ void wide_fused_bwd_body(const FusedBwdArgs& a) {
 #pragma unroll
     for (int c = 0; c < DP / 4; ++c) xs[sm * DP + sq * (DP / 4) + c] = (sq * (DP / 4) + c < a.D) ? xq[c] : 0.0f;
     if (sq == 0) invs[sm] = i1 * wunscale;
+    if constexpr (SPLIT) { if (sq == 0) a.d2s[gm] = i1; }
     // the next tile's first transfers and set-up loads go out now: they land under the epilogue's vector work (every buffer they touch —
     // h2 buffers 0 and 1, weight buffer 0 — was last read before the loop's final barrier)
     const int tn = t + gridDim.x;
@@ -559,9 +580,9 @@ __device__ __forceinline__ void wide_fused_bwd_body(const FusedBwdArgs& a) {
   }
 }
 
-template <int DP, int NA0>   // network 0 (actor) keeps up to NA0 head cotangents per sample in registers, network 1 (critic) one
+template <int DP, int NA0, bool SPLIT>   // network 0 (actor) keeps up to NA0 head cotangents per sample in registers, network 1 (critic) one
 __global__ void __launch_bounds__(512) wide_fused_bwd_kernel(FusedBwdArgs a0, FusedBwdArgs a1) {
-  if (blockIdx.y == 0) wide_fused_bwd_body<DP, NA0>(a0); else wide_fused_bwd_body<DP, 1>(a1);
+  if (blockIdx.y == 0) wide_fused_bwd_body<DP, NA0, SPLIT>(a0); else wide_fused_bwd_body<DP, 1, SPLIT>(a1);
 }
 
 }  // namespace crl
@@ -1237,5 +1258,297 @@ __global__ void __launch_bounds__(512) wide_wgrad_gen_kernel(WgradGenArgs a0, Wg
   if (blockIdx.y == 0) wide_wgrad_gen_body<DP>(a0); else wide_wgrad_gen_body<DP>(a1);
 }
 constexpr int WG_LDS = 2 * 2 * 256 * X3ROW * 2;   // 81,920 bytes
+
+// ======================================================================================================================================
+// The same weight gradient from δ2 as the backward kernel's SPLIT output (FusedBwdArgs::D2h): nothing is converted here, and nothing is loaded into
+// registers — every global read of the slab loop is an LDS-DMA, so the loop has no compiler-counted load and its only vmcnt wait is the one written
+// below. With the operand staging gone, the loop is a ONE-barrier software pipeline: between two barriers every wave multiplies slab m (48 MFMAs from
+// the landed planes and the h1 pieces made during the previous slab) and makes the h1 pieces of slab m + 32 into the other buffer — the matrix work and
+// the vector work of a slab no longer alternate in lock-step phases with a barrier and the block's wave skew between them (in-kernel stamps of the
+// two-barrier form of this kernel: 1.2 µs of h1 arithmetic with the matrix pipe idle, 1.8 µs of products with the vector pipe idle, 0.9 µs of
+// barriers and skew per slab).
+// A slab's 32 sample rows of the hi and the lo plane (2 x 16 KB) are requested one slab ahead, between the slab's two jobs (the buffer is free from the
+// barrier on; the request costs a wave 0.2 µs of issue); the A operand (rows = units, k = samples) is read from that [sample][unit] image with ds_read_b64_tr_b16 —
+// the transposing read — so the image is what the DMA can write: lane-linear rows, 16-byte chunks XORed with the row's low two bits so that the four
+// rows of a transposed block sit in four different bank groups (chunk c of row r lies at 512·r + 16·(c ^ ((r & 3) << 2)); the DMA's lanes fetch the
+// permuted chunk, the reads undo it). Wave 0 also gathers the observation rows (per-lane addresses) and the inverse scales of the slab after next and
+// the permutation indices of the slab after that.
+// The planes carry δ2·s1 with a PER-SAMPLE power of two, and the sum runs over samples: the factor 1/s1 goes onto the other operand — the regenerated
+// h1 tile is multiplied by t = (1/s1) / max over the chunk of (1/s1), a power of two ≤ 1 (samples with small cotangents lose low bits of h1 exactly as
+// they lost low bits of δ2 under the one scale per chunk of wide_wgrad_gen_kernel) — and the chunk's maximum is taken out of the accumulators at the end.
+// db2 = Σ δ2 is summed from the A fragments themselves ((hi + lo)·t, exact in f32) by the four waves that hold distinct fragments.
+// ======================================================================================================================================
+struct WgradSplitArgs {
+  const _Float16* Yh; const float* ys;
+  const float* obs; const int32_t* perm; int D;
+  const float* W1f; const float* w1sc;
+  float* pW; float* pB; int M; int chunk;
+};
+constexpr int WS_YBUF = 2 * 32 * 512;                          // 32,768: one slab, 32 hi rows then 32 lo rows of 512 B
+constexpr int WS_XBUF = 2 * 256 * X3ROW * 2;                   // 40,960: [2 pieces][256][X3ROW] f16, the h1 pieces of one slab
+constexpr int WS_OFF_X = 2 * WS_YBUF;                          // 65,536
+constexpr int WS_OFF_O = WS_OFF_X + 2 * WS_XBUF;               // 147,456: a slab's observation rows as gathered, [2 buffers][2,048 B]
+constexpr int WS_OFF_T = WS_OFF_O + 2 * 2048;                  // 151,552: 1/s1 of a slab's samples, [3][64] f32 (32 used)
+constexpr int WS_OFF_I = WS_OFF_T + 3 * 256;                   // 152,320: permutation indices of a slab, [2][64] i32 (32 used)
+constexpr int WS_LDS = WS_OFF_I + 2 * 256;                     // 152,832
+static_assert(WS_LDS <= 160 * 1024, "split weight gradient: LDS budget");
+typedef __fp16 h16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) h16x4 lds_h16x4;
+
+template <int DP>
+__device__ __forceinline__ void wide_wgrad_split_body(const WgradSplitArgs& a) {
+  constexpr int H = 256, NT = 512;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 31, hf = lane >> 5;
+  const int wn = wave & 3, wk = wave >> 2;
+  const int c0 = blockIdx.x * a.chunk;
+  const int c1 = (c0 + a.chunk) < a.M ? (c0 + a.chunk) : a.M;     // (the launcher guarantees whole 32-sample slabs)
+  // the chunk's largest 1/s1 (every entry is a power of two: the reciprocal below is exact)
+  float imax, iinv;
+  {
+    float mx = 0.0f;
+    for (int m = c0 + tid; m < c1; m += NT) mx = __builtin_fmaxf(mx, a.ys[m]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, o, 64));
+    float* red = reinterpret_cast<float*>(smw);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = red[0];
+    for (int w8 = 1; w8 < NT / 64; ++w8) mx = __builtin_fmaxf(mx, red[w8]);
+    __syncthreads();
+    imax = mx > 0.0f ? mx : 1.0f;
+    iinv = __uint_as_float((254u - ((__float_as_uint(imax) >> 23) & 0xFFu)) << 23);
+  }
+  P2 w1b;
+  {
+    const f16x8* wf = reinterpret_cast<const f16x8*>(a.W1f) + (wave * 2) * 64 + lane;
+    w1b.hi = wf[0]; w1b.lo = wf[64];
+  }
+  const float b1u = a.W1f[4096 + 32 * wave + j];
+  const float w1un = a.w1sc[1];
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.0f;
+  float bsum[2] = {0.0f, 0.0f};
+  const int k0x = (8 * hf < a.D && 8 * hf < DP) ? 8 * hf : 0;
+  const bool obs16 = (a.D & 3) == 0;
+  const unsigned ybase = lds_addr_of(smw);
+  // wave 0's side requests (clamped addresses: a lane past the chunk fetches the chunk's last sample, nobody uses it)
+  auto gather_obs = [&](int idx, int buf) {      // rows of a slab's samples: lane (j, hf) fetches elements 8hf … of sample j
+    const unsigned dst = ybase + WS_OFF_O + buf * 2048;
+    if (obs16) {
+      const float* p = a.obs + (size_t)idx * (size_t)a.D + k0x;
+      lds_dma16_v(p, dst);
+      lds_dma16_v(p + (k0x + 4 < a.D ? 4 : 0), dst + 1024);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { const int cc = k0x + c < a.D ? k0x + c : a.D - 1; lds_dma4_v(a.obs + (size_t)idx * (size_t)a.D + cc, dst + 256 * c); }
+    }
+  };
+  auto fetch_scales = [&](int m, int buf) { int mm = m + lane; mm = mm < c1 ? mm : c1 - 1; lds_dma4_v(a.ys + mm, ybase + WS_OFF_T + buf * 256); };
+  auto fetch_index = [&](int m, int buf) { int mm = m + lane; mm = mm < c1 ? mm : c1 - 1; lds_dma4_v(a.perm + mm, ybase + WS_OFF_I + buf * 256); };
+  // DMA of one slab's planes: piece p (0..31) = rows 2(p & 15), +1 of plane p >> 4; this wave takes pieces wave, wave + 8, +16, +24 (p & 1 = wave & 1 for all four)
+  const unsigned dvoff = (unsigned)(hf * 512 + 16 * (j ^ (((2 * (wave & 1) + hf) & 3) << 2)));
+  const _Float16* ylo = a.Yh + (size_t)256 * a.M;
+  auto dma_slab = [&](int m, int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = wave + 8 * i;
+      const _Float16* plane = (i < 2) ? a.Yh : ylo;
+      lds_dma16(plane + (size_t)256 * (m + 2 * (p & 15)), dvoff, ybase + buf * WS_YBUF + (p >> 4) * 16384 + (p & 15) * 1024);
+    }
+  };
+  // transposed-read addresses (bytes from the buffer's base): 16-lane group gq, q = row of the 4-row block, pp = 4-column piece
+  const int gq = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
+  const int abase = 512 * q4 + 8 * (pp & 1) + 16 * (2 * (gq & 1) + (pp >> 1)) + 4096 * (gq >> 1);
+  int aoff[2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x) aoff[x] = abase + 64 * ((wn * 2 + x) ^ q4);
+  auto tr8 = [&](const unsigned char* base, int off) -> f16x8 {   // samples r0 … r0 + 7 of the lane's unit: two 4-row blocks
+    const h16x4 u = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h16x4*)(base + off));
+    const h16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h16x4*)(base + off + 2048));
+    f16x8 r;
+    r[0] = (_Float16)u[0]; r[1] = (_Float16)u[1]; r[2] = (_Float16)u[2]; r[3] = (_Float16)u[3];
+    r[4] = (_Float16)v[0]; r[5] = (_Float16)v[1]; r[6] = (_Float16)v[2]; r[7] = (_Float16)v[3];
+    return r;
+  };
+  // h1 pieces of one slab, in two halves so that the products of the slab in flight can be issued between them:
+  //   pre: the gathered observation rows → one fp16x2 product (rows = samples in registers, columns = units in lanes);
+  //   post: tanh, times the samples' t, split, 8-byte stores into the [unit][sample] image
+  auto h1_pre = [&](int obuf, float& un1) -> f32x16 {
+    float xo[8];
+    const float* xs = reinterpret_cast<const float*>(smw + WS_OFF_O + obuf * 2048);
+    if (obs16) {
+      const f32x4 q0 = *reinterpret_cast<const f32x4*>(xs + 4 * lane), q1 = *reinterpret_cast<const f32x4*>(xs + 256 + 4 * lane);
+      xo[0] = q0[0]; xo[1] = q0[1]; xo[2] = q0[2]; xo[3] = q0[3]; xo[4] = q1[0]; xo[5] = q1[1]; xo[6] = q1[2]; xo[7] = q1[3];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) xo[c] = xs[64 * c + lane];
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) if (8 * hf + c >= a.D || 8 * hf >= DP) xo[c] = 0.0f;
+    float mx = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) mx = __builtin_fmaxf(mx, __builtin_fabsf(xo[c]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sx, ix;
+    pow2_scale(mx, sx, ix);
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = xo[c] * sx;
+    const P2 xa = split2(v);
+    f32x16 c16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c16[r] = 0.0f;
+    un1 = ix * w1un;
+    return mfma_x2(xa, w1b, c16);
+  };
+  auto h1_post = [&](const f32x16& c16, float un1, int tbuf, int xbuf) {
+    const float* tc = reinterpret_cast<const float*>(smw + WS_OFF_T) + 64 * tbuf;
+    _Float16* Xp = reinterpret_cast<_Float16*>(smw + WS_OFF_X + xbuf * WS_XBUF);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {                               // registers 4g … 4g + 3 = samples 8g + 4hf + {0..3} of the slab
+      const f32x4 tq = *reinterpret_cast<const f32x4*>(tc + 8 * g + 4 * hf) * iinv;
+      f32x4 hv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) hv[e] = tanh_exp2_arg(__builtin_fmaf(c16[4 * g + e], un1, b1u), X2_ACT_SCALE) * tq[e];
+      uint2 hh, ll;
+      split2x4(hv, 1.0f, hh, ll);
+      *reinterpret_cast<uint2*>(Xp + (0 * H + 32 * wave + j) * X3ROW + 8 * g + 4 * hf) = hh;
+      *reinterpret_cast<uint2*>(Xp + (1 * H + 32 * wave + j) * X3ROW + 8 * g + 4 * hf) = ll;
+    }
+  };
+  // the loop below must not contain a compiler-counted wait: the values loaded above are made "used" here, so their s_waitcnt is emitted before the loop
+  // (the compiler does not count the LDS-DMA pieces, so a vmcnt(n) of its own inside the loop would wait for all but n of THEM)
+  asm volatile("" :: "v"(w1b.hi), "v"(w1b.lo), "v"(b1u), "v"(w1un));
+  if (c0 < c1) {
+    dma_slab(c0, 0);
+    if (wave == 0) {
+      int m0 = c0 + j; m0 = m0 < c1 ? m0 : c1 - 1;
+      int m1 = c0 + 32 + j; m1 = m1 < c1 ? m1 : c1 - 1;
+      gather_obs(a.perm ? a.perm[m0] : m0, 0);
+      gather_obs(a.perm ? a.perm[m1] : m1, 1);
+      fetch_scales(c0, 0); fetch_scales(c0 + 32, 1);
+      if (a.perm) fetch_index(c0 + 64, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float un1;
+    const f32x16 c16 = h1_pre(0, un1);
+    h1_post(c16, un1, 0, 0);
+  }
+  // The two waves of a SIMD (w and w + 4) take a slab's two jobs in OPPOSITE order: a wave issues in order, so its own matrix and vector work never overlap,
+  // but its partner's can — while waves 0-3 make their h1 tiles (vector pipe) waves 4-7 run their 48 MFMAs, then they swap. Two copies of the loop, one per
+  // order (as an if / else inside one loop body the compiler spilled 400 bytes per lane); both execute the same barriers.
+  auto slab_loop = [&](auto h1_first_tag) {
+  constexpr bool H1_FIRST = decltype(h1_first_tag)::value;
+  int cur = 0, i3 = 0;                                          // parity of the slab, slab index mod 3
+  for (int m = c0; m < c1; m += 32, cur ^= 1, i3 = i3 == 2 ? 0 : i3 + 1) {
+    const bool more = m + 32 < c1, more2 = m + 64 < c1;
+    const bool gst = m == c0 + 32 * 40;          // (diagnostic builds stamp the chunk's 41st slab)
+    if (gst) CRL_GSTAMP(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this slab's planes (requested a slab ago) and the side requests of the last slab have landed
+    __syncthreads();                                            // … for every wave; the h1 pieces of this slab are complete; the previous slab's products have read their buffers
+    if (gst) CRL_GSTAMP(1);
+    auto requests = [&]() {
+      if (more) dma_slab(m + 32, cur ^ 1);
+      if (more2 && wave == 0) {                                 // observation rows and scales of slab m + 64, indices of slab m + 96
+        int idx = m + 64 + j;
+        if (a.perm) idx = reinterpret_cast<const int*>(smw + WS_OFF_I)[64 * cur + j];
+        gather_obs(idx, cur);
+        fetch_scales(m + 64, i3 == 0 ? 2 : i3 - 1);
+        if (a.perm && m + 96 < c1) fetch_index(m + 96, cur ^ 1);
+      }
+    };
+#if CRL_WS_DMA_AT == 0
+    requests();
+#endif
+    if (gst) CRL_GSTAMP(2);
+    const float* tc = reinterpret_cast<const float*>(smw + WS_OFF_T) + 64 * i3;
+    const unsigned char* yb = smw + cur * WS_YBUF;
+    const _Float16* Xp = reinterpret_cast<const _Float16*>(smw + WS_OFF_X + cur * WS_XBUF);
+    auto products = [&]() {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        P2 af[2], bf[4];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          af[x].hi = tr8(yb, aoff[x] + 8192 * ks);
+          af[x].lo = tr8(yb + 16384, aoff[x] + 8192 * ks);
+        }
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+          const int off = ((wk * 4 + y) * 32 + j) * X3ROW + 16 * ks + 8 * hf;
+          bf[y].hi = *reinterpret_cast<const f16x8*>(Xp + 0 * H * X3ROW + off);
+          bf[y].lo = *reinterpret_cast<const f16x8*>(Xp + 1 * H * X3ROW + off);
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int y = 0; y < 4; ++y) acc[x][y] = mfma_x2(af[x], bf[y], acc[x][y]);
+        if (wk == 0) {                                          // db2: the fragment's 8 samples of unit 32(2wn + x) + j, scaled back per sample
+          const f32x4 t0 = *reinterpret_cast<const f32x4*>(tc + 16 * ks + 8 * hf) * iinv, t1 = *reinterpret_cast<const f32x4*>(tc + 16 * ks + 8 * hf + 4) * iinv;
+#pragma unroll
+          for (int x = 0; x < 2; ++x) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              bsum[x] = __builtin_fmaf((float)af[x].hi[e], t0[e], bsum[x]); bsum[x] = __builtin_fmaf((float)af[x].lo[e], t0[e], bsum[x]);
+              bsum[x] = __builtin_fmaf((float)af[x].hi[4 + e], t1[e], bsum[x]); bsum[x] = __builtin_fmaf((float)af[x].lo[4 + e], t1[e], bsum[x]);
+            }
+          }
+        }
+      }
+    };
+    auto make_h1 = [&]() {
+      if (more) {
+        float un1;
+        const f32x16 c16 = h1_pre(cur ^ 1, un1);
+        h1_post(c16, un1, i3 == 2 ? 0 : i3 + 1, cur ^ 1);
+      }
+    };
+#if CRL_WS_DMA_AT == 0
+    if constexpr (H1_FIRST) { make_h1(); if (gst) CRL_GSTAMP(3); products(); }
+    else { products(); if (gst) CRL_GSTAMP(3); make_h1(); }
+#else
+    if constexpr (H1_FIRST) { make_h1(); requests(); if (gst) CRL_GSTAMP(3); products(); }
+    else { products(); requests(); if (gst) CRL_GSTAMP(3); make_h1(); }
+#endif
+    if (gst) CRL_GSTAMP(7);
+  }
+  };
+  if (wk == 0) slab_loop(std::true_type{}); else slab_loop(std::false_type{});
+  __syncthreads();
+  const float un = imax * (1.0f / X2_ACT_SCALE);
+  float* pw = a.pW + (size_t)blockIdx.x * H * H;
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      const int k = (wk * 4 + y) * 32 + j;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = (wn * 2 + x) * 32 + 8 * g + 4 * hf;
+        f32x4 o; o[0] = acc[x][y][4 * g] * un; o[1] = acc[x][y][4 * g + 1] * un; o[2] = acc[x][y][4 * g + 2] * un; o[3] = acc[x][y][4 * g + 3] * un;
+        *reinterpret_cast<f32x4*>(pw + (size_t)H * k + n) = o;
+      }
+    }
+  if (a.pB && wk == 0) {
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const float v = bsum[x] + xor32(bsum[x]);
+      if (hf == 0) a.pB[(size_t)blockIdx.x * H + (wn * 2 + x) * 32 + j] = v * imax;
+    }
+  }
+}
+
+template <int DP>
+__global__ void __launch_bounds__(512) wide_wgrad_split_kernel(WgradSplitArgs a0, WgradSplitArgs a1) {
+  if (blockIdx.y == 0) wide_wgrad_split_body<DP>(a0); else wide_wgrad_split_body<DP>(a1);
+}
 
 }  // namespace crl

@@ -235,6 +235,9 @@ int32_t crl_comm_destroy(crl_ppo* h);
  *   wide_fwd_wbufs (2)      the producer / consumer forward's weight buffers in LDS: 2 = the producers fetch the next slab (default); 3 = the consumers fetch
  *                           the weight slab AFTER NEXT behind their own MFMAs (two slabs of lead for the LDS-DMA; n_act <= 6) — measured equal (DESIGN §3b:
  *                           the slab loop is bound by the SIMD's vector-issue slots, of which an LDS-DMA piece takes ~100-140 cycles whoever issues it)
+ *   wide_d2_split (1)       wide_fuse = 3 with wide_wgrad_full = 1: the backward kernel hands δ2 to the weight-gradient kernel as the fp16x2 pieces it makes for
+ *                           its own product (two f16 planes, one power-of-two scale per sample; the same bytes as the f32 array) and the weight-gradient kernel
+ *                           multiplies straight from them (LDS-DMA + transposing LDS reads, no conversion); 0 = δ2 as f32, split again by its reader
  *   fuse_optim (1)          single GPU, speculative step: gradient reduction + ClipNorm + Adam as ONE launch (0 = two launches)
  * Read-only through crl_ppo_get_option: gemm_fallback_seen (1 once any launch of the fused 4/2/64 path took the bf16x3 fallback; the
  * layer-wise path needs none: it scales its fp16x2 weight pieces by the largest |w| of the layer at every optimiser step).

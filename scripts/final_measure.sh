@@ -9,9 +9,11 @@ mkdir -p $O
 B="python3 $R/bench.py"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3 -- python3 $R/bench.py --workload c3 --steps 3 --warmup 1 > /dev/null 2> $O/prof_c3.log
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --no-cpu-baseline > $O/prof_bench.json 2> $O/prof.log
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --no-cpu-baseline --no-extras > $O/prof_bench.json 2> $O/prof.log
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_envs8192 -- python3 $R/bench.py --total-envs 8192 --no-cpu-baseline > /dev/null 2>&1
-P="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+# --no-extras: the headline loop only — the default line's side records (configs.c2, configs.shard_8192, with_stats_readback) launch the same update
+# kernel at other sizes, and a per-kernel average over all of them is no longer the headline's (first run of round 5: 45 M instead of 180 M instructions)
+P="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras"
 KR="update_x2_kernel|adv_bucket_sums|pack_records|rollout_cartpole"
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$KR" --output-format csv -d $O/pmc_fetch -- $P > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$KR" --output-format csv -d $O/pmc_write -- $P > /dev/null 2>&1

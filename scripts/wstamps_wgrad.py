@@ -12,7 +12,7 @@ assert lib.crl_debug_read_wstamps(buf.ctypes.data_as(C.c_void_p), buf.size) == 0
 st = buf.reshape(2, 256, 8, 16)[0, :128, :, :8].astype(np.int64)
 ok = (st[:, :, 0] > 0).all(axis=1); st = st[ok]
 us = (st - st[:, :, :1].min(axis=1, keepdims=True)) / 100.0
-names = ["slab top", "after barrier 1", "delta2 split + LDS stores issued", "h1 tile made (MFMA, tanh, split, stores)", "after barrier 2", "next slab's loads issued",
+names = ["slab top", "after barrier 1", "delta2 split + LDS stores issued (split kernel: wave 0's side requests issued)", "h1 tile made (MFMA, tanh, split, stores)", "after barrier 2", "next slab's loads issued (split kernel: the plane DMA of the slab after next)",
          "first k-step's 24 MFMAs issued", "second k-step issued (slab end)"]
 print(len(st), "blocks; us since the first wave of the block reached the top of its 41st slab (median over blocks and waves; min .. max over waves of the block medians)")
 for i, n in enumerate(names):

@@ -139,12 +139,12 @@ def test_wide_update_gradient_matches_oracle(crl, D, A, Hd, nt, k, ret_scale, cl
 @pytest.mark.parametrize("opts", [
     {"wide_fuse": 0}, {"wide_fuse": 1}, {"wide_fuse": 2}, {"wide_fuse": 3},
     {"wide_fuse": 3, "wide_fuse_pc": 0}, {"wide_fuse": 2, "wide_fuse_pc": 0}, {"wide_fuse": 3, "wide_wgrad_full": 0},
-    {"wide_fuse": 3, "shuffle_overlap": 0}, {"wide_fuse": 3, "wide_fwd_wbufs": 3}, {"wide_fuse": 3, "wide_fwd_wbufs": 2}], ids=lambda o: ",".join(f"{a}={b}" for a, b in o.items()))
+    {"wide_fuse": 3, "shuffle_overlap": 0}, {"wide_fuse": 3, "wide_fwd_wbufs": 3}, {"wide_fuse": 3, "wide_d2_split": 0}], ids=lambda o: ",".join(f"{a}={b}" for a, b in o.items()))
 @pytest.mark.parametrize("D,A,nt", [(8, 4, 24), (16, 8, 16), (3, 2, 12)])
 def test_every_2x256_kernel_flavour_matches_the_oracle(crl, opts, D, A, nt):
     """The 2x256 shape has four selectable pipelines (option wide_fuse: 0 layer-wise GEMMs, 1 tile-resident forward, 2 + tile-
     resident backward, 3 + h1 never stored) and the flavours under them (producer/consumer forward, the two weight-gradient
-    kernels, dW3 on the side stream).  Every one of them must give the oracle's loss scalars and gradient on the same
+    kernels, dW3 on the side stream, δ2 handed to the weight gradient as f32 instead of as the backward's fp16x2 planes).  Every one of them must give the oracle's loss scalars and gradient on the same
     buffers — the default is only the fastest of equals.  Shapes: C3's, the largest the fused kernels take (obs 16, 8
     actions) and an odd small one (obs 3, 2 actions)."""
     k, Hd = 128, 256
@@ -166,6 +166,42 @@ def test_every_2x256_kernel_flavour_matches_the_oracle(crl, opts, D, A, nt):
         g_gpu = h.read(crl._lib.F_GRADS)
         g_orc, so = O.loss_grad(cfg, params, st.obs.reshape(D, -1, order="F"), st.action, st.logprob, st.value, st.adv, st.ret,
                                 st.perm[mb * M:(mb + 1) * M])
+        for key in ("loss", "pg_loss", "v_loss", "entropy_loss"):
+            assert loss_close(key, gs[key], so[key], RTOL), (key, gs[key], so[key])
+        _grad_close(g_gpu, g_orc, off)
+    agent.close(); st.close()
+
+
+@pytest.mark.parametrize("split", [1, 0])
+def test_weight_gradient_from_split_planes_with_cotangents_of_very_different_size(crl, split):
+    """Option wide_d2_split = 1 (default): the backward kernel hands δ2 to the weight-gradient kernel as fp16x2 pieces scaled by a power of two PER SAMPLE, and the
+    weight-gradient kernel (wide_wgrad_split_kernel) puts 1/scale onto its other operand, relative to the chunk's largest. Here the samples' cotangents span nine
+    orders of magnitude (advantages and return errors from 1e-6 to 1e3, a block of exact zeros among them): the gradient still matches the oracle at the usual bar,
+    with both flavours — the large samples dominate the sum, and the small ones must neither overflow, underflow to NaN nor disturb it."""
+    D, A, Hd, nt, k = 8, 4, 256, 32, 128
+    rng = np.random.default_rng(77)
+    cfg = ocfg(nt, k, D, A, Hd, clip_value_loss=False)
+    params = O.orthogonal_params(cfg, 5) + (0.05 * rng.standard_normal(O.lib().orc_param_count(cfg))).astype(np.float32)
+    agent = make_wide(crl, nt, k, D, A, Hd, params=params, clip_value_loss=False)
+    h = agent.handle
+    h.set_option("wide_d2_split", split)
+    st = O.State(cfg); st.params[:] = params
+    inject(crl, agent, st, rng, D, A, 3.0)
+    mag = (10.0 ** rng.uniform(-6, 3, (nt, k))).astype(np.float32)
+    mag[:2, :] = 0.0                                              # two envs' worth of samples with advantage 0 and return == value prediction scale 0
+    st.adv[:] = (st.adv * mag).astype(np.float32)
+    st.ret[:] = (st.value + (st.ret - st.value) * mag).astype(np.float32)
+    F = crl._lib
+    h.write(F.F_ADVANTAGE, st.adv); h.write(F.F_RETURN, st.ret)
+    # the advantages are normalised per minibatch (ppo.jl:219): the spread survives it (mean and std are set by the largest samples)
+    h.adv_stats()
+    M = nt * k // 4
+    off = O.param_offsets(cfg)
+    for mb in (0, 2):
+        gs = h.update_minibatch(mb, 2.5e-4, apply_update=False)
+        g_gpu = h.read(F.F_GRADS)
+        assert np.isfinite(g_gpu).all()
+        g_orc, so = O.loss_grad(cfg, params, st.obs.reshape(D, -1, order="F"), st.action, st.logprob, st.value, st.adv, st.ret, st.perm[mb * M:(mb + 1) * M])
         for key in ("loss", "pg_loss", "v_loss", "entropy_loss"):
             assert loss_close(key, gs[key], so[key], RTOL), (key, gs[key], so[key])
         _grad_close(g_gpu, g_orc, off)
