@@ -630,6 +630,9 @@ constexpr int pc_lds(int nwb) { return pc_off_b2(nwb) + 1024; }
 static_assert(pc_lds(3) <= 160 * 1024 && pc_lds(2) == 133120, "producer / consumer forward: LDS budget");
 constexpr int PC_OFF_W1F = FX_OFF_X + 2 * FX_XBYTES;          // (two-buffer layout) 106,496: W1 A-fragments, [slab 8][piece 2][lane 64][8 halves] = 16 KB
 constexpr int PC_OFF_B1 = PC_OFF_W1F + 16384;                // b1·2·log2(e) [256] f32
+#ifndef CRL_FWD_DIRECT_H2
+#define CRL_FWD_DIRECT_H2 1   // 1: the consumers store h2 straight from their accumulators (default: 570 vs 583 µs per launch); 0: through the LDS transposition (whole 128-B lines per instruction)
+#endif
 #ifndef PC_PRODUCER_PRIO
 #define PC_PRODUCER_PRIO 0   // measured: 0, 2 and 3 within noise (45.5-46.2 ms per C3 iteration on one box)
 #endif
@@ -810,7 +813,8 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
     const int c = wave;
     const float cs = a.wsc[1] * (1.0f / X2_ACT_SCALE);
     const int hs = a.A;
-    float* scr = reinterpret_cast<float*>(smx + SCRB * FX_WBYTES) + c * (32 * 36);        // in weight buffer SCRB
+    float* scr = reinterpret_cast<float*>(smx + SCRB * FX_WBYTES) + c * (32 * 36);        // in weight buffer SCRB (CRL_FWD_DIRECT_H2 = 0 only)
+    (void)scr;
     float* hp_all = reinterpret_cast<float*>(smx + OFF_X + FX_XBYTES);                 // in activation buffer 1 (both are free from the loop's last barrier to slab 1 of the next tile)
     float* hp = hp_all + c * (FX_MB * hs);
     // NWB = 0: weight fragments from global memory, HALF a slab (one k-step: 24 MFMAs) ahead in registers, [ai][piece]: two sets of 16 VGPRs that
@@ -927,8 +931,22 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[ai][bi][4 * g + e] = tanh_exp2(__builtin_fmaf(acc[ai][bi][4 * g + e], cs, bv[e]), TWO_LOG2E, 1.0f);
         }
+#if CRL_FWD_DIRECT_H2
+        // h2 straight from the accumulator layout (lane = sample, 4 consecutive units per register quad): 16-byte stores, 32 B per sample and instruction; the
+        // eight instructions of a sample's 256 B of this consumer follow each other, so L2 still writes whole lines
+#pragma unroll
+        for (int bi = 0; bi < 4; ++bi) {
+          float* hrow = a.H2 + (size_t)256 * (m0 + 32 * bi + j) + n0 + 4 * hf;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            f32x4 o; o[0] = acc[ai][bi][4 * g]; o[1] = acc[ai][bi][4 * g + 1]; o[2] = acc[ai][bi][4 * g + 2]; o[3] = acc[ai][bi][4 * g + 3];
+            *reinterpret_cast<f32x4*>(hrow + 8 * g) = o;
+          }
+        }
+#else
 #pragma unroll
         for (int bi = 0; bi < 4; ++bi) tile_out<EPI_STORE>(scr, acc[ai][bi], lane, n0, m0 + 32 * bi, a.M, nullptr, nullptr, 0, a.H2, 256);
+#endif
 #pragma unroll
         for (int aa = 0; aa < pc_amax(NWB); ++aa) {
           if (aa < a.A) {
