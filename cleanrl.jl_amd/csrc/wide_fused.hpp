@@ -630,6 +630,9 @@ constexpr int pc_lds(int nwb) { return pc_off_b2(nwb) + 1024; }
 static_assert(pc_lds(3) <= 160 * 1024 && pc_lds(2) == 133120, "producer / consumer forward: LDS budget");
 constexpr int PC_OFF_W1F = FX_OFF_X + 2 * FX_XBYTES;          // (two-buffer layout) 106,496: W1 A-fragments, [slab 8][piece 2][lane 64][8 halves] = 16 KB
 constexpr int PC_OFF_B1 = PC_OFF_W1F + 16384;                // b1·2·log2(e) [256] f32
+#ifndef CRL_ABL_F
+#define CRL_ABL_F 0   // timing ablations of the forward's epilogue (results are garbage): 1 no tanh, 2 no head partials, 3 no h2 stores
+#endif
 #ifndef CRL_FWD_DIRECT_H2
 #define CRL_FWD_DIRECT_H2 1   // 1: the consumers store h2 straight from their accumulators (default: 570 vs 583 µs per launch); 0: through the LDS transposition (whole 128-B lines per instruction)
 #endif
@@ -929,8 +932,11 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
 #pragma unroll
           for (int bi = 0; bi < 4; ++bi)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[ai][bi][4 * g + e] = tanh_exp2(__builtin_fmaf(acc[ai][bi][4 * g + e], cs, bv[e]), TWO_LOG2E, 1.0f);
+            for (int e = 0; e < 4; ++e) acc[ai][bi][4 * g + e] = CRL_ABL_F == 1 ? __builtin_fmaf(acc[ai][bi][4 * g + e], cs, bv[e]) : tanh_exp2(__builtin_fmaf(acc[ai][bi][4 * g + e], cs, bv[e]), TWO_LOG2E, 1.0f);
         }
+#if CRL_ABL_F == 3
+        if (a.M < 0)   // (timing ablation: no h2 stores)
+#endif
 #if CRL_FWD_DIRECT_H2
         // h2 straight from the accumulator layout (lane = sample, 4 consecutive units per register quad): 16-byte stores, 32 B per sample and instruction; the
         // eight instructions of a sample's 256 B of this consumer follow each other, so L2 still writes whole lines
@@ -948,7 +954,7 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
         for (int bi = 0; bi < 4; ++bi) tile_out<EPI_STORE>(scr, acc[ai][bi], lane, n0, m0 + 32 * bi, a.M, nullptr, nullptr, 0, a.H2, 256);
 #endif
 #pragma unroll
-        for (int aa = 0; aa < pc_amax(NWB); ++aa) {
+        for (int aa = 0; aa < (CRL_ABL_F == 2 ? 0 : pc_amax(NWB)); ++aa) {
           if (aa < a.A) {
             const float* w3l = reinterpret_cast<const float*>(smx + OFF_W3) + 256 * aa + n0 + 4 * hf;
             f32x4 w[4];
