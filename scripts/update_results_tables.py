@@ -27,15 +27,15 @@ p = os.path.join(ROOT, "BASELINE.md")
 s = open(p).read()
 a = s.index("| **C4 shape on ONE GPU: nt=65536, k=128** (`bench.py`, N=1; `" + tag + "_bench_n1.json`)")
 b = s.index("| C4 on 8 GPUs | 8 |")
-new = f'''| **C4 shape on ONE GPU: nt=65536, k=128** (`bench.py`, N=1; `{tag}_bench_n1.json`) | 1 | **{g3(n1['value'])}** ({g3(bd['value'])} with `--kernel-breakdown`) | {n1['ms_per_step']:.2f} | {r['avg_launch_ms']:.3f} ms/launch (HIP events; rocprofv3 agrees within its own overhead); `roofline`: **bound valu-issue, {r['valu_instructions_per_launch']/1e6:.1f} M vector instructions per launch (SQ_INSTS_VALU) ÷ {r['avg_launch_ms']:.3f} ms = {r['achieved']:.0f} G/s = {r['frac']:.3f} of 1228.8 G/s** ({r['frac_of_measured_two_wave_ceiling']:.3f} of what two waves per SIMD were measured to sustain on independent FMAs; by the hardware's own busy counters some pipe of a SIMD is busy {valu + mfma - both:.2f} of the time: vector {valu:.2f}, matrix {mfma:.2f}, both {both:.2f}); matrix pipe {r['matrix_pipe']['frac']:.3f} of 2.5 PFLOP/s; f32-equivalent {r['f32_equivalent']['tflops']:.0f} TFLOP/s; **HBM traffic {r['traffic']/1e6:.1f} MB per launch vs 75.5 MB algorithmic** (271.9 MB before a tile's two readers shared an XCD; the rest is the 64-byte record format, which carries 36 bytes) | unchanged kernels this round (the bounded grid barrier and the option table are the only edits of `update.hip`); `update_prio_small` sweep in DESIGN.md §3 |
+new = f'''| **C4 shape on ONE GPU: nt=65536, k=128** (`bench.py`, N=1; `{tag}_bench_n1.json`) | 1 | **{g3(n1['value'])}** ({g3(bd['value'])} with `--kernel-breakdown`) | {n1['ms_per_step']:.2f} | {r['avg_launch_ms']:.3f} ms/launch (HIP events; rocprofv3 agrees within its own overhead); `roofline`: **bound valu-issue, {r['valu_instructions_per_launch']/1e6:.1f} M vector instructions per launch (SQ_INSTS_VALU) ÷ {r['avg_launch_ms']:.3f} ms = {r['achieved']:.0f} G/s = {r['frac']:.3f} of 1228.8 G/s** ({r['frac_of_measured_two_wave_ceiling']:.3f} of what two waves per SIMD were measured to sustain on independent FMAs; by the hardware's own busy counters some pipe of a SIMD is busy {valu + mfma - both:.2f} of the time: vector {valu:.2f}, matrix {mfma:.2f}, both {both:.2f}); matrix pipe {r['matrix_pipe']['frac']:.3f} of 2.5 PFLOP/s; f32-equivalent {r['f32_equivalent']['tflops']:.0f} TFLOP/s; **HBM traffic {r['traffic']/1e6:.1f} MB per launch vs 75.5 MB algorithmic** (271.9 MB before a tile's two readers shared an XCD; the rest is the 64-byte record format, which carries 36 bytes) | the update kernel is unchanged this round (its per-phase timeline and the floor argument: DESIGN.md §3, round 5) |
 | same, `--shuffle bijection` | 1 | {g3(bij[0])} | {bij[1]:.2f} | same | slower than the exact shuffle: its advantage sums gather through the permutation |
 | same, `--minibatches 1` | 1 | {g3(mb1[0])} | {mb1[1]:.2f} | {mb1[2]:.2f} ms/launch (M = 8,388,608) | north_star's one gradient message per epoch |
 | same, `--opt gemm=1` (bf16x3 products — the flavour a launch falls back to by itself when a weight leaves the fp16 window) | 1 | {g3(x3[0])} | {x3[1]:.2f} | {x3[2]:.3f} ms/launch | |
 | nt=32768 (one GPU's share at N=2) | 1 | {g3(e32[0])} | {e32[1]:.2f} | {e32[2]*1e3:.0f} µs/launch | |
 | nt=16384 (share at N=4) | 1 | {g3(e16[0])} | {e16[1]:.2f} | {e16[2]*1e3:.0f} µs/launch | |
-| nt=8192 (share at N=8) | 1 | {g3(e8[0])} (×8 ideal {g3(e8[0]*8)} before the 16 + 1 all-reduces) | {e8[1]:.2f} | {e8[2]*1e3:.0f} µs/launch | breakdown (ms, events around every kernel): update {k8['update']:.2f} · rollout {k8['rollout']:.2f} · reduce + optimiser (one launch) {k8['reduce']+k8['optim']:.2f} · shuffle {k8['shuffle']:.2f} · pack {k8['pack']:.2f} · advantage sums {k8['adv_stats']:.2f}; with a communicator the two-launch path runs (0.33) |
+| nt=8192 (share at N=8) | 1 | {g3(e8[0])} (×8 ideal {g3(e8[0]*8)} before the 16 + 1 all-reduces) | {e8[1]:.2f} | {e8[2]*1e3:.0f} µs/launch | breakdown (ms, events around every kernel): update {k8['update']:.2f} · rollout {k8['rollout']:.2f} · reduce + optimiser (one launch) {k8['reduce']+k8['optim']:.2f} · shuffle {k8['shuffle']:.2f} · pack {k8['pack']:.2f} · advantage sums {k8['adv_stats']:.2f}; with a peer-mailbox communicator the exchange runs inside the same launch (`r05_bench_n1_envs8192_peer_forced.json`), over RCCL as reduce / all-reduce / optimiser |
 | **C2: nt=4096** (`bench.py --workload c2`, also a `--suite` sub-record) | 1 | **{g3(c2[0])}** | {c2[1]:.2f} | {c2[2]*1e3:.0f} µs/launch (four tiles per wave, launch floor ≈17 µs) | BASELINE configs[1] |
-| **C3: obs 8 / act 4 / 2×256, nt=16384** (`bench.py --workload c3`) | 1 | **{g3(c3d['value'])}** | {c3d['ms_per_step']:.1f} (59.1 for the round-3 pipeline; the bench line is from the box of the round's measurement set, same-box A/Bs in DESIGN.md §3b) | layer-wise GEMMs: {c3r['avg_launch_ms']:.2f} ms per minibatch = {c3r['achieved']:.0f} TFLOP/s issued to the f16 pipe = {c3r['frac']:.3f} of 2.5 PFLOP/s ({c3r['f32_equivalent']['tflops']:.0f} TFLOP/s f32-equivalent); counters and what bounds it: DESIGN.md §3b | full-iteration oracle parity at 1024 envs at 1e-5 (`tests/test_gpu_wide.py`) |
+| **C3: obs 8 / act 4 / 2×256, nt=16384** (`bench.py --workload c3`) | 1 | **{g3(c3d['value'])}** | {c3d['ms_per_step']:.1f} (42.2 in round 4, 59.1 in round 3; this line is from the box of the round's measurement set — boxes differ by 3 % on this workload — the same-box A/Bs are in DESIGN.md §3b) | layer-wise GEMMs: {c3r['avg_launch_ms']:.2f} ms per minibatch = {c3r['achieved']:.0f} TFLOP/s issued to the f16 pipe = {c3r['frac']:.3f} of 2.5 PFLOP/s ({c3r['f32_equivalent']['tflops']:.0f} TFLOP/s f32-equivalent); counters and what bounds it: DESIGN.md §3b | full-iteration oracle parity at 1024 envs at 1e-5 (`tests/test_gpu_wide.py`) |
 '''
 s = s[:a] + new + s[b:]
 rf, pf = L("bench_n1_rccl_forced.json")["value"], L("bench_n1_peer_forced.json")["value"]
