@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak of the round-4 2x256 kernels (fused forward / backward / weight gradient, producer-consumer rollout): long runs at several
 sizes — whole tiles only, fewer tiles than blocks, the C3 size — checking for non-finite parameters / losses and for the sticky
-time-out words. python scripts/soak_c3.py > profiles/r04_soak_c3.json"""
+time-out words. python scripts/soak_c3.py > profiles/<tag>_soak_c3.json"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
