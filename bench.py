@@ -317,7 +317,7 @@ def parse_opts(items):
     return out
 
 
-def time_gae_standalone(torch, h, nt, device, reps=6):
+def time_gae_standalone(torch, h, nt, device, reps=6, crl=None):
     """The standalone gae_kernel (crl_compute_gae) on the resident buffer: cold (caches flushed by a 1 GiB fill first) and warm
     (launched again right away), median of `reps`; next to it a plain copy of the same footprint through torch (the read + write bytes
     of one GAE launch as one float tensor copy), cold — the practical ceiling the cold figure should be read against."""
@@ -347,7 +347,7 @@ def time_gae_standalone(torch, h, nt, device, reps=6):
         copy_cold.append(e0.elapsed_time(e1))
     del flush, src, dst
     med = lambda v: sorted(v)[len(v) // 2]   # noqa: E731
-    rec = {"bound": "hbm", "kernel": "gae_kernel (advantages + returns), standalone launch (crl_compute_gae)", "num_envs": nt,
+    rec = {"bound": "hbm", "kernel": "standalone GAE scan (advantages + returns; crl_compute_gae: gae_seg2_kernel from 4096 envs, gae_kernel below)", "num_envs": nt,
            "peak": PEAK_HBM_GBPS, "unit": "GB/s", "bytes_per_launch": gae_bytes}
     for name, ms in (("cold", med(cold)), ("warm", med(warm))):
         rec[name] = {"avg_launch_ms": ms, "achieved": gae_bytes / (ms * 1e-3) / 1e9, "frac": gae_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS}
@@ -359,6 +359,17 @@ def time_gae_standalone(torch, h, nt, device, reps=6):
                            "cold_over_copy": cc / med(cold), "cold_nt_loads_over_copy": cc / cn,
                            "note": "torch float copy moving the same number of bytes (half read, half written), caches flushed first; "
                                    "cold_over_copy = copy time ÷ GAE cold time (1 = the scan runs at copy speed)"}
+    if crl is not None:
+        # the library's own copy of the same bytes (crl_gae_bench: one 16-byte piece per thread, nontemporal both ways), flushed like the scan: the torch copy
+        # above reaches 3.5 TB/s at 143 MB, this one 5.6 — the ceiling to hold the scan against
+        try:
+            g, c = crl._lib.gae_bench(nt, NUM_STEPS, seg=0, tile=0, nt_loads=1, flush_mb=1024, reps=reps)
+            lc, lg = med(list(c)), med(list(g))
+            rec["copy_ceiling"]["library_copy"] = {"avg_launch_ms": lc, "achieved": gae_bytes / (lc * 1e-3) / 1e9, "frac": gae_bytes / (lc * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                                                   "scan_same_buffers_ms": lg, "scan_over_copy": lc / lg,
+                                                   "note": "crl_gae_bench on synthetic device buffers of this size, nontemporal loads, caches flushed before every launch"}
+        except Exception as e:   # noqa: BLE001 — a side measurement must not take the line down
+            rec["copy_ceiling"]["library_copy"] = {"error": str(e)}
     rec.update({"achieved": rec["cold"]["achieved"], "frac": rec["cold"]["frac"], "avg_launch_ms": rec["cold"]["avg_launch_ms"], "state": "cold"})
     return rec
 
@@ -460,7 +471,7 @@ def run_workload(args, wl, world, rank, local_rank, dist, torch, crl, crl_dist, 
     fallback_seen = h.get_option("gemm_fallback_seen")
     gae_rec = None
     if rank == 0 and not c3 and world == 1 and with_gae:
-        gae_rec = time_gae_standalone(torch, h, nt_local, f"cuda:{local_rank}")
+        gae_rec = time_gae_standalone(torch, h, nt_local, f"cuda:{local_rank}", crl=crl)
         if headline_size(total_envs, wl, args):
             try:
                 gae_rec["beyond_cache"] = gae_beyond_cache(crl)
@@ -488,9 +499,9 @@ def run_workload(args, wl, world, rank, local_rank, dist, torch, crl, crl_dist, 
     if headline_shape:
         pm, traffic_src = load_profile("pmc_hbm_traffic", strict)
         if pm:
-            for key, frag in (("update", "update_x2_kernel"), ("gae", "gae_kernel")):
+            for key, frags in (("update", ("update_x2_kernel",)), ("gae", ("gae_seg2_kernel", "gae_kernel"))):
                 for name, rec in pm.get("kernels", {}).items():
-                    if frag in name:
+                    if any(f in name for f in frags):
                         # how FETCH_SIZE compares with bytes for this kernel's access pattern (scripts/summarize_pmc.py)
                         traffic[key] = (float(rec.get("fetch_factor", 1.0)) * rec["FETCH_SIZE_KB_per_launch_mean"] + rec["WRITE_SIZE_KB_per_launch_mean"]) * 1024
                         break

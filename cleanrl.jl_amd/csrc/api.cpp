@@ -35,7 +35,7 @@ static const OptDesc kOpts[OPT_COUNT] = {
     {"wide_gemm", 2, 0, 2},
     {"wide_tanh_rational", 0, 0, 1},
     {"gae_seg", 0, 0, 16},
-    {"gae_tile", 0, 0, 64},
+    {"gae_tile", 0, 0, 256},
     {"gae_nt_loads", 2, 0, 2},
     {"wide_rollout_persist", 2, 0, 2},
     {"fuse_optim", 1, 0, 1},
@@ -48,7 +48,7 @@ static const OptDesc kOpts[OPT_COUNT] = {
     {"wide_d2_split", 1, 0, 1},
 };
 static bool gae_seg_ok(int64_t v) { return v == 0 || v == 4 || v == 8 || v == 16; }
-static bool gae_tile_ok(int64_t v) { return v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64; }
+static bool gae_tile_ok(int64_t v) { return v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64 || v == 128 || v == 256; }
 static int opt_find(const char* key) {
   if (!key) return -1;
   for (int i = 0; i < OPT_COUNT; ++i) if (std::strcmp(kOpts[i].name, key) == 0) return i;
@@ -64,7 +64,7 @@ static int opt_set(crl_ppo* h, const char* key, int64_t value) {
   }
   if (id == OPT_GAE_SEG && !gae_seg_ok(value)) { set_error("crl_ppo_set_option: gae_seg is 0 (automatic), 8 or 16 (4: streaming kernel only)"); return 1; }
   if (id == OPT_WIDE_FWD_WBUFS && value == 1) { set_error("crl_ppo_set_option: wide_fwd_wbufs is 0 (weight fragments to registers), 2 or 3 (LDS buffers)"); return 1; }
-  if (id == OPT_GAE_TILE && !gae_tile_ok(value)) { set_error("crl_ppo_set_option: gae_tile is 0 (automatic), 1 / 2 / 4 (streaming kernel, envs per thread), 8, 16, 32 or 64"); return 1; }
+  if (id == OPT_GAE_TILE && !gae_tile_ok(value)) { set_error("crl_ppo_set_option: gae_tile is 0 (automatic), 1 / 2 / 4 (streaming kernel, envs per thread), 8, 16, 32 or 64 (segmented kernel, envs per block), 128 or 256 (two envs per thread, 32 / 64 pairs per block)"); return 1; }
   h->opt[id] = value;
   if (id == OPT_GUARD_WINDOW) h->window_len = (int)value;
   if (id == OPT_WIDE_GEMM) wide_mark_params_changed(h);   // the packed weight copies depend on the flavour
@@ -461,7 +461,7 @@ int32_t crl_gae_opt(int32_t device, const float* value, const float* reward, con
                     float* ret, int32_t gae_seg, int32_t gae_tile, int32_t gae_nt_loads) {
   if (nt < 0 || k < 0) { set_error("crl_gae: negative size"); return 1; }
   if (!gae_seg_ok(gae_seg) || !gae_tile_ok(gae_tile) || (gae_seg == 4 && gae_tile > 4) || gae_nt_loads < 0 || gae_nt_loads > 2) {
-    set_error("crl_gae_opt: gae_seg is 0 / 8 / 16 (4 with the streaming kernel), gae_tile 0 / 1 / 2 / 4 (streaming kernel) / 8 / 16 / 32 / 64, gae_nt_loads 0 / 1 / 2 (automatic)");
+    set_error("crl_gae_opt: gae_seg is 0 / 8 / 16 (4 with the streaming kernel), gae_tile 0 / 1 / 2 / 4 (streaming kernel) / 8 / 16 / 32 / 64 / 128 / 256, gae_nt_loads 0 / 1 / 2 (automatic)");
     return 1;
   }
   if (nt == 0 || k == 0) return 0;  // gae of an empty rollout is empty

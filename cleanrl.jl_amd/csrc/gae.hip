@@ -190,6 +190,98 @@ __global__ void __launch_bounds__(256) gae_stream_kernel(const float* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The segmented scan with TWO envs per thread (8-byte accesses): gae_kernel's arithmetic element by element — the same affine maps composed in
+// the same order, so its outputs are bit-identical to gae_kernel's — but every load and store moves 512 bytes per wave instead of 256. At the size
+// BASELINE's metric is quoted on (65536 envs x 128 steps, 143 MB, caches flushed) gae_kernel runs 41 µs whatever its tile shape while the library's
+// own copy of the same bytes takes 25: with 4 bytes per lane the memory pipeline, not HBM, is the limit (the streaming kernel has known this since
+// round 4, but it needs >= 262144 envs to have enough waves). δ_t and c_t are kept from phase 1 for phase 2 here (L = 8: 64 registers).
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int EB, int GAE_L, bool NTL>
+__global__ void __launch_bounds__(512) gae_seg2_kernel(const float* __restrict__ value, const float* __restrict__ reward,
+                                                        const uint8_t* __restrict__ terminal, const float* __restrict__ next_value,
+                                                        const uint8_t* __restrict__ next_done, int nt, int k, float gamma, float gl, int mode,
+                                                        float* __restrict__ adv, float* __restrict__ ret) {
+#pragma clang fp contract(off)
+  extern __shared__ double sm[];
+  constexpr int E = 2;
+  const int S = blockDim.x / EB;
+  const int el = threadIdx.x % EB, seg = threadIdx.x / EB;
+  const int e = (blockIdx.x * EB + el) * E;                    // first of this thread's two envs (nt is even: both or neither exist)
+  const bool ev = e < nt;
+  const int lo = seg * GAE_L;
+  double* smD = sm;                                            // [S][EB][E]
+  double* smC = sm + S * EB * E;
+  gf2 v[GAE_L + 1], r[GAE_L];
+  uint32_t tm[GAE_L];
+  const gf2 zero2 = {0.0f, 0.0f};
+#pragma unroll
+  for (int i = 0; i < GAE_L; ++i) {
+    const int t = lo + i;
+    const bool ok = ev && t < k;
+    const size_t idx = (size_t)e + (size_t)nt * t;
+    const gf2* pv = reinterpret_cast<const gf2*>(value + idx); const gf2* pr = reinterpret_cast<const gf2*>(reward + idx);
+    v[i] = ok ? (NTL ? __builtin_nontemporal_load(pv) : *pv) : zero2;
+    r[i] = ok ? (NTL ? __builtin_nontemporal_load(pr) : *pr) : zero2;
+    const uint16_t* pt = reinterpret_cast<const uint16_t*>(terminal + idx + nt);
+    tm[i] = ok ? ((t + 1 < k) ? (uint32_t)(NTL ? __builtin_nontemporal_load(pt) : *pt)
+                              : (next_done ? (uint32_t)*reinterpret_cast<const uint16_t*>(next_done + e) : 0u)) : 0u;
+  }
+  {
+    const int t = lo + GAE_L;
+    const gf2* pv = reinterpret_cast<const gf2*>(value + (size_t)e + (size_t)nt * t);
+    v[GAE_L] = (ev && t < k) ? (NTL ? __builtin_nontemporal_load(pv) : *pv) : zero2;
+  }
+  const gf2 nv = (ev && next_value) ? *reinterpret_cast<const gf2*>(next_value + e) : zero2;
+  double dl[GAE_L][E], cl[GAE_L][E];
+  double D[E] = {0.0, 0.0}, Cc[E] = {1.0, 1.0};
+#pragma unroll
+  for (int i = GAE_L - 1; i >= 0; --i) {
+    const int t = lo + i;
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      const float vnext = (t + 1 < k) ? v[i + 1][q] : nv[q];
+      const double nonterm = 1.0 - (double)(((tm[i] >> (8 * q)) & 0xFFu) ? 1 : 0);
+      double delta = (double)r[i][q] + ((double)gamma * nonterm) * (double)vnext - (double)v[i][q];
+      double cc = (double)gl * nonterm;
+      if (t >= k) { delta = 0.0; cc = 1.0; }
+      else if (mode == CRL_GAE_COMPAT && t == k - 1) { delta = 0.0; cc = 0.0; }
+      dl[i][q] = delta; cl[i][q] = cc;
+      D[q] = delta + cc * D[q];
+      Cc[q] = cc * Cc[q];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < E; ++q) { smD[(seg * EB + el) * E + q] = D[q]; smC[(seg * EB + el) * E + q] = Cc[q]; }
+  __syncthreads();
+  double A[E] = {0.0, 0.0};
+  for (int s = S - 1; s > seg; --s) {
+#pragma unroll
+    for (int q = 0; q < E; ++q) A[q] = smD[(s * EB + el) * E + q] + smC[(s * EB + el) * E + q] * A[q];
+  }
+#pragma unroll
+  for (int i = GAE_L - 1; i >= 0; --i) {
+    const int t = lo + i;
+    gf2 a32, r32;
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      A[q] = dl[i][q] + (cl[i][q] * A[q]);
+      a32[q] = (float)A[q];
+      r32[q] = a32[q] + v[i][q];
+    }
+    if (ev && t < k) {
+      const size_t idx = (size_t)e + (size_t)nt * t;
+      if (NTL) {
+        __builtin_nontemporal_store(a32, reinterpret_cast<gf2*>(adv + idx));
+        if (ret) __builtin_nontemporal_store(r32, reinterpret_cast<gf2*>(ret + idx));
+      } else {
+        *reinterpret_cast<gf2*>(adv + idx) = a32;
+        if (ret) *reinterpret_cast<gf2*>(ret + idx) = r32;
+      }
+    }
+  }
+}
+
 int launch_gae(hipStream_t st, const float* value, const float* reward, const uint8_t* terminal,
                const float* next_value, const uint8_t* next_done, int nt, int k, float gamma, float lambda, int mode,
                float* adv, float* ret, hipEvent_t ev_start, hipEvent_t ev_stop, int seg, int tile, int nt_loads) {
@@ -222,6 +314,33 @@ int launch_gae(hipStream_t st, const float* value, const float* reward, const ui
     CRL_GAE_STREAM(1, 4) CRL_GAE_STREAM(1, 8) CRL_GAE_STREAM(1, 16)
     { set_error("gae: unsupported streaming configuration"); return 1; }
 #undef CRL_GAE_STREAM
+    CRL_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
+  // tile = 128 / 256: the two-envs-per-thread segmented kernel with 32 / 64 env pairs per block (gae_seg2_kernel); L as below
+  // Automatic (tile = 0) from 4096 envs on when the buffers allow it — measured against gae_kernel at 128 steps, µs per launch, caches flushed / warm
+  // (profiles/r05_gae_pair_kernel.txt): 4096 envs 8.6 vs 10.8 / 6.1 vs 6.6; 8192: 10.0 vs 14.4 / 6.8 vs 12.0; 16384: 14.1 vs 20.2 / 9.2 vs 13.8; 65536: 47.6 vs 50.7
+  // / 26.3 vs 30.0, with nontemporal loads 32-34 vs 41-42 (0.56-0.59 of 8 TB/s instead of 0.43; the copy of the same bytes: 25); 1024 envs: 5.6 vs 4.6 (stays).
+  if ((tile == 128 || tile == 256) && !aligned(2)) { set_error("gae: gae_tile = 128 / 256 (two envs per thread) needs an even num_envs and 8-byte aligned buffers"); return 1; }
+  if (tile == 128 || tile == 256 || (tile == 0 && nt >= 4096 && aligned(2))) {
+    int L2 = (seg == 8 || seg == 16) ? seg : (k <= 128 ? 8 : 16);
+    int S2 = (k + L2 - 1) / L2;
+    int EB2 = tile == 256 ? 64 : 32;                            // (automatic: 32 pairs per block)
+    while (EB2 > 8 && S2 * EB2 > 512) EB2 >>= 1;
+    if (S2 * EB2 > 512 && L2 == 8) { L2 = 16; S2 = (k + L2 - 1) / L2; }
+    if (S2 * EB2 > 512) { set_error("gae: num_steps > 1024 is not supported"); return 1; }
+    const dim3 block2(S2 * EB2), grid2((nt / 2 + EB2 - 1) / EB2);
+    const size_t smem2 = sizeof(double) * 2 * S2 * EB2 * 2;
+#define CRL_GAE2_CASE(eb, l)                                                                                                              \
+    if (EB2 == eb && L2 == l) {                                                                                                             \
+      if (nt_loads) hipExtLaunchKernelGGL((gae_seg2_kernel<eb, l, true>), grid2, block2, smem2, st, ev_start, ev_stop, 0, value, reward, terminal, \
+                                          next_value, next_done, nt, k, gamma, gl, mode, adv, ret);                                       \
+      else hipExtLaunchKernelGGL((gae_seg2_kernel<eb, l, false>), grid2, block2, smem2, st, ev_start, ev_stop, 0, value, reward, terminal,         \
+                                 next_value, next_done, nt, k, gamma, gl, mode, adv, ret);                                                \
+    } else
+    CRL_GAE2_CASE(64, 8) CRL_GAE2_CASE(32, 8) CRL_GAE2_CASE(16, 8) CRL_GAE2_CASE(8, 8) CRL_GAE2_CASE(64, 16) CRL_GAE2_CASE(32, 16) CRL_GAE2_CASE(16, 16) CRL_GAE2_CASE(8, 16)
+    { set_error("gae: unsupported pair-tile configuration"); return 1; }
+#undef CRL_GAE2_CASE
     CRL_HIP_CHECK(hipGetLastError());
     return 0;
   }

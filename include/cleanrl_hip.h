@@ -216,8 +216,10 @@ int32_t crl_comm_destroy(crl_ppo* h);
  *   peer_timeout_ms         in-kernel time-out of the peer all-reduce (20000)
  *   wide_gemm               layer-wise path, 256-wide layers: 2 = fp16x2 (default), 1 = bf16x3, 0 = f32 MFMA
  *   wide_tanh_rational      1 = the layer-wise path evaluates NNlib's rational tanh_fast everywhere (default 0)
- *   gae_seg, gae_tile       standalone GAE kernel: steps per segment / envs per block, 0 = automatic; gae_tile = 4 = the streaming kernel
- *                           (four envs per thread, 16-byte accesses, serial Float64 recurrence: what batches of 67 M samples or more take by themselves)
+ *   gae_seg, gae_tile       standalone GAE kernel: steps per segment (8 / 16; 4 / 8 / 16 = window depth of the streaming kernel) / kernel shape, 0 = automatic:
+ *                           gae_tile = 8 / 16 / 32 / 64 the segmented kernel with that many envs per block; 128 / 256 its two-envs-per-thread form (32 / 64 env
+ *                           pairs per block, 8-byte accesses: what 4096 envs or more take by themselves when num_envs is even); 4 / 2 / 1 the streaming kernel
+ *                           (that many envs per thread, serial Float64 recurrence: what batches of 33 M samples or more with >= 262144 envs take by themselves)
  *   gae_nt_loads (2)        standalone GAE kernel: 1 = nontemporal input loads (inputs not in the caches), 0 = cached, 2 = 1 for an external env with 4 M samples or more per rollout, else 0
  *   wide_rollout_persist (2)  layer-wise path, 2x256 fp16x2, obs_dim <= 16: the whole rollout as one launch — 2 = producer / consumer form (64 envs per
  *                           block, weight slabs by LDS-DMA, layer 1 on the matrix pipe; num_envs % 64 == 0, n_act <= 8, else 1), 1 = the first

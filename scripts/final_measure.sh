@@ -19,8 +19,8 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$KR" --output-for
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$KR" --output-format csv -d $O/pmc_write -- $P > /dev/null 2>&1
 # the standalone GAE kernel (the loop fuses the scan into the rollout): same counters over scripts/pmc_gae_write.py — a handle's crl_compute_gae launches with
 # NOTHING on another stream (the TCC counters are device-wide: under `bench.py --opt gae_fuse=0` the scan was charged with the side stream's shuffle stores, round 4)
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "gae_kernel" --output-format csv -d $O/pmc_fetch_gae -- python3 $R/scripts/pmc_gae_write.py > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "gae_kernel" --output-format csv -d $O/pmc_write_gae -- python3 $R/scripts/pmc_gae_write.py > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "gae_kernel|gae_seg2_kernel" --output-format csv -d $O/pmc_fetch_gae -- python3 $R/scripts/pmc_gae_write.py > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "gae_kernel|gae_seg2_kernel" --output-format csv -d $O/pmc_write_gae -- python3 $R/scripts/pmc_gae_write.py > /dev/null 2>&1
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   n=$(echo $set | cut -d' ' -f1)
   timeout 300 rocprofv3 --pmc $set --kernel-include-regex "update_x2_kernel|rollout_cartpole" --output-format csv -d $O/pmc_sq_$n -- $P > /dev/null 2>&1

@@ -1013,6 +1013,24 @@ def test_automatic_gae_kernel_choice_past_the_infinity_cache_is_bit_equal(crl, m
     assert np.sum(adv_s != adv_o) <= adv_o.size * 1e-6 and rel_err(adv_s, adv_o) < 1e-6
 
 
+@pytest.mark.parametrize("nt_loads", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("nt,k,tile,seg", [(65536, 128, 128, 0), (65536, 128, 256, 8), (65536, 128, 128, 16), (1030, 37, 128, 0), (65542, 9, 256, 0), (2, 1, 128, 0),
+                                           (4096, 300, 128, 0)])
+def test_two_envs_per_thread_segmented_gae_kernel_equals_the_one_env_kernel_bit_for_bit(crl, nt, k, tile, seg, mode, nt_loads):
+    """gae_seg2_kernel (gae_tile = 128 / 256: 32 / 64 env PAIRS per block, 8-byte accesses) composes the same affine maps in the same order as gae_kernel: its
+    outputs must be bit-identical to the one-env-per-thread segmented kernel's on the same inputs (same segment length), and like those differ from the oracle's
+    serial recurrence in the last bit of at most 1e-6 of the outputs. Many blocks, ragged last blocks, both modes with a live bootstrap, both load flavours,
+    k not a multiple of the segment length, k > 256 (16-step segments)."""
+    value, reward, term, nv, nd = _gae_inputs(nt, k, nt * 3 + k + mode)
+    adv_o, ret_o = O.gae_batch(value, reward, term, nv, nd, 0.99, 0.95, mode)
+    adv_p, ret_p = crl._lib.gae_host(value, reward, term, nv, nd, 0.99, 0.95, mode, tile=tile, seg=seg, nt_loads=nt_loads)
+    L = seg if seg in (8, 16) else (8 if k <= 128 else 16)
+    adv_1, ret_1 = crl._lib.gae_host(value, reward, term, nv, nd, 0.99, 0.95, mode, tile=64, seg=L, nt_loads=nt_loads)
+    assert np.array_equal(adv_p, adv_1) and np.array_equal(ret_p, ret_1)
+    assert np.sum(adv_p != adv_o) <= max(1, adv_o.size * 1e-6) and rel_err(adv_p, adv_o) < 1e-6 and rel_err(ret_p, ret_o) < 1e-6
+
+
 def test_gae_opt_rejects_bad_flavours(crl):
     value, reward, term, nv, nd = _gae_inputs(8, 4, 1)
     for kw in (dict(seg=5), dict(tile=3), dict(nt_loads=3)):
@@ -1021,6 +1039,9 @@ def test_gae_opt_rejects_bad_flavours(crl):
     value, reward, term, nv, nd = _gae_inputs(6, 4, 1)
     with pytest.raises(crl.CrlError, match="num_envs % gae_tile"):
         crl._lib.gae_host(value, reward, term, nv, nd, 0.99, 0.95, 0, tile=4)
+    value, reward, term, nv, nd = _gae_inputs(7, 4, 1)
+    with pytest.raises(crl.CrlError, match="even num_envs"):
+        crl._lib.gae_host(value, reward, term, nv, nd, 0.99, 0.95, 0, tile=128)
 
 
 def test_gae_bench_entry_point_times_the_scan_and_its_copy(crl):
