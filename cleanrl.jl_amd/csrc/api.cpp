@@ -29,7 +29,7 @@ static const OptDesc kOpts[OPT_COUNT] = {
     {"guard_window", 8, 1, 1 << 20},
     {"update_stagger", 3, 0, 64},
     {"actor_block_pct", 53, 1, 99},
-    {"adv_seq", 1, 0, 1},
+    {"adv_seq", 1, 0, 2},
     {"comm_force", 0, 0, 1},
     {"peer_timeout_ms", 20000, 1, 3600000},
     {"wide_gemm", 2, 0, 2},
@@ -300,7 +300,7 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
     rc |= dalloc(&h->perm_tmp, E * k1 * 5632);   // padded L1 buckets (K1 x BFY_CAP), one slice per epoch slot
     rc |= dalloc(&h->bfy_ws, E * ((size_t)4 * 16384 + 8));
     rc |= dalloc(&h->bfy_adv_part, (size_t)c.nmb * k1 * 2);
-    if (!wide) { rc |= dalloc(&h->bfy_bucket_mb, E * (size_t)16384); rc |= dalloc(&h->bfy_mbid, E * B); }
+    if (!wide) { rc |= dalloc(&h->bfy_bucket_mb, E * (size_t)16384); rc |= dalloc(&h->bfy_mbid, E * B); rc |= dalloc(&h->bfy_dig1, E * B); }
   }
   // update grid: two 256-thread blocks per CU, alternating roles; never more waves than tiles
   hipDeviceProp_t prop;
@@ -342,7 +342,7 @@ int32_t crl_ppo_destroy(crl_ppo* h) {
   wide_destroy(h);
   void* ptrs[] = {h->obs, h->action, h->logprob, h->reward, h->terminal, h->value, h->adv, h->ret, h->env_state, h->env_t,
                   h->cur_obs, h->next_done, h->ep_return, h->ep_length, h->next_value, h->ep_stats, h->ep_ring, h->ep_ring_count, h->params,
-                  h->adam_m, h->adam_v, h->betap, h->optim_part, h->ticket, h->perm_base, h->recs, h->adv_part, h->perm_tmp, h->bfy_ws, h->bfy_adv_part, h->bfy_bucket_mb, h->bfy_mbid, h->gpart, h->lpart,
+                  h->adam_m, h->adam_v, h->betap, h->optim_part, h->ticket, h->perm_base, h->recs, h->adv_part, h->perm_tmp, h->bfy_ws, h->bfy_adv_part, h->bfy_bucket_mb, h->bfy_mbid, h->bfy_dig1, h->gpart, h->lpart,
                   h->adv_sums_base, h->adv_ms_base, h->newv, h->vfix, h->dscale, h->stats_dev, h->comm_buf, h->snap, h->snap_betap, h->snap_env, h->stage};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int k = 0; k < CRL_K_COUNT; ++k)

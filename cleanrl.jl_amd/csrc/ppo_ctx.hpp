@@ -55,7 +55,7 @@ enum OptId {
   OPT_GUARD_WINDOW,           // iterations per speculation guard window (api.cpp)
   OPT_UPDATE_STAGGER,         // start delay of waves 4-7 of an update block
   OPT_ACTOR_BLOCK_PCT,        // share of update blocks given to the actor role
-  OPT_ADV_SEQ,                // 1 = advantage sums from one sequential pass over adv (blocked shuffle tables)
+  OPT_ADV_SEQ,                // advantage sums from one sequential pass over adv (blocked shuffle tables): 1 = with the bucket digits the shuffle stored (default), 2 = recomputed (one Philox call per sample and epoch), 0 = gathers through the permutations
   OPT_COMM_FORCE,             // 1 = crl_comm_init with world_size 1 still creates an RCCL communicator (1-GPU test of the path)
   OPT_PEER_TIMEOUT_MS,        // in-kernel time-out of the peer all-reduce
   OPT_WIDE_GEMM,              // layer-wise path, 256-wide layers: 2 = fp16x2 (default), 1 = bf16x3, 0 = f32 MFMA
@@ -134,6 +134,8 @@ struct crl_ppo {
   // bfy_mbid) — lets the advantage statistics run as ONE sequential pass over adv (records.hip) instead of a gather per epoch
   uint16_t* bfy_bucket_mb = nullptr;   // [update_epochs][BFY_MAXK1]
   uint8_t* bfy_mbid = nullptr;         // [update_epochs][B], written for members of straddling buckets only
+  uint16_t* bfy_dig1 = nullptr;        // [update_epochs][B]: every sample's L1 bucket per epoch, left by bfy_l1_kernel for adv_bucket_sums_kernel (option adv_seq = 1; 2 = that pass recomputes it)
+  bool bfy_dig1_valid = false;
   uint32_t bfy_tbl_slots = 0;          // bit s: the two tables of slot s describe perm[s]
   uint64_t bfy_tbl_epoch0 = 0;         // epoch id of slot 0's permutation (slot s holds epoch0 + s)
   uint32_t bfy_tbl_K1 = 0;

@@ -10,6 +10,50 @@
 
 namespace crl {
 
+#ifndef CRL_PACK_LDS
+#define CRL_PACK_LDS 1
+#endif
+// Round 5: the same records with every global READ 16 bytes per lane. The kernel below gives a sample to four lanes, and the lanes with q = 1 / 2 read the
+// five scalar fields — sixteen consecutive floats per wave and instruction, 64-byte transactions; here a block of 256 threads takes 1,024 consecutive samples:
+// five waves' worth of 16-byte loads bring the five scalar arrays of the tile into LDS (thread t: floats 4t … 4t + 3 of one array), then every lane assembles its
+// quarter as before from LDS and stores it (1 KiB of consecutive records per wave and store instruction, unchanged).
+__global__ void __launch_bounds__(256) pack_records_lds_kernel(int B, const float* __restrict__ obs, const int32_t* __restrict__ action,
+                                                               const float* __restrict__ logprob, const float* __restrict__ adv,
+                                                               const float* __restrict__ value, const float* __restrict__ ret,
+                                                               SampleRec* __restrict__ recs) {
+  __shared__ __attribute__((aligned(16))) float fld[5][1024];
+  __shared__ f32x4 ob[1024];                                    // the tile's observations, brought in by all 256 lanes (sixteen of a wave's lanes used to read them)
+  const int q = threadIdx.x & 3;
+  const float* arr[5] = {reinterpret_cast<const float*>(action), logprob, adv, value, ret};
+  for (int b0 = blockIdx.x * 1024; b0 < B; b0 += gridDim.x * 1024) {
+    const bool full = b0 + 1024 <= B && (B & 3) == 0;
+    __syncthreads();                                            // the previous tile's readers are done
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+      const int i = 4 * threadIdx.x;
+      if (full) *reinterpret_cast<f32x4*>(&fld[a][i]) = *reinterpret_cast<const f32x4*>(arr[a] + b0 + i);
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fld[a][i + e] = (b0 + i + e < B) ? arr[a][b0 + i + e] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int l = 256 * r + threadIdx.x; if (b0 + l < B) ob[l] = reinterpret_cast<const f32x4*>(obs)[b0 + l]; }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int l = 64 * r + (threadIdx.x >> 2), b = b0 + l;    // sample of this lane in round r
+      if (b < B) {
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (q == 0) v = ob[l];
+        else if (q == 1) { v[0] = fld[0][l]; v[1] = fld[1][l]; v[2] = fld[2][l]; }
+        else if (q == 2) { v[0] = fld[3][l]; v[1] = fld[4][l]; }
+        reinterpret_cast<f32x4*>(recs)[(size_t)b * 4 + q] = v;
+      }
+    }
+  }
+}
+
 // four lanes per sample, lane q writes quarter q: every store instruction of a wave covers 1 KiB of consecutive records
 __global__ void __launch_bounds__(256) pack_records_kernel(int B, const float* __restrict__ obs, const int32_t* __restrict__ action,
                                                            const float* __restrict__ logprob, const float* __restrict__ adv,
@@ -67,6 +111,10 @@ int launch_pack_records(crl_ppo* h) {
   int blocks = (B + 63) / 64;
   if (blocks > 8192) blocks = 8192;
   ProfScope ps(h, CRL_K_PACK);
+  if (CRL_PACK_LDS) {
+    int tiles = (B + 1023) / 1024; if (tiles > 4096) tiles = 4096;
+    hipLaunchKernelGGL(pack_records_lds_kernel, dim3(tiles), dim3(256), 0, h->stream, B, h->obs, h->action, h->logprob, h->adv, h->value, h->ret, h->recs);
+  } else
   hipLaunchKernelGGL(pack_records_kernel, dim3(blocks), dim3(256), 0, h->stream, B, h->obs, h->action, h->logprob, h->adv, h->value, h->ret, h->recs);
   CRL_HIP_CHECK(hipGetLastError());
   h->recs_dirty = false;

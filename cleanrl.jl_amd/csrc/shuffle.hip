@@ -69,13 +69,16 @@ constexpr int BFY_WS_STRIDE = 4 * 16384 + 8;   // u32 words of workspace per epo
 // the top byte of its S entry, so the leaf pass needs no Philox call to find it again.
 template <int BFY_T1>
 __global__ void __launch_bounds__(BFY_T1) bfy_l1_kernel(int n, uint32_t K1, uint64_t seed, uint64_t epoch0, uint32_t* __restrict__ ws,
-                                                     int32_t* __restrict__ S0, size_t sstride, int packed) {
+                                                     int32_t* __restrict__ S0, size_t sstride, int packed, uint16_t* __restrict__ dig1_0) {
   constexpr int EPT = 8192 / BFY_T1;
   const uint64_t epoch = epoch0 + blockIdx.y;
   uint32_t* tot = ws + (size_t)blockIdx.y * BFY_WS_STRIDE;
   uint32_t* cur = tot + 2 * BFY_MAXK1 + 1;
   uint32_t* err = cur + BFY_MAXK1;
   int32_t* S = S0 + (size_t)blockIdx.y * sstride;
+  // the element's first digit for adv_bucket_sums_kernel (round 5): that pass recomputed it — one Philox call per sample and epoch, most of its 108 µs on the
+  // iteration's critical path — although this kernel has it in a register; 2 bytes per sample and epoch
+  uint16_t* dig1 = dig1_0 ? dig1_0 + (size_t)blockIdx.y * n : nullptr;
   extern __shared__ uint32_t lds[];   // hist[K1] → (after the reservations) the block's base inside every bucket
   uint32_t* hist = lds;
   for (uint32_t d = threadIdx.x; d < K1; d += BFY_T1) hist[d] = 0;
@@ -93,6 +96,7 @@ __global__ void __launch_bounds__(BFY_T1) bfy_l1_kernel(int n, uint32_t K1, uint
       bfy_digits((uint32_t)i, K1, seed, epoch, d1, d2);
       w = d1 | (atomicAdd(&hist[d1], 1u) << 14);
       d2p[q >> 2] |= d2 << (8 * (q & 3));
+      if (dig1) dig1[i] = (uint16_t)d1;
     }
     dig[q] = w;
   }
@@ -281,12 +285,14 @@ static int launch_blocked_fy(crl_ppo* h, uint64_t epoch_id, int nslots, bool fus
   const bool big = n >= (4 << 20);
   const int chunks = (n + 8191) / 8192, packed = n <= (1 << 24) ? 1 : 0;
   const dim3 g1(chunks, nslots);
-  if (big) hipLaunchKernelGGL((bfy_l1_kernel<1024>), g1, dim3(1024), sizeof(uint32_t) * K1, h->stream, n, K1, seed, epoch_id, ws, S, sstride, packed);
-  else hipLaunchKernelGGL((bfy_l1_kernel<256>), g1, dim3(256), sizeof(uint32_t) * K1, h->stream, n, K1, seed, epoch_id, ws, S, sstride, packed);
-  hipLaunchKernelGGL(bfy_scan_kernel, dim3(nslots), dim3(1024), 0, h->stream, K1, ws);
   const bool fuse = fused && nslots == 1 && h->bfy_adv_part && h->dc.M >= BFY_CAP && h->dc.nmb <= 256;
   // the bucket → minibatch tables (sequential advantage statistics, below) describe slots [0, nslots) of one iterate call
   const bool tables = !fuse && h->bfy_bucket_mb && h->cur_slot == 0 && h->dc.nmb <= 255;
+  uint16_t* dig1 = (tables && h->bfy_dig1) ? h->bfy_dig1 : nullptr;
+  if (big) hipLaunchKernelGGL((bfy_l1_kernel<1024>), g1, dim3(1024), sizeof(uint32_t) * K1, h->stream, n, K1, seed, epoch_id, ws, S, sstride, packed, dig1);
+  else hipLaunchKernelGGL((bfy_l1_kernel<256>), g1, dim3(256), sizeof(uint32_t) * K1, h->stream, n, K1, seed, epoch_id, ws, S, sstride, packed, dig1);
+  hipLaunchKernelGGL(bfy_scan_kernel, dim3(nslots), dim3(1024), 0, h->stream, K1, ws);
+  h->bfy_dig1_valid = dig1 != nullptr;
   hipLaunchKernelGGL(bfy_leaf_kernel, dim3(K1, nslots), dim3(BFY_LT), 0, h->stream, K1, seed, epoch_id, n, ws, S, sstride, h->perm, fuse ? h->adv : nullptr,
                      h->dc.M, h->dc.nmb, h->bfy_adv_part, tables ? h->bfy_bucket_mb : nullptr, h->bfy_mbid, packed);
   CRL_HIP_CHECK(hipGetLastError());
@@ -306,19 +312,26 @@ static int launch_blocked_fy(crl_ppo* h, uint64_t epoch_id, int nslots, bool fus
 template <int NMB>
 __global__ void __launch_bounds__(256) adv_bucket_sums_kernel(int n, uint32_t K1, uint64_t seed, uint64_t epoch0, int slot0,
                                                              const float* __restrict__ adv, const uint16_t* __restrict__ bucket_mb0,
-                                                             const uint8_t* __restrict__ mbid0, double* __restrict__ part /* [z][mb][gridDim.x][2] */) {
+                                                             const uint8_t* __restrict__ mbid0, double* __restrict__ part /* [z][mb][gridDim.x][2] */,
+                                                             const uint16_t* __restrict__ dig1_0) {
   const int z = blockIdx.z;
   const uint64_t epoch = epoch0 + (uint64_t)(slot0 + z);
   const uint16_t* bmb = bucket_mb0 + (size_t)(slot0 + z) * BFY_MAXK1;
   const uint8_t* mbid = mbid0 + (size_t)(slot0 + z) * n;
+  // the epoch's bucket table in LDS: out of global memory the per-lane lookup (64 different 2-byte addresses inside a 4 KB table per wave and sample row) cost the
+  // address unit a cycle per lane — most of this kernel's 108 µs (round 5)
+  extern __shared__ uint16_t lbmb[];
+  for (uint32_t i = threadIdx.x; i < K1; i += 256) lbmb[i] = bmb[i];
+  __syncthreads();
   double s[NMB], s2[NMB];
 #pragma unroll
   for (int m = 0; m < NMB; ++m) { s[m] = 0.0; s2[m] = 0.0; }
   for (int v = blockIdx.x * 256 + threadIdx.x; v < n; v += gridDim.x * 256) {
     const double a = (double)adv[v];
     uint32_t d1, d2;
-    bfy_digits((uint32_t)v, K1, seed, epoch, d1, d2);
-    const uint32_t e = bmb[d1];
+    if (dig1_0) d1 = dig1_0[(size_t)(slot0 + z) * n + v];       // left by bfy_l1_kernel
+    else bfy_digits((uint32_t)v, K1, seed, epoch, d1, d2);
+    const uint32_t e = lbmb[d1];
     const int mb = (e & 0x8000u) ? (int)mbid[v] : (int)e;
 #pragma unroll
     for (int m = 0; m < NMB; ++m) { const bool hit = mb == m; s[m] += hit ? a : 0.0; s2[m] += hit ? a * a : 0.0; }
@@ -346,8 +359,8 @@ int launch_adv_bucket_sums(crl_ppo* h, int slot0, int nslots, double* part, int 
   for (int z = slot0; z < slot0 + nslots; ++z) if (!(h->bfy_tbl_slots >> z & 1u)) return 1;
   const int nmb = h->dc.nmb;
   const dim3 g(nblk, 1, nslots);
-#define CRL_GO(N) hipLaunchKernelGGL((adv_bucket_sums_kernel<N>), g, dim3(256), 0, h->stream, h->dc.B, h->bfy_tbl_K1, shuffle_seed(h), \
-                                     h->bfy_tbl_epoch0, slot0, h->adv, h->bfy_bucket_mb, h->bfy_mbid, part)
+#define CRL_GO(N) hipLaunchKernelGGL((adv_bucket_sums_kernel<N>), g, dim3(256), sizeof(uint16_t) * h->bfy_tbl_K1, h->stream, h->dc.B, h->bfy_tbl_K1, shuffle_seed(h), \
+                                     h->bfy_tbl_epoch0, slot0, h->adv, h->bfy_bucket_mb, h->bfy_mbid, part, (h->bfy_dig1_valid && opt(h, OPT_ADV_SEQ) == 1) ? h->bfy_dig1 : nullptr)
   if (nmb == 1) CRL_GO(1); else if (nmb == 2) CRL_GO(2); else if (nmb == 4) CRL_GO(4); else if (nmb == 8) CRL_GO(8); else return 1;
 #undef CRL_GO
   return hipGetLastError() == hipSuccess ? 0 : 1;

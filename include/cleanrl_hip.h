@@ -211,7 +211,10 @@ int32_t crl_comm_destroy(crl_ppo* h);
  *   gae_fuse                1 = inside crl_ppo_iterate the compat-mode GAE is the tail of the rollout kernel (default), 0 = own launch
  *   shuffle_overlap         1 = epoch permutations are drawn on a second stream next to the rollout (default)
  *   guard_window            iterations crl_ppo_iterate enqueues between two read-backs of the value-loss speculation flag (8)
- *   update_stagger, actor_block_pct, adv_seq   launch-shape knobs of the update pass (3, 53, 1)
+ *   update_stagger, actor_block_pct   launch-shape knobs of the update pass (3, 53)
+ *   adv_seq (1)             per-minibatch advantage sums of crl_ppo_iterate: 1 = one sequential pass over the advantages that finds a sample's minibatch through
+ *                           the blocked shuffle's bucket table, with the bucket digit the shuffle stored per sample and epoch; 2 = the same with the digit
+ *                           recomputed (one Philox call per sample and epoch); 0 = gathers through the finished permutations
  *   comm_force              1 = crl_comm_init with world_size 1 still creates an RCCL communicator (1-GPU test of that path)
  *   peer_timeout_ms         in-kernel time-out of the peer all-reduce (20000)
  *   wide_gemm               layer-wise path, 256-wide layers: 2 = fp16x2 (default), 1 = bf16x3, 0 = f32 MFMA

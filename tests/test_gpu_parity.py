@@ -1053,3 +1053,32 @@ def test_gae_bench_entry_point_times_the_scan_and_its_copy(crl):
         assert len(g) == 3 and len(c) == 3 and min(g) > 0 and min(c) > 0 and max(g) < 50.0
     with pytest.raises(crl.CrlError):
         crl._lib.gae_bench(4098, 128, seg=0, tile=4, nt_loads=0, flush_mb=0, reps=1)
+
+
+@pytest.mark.parametrize("nt,nmb", [(4096, 4), (4096, 8), (1024, 2)])
+def test_advantage_sums_of_every_flavour_equal_the_sums_through_the_permutation(crl, nt, nmb):
+    """crl_ppo_iterate's per-minibatch advantage sums (ppo.jl:219-221 needs mean / std of mb_advantages) come from one sequential pass over the advantages that
+    looks a sample's minibatch up in the blocked shuffle's bucket table: option adv_seq = 1 (default) with the bucket digit the shuffle's first pass stored per
+    sample and epoch, 2 with the digit recomputed (one Philox call), 0 by gathers through the finished permutations. All three must give, to float64 rounding,
+    the sums a plain numpy walk through the LAST epoch's permutation gives (the current slot after iterate), and the same run."""
+    F = crl._lib
+    k = 128
+    runs = {}
+    for seq in (1, 2, 0):
+        agent = make_agent(crl, nt=nt, k=k, num_minibatches=nmb, options={"adv_seq": seq})
+        h = agent.handle
+        assert h.get_option("adv_seq") == seq
+        h.env_reset()
+        st = h.iterate(1, want_stats=True)
+        adv = h.read(F.F_ADVANTAGE).astype(np.float64).reshape(-1, order="F")
+        perm = h.read(F.F_PERM).reshape(-1)
+        sums = h.read(F.F_ADV_SUMS).reshape(nmb, 2)
+        M = nt * k // nmb
+        ref = np.array([[adv[perm[m * M:(m + 1) * M]].sum(), (adv[perm[m * M:(m + 1) * M]] ** 2).sum()] for m in range(nmb)])
+        assert np.allclose(sums, ref, rtol=1e-11, atol=1e-9), (seq, sums, ref)
+        runs[seq] = (sums, np.asarray([r["loss"] for r in st]), agent.get_params())
+        agent.close()
+    for seq in (2, 0):
+        assert np.allclose(runs[1][0], runs[seq][0], rtol=1e-11, atol=1e-9)
+        assert np.allclose(runs[1][1], runs[seq][1], rtol=1e-5, atol=1e-6)       # the loss records of the iteration's 4 x nmb optimiser steps
+        assert np.allclose(runs[1][2], runs[seq][2], rtol=1e-5, atol=1e-7)       # parameters after them
