@@ -326,6 +326,24 @@ __global__ void __launch_bounds__(256) adv_bucket_sums_kernel(int n, uint32_t K1
   double s[NMB], s2[NMB];
 #pragma unroll
   for (int m = 0; m < NMB; ++m) { s[m] = 0.0; s2[m] = 0.0; }
+  if (dig1_0 && (n & 3) == 0) {
+    // four consecutive samples per thread: 16 bytes of advantages and 8 bytes of stored digits per lane and load (one sample per thread: 4 + 2 bytes)
+    const uint16_t* dg = dig1_0 + (size_t)(slot0 + z) * n;
+    typedef float af4 __attribute__((ext_vector_type(4)));
+    typedef unsigned short ud4 __attribute__((ext_vector_type(4)));
+    for (int v = 4 * (blockIdx.x * 256 + threadIdx.x); v < n; v += gridDim.x * 1024) {
+      const af4 a4 = *reinterpret_cast<const af4*>(adv + v);
+      const ud4 d4 = *reinterpret_cast<const ud4*>(dg + v);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double a = (double)a4[q];
+        const uint32_t e = lbmb[d4[q]];
+        const int mb = (e & 0x8000u) ? (int)mbid[v + q] : (int)e;
+#pragma unroll
+        for (int m = 0; m < NMB; ++m) { const bool hit = mb == m; s[m] += hit ? a : 0.0; s2[m] += hit ? a * a : 0.0; }
+      }
+    }
+  } else
   for (int v = blockIdx.x * 256 + threadIdx.x; v < n; v += gridDim.x * 256) {
     const double a = (double)adv[v];
     uint32_t d1, d2;
