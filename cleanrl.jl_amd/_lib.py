@@ -58,6 +58,7 @@ EXPORTS = [
     "crl_a2c_read_env", "crl_a2c_read_buffer", "crl_a2c_run_until_update", "crl_a2c_discounted_future_rewards",
     "crl_dqn_create", "crl_dqn_destroy", "crl_dqn_write_params", "crl_dqn_read_params", "crl_dqn_status_read", "crl_dqn_run",
     "crl_dqn_q_values",
+    "crl_make_actor_critic", "crl_ppo_init_params", "crl_a2c_init_params", "crl_dqn_make_nn", "crl_dqn_init_params",
 ]
 
 DQN_PARAM_COUNT = 10934
@@ -180,6 +181,11 @@ def load():
     L.crl_dqn_status_read.argtypes = [vp, C.POINTER(CrlDQNStatus)]
     L.crl_dqn_run.argtypes = [vp, C.c_int64, C.POINTER(CrlDQNEpisode), C.c_int32, ip, C.POINTER(CrlDQNLossRecord), C.c_int32, ip, i64p]
     L.crl_dqn_q_values.argtypes = [vp, dp, C.c_int32, dp]
+    L.crl_make_actor_critic.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, fp, C.c_size_t]
+    L.crl_ppo_init_params.argtypes = [vp, C.c_uint64]
+    L.crl_a2c_init_params.argtypes = [vp, C.c_uint64]
+    L.crl_dqn_make_nn.argtypes = [C.c_uint64, fp, C.c_size_t]
+    L.crl_dqn_init_params.argtypes = [vp, C.c_uint64]
     for name in EXPORTS:
         if name not in ("crl_version", "crl_last_error"):
             getattr(L, name).restype = C.c_int32
@@ -200,6 +206,22 @@ def device_count():
 
 def _ptr(a, ct):
     return a.ctypes.data_as(C.POINTER(ct))
+
+
+def make_actor_critic_host(obs_dim, n_act, hidden, seed=0):
+    """crl_make_actor_critic: the library's host-side restatement of Networks.make_actor_critic (networks.jl:36-49) — the start
+    crl_ppo_init_params gives a handle; runs without a GPU."""
+    n = 2 * (hidden * obs_dim + hidden + hidden * hidden + hidden) + n_act * hidden + n_act + hidden + 1
+    out = np.zeros(n, np.float32)
+    check(load().crl_make_actor_critic(obs_dim, n_act, hidden, seed, _ptr(out, C.c_float), n))
+    return out
+
+
+def dqn_make_nn_host(seed=0):
+    """crl_dqn_make_nn: make_nn(env) of dqn.jl:22-26 (glorot-uniform weights, zero biases), flat in Flux.params order."""
+    out = np.zeros(DQN_PARAM_COUNT, np.float32)
+    check(load().crl_dqn_make_nn(seed, _ptr(out, C.c_float), out.size))
+    return out
 
 
 _FIELD_DTYPES = {
@@ -254,6 +276,10 @@ class Handle:
 
     def sync(self):
         check(load().crl_sync(self._h))
+
+    def init_params(self, seed=0):
+        """ppo.jl:87 through the library's own initialiser (crl_ppo_init_params)."""
+        check(load().crl_ppo_init_params(self._h, seed))
 
     def policy_act(self, obs, u, with_value=True):
         obs = np.asfortranarray(obs, np.float32)
@@ -461,6 +487,9 @@ class A2CHandle:
         p = np.ascontiguousarray(p, np.float32)
         check(self._L.crl_a2c_write_params(self._h, _ptr(p, C.c_float), p.size))
 
+    def init_params(self, seed=0):
+        check(self._L.crl_a2c_init_params(self._h, seed))
+
     def read_params(self):
         p = np.zeros(self.param_count, np.float32)
         check(self._L.crl_a2c_read_params(self._h, _ptr(p, C.c_float), p.size))
@@ -516,6 +545,9 @@ class DQNHandle:
     def write_params(self, p):
         p = np.ascontiguousarray(p, np.float32)
         check(self._L.crl_dqn_write_params(self._h, _ptr(p, C.c_float), p.size))
+
+    def init_params(self, seed=0):
+        check(self._L.crl_dqn_init_params(self._h, seed))
 
     def read_params(self):
         q = np.zeros(DQN_PARAM_COUNT, np.float32); t = np.zeros(DQN_PARAM_COUNT, np.float32)

@@ -63,11 +63,14 @@ def a2c(config: A2CConfig = None, *, device=0, seed=0x5EED, params=None, **logge
     start = time.time()
     while True:
         taken, ts, episodes = agent.handle.run_until_update()
-        for ret, length, gstep in episodes:                                   # a2c.jl:105-106
+        # the episode whose end triggered the update is the call's LAST record, and the reference logs the update first (a2c.jl:100, then :106)
+        for i, (ret, length, gstep) in enumerate(episodes):                   # a2c.jl:105-106
+            if ts["trained"] and i == len(episodes) - 1:
+                log("Training Statistics", actor_loss=ts["actor_loss"], critic_loss=ts["critic_loss"])   # a2c.jl:100
             log("Episode Statistics", episode_return=ret, episode_length=length, global_step=gstep,
                 steps_per_sec=int(gstep / max(time.time() - start, 1e-9)))
-        if ts["trained"]:
-            log("Training Statistics", actor_loss=ts["actor_loss"], critic_loss=ts["critic_loss"])   # a2c.jl:100
+        if ts["trained"] and not episodes:
+            log("Training Statistics", actor_loss=ts["actor_loss"], critic_loss=ts["critic_loss"])
         if taken == 0 or agent.handle.env()[1] >= config.total_timesteps:
             break
     return agent

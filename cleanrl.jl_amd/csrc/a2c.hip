@@ -371,6 +371,7 @@ __global__ void a2c_init_kernel(A2CDev a) {
 struct crl_a2c {
   crl_a2c_config cfg;
   int device = 0; int cap = 0; int64_t P = 0;
+  bool params_set = false;   // a2c.jl:37 has happened: parameters were uploaded or crl_a2c_init_params ran (a fresh handle holds zeros)
   hipStream_t stream = nullptr;
   float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr; double* betap = nullptr;
   crl::A2CCtl* ctl = nullptr; crl_a2c_episode* eps = nullptr;
@@ -493,7 +494,15 @@ int32_t crl_a2c_write_params(crl_a2c* h, const float* params, size_t n) {
   if (!params || n != (size_t)h->P) { set_error("crl_a2c_write_params: expected " + std::to_string(h->P) + " floats"); return 1; }
   CRL_HIP_CHECK(hipMemcpyAsync(h->params, params, n * 4, hipMemcpyHostToDevice, h->stream));
   CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  h->params_set = true;
   return 0;
+}
+
+int32_t crl_a2c_init_params(crl_a2c* h, uint64_t seed) {
+  A2C_GUARD(h);
+  std::vector<float> w((size_t)h->P);
+  if (crl_make_actor_critic(AD, AA, AH, seed, w.data(), w.size())) return 1;
+  return crl_a2c_write_params(h, w.data(), w.size());
 }
 int32_t crl_a2c_read_params(crl_a2c* h, float* params, size_t n) {
   A2C_GUARD(h);
@@ -535,6 +544,7 @@ int32_t crl_a2c_read_buffer(crl_a2c* h, double* state, int32_t* action, double* 
 int32_t crl_a2c_run_until_update(crl_a2c* h, int64_t max_env_steps, crl_a2c_train_stats* stats, crl_a2c_episode* eps,
                                  int32_t max_eps, int32_t* n_eps, int64_t* steps_taken) {
   A2C_GUARD(h);
+  if (!h->params_set) { set_error("crl_a2c_run_until_update: parameters not set — crl_a2c_write_params or crl_a2c_init_params first (a2c.jl:37; a fresh handle holds zeros)"); return 1; }
   if (!stats || !n_eps || (max_eps > 0 && !eps) || max_eps < 0) { set_error("crl_a2c_run_until_update: bad arguments"); return 1; }
   stats->actor_loss = 0.0; stats->critic_loss = 0.0; stats->n = 0; stats->trained = 0;
   *n_eps = 0;

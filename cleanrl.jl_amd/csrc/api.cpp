@@ -6,6 +6,7 @@
 #include <cstring>
 #include <new>
 #include <utility>
+#include <vector>
 
 #include "ppo_ctx.hpp"
 
@@ -200,6 +201,14 @@ static int check_bfy(crl_ppo* h, bool host_syncs = true);
 #define CRL_GUARD_SETTLED(h) \
   CRL_GUARD(h);              \
   if (settle(h)) return 1;
+// ppo.jl:87 builds the networks before anything uses them. A fresh handle holds all-zero parameters, with which h1 = h2 = 0 and every
+// gradient except the head biases' is 0 for ever: computing with them is refused, never done silently.
+#define CRL_NEED_PARAMS(h, who)                                                                                                        \
+  if (!(h)->params_set) {                                                                                                              \
+    set_error(std::string(who) + ": parameters not set — upload Flux.params(actor, critic) with crl_ppo_write(CRL_F_PARAMS) or call " \
+              "crl_ppo_init_params first (ppo.jl:87; a fresh handle holds zeros)");                                                    \
+    return 1;                                                                                                                          \
+  }
 
 extern "C" {
 
@@ -389,13 +398,20 @@ int32_t crl_ppo_write(crl_ppo* h, int32_t field, const void* host, size_t nbytes
   }
   CRL_HIP_CHECK(hipMemcpyAsync(fr.ptr, host, nbytes, hipMemcpyHostToDevice, h->stream));
   CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
-  if (field == CRL_F_PARAMS) wide_mark_params_changed(h);
+  if (field == CRL_F_PARAMS) { wide_mark_params_changed(h); h->params_set = true; }
   if (field == CRL_F_PERM) { h->perm_is_bijection = false; h->slot_fresh &= ~(1u << h->cur_slot); h->bfy_tbl_slots &= ~(1u << h->cur_slot); }
   if (field == CRL_F_PERM || field == CRL_F_ADVANTAGE) h->bfy_adv_parts = 0;  // a caller-supplied permutation has no closed-form inverse
   if (field == CRL_F_OBS || field == CRL_F_ACTION || field == CRL_F_LOGPROB || field == CRL_F_VALUE || field == CRL_F_ADVANTAGE ||
       field == CRL_F_RETURN) h->recs_dirty = true;
   if (field == CRL_F_ENV_STATE || field == CRL_F_CUR_OBS) h->env_ready = true;  // caller-supplied env state
   return 0;
+}
+
+int32_t crl_ppo_init_params(crl_ppo* h, uint64_t seed) {
+  CRL_GUARD_SETTLED(h);
+  std::vector<float> w((size_t)h->P);
+  if (crl_make_actor_critic(h->cfg.obs_dim, h->cfg.n_act, h->cfg.hidden, seed, w.data(), w.size())) return 1;
+  return crl_ppo_write(h, CRL_F_PARAMS, w.data(), w.size() * sizeof(float));
 }
 
 int32_t crl_ppo_read(crl_ppo* h, int32_t field, void* host, size_t nbytes) {
@@ -413,6 +429,7 @@ int32_t crl_ppo_read(crl_ppo* h, int32_t field, void* host, size_t nbytes) {
 int32_t crl_policy_act(crl_ppo* h, const float* obs, const double* u, int32_t n, int32_t* action, float* logprob,
                        float* value) {
   CRL_GUARD_SETTLED(h);
+  CRL_NEED_PARAMS(h, "crl_policy_act");
   if (n < 0 || (n > 0 && (!obs || !u || !action || !logprob))) { set_error("crl_policy_act: bad arguments"); return 1; }
   if (n == 0) return 0;
   const size_t d = (size_t)h->dc.D, N = (size_t)n;
@@ -434,6 +451,7 @@ int32_t crl_policy_act(crl_ppo* h, const float* obs, const double* u, int32_t n,
 int32_t crl_logprob_actions(crl_ppo* h, const float* obs, const int32_t* actions, int32_t n, float* logprob,
                             float* entropy) {
   CRL_GUARD_SETTLED(h);
+  CRL_NEED_PARAMS(h, "crl_logprob_actions");
   if (n < 0 || (n > 0 && (!obs || !actions || !logprob || !entropy))) { set_error("crl_logprob_actions: bad arguments"); return 1; }
   if (n == 0) return 0;
   const size_t d = (size_t)h->dc.D, A = (size_t)h->dc.A, N = (size_t)n;
@@ -526,6 +544,7 @@ static int ensure_env(crl_ppo* h) {  // ppo.jl:112-115 runs once before the loop
 
 int32_t crl_rollout_run(crl_ppo* h) {
   CRL_GUARD_SETTLED(h);
+  CRL_NEED_PARAMS(h, "crl_rollout_run");
   if (ensure_env(h)) return 1;
   h->recs_dirty = true;
   return launch_rollout(h);
@@ -587,6 +606,7 @@ static int compute_gae(crl_ppo* h) {
 }
 int32_t crl_compute_gae(crl_ppo* h) {
   CRL_GUARD_SETTLED(h);
+  if (h->cfg.gae_mode == CRL_GAE_FIXED) CRL_NEED_PARAMS(h, "crl_compute_gae (fixed mode bootstraps from critic(next_obs))");
   return compute_gae(h);
 }
 
@@ -656,6 +676,7 @@ static int update_step(crl_ppo* h, int mb, double eta, int apply, int slot, bool
 
 int32_t crl_ppo_update_minibatch(crl_ppo* h, int32_t mb, double eta, int32_t apply_update, crl_ppo_stats* stats) {
   CRL_GUARD_SETTLED(h);
+  CRL_NEED_PARAMS(h, "crl_ppo_update_minibatch");
   if (mb < 0 || mb >= h->dc.nmb) { set_error("crl_ppo_update_minibatch: minibatch index out of range"); return 1; }
   if (ensure_records(h)) return 1;
   if (update_step(h, mb, eta, apply_update, mb)) return 1;
@@ -821,6 +842,7 @@ static int settle(crl_ppo* h) {
 
 int32_t crl_ppo_iterate(crl_ppo* h, int32_t n_iters, crl_ppo_stats* stats) {
   CRL_GUARD(h);
+  CRL_NEED_PARAMS(h, "crl_ppo_iterate");
   if (h->cfg.env_kind == CRL_ENV_EXTERNAL) { set_error("crl_ppo_iterate needs an on-device env (CRL_ENV_CARTPOLE or CRL_ENV_SYNTHETIC)"); return 1; }
   const int E = h->cfg.update_epochs, nmb = h->dc.nmb;
   if (ensure_env(h)) return 1;

@@ -416,6 +416,7 @@ __global__ void __launch_bounds__(128) dqn_q_kernel(const float* __restrict__ q,
 struct crl_dqn {
   crl_dqn_config cfg;
   int device = 0;
+  bool params_set = false;   // dqn.jl:39-40 has happened: q_net was uploaded or crl_dqn_init_params ran (a fresh handle holds zeros)
   hipStream_t stream = nullptr;
   crl::DQNDev d;
   void* stage = nullptr; size_t stage_bytes = 0;
@@ -511,8 +512,16 @@ int32_t crl_dqn_write_params(crl_dqn* h, const float* q_params, size_t n) {
   CRL_HIP_CHECK(hipMemcpyAsync(h->d.q, q_params, n * 4, hipMemcpyHostToDevice, h->stream));
   CRL_HIP_CHECK(hipMemcpyAsync(h->d.t, q_params, n * 4, hipMemcpyHostToDevice, h->stream));   // dqn.jl:40 deepcopy(q_net)
   CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
+  h->params_set = true;
   return 0;
 }
+int32_t crl_dqn_init_params(crl_dqn* h, uint64_t seed) {
+  DQN_GUARD(h);
+  std::vector<float> w((size_t)QP);
+  if (crl_dqn_make_nn(seed, w.data(), w.size())) return 1;
+  return crl_dqn_write_params(h, w.data(), w.size());
+}
+
 int32_t crl_dqn_read_params(crl_dqn* h, float* q_params, float* target_params, size_t n) {
   DQN_GUARD(h);
   if (!q_params || n != (size_t)QP) { set_error("crl_dqn_read_params: expected 10934 floats"); return 1; }
@@ -535,6 +544,7 @@ int32_t crl_dqn_status_read(crl_dqn* h, crl_dqn_status* out) {
 int32_t crl_dqn_run(crl_dqn* h, int64_t max_env_steps, crl_dqn_episode* eps, int32_t max_eps, int32_t* n_eps,
                     crl_dqn_loss_record* losses, int32_t max_losses, int32_t* n_losses, int64_t* steps_taken) {
   DQN_GUARD(h);
+  if (!h->params_set) { set_error("crl_dqn_run: parameters not set — crl_dqn_write_params or crl_dqn_init_params first (dqn.jl:39; a fresh handle holds zeros)"); return 1; }
   if (!n_eps || !n_losses || max_eps < 0 || max_losses < 0 || (max_eps > 0 && !eps) || (max_losses > 0 && !losses)) {
     set_error("crl_dqn_run: bad arguments"); return 1;
   }
@@ -584,6 +594,7 @@ int32_t crl_dqn_run(crl_dqn* h, int64_t max_env_steps, crl_dqn_episode* eps, int
 
 int32_t crl_dqn_q_values(crl_dqn* h, const double* obs, int32_t n, double* q) {
   DQN_GUARD(h);
+  if (!h->params_set) { set_error("crl_dqn_q_values: parameters not set — crl_dqn_write_params or crl_dqn_init_params first (dqn.jl:39)"); return 1; }
   if (n < 0 || (n > 0 && (!obs || !q))) { set_error("crl_dqn_q_values: bad arguments"); return 1; }
   if (n == 0) return 0;
   const size_t N = (size_t)n, need = N * (QD + QA) * 8;

@@ -96,6 +96,7 @@ struct crl_ppo {
   int64_t iteration = 0;
   int64_t exact_reruns = 0;        // iterations whose update phase was re-run exactly under data parallelism (Q4)
   bool env_ready = false;          // crl_env_reset has run (crl_ppo_iterate / crl_rollout_run do it on first use)
+  bool params_set = false;         // CRL_F_PARAMS was written or crl_ppo_init_params ran: ppo.jl:87 has happened (a fresh handle holds zeros, and zeros never train)
   int64_t num_updates = 1;
 
   // rollout buffer, Julia (·, nt, k) column-major (replay_buffer.jl:15-18)

@@ -113,6 +113,18 @@ int32_t crl_ppo_destroy(crl_ppo* h);
 int32_t crl_ppo_param_count(const crl_ppo* h, int64_t* n);
 int32_t crl_sync(crl_ppo* h);
 
+/* `actor, critic = Networks.make_actor_critic(single_act_space, single_obs_space) .|> Flux.f32` — ppo.jl:87 / networks.jl:36-49: separate
+ * actor and critic Dense(in,h,tanh_fast) → Dense(h,h,tanh_fast) → Dense(h,out), Flux.orthogonal weights with gains √2 / √2 / 0.01 (actor
+ * head) and √2 / √2 / 1.0 (critic head), zero biases, as one flat float vector in Flux.params(actor, critic) order. Stateless, host-only
+ * (runs without a GPU). The random stream is the library's own (seeded; Flux's task-local Xoshiro stream is not reproducible outside
+ * Julia) — the distribution is the reference's. n must be the parameter count of the shape (crl_ppo_param_count). */
+int32_t crl_make_actor_critic(int32_t obs_dim, int32_t n_act, int32_t hidden, uint64_t seed, float* out, size_t n);
+/* ppo.jl:87 for a handle: crl_make_actor_critic for its shape, uploaded like a CRL_F_PARAMS write. A FRESH HANDLE HOLDS ALL-ZERO
+ * PARAMETERS (h1 = h2 = 0: every gradient but the head biases' is zero for ever), so every entry point that computes with the networks —
+ * crl_policy_act, crl_logprob_actions, crl_rollout_run, crl_ppo_update_minibatch, crl_ppo_iterate, crl_compute_gae in fixed mode —
+ * returns an error ("parameters not set") until CRL_F_PARAMS has been written or this call has run. */
+int32_t crl_ppo_init_params(crl_ppo* h, uint64_t seed);
+
 /* Raw field access (parity tests, checkpointing, Julia-side inspection). nbytes must match the field size. */
 int32_t crl_ppo_write(crl_ppo* h, int32_t field, const void* host, size_t nbytes);
 int32_t crl_ppo_read(crl_ppo* h, int32_t field, void* host, size_t nbytes);
@@ -296,6 +308,9 @@ int32_t crl_a2c_destroy(crl_a2c* h);
 int32_t crl_a2c_param_count(const crl_a2c* h, int64_t* n);
 int32_t crl_a2c_write_params(crl_a2c* h, const float* params, size_t n);
 int32_t crl_a2c_read_params(crl_a2c* h, float* params, size_t n);
+/* `actor, critic = Networks.make_actor_critic(env)` — a2c.jl:37: crl_make_actor_critic(4, 2, 64, seed) uploaded. crl_a2c_run_until_update
+ * on a handle whose parameters were neither written nor initialised is an error (a fresh handle holds zeros). */
+int32_t crl_a2c_init_params(crl_a2c* h, uint64_t seed);
 /* env state (4 doubles), global_step, current buffer size */
 int32_t crl_a2c_read_env(crl_a2c* h, double* state4, int64_t* global_step, int32_t* rb_size);
 /* replay buffer columns 1..size (a2c.jl:77 `x[:, 1:rb.size]`): state (4,size) Float64, action 0-based, reward, terminal */
@@ -336,6 +351,12 @@ int32_t crl_dqn_create(const crl_dqn_config* cfg, int32_t device, crl_dqn** out)
 int32_t crl_dqn_destroy(crl_dqn* h);
 int32_t crl_dqn_write_params(crl_dqn* h, const float* q_params, size_t n);                  /* q_net; target_net = deepcopy(q_net) */
 int32_t crl_dqn_read_params(crl_dqn* h, float* q_params, float* target_params, size_t n);   /* target_params may be NULL */
+/* `q_net = make_nn(env)` — dqn.jl:22-26,39: Dense(4,120,relu) → Dense(120,84,relu) → Dense(84,2) with Flux's default glorot_uniform
+ * weights and zero biases, flat in Flux.params(q_net) order; stateless and host-only. n must be CRL_DQN_PARAM_COUNT. */
+int32_t crl_dqn_make_nn(uint64_t seed, float* out, size_t n);
+/* dqn.jl:39-40 for a handle: crl_dqn_make_nn uploaded to q_net and target_net. crl_dqn_run / crl_dqn_q_values on a handle whose
+ * parameters were neither written nor initialised are errors (a fresh handle holds zeros). */
+int32_t crl_dqn_init_params(crl_dqn* h, uint64_t seed);
 int32_t crl_dqn_status_read(crl_dqn* h, crl_dqn_status* out);
 /* dqn.jl:57-119: up to max_env_steps iterations of the loop (or to total_timesteps), enqueued without host read-backs. Episode records
  * (dqn.jl:88) and the "Training Statistics" losses of steps that are multiples of log_frequency (dqn.jl:115-117) come

@@ -7,7 +7,7 @@
 # tests/test_host_cpu.py::test_config_struct_matches_header_and_reference_defaults pins (104 bytes).
 module CleanRLHip
 
-export PPOConfig, ppo, get_action, logprob_actions, gae, a2c, dqn, q_values, comm_unique_id, comm_init!, comm_peer_export!, comm_peer_attach!,
+export PPOConfig, ppo, get_action, logprob_actions, gae, a2c, dqn, q_values, reference_params, init_params!, comm_unique_id, comm_init!, comm_peer_export!, comm_peer_attach!,
        comm_destroy!, set_option!, get_option
 
 const libcrl = get(ENV, "CLEANRL_HIP_LIB", joinpath(@__DIR__, "..", "cleanrl.jl_amd", "libcleanrl_hip.so"))
@@ -90,6 +90,26 @@ end
 set_params!(a::Agent, flat::Vector{Float32}) =
   GC.@preserve flat check(ccall((:crl_ppo_write, libcrl), Int32, (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Csize_t), a.h, 9, pointer(flat), sizeof(flat)))
 
+# ppo.jl:87 — `actor, critic = Networks.make_actor_critic(single_act_space, single_obs_space) .|> Flux.f32` — when the caller has no Flux
+# networks to upload: the library's own host-side restatement of networks.jl:36-49 (orthogonal weights, gains √2 / 0.01 / 1.0, zero biases;
+# crl_ppo_init_params). A fresh handle holds zeros and every computing entry point refuses to run on them ("parameters not set").
+init_params!(a::Agent, seed::Integer=0) = check(ccall((:crl_ppo_init_params, libcrl), Int32, (Ptr{Cvoid}, UInt64), a.h, UInt64(seed)))
+
+# The reference's own builder, flattened the way the boundary wants it: `Networks` is the reference's module (src/utils/networks.jl), `Flux` the
+# Flux it loaded. make_actor_critic only takes `length` of its two spaces (networks.jl:37-38), so Base.OneTo stands in for them.
+function reference_params(Networks, Flux, n_act::Integer, obs_dim::Integer, hidden::Integer)
+  actor, critic = Networks.make_actor_critic(Base.OneTo(n_act), Base.OneTo(obs_dim), Int[hidden, hidden]) .|> Flux.f32     # ppo.jl:87
+  Vector{Float32}(vcat(vec.(Flux.params(actor, critic))...))                                                             # ppo.jl:196 order
+end
+# Default network builder of ppo / a2c: inside the reference package (this file included next to src/algorithms/ppo.jl, where `Networks` and
+# `Flux` are names of the enclosing module, src/CleanRL.jl:12,23) the reference's own make_actor_critic; standalone `nothing`, and the entry
+# points then take the library's initialiser — never zeros.
+function _default_init()
+  pm = parentmodule(@__MODULE__)
+  (isdefined(pm, :Networks) && isdefined(pm, :Flux)) || return nothing
+  (n_act, obs_dim, hidden) -> reference_params(getfield(pm, :Networks), getfield(pm, :Flux), n_act, obs_dim, hidden)
+end
+
 # ppo.jl:21-32 — `actor` is the Agent holding the weights on the GPU; u are the rand() draws of StatsBase.sample
 function get_action(obs::AbstractVecOrMat{Float32}, actor::Agent; u::Vector{Float64}=rand(size(obs, ndims(obs))))
   n = size(obs, ndims(obs)); o = Array(obs)
@@ -167,14 +187,26 @@ end
 # is that function — by default the `Logger` module of the package this file is included into (src/CleanRL.jl includes utils/logger.jl before
 # the algorithms), `nothing` when there is none (standalone use: the caller's own global logger receives the @info records).
 _default_make_logger() = isdefined(parentmodule(@__MODULE__), :Logger) ? getfield(parentmodule(@__MODULE__), :Logger).make_logger : nothing
-function ppo(config::PPOConfig=PPOConfig(); device::Integer=0, params::Union{Nothing,Vector{Float32}}=nothing, episode_records::Integer=4096,
-             comm::Union{Nothing,Tuple{Vector{UInt8},Int,Int}}=nothing, run_name::AbstractString="ppo-2-test", make_logger=_default_make_logger(),
-             shape...)
+# ppo.jl:87 — the networks: `params` (a caller's own `vcat(vec.(Flux.params(actor, critic))...)`) wins; otherwise `init(n_act, obs_dim, hidden)` builds them —
+# by default the reference's Networks.make_actor_critic(...) .|> Flux.f32 when this file lives inside the reference package (_default_init), and
+# the library's restatement of it (init_params!, seeded by init_seed) when it does not. There is no path that leaves the handle's zeros in place:
+# under data parallelism every rank must end up with the SAME parameters, so pass `params` or a seeded init there (init_params! with one
+# init_seed is identical on all ranks; the reference builder draws from each process's own RNG).
+function ppo(config::PPOConfig=PPOConfig(); device::Integer=0, params::Union{Nothing,Vector{Float32}}=nothing, init=_default_init(), init_seed::Integer=0,
+             episode_records::Integer=4096, comm::Union{Nothing,Tuple{Vector{UInt8},Int,Int}}=nothing, run_name::AbstractString="ppo-2-test",
+             make_logger=_default_make_logger(), shape...)
   make_logger === nothing || make_logger(run_name; to_terminal=false)      # ppo.jl:77
   world, rank = comm === nothing ? (1, 0) : (comm[2], comm[3])
   agent = Agent(config; device, env_id_offset=rank * config.num_envs, shape...)
-  params === nothing || length(params) == param_count(agent) || error("params has $(length(params)) entries, the networks have $(param_count(agent))")
-  params === nothing || set_params!(agent, params)
+  if params === nothing && init !== nothing && world == 1
+    params = init(agent.n_act, agent.obs_dim, agent.hidden)                # ppo.jl:87 with the reference's own builder
+  end
+  if params === nothing
+    init_params!(agent, init_seed)                                         # ppo.jl:87 through crl_ppo_init_params (same on every rank)
+  else
+    length(params) == param_count(agent) || error("params has $(length(params)) entries, the networks have $(param_count(agent))")
+    set_params!(agent, params)
+  end
   comm === nothing || comm_init!(agent, comm[1], world, rank)
   episode_records > 0 && check(ccall((:crl_episode_ring_enable, libcrl), Int32, (Ptr{Cvoid}, Int32), agent.h, episode_records))
   check(ccall((:crl_env_reset, libcrl), Int32, (Ptr{Cvoid},), agent.h))
@@ -234,12 +266,21 @@ function discounted_future_rewards(rewards::Vector{Float64}, terminals::Vector{B
   out
 end
 
-# a2c.jl:29 — same signature; `config` is the reference's A2CConfig
-function a2c(config; device=0, seed=UInt64(0x5EED), params::Vector{Float32})
+# a2c.jl:29 — same signature; `config` is the reference's A2CConfig. a2c.jl:30 installs the logger (terminal + TensorBoard: make_logger's own
+# defaults), a2c.jl:37 builds the networks: `params` wins, else `init` (the reference's Networks.make_actor_critic inside the package — a2c.jl:37
+# does not pipe through Flux.f32, Flux.orthogonal is Float32 already), else the library's initialiser. Never the handle's zeros.
+function a2c(config; device=0, seed=UInt64(0x5EED), params::Union{Nothing,Vector{Float32}}=nothing, init=_default_init(), init_seed::Integer=0,
+             make_logger=_default_make_logger())
+  make_logger === nothing || make_logger("a2c|$(config.run_name)")         # a2c.jl:30
   cfg = CrlA2CConfig(config.lr, config.total_timesteps, config.min_replay_size, 500, config.gamma, seed)
   h = Ref{Ptr{Cvoid}}(C_NULL)
   check(ccall((:crl_a2c_create, libcrl), Int32, (Ref{CrlA2CConfig}, Int32, Ref{Ptr{Cvoid}}), cfg, device, h))
-  GC.@preserve params check(ccall((:crl_a2c_write_params, libcrl), Int32, (Ptr{Cvoid}, Ptr{Float32}, Csize_t), h[], params, length(params)))
+  params === nothing && init !== nothing && (params = init(2, 4, 64))      # a2c.jl:37 make_actor_critic(env): CartPole 4 / 2, hidden [64, 64]
+  if params === nothing
+    check(ccall((:crl_a2c_init_params, libcrl), Int32, (Ptr{Cvoid}, UInt64), h[], UInt64(init_seed)))
+  else
+    GC.@preserve params check(ccall((:crl_a2c_write_params, libcrl), Int32, (Ptr{Cvoid}, Ptr{Float32}, Csize_t), h[], params, length(params)))
+  end
   stats = Ref{CrlA2CTrainStats}(); eps = Vector{CrlA2CEpisode}(undef, 4096); n_eps = Ref{Int32}(0); taken = Ref{Int64}(0)
   start_time = time(); global_step = 0
   while global_step < config.total_timesteps
@@ -248,11 +289,13 @@ function a2c(config; device=0, seed=UInt64(0x5EED), params::Vector{Float32})
       h[], typemax(Int64), stats, eps, length(eps), n_eps, taken))
     taken[] == 0 && break
     global_step += taken[]
-    for e in @view eps[1:n_eps[]]
+    # the episode whose end triggered the update is the call's LAST record, and the reference logs the update first (a2c.jl:100, then :106)
+    for (i, e) in enumerate(@view eps[1:n_eps[]])
+      i == n_eps[] && stats[].trained == 1 && @info "Training Statistics" actor_loss = stats[].actor_loss critic_loss = stats[].critic_loss
       steps_per_sec = trunc(e.global_step / (time() - start_time))
       @info "Episode Statistics" episode_return = e.episode_return episode_length = e.episode_length global_step = e.global_step steps_per_sec
     end
-    stats[].trained == 1 && @info "Training Statistics" actor_loss = stats[].actor_loss critic_loss = stats[].critic_loss
+    n_eps[] == 0 && stats[].trained == 1 && @info "Training Statistics" actor_loss = stats[].actor_loss critic_loss = stats[].critic_loss
   end
   check(ccall((:crl_a2c_destroy, libcrl), Int32, (Ptr{Cvoid},), h[]))
 end
@@ -284,7 +327,16 @@ end
 
 # dqn.jl:34 — same signature; `config` is the reference's DQNConfig (note its field `log_frequencey`, sic), `params` =
 # vcat(vec.(Flux.params(q_net))...) of make_nn(env) (dqn.jl:22-26: 4 → 120 → 84 → 2, 10,934 parameters)
-function dqn(config; device=0, seed=UInt64(0x5EED), params::Vector{Float32}, chunk::Integer=10_000)
+# dqn.jl:35 installs the logger, dqn.jl:39 builds q_net: `params` wins, else `init()` (inside the reference package its own make_nn(CartPoleEnv()),
+# dqn.jl:22-26), else the library's initialiser (crl_dqn_init_params: the same glorot-uniform layers). Never the handle's zeros.
+function _default_dqn_init()
+  pm = parentmodule(@__MODULE__)
+  (isdefined(pm, :make_nn) && isdefined(pm, :CartPoleEnv) && isdefined(pm, :Flux)) || return nothing
+  () -> Vector{Float32}(vcat(vec.(getfield(pm, :Flux).params(getfield(pm, :make_nn)(getfield(pm, :CartPoleEnv)())))...))
+end
+function dqn(config; device=0, seed=UInt64(0x5EED), params::Union{Nothing,Vector{Float32}}=nothing, init=_default_dqn_init(), init_seed::Integer=0,
+             chunk::Integer=10_000, make_logger=_default_make_logger())
+  make_logger === nothing || make_logger("dqn|$(config.run_name)")         # dqn.jl:35
   cfg = CrlDQNConfig(config.log_frequencey, config.total_timesteps, config.buffer_size, config.min_buff_size, config.lr,
                      config.train_freq, config.target_net_freq, config.batch_size, config.gamma, config.epsilon_start,
                      config.epsilon_end, config.epsilon_duration, 200, 0, seed)
@@ -292,7 +344,12 @@ function dqn(config; device=0, seed=UInt64(0x5EED), params::Vector{Float32}, chu
   check(ccall((:crl_dqn_create, libcrl), Int32, (Ref{CrlDQNConfig}, Int32, Ref{Ptr{Cvoid}}), cfg, device, h))
   agent = DQNAgent(h[])
   finalizer(x -> ccall((:crl_dqn_destroy, libcrl), Int32, (Ptr{Cvoid},), x.h), agent)
-  GC.@preserve params check(ccall((:crl_dqn_write_params, libcrl), Int32, (Ptr{Cvoid}, Ptr{Float32}, Csize_t), agent.h, params, length(params)))
+  params === nothing && init !== nothing && (params = init())             # dqn.jl:39 make_nn(env)
+  if params === nothing
+    check(ccall((:crl_dqn_init_params, libcrl), Int32, (Ptr{Cvoid}, UInt64), agent.h, UInt64(init_seed)))
+  else
+    GC.@preserve params check(ccall((:crl_dqn_write_params, libcrl), Int32, (Ptr{Cvoid}, Ptr{Float32}, Csize_t), agent.h, params, length(params)))
+  end
   eps = Vector{CrlDQNEpisode}(undef, 8192); losses = Vector{CrlDQNLossRecord}(undef, 4096)
   n_eps = Ref{Int32}(0); n_losses = Ref{Int32}(0); taken = Ref{Int64}(0)
   start_time = time(); global_step = 0

@@ -11,4 +11,7 @@ include(joinpath(@__DIR__, "CleanRLHip.jl"))
 using .CleanRLHip
 
 config = CleanRL.ConfigParser.argparse_struct(CleanRLHip.PPOConfig())
-CleanRLHip.ppo(config; make_logger = CleanRL.Logger.make_logger)     # ppo.jl:75-77: same entry point, same logger call
+# ppo.jl:75-87: same entry point, same logger call, and the reference's OWN networks — Networks.make_actor_critic(...) .|> Flux.f32 (ppo.jl:87),
+# flattened in Flux.params order. (CleanRLHip is included at top level here, so its in-package default cannot see CleanRL.Networks: hand it over.)
+CleanRLHip.ppo(config; make_logger = CleanRL.Logger.make_logger,
+               init = (n_act, obs_dim, hidden) -> CleanRLHip.reference_params(CleanRL.Networks, CleanRL.Flux, n_act, obs_dim, hidden))

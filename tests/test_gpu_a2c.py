@@ -106,7 +106,27 @@ def test_a2c_entry_point_logs_reference_records(crl, tmp_path):
     assert set(ep) >= {"episode_return", "episode_length", "global_step", "steps_per_sec"}     # a2c.jl:106
     tr = next(r for r in recs if r["msg"] == "Training Statistics")
     assert set(tr) >= {"actor_loss", "critic_loss"}                                             # a2c.jl:100
+    # a2c.jl:100 comes before a2c.jl:106: an update's record precedes the record of the episode whose end triggered it, and that episode is
+    # the first one whose buffer passed min_replay_size
+    names_seq = [r["msg"] for r in recs]
+    first = names_seq.index("Training Statistics")
+    assert names_seq[first + 1] == "Episode Statistics"
+    assert recs[first + 1]["global_step"] > cfg.min_replay_size >= (recs[first - 1]["global_step"] if first else 0)
     agent.close()
+
+
+def test_a2c_fresh_handle_refuses_to_run_and_library_init_is_reference_shaped(crl):
+    """a2c.jl:37 must have happened: a handle whose parameters were never set errors instead of training zeros; crl_a2c_init_params
+    gives the orthogonal start of networks.jl:36-49."""
+    L = crl._lib
+    h = L.A2CHandle(L.CrlA2CConfig(1e-4, 2000, 512, 500, 0.99, 3), 0)
+    with pytest.raises(crl.CrlError, match="parameters not set"):
+        h.run_until_update()
+    h.init_params(7)
+    assert np.array_equal(h.read_params(), L.make_actor_critic_host(4, 2, 64, seed=7))
+    taken, ts, _ = h.run_until_update()
+    assert taken > 0
+    h.close()
 
 
 def test_a2c_errors(crl):

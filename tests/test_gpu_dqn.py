@@ -92,3 +92,22 @@ def test_dqn_budget_and_total_timesteps_edges(crl):
     ref = O.DQNState(O.dqn_config(total_timesteps=455, seed=4), O.dqn_params(1)); ref.run(10_000)
     assert np.array_equal(h.read_params()[0], ref.params()[0])
     agent.close(); ref.close()
+
+
+def test_dqn_fresh_handle_refuses_to_run_and_library_init_is_reference_shaped(crl):
+    """dqn.jl:39-40 must have happened: no run and no q-values on the zeros of a fresh handle; crl_dqn_init_params = make_nn's
+    glorot-uniform layers in q_net AND target_net."""
+    L = crl._lib
+    agent = crl.DQNAgent(crl.DQNConfig(total_timesteps=500), params=L.dqn_make_nn_host(seed=2))
+    cfg = agent.crl_cfg
+    agent.close()
+    h = L.DQNHandle(cfg, 0)
+    with pytest.raises(crl.CrlError, match="parameters not set"):
+        h.run(100)
+    with pytest.raises(crl.CrlError, match="parameters not set"):
+        h.q_values(np.zeros((4, 1)))
+    h.init_params(2)
+    q, t = h.read_params()
+    assert np.array_equal(q, L.dqn_make_nn_host(seed=2)) and np.array_equal(q, t)
+    h.run(100)
+    h.close()

@@ -1082,3 +1082,39 @@ def test_advantage_sums_of_every_flavour_equal_the_sums_through_the_permutation(
         assert np.allclose(runs[1][0], runs[seq][0], rtol=1e-11, atol=1e-9)
         assert np.allclose(runs[1][1], runs[seq][1], rtol=1e-5, atol=1e-6)       # the loss records of the iteration's 4 x nmb optimiser steps
         assert np.allclose(runs[1][2], runs[seq][2], rtol=1e-5, atol=1e-7)       # parameters after them
+
+
+def test_fresh_handle_refuses_to_compute_and_library_init_trains(crl):
+    """ppo.jl:87 at the C boundary (verdict r5, row b): a handle whose parameters were never written holds zeros — h1 = h2 = 0, every gradient
+    except the head biases' is 0 for ever — so every entry point that computes with the networks fails loudly until CRL_F_PARAMS is
+    written or crl_ppo_init_params has run; after crl_ppo_init_params the handle holds the reference-shaped start and an iteration
+    moves every parameter array."""
+    from cleanrl_jl_amd.ppo import _crl_config
+    L = crl._lib
+    cfg = _crl_config(crl.PPOConfig(num_envs=64, num_steps=16, total_timesteps=64 * 16 * 4))
+    h = L.Handle(cfg, 0)
+    obs = np.zeros((4, 3), np.float32, order="F")
+    for call in (lambda: h.iterate(1), lambda: h.rollout_run(), lambda: h.policy_act(obs, np.zeros(3)),
+                 lambda: h.logprob_actions(obs, np.zeros(3, np.int32)), lambda: h.update_minibatch(0, 1e-3)):
+        with pytest.raises(crl.CrlError, match="parameters not set"):
+            call()
+    assert not h.read(L.F_PARAMS).any()                    # nothing ran on them
+    h.init_params(5)
+    p0 = h.read(L.F_PARAMS)
+    assert np.array_equal(p0, L.make_actor_critic_host(4, 2, 64, seed=5))
+    h.iterate(1)
+    p1 = h.read(L.F_PARAMS)
+    from cleanrl_jl_amd import networks
+    off = networks.param_offsets(2, 4, [64, 64])
+    for i in range(12):
+        assert not np.array_equal(p0[off[i]:off[i + 1]], p1[off[i]:off[i + 1]]), "array %d did not move" % i
+    h.close()
+    # a written vector counts as set too (the Julia shell's set_params! path), on the layer-wise path as well
+    cfgw = _crl_config(crl.PPOConfig(num_envs=64, num_steps=16, total_timesteps=64 * 16 * 4), obs_dim=8, n_act=4, hidden=256, env_kind=L.ENV_SYNTHETIC)
+    hw = L.Handle(cfgw, 0)
+    with pytest.raises(crl.CrlError, match="parameters not set"):
+        hw.iterate(1)
+    hw.init_params(1)
+    hw.iterate(1)
+    assert np.isfinite(hw.read(L.F_PARAMS)).all()
+    hw.close()

@@ -195,8 +195,86 @@ def test_julia_shell_structs_and_symbols_follow_the_header(crl):
     assert 'run_name::AbstractString="ppo-2-test"' in body and "make_logger=_default_make_logger()" in body
     assert body.index("make_logger(run_name; to_terminal=false)") < body.index("agent = Agent(")
     run = open(os.path.join(ROOT, "julia", "run_ppo.jl")).read()
-    assert "ConfigParser.argparse_struct(CleanRLHip.PPOConfig())" in run and "CleanRLHip.ppo(config; make_logger = CleanRL.Logger.make_logger)" in run
+    assert "ConfigParser.argparse_struct(CleanRLHip.PPOConfig())" in run and "CleanRLHip.ppo(config; make_logger = CleanRL.Logger.make_logger" in run
     assert 'include(joinpath(@__DIR__, "CleanRLHip.jl"))' in run
+
+
+def _jl_function(jl, head):
+    """Source of the Julia function whose definition starts with `head` (up to the first column-0 `end`)."""
+    i = jl.index(head)
+    return jl[i:jl.index("\nend\n", i)]
+
+
+def test_julia_shell_cannot_train_a_dead_network(crl):
+    """ppo.jl:87 / a2c.jl:37 / dqn.jl:39 on the Julia side of the boundary (verdict r5, row b): every default-keyword path of the three
+    entry points builds the reference's networks — the reference's own builder when the shell sits inside the package, the library's
+    restatement otherwise — and NO path leaves the zeros of a fresh handle in place. Desk-checked list: VERIFY_WITH_JULIA.md §B."""
+    jl = open(os.path.join(ROOT, "julia", "CleanRLHip.jl")).read()
+    # the reference builder, exactly as ppo.jl:87 calls it, flattened in Flux.params order (ppo.jl:196)
+    ref = _jl_function(jl, "function reference_params(")
+    assert "Networks.make_actor_critic(Base.OneTo(n_act), Base.OneTo(obs_dim), Int[hidden, hidden]) .|> Flux.f32" in ref
+    assert "vcat(vec.(Flux.params(actor, critic))...)" in ref
+    dflt = _jl_function(jl, "function _default_init()")
+    assert "isdefined(pm, :Networks)" in dflt and "reference_params(" in dflt
+    ppo = _jl_function(jl, "function ppo(config::PPOConfig=PPOConfig();")
+    assert "params::Union{Nothing,Vector{Float32}}=nothing" in ppo and "init=_default_init()" in ppo
+    # with params === nothing: the builder, else crl_ppo_init_params — an if / else with no third way out — and all of it before the first iterate
+    assert "params = init(agent.n_act, agent.obs_dim, agent.hidden)" in ppo
+    m = re.search(r"if params === nothing\n\s+init_params!\(agent, init_seed\).*?\n\s+else\n(.*?)\n\s+end", ppo, re.S)
+    assert m and "set_params!(agent, params)" in m.group(1)
+    assert ppo.index("init_params!(agent, init_seed)") < ppo.index(":crl_ppo_iterate")
+    assert "crl_ppo_init_params" in _jl_function(jl + "\nend\n", "init_params!(a::Agent")
+    # a2c / dqn: same rule (they used to demand `params`; now the reference's default call works and still cannot reach zeros)
+    a2c = _jl_function(jl, "function a2c(config;")
+    assert "init=_default_init()" in a2c and "params = init(2, 4, 64)" in a2c and ":crl_a2c_init_params" in a2c and ":crl_a2c_write_params" in a2c
+    assert a2c.index(":crl_a2c_init_params") < a2c.index(":crl_a2c_run_until_update")
+    assert 'make_logger("a2c|$(config.run_name)")' in a2c              # a2c.jl:30
+    dqn = _jl_function(jl, "function dqn(config;")
+    assert "init=_default_dqn_init()" in dqn and ":crl_dqn_init_params" in dqn and ":crl_dqn_write_params" in dqn
+    assert dqn.index(":crl_dqn_init_params") < dqn.index(":crl_dqn_run")
+    assert 'make_logger("dqn|$(config.run_name)")' in dqn              # dqn.jl:35
+    assert "make_nn" in _jl_function(jl, "function _default_dqn_init()")
+    # the runner hands the reference's own Networks / Flux over (its include is at top level, where the in-package default sees nothing)
+    run = open(os.path.join(ROOT, "julia", "run_ppo.jl")).read()
+    assert "CleanRLHip.reference_params(CleanRL.Networks, CleanRL.Flux, n_act, obs_dim, hidden)" in run
+    # and the header says what a fresh handle is
+    hdr = open(os.path.join(ROOT, "include", "cleanrl_hip.h")).read()
+    assert "parameters not set" in hdr and "crl_ppo_init_params" in hdr
+
+
+def test_library_initialisers_are_reference_shaped(crl):
+    """crl_make_actor_critic (networks.jl:36-49: orthogonal weights with gains sqrt(2) / 0.01 / 1.0, zero biases, Flux.params order) and
+    crl_dqn_make_nn (dqn.jl:22-26: glorot-uniform weights, zero biases) — host-only, so checked without a GPU."""
+    L = crl._lib
+    from cleanrl_jl_amd import networks
+    for d, A, h in ((4, 2, 64), (8, 4, 256), (3, 5, 128)):
+        w = L.make_actor_critic_host(d, A, h, seed=11)
+        off = networks.param_offsets(A, d, [h, h])
+        assert w.size == off[-1]
+        shapes = {0: (h, d, 2 ** 0.5), 2: (h, h, 2 ** 0.5), 4: (A, h, 0.01), 6: (h, d, 2 ** 0.5), 8: (h, h, 2 ** 0.5), 10: (1, h, 1.0)}
+        for i in range(12):
+            seg = w[off[i]:off[i + 1]]
+            if i % 2:
+                assert not seg.any(), "bias %d is not zero" % i
+                continue
+            r, c, g = shapes[i]
+            W = seg.reshape((r, c), order="F").astype(np.float64) / g
+            G = W.T @ W if r >= c else W @ W.T
+            assert np.abs(G - np.eye(min(r, c))).max() < 1e-6, (d, A, h, i)
+        assert np.array_equal(w, L.make_actor_critic_host(d, A, h, seed=11))          # seeded: the same on every rank
+        assert not np.array_equal(w, L.make_actor_critic_host(d, A, h, seed=12))
+    with pytest.raises(L.CrlError, match="expected"):
+        L.check(L.load().crl_make_actor_critic(4, 2, 64, 0, L._ptr(np.zeros(7, np.float32), C.c_float), 7))
+    q = L.dqn_make_nn_host(seed=5)
+    lay = [(120, 4), (84, 120), (2, 84)]
+    o = 0
+    for out_dim, in_dim in lay:
+        W = q[o:o + out_dim * in_dim]; b = q[o + out_dim * in_dim:o + out_dim * in_dim + out_dim]
+        lim = np.sqrt(6.0 / (in_dim + out_dim))
+        assert not b.any() and np.abs(W).max() <= lim * (1 + 1e-6) and np.abs(W).max() > 0.9 * lim
+        assert abs(W.std() - lim / np.sqrt(3)) < 0.1 * lim                          # uniform on (-lim, lim)
+        o += out_dim * in_dim + out_dim
+    assert o == L.DQN_PARAM_COUNT
 
 
 def _pb_fields(buf):
