@@ -58,7 +58,7 @@ EXPORTS = [
     "crl_a2c_read_env", "crl_a2c_read_buffer", "crl_a2c_run_until_update", "crl_a2c_discounted_future_rewards",
     "crl_dqn_create", "crl_dqn_destroy", "crl_dqn_write_params", "crl_dqn_read_params", "crl_dqn_status_read", "crl_dqn_run",
     "crl_dqn_q_values",
-    "crl_make_actor_critic", "crl_ppo_init_params", "crl_a2c_init_params", "crl_dqn_make_nn", "crl_dqn_init_params",
+    "crl_make_actor_critic", "crl_ppo_init_params", "crl_a2c_init_params", "crl_dqn_make_nn", "crl_dqn_init_params", "crl_comm_info", "crl_clock_probe", "crl_product_probe",
 ]
 
 DQN_PARAM_COUNT = 10934
@@ -186,6 +186,9 @@ def load():
     L.crl_a2c_init_params.argtypes = [vp, C.c_uint64]
     L.crl_dqn_make_nn.argtypes = [C.c_uint64, fp, C.c_size_t]
     L.crl_dqn_init_params.argtypes = [vp, C.c_uint64]
+    L.crl_comm_info.argtypes = [C.c_char_p, C.c_size_t, ip]
+    L.crl_clock_probe.argtypes = [C.c_int32, C.c_double, dp, dp, dp]
+    L.crl_product_probe.argtypes = [C.c_int32, C.c_int32, fp, fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, fp, fp]
     for name in EXPORTS:
         if name not in ("crl_version", "crl_last_error"):
             getattr(L, name).restype = C.c_int32
@@ -206,6 +209,32 @@ def device_count():
 
 def _ptr(a, ct):
     return a.ctypes.data_as(C.POINTER(ct))
+
+
+def product_probe(flavour, A, B, chunks=1, scale_a=1.0, scale_b=1.0, col_scale=None, device=0):
+    """crl_product_probe: A [rows, K] (C order), B [cols, K] (C order) float32 → C [chunks, cols, rows] float32 partial products."""
+    A = np.ascontiguousarray(A, np.float32); B = np.ascontiguousarray(B, np.float32)
+    rows, K = A.shape; cols = B.shape[0]
+    out = np.zeros((chunks, cols, rows), np.float32)
+    cs = None if col_scale is None else np.ascontiguousarray(col_scale, np.float32)
+    check(load().crl_product_probe(device, flavour, _ptr(A, C.c_float), _ptr(B, C.c_float), rows, cols, K, chunks, scale_a, scale_b,
+                                   None if cs is None else _ptr(cs, C.c_float), _ptr(out, C.c_float)))
+    return out
+
+
+def clock_probe(device=0, span_ms=5.0):
+    """crl_clock_probe: shader clock under vector load, MHz (median, min, max over all waves of a chip-filling launch)."""
+    med, lo, hi = C.c_double(0), C.c_double(0), C.c_double(0)
+    check(load().crl_clock_probe(device, span_ms, C.byref(med), C.byref(lo), C.byref(hi)))
+    return med.value, lo.value, hi.value
+
+
+def comm_info():
+    """crl_comm_info: (path of the librccl the library's all-reduce resolves to, ncclGetVersion code). Raises when librccl cannot be loaded."""
+    buf = C.create_string_buffer(4096)
+    ver = C.c_int32(0)
+    check(load().crl_comm_info(buf, len(buf), C.byref(ver)))
+    return buf.value.decode("utf-8", "replace"), int(ver.value)
 
 
 def make_actor_critic_host(obs_dim, n_act, hidden, seed=0):

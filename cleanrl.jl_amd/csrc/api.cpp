@@ -15,6 +15,7 @@ thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
 int comm_unique_id(uint8_t id[128]);
 int comm_init(crl_ppo* h, const uint8_t id[128], int world, int rank);
+int comm_info(char* path, size_t path_cap, int* version);
 int launch_iota(crl_ppo* h);
 
 // Option table of crl_ppo_set_option / crl_ppo_get_option (ids: ppo_ctx.hpp). Every switch that selects a kernel flavour or changes
@@ -665,7 +666,7 @@ static int update_step(crl_ppo* h, int mb, double eta, int apply, int slot, bool
   const long nb_step = (long)((h->P + 4 + 63) / 64);
   const bool local_or_peer = !has_comm(h) || (peer_active(h) && !h->comm && (long)peer_ranks_on_my_device(h) * nb_step * 10 <= h->fuse_optim_capacity * 6);
   const bool fused = apply && !h->wide && local_or_peer && !h->external_comm && !(inline_fix && h->cfg.clip_value_loss) && opt(h, OPT_FUSE_OPTIM) &&
-                     h->fuse_optim_fits && (h->P & 63) <= 60;
+                     h->fuse_optim_fits && (h->P & 63) <= 60;   // (the four loss sums ride behind the gradient in the last 64-float chunk; only the 4 / 2 / 64 shape reaches this path — P = 9,155, P mod 64 = 3 — so the last condition never decides; it documents the kernel's layout assumption)
   h->defer_stats = !fused && apply && !h->wide && has_comm(h) && !(inline_fix && h->cfg.clip_value_loss && h->world == 1);
   const int rc = launch_update(h, mb, h->stats_dev + slot, inline_fix, fused, eta);
   h->defer_stats = false;
@@ -889,6 +890,7 @@ int32_t crl_ppo_iteration(const crl_ppo* h, int64_t* it) {
 }
 
 int32_t crl_comm_unique_id(uint8_t id[128]) { return comm_unique_id(id); }
+int32_t crl_comm_info(char* path, size_t path_cap, int32_t* version) { int v = 0; const int rc = comm_info(path, path_cap, &v); if (version) *version = v; return rc; }
 
 int32_t crl_comm_init(crl_ppo* h, const uint8_t id[128], int32_t world_size, int32_t rank) {
   CRL_GUARD_SETTLED(h);

@@ -4,6 +4,7 @@
 // it stays ordered with the kernels around it and never returns to the host.
 // librccl is opened lazily (dlopen) so single-GPU users never load it.
 #include <dlfcn.h>
+#include <link.h>
 #include <rccl/rccl.h>
 
 #include <cstdlib>
@@ -21,15 +22,34 @@ struct Rccl {
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*GetVersion)(int*) = nullptr;
 };
 Rccl g_rccl;
 
+// A librccl that is ALREADY mapped into this process wins over the soname search: a host framework (torch ships its own copy under torch/lib) and this
+// library must run their collectives on ONE RCCL — two copies in a process each register with the runtime and crash at exit (seen here: crl first,
+// torch second → "double free or corruption"). With the launcher importing torch first, dlopen by soname finds torch's copy anyway (same SONAME,
+// librccl.so.1); the scan also covers a copy mapped under another name. The reverse order cannot be mended from here: import torch before the first
+// crl_comm_* call (cleanrl.jl_amd/dist.py and bench.py do).
+int find_mapped_rccl(struct dl_phdr_info* info, size_t, void* out) {
+  const char* name = info->dlpi_name;
+  if (!name || !*name) return 0;
+  const char* base = std::strrchr(name, '/');
+  base = base ? base + 1 : name;
+  if (std::strncmp(base, "librccl.so", 10) != 0) return 0;
+  *static_cast<std::string*>(out) = name;
+  return 1;
+}
+
 int load_rccl() {
   if (g_rccl.lib) return 0;
+  std::string mapped;
+  dl_iterate_phdr(find_mapped_rccl, &mapped);
+  if (!mapped.empty()) g_rccl.lib = dlopen(mapped.c_str(), RTLD_NOW | RTLD_GLOBAL);
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
   for (const char* n : names) {
-    g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
     if (g_rccl.lib) break;
+    g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
   }
   if (!g_rccl.lib) { set_error(std::string("cannot load librccl: ") + dlerror()); return 1; }
 #define CRL_SYM(field, name)                                                         \
@@ -40,6 +60,7 @@ int load_rccl() {
   CRL_SYM(AllReduce, "ncclAllReduce")
   CRL_SYM(CommDestroy, "ncclCommDestroy")
   CRL_SYM(GetErrorString, "ncclGetErrorString")
+  CRL_SYM(GetVersion, "ncclGetVersion")
 #undef CRL_SYM
   return 0;
 }
@@ -85,6 +106,25 @@ int comm_allreduce(crl_ppo* h, void* buf, size_t count, bool is_double) {
   ncclResult_t r = g_rccl.AllReduce(buf, buf, count, is_double ? ncclDouble : ncclFloat, ncclSum,
                                     static_cast<ncclComm_t>(h->comm), h->stream);
   if (r != ncclSuccess) return nccl_fail("ncclAllReduce", r);
+  return 0;
+}
+
+// Which librccl this process's exchange runs on: the file the loaded ncclAllReduce lives in (dladdr) and ncclGetVersion. A launcher that imports
+// torch has torch's own librccl mapped already; dlopen by soname then resolves to whichever copy the loader finds first — the bench line records this
+// per rank so that the first real N > 1 run shows at a glance that all ranks, and torch, use ONE RCCL (verdict r5 item 7).
+int comm_info(char* path, size_t path_cap, int* version) {
+  if (load_rccl()) return 1;
+  Dl_info info;
+  std::memset(&info, 0, sizeof(info));
+  const char* fname = "?";
+  if (dladdr(reinterpret_cast<void*>(g_rccl.AllReduce), &info) && info.dli_fname) fname = info.dli_fname;
+  if (path && path_cap) { std::strncpy(path, fname, path_cap - 1); path[path_cap - 1] = 0; }
+  if (version) {
+    int v = 0;
+    ncclResult_t r = g_rccl.GetVersion(&v);
+    if (r != ncclSuccess) return nccl_fail("ncclGetVersion", r);
+    *version = v;
+  }
   return 0;
 }
 

@@ -295,7 +295,7 @@ int launch_gae(hipStream_t st, const float* value, const float* reward, const ui
            ((uintptr_t)terminal & da) == 0 && (!next_value || ((uintptr_t)next_value & fa) == 0) && (!next_done || ((uintptr_t)next_done & da) == 0);
   };
   const bool forced = tile == 4 || tile == 2 || tile == 1;
-  if (forced && !aligned(tile)) { set_error("gae: the streaming kernel (gae_tile = 4 / 2) needs num_envs % gae_tile == 0 and buffers aligned to gae_tile floats"); return 1; }
+  if (forced && !aligned(tile)) { set_error("gae: the streaming kernel (gae_tile = 4 / 2 / 1) needs num_envs % gae_tile == 0 and buffers aligned to gae_tile floats"); return 1; }
   // measured (profiles/r05_gae_beyond_cache.txt; launch-to-launch spread about 2 %): at 524288 envs x 128 four envs per thread with a window of 4
   // steps 0.73 of 8 TB/s (two envs / window 8: 0.72; the segmented kernel 0.44-0.50), at 262144 envs two envs per thread / window 4 0.70 (four envs: 0.68;
   // segmented 0.49-0.53); at 65536 envs (143 MB: 256-512 waves of this kernel) the segmented kernel stays ahead (0.44 against 0.24 with caches flushed)
@@ -322,7 +322,9 @@ int launch_gae(hipStream_t st, const float* value, const float* reward, const ui
   // (profiles/r05_gae_pair_kernel.txt): 4096 envs 8.6 vs 10.8 / 6.1 vs 6.6; 8192: 10.0 vs 14.4 / 6.8 vs 12.0; 16384: 14.1 vs 20.2 / 9.2 vs 13.8; 65536: 47.6 vs 50.7
   // / 26.3 vs 30.0, with nontemporal loads 32-34 vs 41-42 (0.56-0.59 of 8 TB/s instead of 0.43; the copy of the same bytes: 25); 1024 envs: 5.6 vs 4.6 (stays).
   if ((tile == 128 || tile == 256) && !aligned(2)) { set_error("gae: gae_tile = 128 / 256 (two envs per thread) needs an even num_envs and 8-byte aligned buffers"); return 1; }
-  if (tile == 128 || tile == 256 || (tile == 0 && nt >= 4096 && aligned(2))) {
+  // (the automatic route is gated on k <= 128, the only depth it was timed at: at k > 128 the pair kernel takes L = 16 — 64 doubles of δ / c and 17 value pairs
+  // per thread under launch_bounds(512) — which is parity-tested at k = 300 but was never measured against gae_kernel)
+  if (tile == 128 || tile == 256 || (tile == 0 && nt >= 4096 && k <= 128 && aligned(2))) {
     int L2 = (seg == 8 || seg == 16) ? seg : (k <= 128 ? 8 : 16);
     int S2 = (k + L2 - 1) / L2;
     int EB2 = tile == 256 ? 64 : 32;                            // (automatic: 32 pairs per block)

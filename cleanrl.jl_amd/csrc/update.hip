@@ -1012,19 +1012,30 @@ __global__ void __launch_bounds__(64 * RG) reduce_optim_kernel(const float* __re
 #endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the partials have arrived before the ticket moves
   if (o == 0) {
+    if (timed_out) {   // gave up waiting for a peer's chunk: raise the grid's sticky word BEFORE arriving, so that every block that passes the meeting point sees it
+      __hip_atomic_store(oa.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __hip_atomic_fetch_add(oa.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // bounded: if a block of the grid is not resident (a partitioned device, CUs held by another tenant — crl_ppo_create checks the
     // occupancy and turns the fused step off where the grid cannot fit, this is the second line of defence) or an arrival is lost, the
     // wait ends after oa.timeout ticks of the 100 MHz wall clock with a sticky error word instead of hanging the GPU; crl_sync /
     // crl_ppo_iterate / every read-back report it
+    // The arrival count and the sticky word are neighbours (ticket[0], ticket[1]; the pair is 8-byte aligned): ONE 64-bit load per poll reads both, so the
+    // load that lets a block through also tells it whether ANY block of the grid gave up before arriving — no second round trip on the step's critical path.
     const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(oa.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - oa.target > 0x7FFFFFFFu) {
+    unsigned long long both = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(oa.ticket), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while ((unsigned)both - oa.target > 0x7FFFFFFFu) {
       __builtin_amdgcn_s_sleep(1);
       if (wall_clock64() - t0 > oa.timeout) { __hip_atomic_store(oa.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); timed_out = 1; break; }
+      both = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(oa.ticket), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if ((unsigned)(both >> 32) != 0u) timed_out = 1;
   }
-  // a block that gave up (at the ticket, or waiting for a peer's chunk) must not step its slice from incomplete sums: parameters, Adam state and
-  // the β powers keep their pre-step values and the sticky words report the failure at the next host synchronisation
+  // If ANY block gave up (at the ticket, or waiting for a peer's chunk) NO block steps: a norm built from an incomplete chunk must not clip anybody's slice.
+  // Parameters, Adam state and the β powers of the whole rank keep their pre-step values, the sticky words (ticket[1], and the peer exchange's own) report
+  // the failure at the next host synchronisation, and — the word being sticky — every later launch on this handle skips its step too: the handle is poisoned
+  // until it is destroyed, which is what a lost rank means for a data-parallel job anyway.
   if (__builtin_amdgcn_readfirstlane(timed_out)) return;
   __builtin_amdgcn_wave_barrier();
   asm volatile("" ::: "memory");
@@ -1051,8 +1062,8 @@ __global__ void __launch_bounds__(64 * RG) reduce_optim_kernel(const float* __re
   if (i == oa.off[arr]) { oa.betap[2 * arr] = bp0 * b1c; oa.betap[2 * arr + 1] = bp1 * b2c; }
 }
 
-// Can the whole grid of reduce_optim_kernel be resident at once on this device? Its meeting point needs every block running: (P+63)/64
-// blocks of 1024 threads (144 for the 4/2/64 networks = 72 CUs at two blocks per CU). On a partitioned (CPX) device or a smaller GPU it
+// Can the whole grid of reduce_optim_kernel be resident at once on this device? Its meeting point needs every block running: (P+4+63)/64
+// blocks of 1024 threads (the gradient's chunks, the four loss sums riding in the last one: 144 for the 4/2/64 networks = 72 CUs at two blocks per CU). On a partitioned (CPX) device or a smaller GPU it
 // may not fit; the handle then keeps the two-launch optimiser step (reduce_kernel + clipnorm_adam_kernel).
 int fused_optim_fits(crl_ppo* h, bool* fits) {
   int per_cu = 0;
@@ -1061,7 +1072,7 @@ int fused_optim_fits(crl_ppo* h, bool* fits) {
   CRL_HIP_CHECK(hipGetDeviceProperties(&prop, h->device));
   // one block per CU of margin: the occupancy query can read one high near a register-file edge (MI355X guide, "Residency")
   const long resident = (long)(per_cu > 1 ? per_cu - 1 : per_cu) * (long)prop.multiProcessorCount;
-  *fits = resident >= (long)((h->P + 63) / 64);
+  *fits = resident >= (long)((h->P + 4 + 63) / 64);
   h->fuse_optim_capacity = (long)per_cu * (long)prop.multiProcessorCount;
   return 0;
 }

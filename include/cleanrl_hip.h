@@ -194,6 +194,10 @@ int32_t crl_ppo_exact_reruns(const crl_ppo* h, int64_t* n);
  * all-reduced once per optimiser step (ppo.jl:250 cadence) and averaged; ClipNorm/Adam then run replicated. */
 int32_t crl_comm_unique_id(uint8_t id[128]);
 int32_t crl_comm_init(crl_ppo* h, const uint8_t id[128], int32_t world_size, int32_t rank);
+/* Which RCCL the exchange runs on: the file the loaded ncclAllReduce lives in (dladdr; NUL-terminated into path[0..path_cap)) and ncclGetVersion's
+ * code (e.g. 22203). Loads librccl if it is not loaded yet; stateless. A launcher records it per rank (bench.py: comm.rccl_path / rccl_version)
+ * so that a multi-GPU run shows that every rank — and a host framework that maps its own copy — uses one library. No reference counterpart. */
+int32_t crl_comm_info(char* path, size_t path_cap, int32_t* version);
 /* The same data-parallel exchange without RCCL: a one-shot all-reduce over peer-mapped mailboxes (csrc/peer.hip) — every rank
  * pushes its message into every peer's mailbox over xGMI and adds the world_size slots in rank order, one launch per message
  * (the 36.6 KB gradient message of a 3 ms shard iteration is latency-bound on a ring). crl_comm_peer_export allocates this
@@ -255,7 +259,10 @@ int32_t crl_comm_destroy(crl_ppo* h);
  *   wide_d2_split (1)       wide_fuse = 3 with wide_wgrad_full = 1: the backward kernel hands δ2 to the weight-gradient kernel as the fp16x2 pieces it makes for
  *                           its own product (two f16 planes, one power-of-two scale per sample; the same bytes as the f32 array) and the weight-gradient kernel
  *                           multiplies straight from them (LDS-DMA + transposing LDS reads, no conversion); 0 = δ2 as f32, split again by its reader
- *   fuse_optim (1)          single GPU, speculative step: gradient reduction + ClipNorm + Adam as ONE launch (0 = two launches)
+ *   fuse_optim (1)          speculative step of the 4 / 2 / 64 path: gradient reduction + ClipNorm + Adam as ONE launch (reduce_optim_kernel; 0 = two launches) — on one
+ *                           GPU, and under data parallelism over the peer mailboxes, where the same launch also runs the exchange (reduce -> push -> wait ->
+ *                           rank-order sum -> ClipNorm + Adam). Taken only where the launch's whole grid can be resident (checked at crl_ppo_create) and never
+ *                           with an RCCL communicator, a host-side exchange or the inline value-loss fix-up
  * Read-only through crl_ppo_get_option: gemm_fallback_seen (1 once any launch of the fused 4/2/64 path took the bf16x3 fallback; the
  * layer-wise path needs none: it scales its fp16x2 weight pieces by the largest |w| of the layer at every optimiser step).
  * The environment variable CRL_OPTIONS="key=value,key=value" applies options at crl_ppo_create (shell-driven experiments). */
@@ -279,6 +286,18 @@ enum crl_kernel_id { CRL_K_ROLLOUT = 0, CRL_K_GAE = 1, CRL_K_SHUFFLE = 2, CRL_K_
  * every timed launch (sizes that fit the 256 MiB Infinity Cache); gae_ms / copy_ms receive `reps` values each. */
 int32_t crl_gae_bench(int32_t device, int32_t nt, int32_t k, int32_t seg, int32_t tile, int32_t nt_loads, int32_t flush_mb,
                       int32_t reps, double* gae_ms, double* copy_ms);
+/* Measurement entry (bench.py `clock`): the shader clock the GPU sustains under vector load — one 8-wave block per CU runs independent v_fma_f32 chains
+ * for span_ms of the constant 100 MHz counter (s_memrealtime) and reports shader cycles (s_memtime) per microsecond: median / min / max over all waves,
+ * in MHz. Boxes of one pool differ by more than a round's kernel work moves the headline; a line that carries its own clock can be normalised. */
+int32_t crl_clock_probe(int32_t device, double span_ms, double* median_mhz, double* min_mhz, double* max_mhz);
+/* Measurement entry (scripts/product_error.py → profiles/<tag>_product_error.json): C = A·B for the same Float32 host operands through every way the
+ * hidden-layer products of networks.jl:6-13 could be multiplied on this GPU — flavour 0 = fp16x2 split operands (the default of option gemm; scale_a,
+ * scale_b or a per-column col_scale[cols] are the exact powers of two the production kernels use), 1 = bf16x3 (gemm = 1), 2 = v_mfma_f32_32x32x2_f32,
+ * 3 = a sequential v_fma_f32 chain per element (a scalar f32 matmul) — so that their errors against a Float64 product can be compared on real operands.
+ * A [rows][K] row-major, B [cols][K]; K is cut into `chunks` pieces with one f32 accumulator each: C [chunks][cols][rows]. rows / cols multiples of 32,
+ * K / chunks a multiple of 16. */
+int32_t crl_product_probe(int32_t device, int32_t flavour, const float* A, const float* B, int32_t rows, int32_t cols, int32_t K, int32_t chunks,
+                          float scale_a, float scale_b, const float* col_scale, float* C);
 int32_t crl_prof_enable(crl_ppo* h, int32_t on);
 int32_t crl_prof_read(crl_ppo* h, int32_t kernel_id, double* total_ms, int64_t* launches);
 int32_t crl_prof_reset(crl_ppo* h);
