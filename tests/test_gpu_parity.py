@@ -1118,3 +1118,24 @@ def test_fresh_handle_refuses_to_compute_and_library_init_trains(crl):
     hw.iterate(1)
     assert np.isfinite(hw.read(L.F_PARAMS)).all()
     hw.close()
+
+
+def test_product_probe_flavours_agree_with_a_float64_product(crl):
+    """crl_product_probe (the measurement behind profiles/*_product_error.json) multiplies through the production split functions: every flavour within
+    2e-6 relative L2 of a Float64 product on well-scaled operands, per-column scales and K-chunking included."""
+    L = crl._lib
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((64, 128)).astype(np.float32)
+    B = (rng.standard_normal((96, 128)) * 0.5).astype(np.float32)
+    ref = B.astype(np.float64) @ A.astype(np.float64).T
+    for fl in range(4):
+        for chunks in (1, 4):
+            got = L.product_probe(fl, A, B, chunks=chunks, scale_a=256.0, scale_b=1024.0).astype(np.float64).sum(0)
+            assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 2e-6, (fl, chunks)
+    cs = np.ldexp(1.0, rng.integers(0, 12, 96)).astype(np.float32)
+    got = L.product_probe(0, A, B, col_scale=cs, scale_a=256.0)[0].astype(np.float64)
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 2e-6
+    with pytest.raises(crl.CrlError, match="multiples of 32"):
+        L.product_probe(0, A[:33], B)
+    med, lo, hi = L.clock_probe(0, 2.0)
+    assert 500.0 < lo <= med <= hi < 3000.0, (lo, med, hi)      # MHz: a shader clock, not a tick counter
