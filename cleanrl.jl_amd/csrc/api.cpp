@@ -48,6 +48,7 @@ static const OptDesc kOpts[OPT_COUNT] = {
     {"wide_fuse", 3, 0, 3},
     {"wide_fwd_wbufs", 2, 0, 3},
     {"wide_d2_split", 1, 0, 1},
+    {"update_tile", 0, 0, 32},
 };
 static bool gae_seg_ok(int64_t v) { return v == 0 || v == 4 || v == 8 || v == 16; }
 static bool gae_tile_ok(int64_t v) { return v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64 || v == 128 || v == 256; }
@@ -66,6 +67,7 @@ static int opt_set(crl_ppo* h, const char* key, int64_t value) {
   }
   if (id == OPT_GAE_SEG && !gae_seg_ok(value)) { set_error("crl_ppo_set_option: gae_seg is 0 (automatic), 8 or 16 (4: streaming kernel only)"); return 1; }
   if (id == OPT_WIDE_FWD_WBUFS && value == 1) { set_error("crl_ppo_set_option: wide_fwd_wbufs is 0 (weight fragments to registers), 2 or 3 (LDS buffers)"); return 1; }
+  if (id == OPT_UPDATE_TILE && value != 0 && value != 16 && value != 17 && value != 32) { set_error("crl_ppo_set_option: update_tile is 0 (by launch size), 16 (16-sample tiles, three waves per SIMD; 17 = the same with every tile reporting a scale miss: test hook) or 32"); return 1; }
   if (id == OPT_GAE_TILE && !gae_tile_ok(value)) { set_error("crl_ppo_set_option: gae_tile is 0 (automatic), 1 / 2 / 4 (streaming kernel, envs per thread), 8, 16, 32 or 64 (segmented kernel, envs per block), 128 or 256 (two envs per thread, 32 / 64 pairs per block)"); return 1; }
   h->opt[id] = value;
   if (id == OPT_GUARD_WINDOW) h->window_len = (int)value;
@@ -100,7 +102,7 @@ static int opt_apply_env(crl_ppo* h) {
 int reset_dw_scale(crl_ppo* h) {
   const double lm = std::log2((double)h->dc.M * (double)h->world);
   const int ka = 8 * (int)std::lround((lm + 19.0) / 8.0), kc = 8 * (int)std::lround((lm + 3.0) / 8.0);
-  const float init[4] = {std::ldexp(1.0f, ka), std::ldexp(1.0f, kc), 0.0f, 0.0f};
+  const float init[8] = {std::ldexp(1.0f, ka), std::ldexp(1.0f, kc), 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};   // G x2 | max bits x2 | miss flag of the 16-sample-tile kernel
   CRL_HIP_CHECK(hipMemcpy(h->dscale, init, sizeof(init), hipMemcpyHostToDevice));
   return 0;
 }
@@ -323,7 +325,7 @@ int32_t crl_ppo_create(const crl_ppo_config* cfg, int32_t device, crl_ppo** out)
   h->update_blocks = ub;
   if (!wide) { rc |= dalloc(&h->gpart, (size_t)4 * ub * h->Pa + 4096); rc |= dalloc(&h->lpart, (size_t)4 * ub * 2); }
   rc |= dalloc(&h->adv_sums_base, E * c.nmb * 2); rc |= dalloc(&h->adv_ms_base, E * c.nmb * 2);
-  rc |= dalloc(&h->newv, (size_t)c.M + 64); rc |= dalloc(&h->vfix, 8); rc |= dalloc(&h->dscale, 4);
+  rc |= dalloc(&h->newv, (size_t)c.M + 64); rc |= dalloc(&h->vfix, 8); rc |= dalloc(&h->dscale, 8);
   rc |= dalloc(&h->stats_dev, (size_t)cfg->update_epochs * c.nmb);
   rc |= dalloc(&h->comm_buf, (size_t)h->P + 8);
   rc |= dalloc(&h->snap, (size_t)3 * h->P); rc |= dalloc(&h->snap_betap, 24);

@@ -759,6 +759,18 @@ __global__ void __launch_bounds__(512, 2) update_x3_kernel(UpdateArgs a) {
   if ((int)blockIdx.x < a.nblk[0]) update_role<D, A, 0, false, true, 8>(a, blockIdx.x, smem, smem + NetImageX3<D, A, true>::SIZE);
   else update_role<D, A, 1, false, true, 8>(a, blockIdx.x - a.nblk[0], smem, smem + NetImageX3<D, 1, true>::SIZE);
 }
+// After update_t16_kernel (update16.hpp): nothing unless a tile of that launch did not fit the carried weight-gradient scale (or a weight left the fp16
+// window) — then the whole minibatch is recomputed on bf16x3 (no range limits) into the same partial buffers, before the reduce reads them.
+template <int D, int A>
+__global__ void __launch_bounds__(512, 2) update_repair_kernel(UpdateArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (*a.dw_miss == 0u) return;
+  if ((int)blockIdx.x < a.nblk[0]) update_role<D, A, 0, false, true, 8>(a, blockIdx.x, smem, smem + NetImageX3<D, A, true>::SIZE);
+  else update_role<D, A, 1, false, true, 8>(a, blockIdx.x - a.nblk[0], smem, smem + NetImageX3<D, 1, true>::SIZE);
+}
+}  // namespace crl
+#include "update16.hpp"   // the 16-sample-tile flavour (needs sgpr / CRL_PHASE above)
+namespace crl {
 // fp16x2 flavour (the default): forward / backward-data products on the f16 matrix pipe, three MFMAs per product
 constexpr int X2_KERNEL_LDS_FLOATS = NetImageX3<4, 2, true>::SIZE + 8 * SCR_FLOATS_X3 + 12;   // + the staging flag / the 8 progress counters   // the bf16x3 fallback's layout is the larger one
 static_assert(X2_KERNEL_LDS_FLOATS % 4 == 0, "prefetch slots are 16-byte aligned");
@@ -858,6 +870,7 @@ __global__ void __launch_bounds__(64 * RG) reduce_kernel(const float* __restrict
     unsigned* mx = reinterpret_cast<unsigned*>(st.dscale + 2);
     st.dscale[threadIdx.x] = dw_next_scale(mx[threadIdx.x], st.dscale[threadIdx.x]);
     mx[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) mx[2] = 0u;   // the 16-sample kernel's miss flag: update_repair_kernel has run by now
   }
   if (last && st.fused) {
     __syncthreads();  // the four sums written above are visible to thread 0 of this block
@@ -998,6 +1011,7 @@ __global__ void __launch_bounds__(64 * RG) reduce_optim_kernel(const float* __re
     unsigned* mx = reinterpret_cast<unsigned*>(st.dscale + 2);
     st.dscale[threadIdx.x] = dw_next_scale(mx[threadIdx.x], st.dscale[threadIdx.x]);
     mx[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) mx[2] = 0u;   // the 16-sample kernel's miss flag: update_repair_kernel has run by now
   }
   if (last) {
     __syncthreads();
@@ -1119,6 +1133,19 @@ __global__ void vfix_count_kernel(DevCfg c, const SampleRec* __restrict__ recs, 
 }
 
 
+// option update_tile: 32 = update_x2_kernel always; 16 (17: + the miss test hook) = the 16-sample-tile kernel always; 0 = automatic — the 16-sample kernel
+// for launches with at most UPDATE16_MAX_TILES_PER_WAVE 32-sample tiles per wave of update_x2_kernel's grid (shards of 8192 envs and below, C2)
+constexpr int UPDATE16_MAX_TILES_PER_WAVE = 8;
+constexpr bool UPDATE16_AUTO = false;   // flipped only by a same-box A/B at 4096 / 8192 envs (profiles/r06_update_tile16_ab.txt)
+static bool update_uses_tile16(const crl_ppo* h) {
+  const int64_t t = opt(h, OPT_UPDATE_TILE);
+  if (t == 16 || t == 17) return true;
+  if (t == 32) return false;
+  const long tiles32 = ((long)h->dc.M + 31) / 32;
+  const long waves_per_role = (long)((h->update_blocks + 1) / 2) * 8;
+  return UPDATE16_AUTO && tiles32 <= (long)UPDATE16_MAX_TILES_PER_WAVE * waves_per_role;
+}
+
 // block counts of the main pass: {actor, critic}
 static void main_pass_blocks(crl_ppo* h, int* nA, int* nC) {
   // one role per block; the actor tile is a little longer (softmax + Float64 policy-loss terms), so it gets more blocks
@@ -1138,7 +1165,7 @@ static int run_update(crl_ppo* h, int mb, int mode, hipEvent_t ev0 = nullptr, hi
   a.c = h->dc; a.params = h->params;
   a.recs = h->recs; a.perm = h->perm_base + (size_t)h->cur_slot * h->dc.B + (size_t)mb * h->dc.M; a.adv_ms = h->adv_ms; a.vfix = h->vfix;
   a.gpart = h->gpart; a.lpart = h->lpart; a.newv = h->newv; a.range_err = h->vfix + 5;
-  a.dscale = h->dscale; a.dmax = reinterpret_cast<unsigned*>(h->dscale + 2);
+  a.dscale = h->dscale; a.dmax = reinterpret_cast<unsigned*>(h->dscale + 2); a.dw_miss = reinterpret_cast<unsigned*>(h->dscale + 4);
   a.mb = mb; a.mode = mode; a.gstride = (int)h->Pa; a.pmax = h->update_blocks; a.stagger = 0;
   a.Mglobal = (double)h->dc.M * h->world;
   if (mode == 1) {
@@ -1153,7 +1180,16 @@ static int run_update(crl_ppo* h, int mb, int mode, hipEvent_t ev0 = nullptr, hi
     // LDS for the larger of the two layouts: the fp16x2 kernel runs a role as bf16x3 when its weights leave the fp16 window
     const size_t smem = sizeof(float) * (X2_KERNEL_LDS_FLOATS + 8 * PF_SLOT_FLOATS);
     static_assert(NetImageX3<4, 2, true>::SIZE >= NetImageX2<4, 2>::SIZE, "the bf16x3 image is the larger one");
-    if (gemm_x2(h)) hipExtLaunchKernelGGL((update_x2_kernel<4, 2>), dim3(a.nblk[0] + a.nblk[1]), dim3(512), smem, h->stream, ev0, ev1, 0, a);
+    if (gemm_x2(h) && update_uses_tile16(h)) {
+      // small launches (option update_tile): 16-sample tiles, twelve waves per block = three per SIMD; a tile that does not fit the carried
+      // weight-gradient scale raises a flag and the early-exit repair launch behind it redoes the minibatch as bf16x3
+      const size_t smem16 = sizeof(float) * update16_smem_floats();
+      a.stagger = 3;
+      if (opt(h, OPT_UPDATE_TILE) == 17) a.mode = 2;   // test hook: every tile reports a miss, the repair launch produces the result
+      hipExtLaunchKernelGGL((update_t16_kernel<2>), dim3(a.nblk[0] + a.nblk[1]), dim3(64 * RW16), smem16, h->stream, ev0, ev1, 0, a);
+      a.mode = 0; a.stagger = (int)opt(h, OPT_UPDATE_STAGGER);
+      hipLaunchKernelGGL((update_repair_kernel<4, 2>), dim3(a.nblk[0] + a.nblk[1]), dim3(512), smem, h->stream, a);
+    } else if (gemm_x2(h)) hipExtLaunchKernelGGL((update_x2_kernel<4, 2>), dim3(a.nblk[0] + a.nblk[1]), dim3(512), smem, h->stream, ev0, ev1, 0, a);
     else hipExtLaunchKernelGGL((update_x3_kernel<4, 2>), dim3(a.nblk[0] + a.nblk[1]), dim3(512), smem, h->stream, ev0, ev1, 0, a);
   }
   CRL_HIP_CHECK(hipGetLastError());

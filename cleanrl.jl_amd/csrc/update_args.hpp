@@ -15,6 +15,7 @@ struct UpdateArgs {
   double* range_err;      // vfix[5]: set when a hidden-layer weight does not fit the fp16x2 window (mlp_x2.hpp)
   const float* dscale;    // [2] fp16x2 weight-gradient scale G of this launch, actor / critic
   unsigned* dmax;         // [2] largest |δ2| seen by this launch (float bits), turned into the next G by reduce_kernel
+  unsigned* dw_miss = nullptr;  // 16-sample-tile kernel (update16.hpp): set when a tile did not fit G or a weight left the fp16 window — update_repair_kernel then redoes the minibatch as bf16x3
   int mb, mode, gstride;
   int nblk[2];            // blocks working on the actor / the critic
   int pmax;               // capacity (blocks per role) of the partial buffers
