@@ -1,26 +1,47 @@
 #!/usr/bin/env python3
-"""End-to-end sanity: PPO on the on-device CartPole with the reference's default hyper-parameters (only num_envs / num_steps
-scaled up) — mean episode return per block of iterations. Not a benchmark; shows that the loop learns."""
-import json, os, sys
+"""End-to-end functional proof through the ENTRY POINT (verdict r5 item 6): `ppo(config)` — cleanrl.jl_amd/ppo.py, the mirror of ppo.jl:75 — on the on-device
+CartPole with the reference's default hyper-parameters (only num_envs / num_steps scaled up), 300 iterations = 39.3 M env steps, for both product flavours
+(gemm = 2: fp16x2, the default; gemm = 1: bf16x3) and both GAE / reset semantics. The curve is read off the run's own "Episode Statistics" records
+(ppo.jl:157) as they reach the "CleanRL" logger: mean episode return per block of 30 updates. Over 300 iterations the speculation guard, the fp16x2
+window logic and the blocked shuffle all run 4,800 optimiser steps — a run that reaches >= 475 says they hold up beyond the three iterations the parity
+tests cover. Not a benchmark.   python scripts/train_curve.py > profiles/<tag>_train_curve.json"""
+import json, logging, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import cleanrl_jl_amd as crl
 
 nt, k, iters = 1024, 128, 300
+
+
+class Collect(logging.Handler):
+    def __init__(self):
+        super().__init__(); self.returns = []; self.losses = 0
+    def emit(self, record):
+        kv = getattr(record, "crl", None) or {}
+        if record.getMessage() == "Episode Statistics": self.returns.append(float(kv["episode_return"]))
+        elif record.getMessage() == "Training Statistics": self.losses += 1
+
+
 out = {}
-for name, kw in (("compat (reference semantics: stale obs after reset, GAE slot k = 0)", dict(gae_mode=crl._lib.GAE_COMPAT, stale_obs=1)),
-                 ("fixed (bootstrap GAE, fresh obs after reset)", dict(gae_mode=crl._lib.GAE_FIXED, stale_obs=0))):
-    agent = crl.Agent(crl.PPOConfig(num_envs=nt, num_steps=k, total_timesteps=nt * k * iters), seed=1, **kw)
-    h = agent.handle
-    h.env_reset()
-    curve = []
-    acc_ret = acc_n = 0.0
-    for it in range(iters):
-        h.iterate(1, want_stats=False)
-        es = h.episode_stats()
-        acc_ret += es["return_sum"]; acc_n += es["episodes"]
-        if (it + 1) % 30 == 0:
-            curve.append(round(acc_ret / max(acc_n, 1.0), 1)); acc_ret = acc_n = 0.0
-    out[name] = curve
-    agent.close()
-print(json.dumps({"config": f"num_envs={nt}, num_steps={k}, {iters} iterations ({nt*k*iters/1e6:.1f} M env steps), mean episode return per 30 iterations", "curves": out}, indent=1))
+for name, kw in (("compat (reference semantics: stale obs after reset, GAE slot k = 0), gemm = 2 (fp16x2)", dict(gae_mode=crl._lib.GAE_COMPAT, stale_obs=1, options={"gemm": 2})),
+                 ("compat, gemm = 1 (bf16x3: strict_f32)", dict(gae_mode=crl._lib.GAE_COMPAT, stale_obs=1, options={"gemm": 1})),
+                 ("fixed (bootstrap GAE, fresh obs after reset), gemm = 2", dict(gae_mode=crl._lib.GAE_FIXED, stale_obs=0, options={"gemm": 2}))):
+    col = Collect()
+    lg = logging.getLogger("CleanRL")
+    # ppo() installs its logger first (ppo.jl:77: make_logger replaces every handler): the collector is added right behind that call
+    import importlib
+    _logger = importlib.import_module("cleanrl_jl_amd.logger")
+    _orig = _logger.make_logger
+    def _mk(*a, **kw_):
+        r_ = _orig(*a, **kw_); lg.addHandler(col); return r_
+    _logger.make_logger = _mk
+    # episode_records = 0: one aggregate "Episode Statistics" record per update (the mean over the episodes that ended in its rollout)
+    crl.ppo(crl.PPOConfig(num_envs=nt, num_steps=k, total_timesteps=nt * k * iters), seed=1, episode_records=0,
+            logger_kw=dict(to_terminal=False, to_tensorboard=False, to_json=False), **kw)
+    lg.removeHandler(col); _logger.make_logger = _orig
+    r = col.returns
+    per = max(1, len(r) // 10)
+    curve = [round(sum(r[i:i + per]) / len(r[i:i + per]), 1) for i in range(0, per * 10, per)]
+    out[name] = {"mean_episode_return_per_30_updates": curve, "episode_records": len(r), "training_records": col.losses, "final": curve[-1], "reaches_475": curve[-1] >= 475.0}
+print(json.dumps({"config": f"ppo(PPOConfig(num_envs={nt}, num_steps={k}, total_timesteps={nt*k*iters})) — {iters} updates, {nt*k*iters/1e6:.1f} M env steps, reference defaults otherwise",
+                  "entry_point": "cleanrl.jl_amd/ppo.py: ppo() -> train() -> crl_ppo_iterate (one call per update), records collected from the CleanRL logger", "curves": out}, indent=1))
