@@ -632,6 +632,309 @@ __global__ void __launch_bounds__(192) rollout_split3_kernel(RolloutArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The same shards on SIX waves per tile (option rollout_split = 3; verdict r5 item 4 ii). What a small shard's rollout costs is the latency of one step
+// (128 dependent steps; 3.5 µs each in rollout_split3_kernel), and a lone wave issues an instruction every ≈5 cycles — so a step is as long as the
+// longest wave's instruction stream plus its matrix chain. Here the actor's 64 hidden rows go over FOUR waves (16 rows each: 8 tanh_fast and 8 split
+// elements per lane and layer instead of 16) and its 64x64 product runs on v_mfma_f32_16x16x32_bf16 — two independent 12-deep chains of short
+// instructions per wave instead of one 24-deep chain of v_mfma_f32_32x32x16_bf16 — and the critic's rows over TWO waves (fp16x2, exp2 activation; the
+// split3 kernel's actor structure). Operands cross waves through LDS in the consumer's fragment order:
+//   * C layout of the 16x16 tiles: lane (n = l & 15, g = l >> 4), register i = row 4g + i of the wave's 16 rows, one tile per 16 samples (ct = 0, 1);
+//   * B fragment of k-step s (32 of the 64 h1 rows), lane (n, g), slot j = row 16·(2s + (j >> 2)) + 4g + (j & 3): four rows from wave 2s, four from
+//     wave 2s + 1, both in the SAME lane's registers — a producer stores 8 bytes per piece, a consumer loads 16 (update16.hpp's kmap16 order);
+//   * the weight A-fragments are staged in that k order.
+// The head is a plain sum here (each wave its 16 rows, folded over row groups and waves): the 16x16x32 product already sums a logit's terms in another order
+// than the one-wave forward, so logits agree with it — and with the oracle — to float32 rounding, not bit for bit; actions then differ from the
+// oracle's only where the draw sits within rounding of a CDF knot, which is the rule every rollout kernel is tested under (tests/test_gpu_parity.py).
+// Wave 0, lanes 0-31, samples and owns the envs. Three block barriers per step, as in the three-wave kernel.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 mfma16_bf16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float rows4_sum_f(float v) {     // v + the same lane's value in the three other 16-lane rows of the wave
+  const unsigned x = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+  const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const unsigned y = __float_as_uint(s);
+  const auto b = __builtin_amdgcn_permlane32_swap(y, y, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+template <int A>
+struct NetImageA16 {   // actor image of the six-wave kernel, offsets in floats
+  static constexpr int WF2 = 0;                       // [piece 3][t 4][s 2][lane 64][8 bf16]: W2[16t + (lane & 15)][16(2s + (j >> 2)) + 4(lane >> 4) + (j & 3)]
+  static constexpr int WF1 = WF2 + 3 * 4 * 2 * 64 * 4;   // [t 4][lane 64]: W1[16t + (lane & 15)][lane >> 4]
+  static constexpr int B1 = WF1 + 256;                // plain [64]
+  static constexpr int B2 = B1 + 64;
+  static constexpr int W3 = B2 + 64;                  // [a][64]
+  static constexpr int B3 = W3 + A * 64;
+  static constexpr int SIZE = ((B3 + A + 3) / 4) * 4;
+};
+template <int A>
+__device__ __forceinline__ void stage_net_a16(float* img, const float* __restrict__ p, int tid, int nthreads) {
+  using I = NetImageA16<A>;
+  using P = NetParams<4, A>;
+  __bf16* wf = reinterpret_cast<__bf16*>(img + I::WF2);
+  for (int idx = tid; idx < 4096; idx += nthreads) {
+    const int j = idx & 7, lane = (idx >> 3) & 63, s2 = (idx >> 9) & 1, t = idx >> 10;
+    const int row = 16 * t + (lane & 15), k = 16 * (2 * s2 + (j >> 2)) + 4 * (lane >> 4) + (j & 3);
+    const float w = p[P::W2 + row + H * k];
+    const __bf16 h = (__bf16)w; const float r1 = w - (float)h;
+    const __bf16 m = (__bf16)r1; const float r2 = r1 - (float)m;
+    wf[idx] = h; wf[4096 + idx] = m; wf[8192 + idx] = (__bf16)r2;
+  }
+  for (int idx = tid; idx < 256; idx += nthreads) img[I::WF1 + idx] = p[P::W1 + (16 * (idx >> 6) + (idx & 15)) + H * ((idx & 63) >> 4)];
+  for (int idx = tid; idx < 64; idx += nthreads) { img[I::B1 + idx] = p[P::B1 + idx]; img[I::B2 + idx] = p[P::B2 + idx]; }
+  for (int idx = tid; idx < A * 64; idx += nthreads) img[I::W3 + idx] = p[P::W3 + (idx >> 6) + A * (idx & 63)];
+  for (int idx = tid; idx < A; idx += nthreads) img[I::B3 + idx] = p[P::B3 + idx];
+}
+
+template <int A>
+__global__ void __launch_bounds__(384) rollout_split6_kernel(RolloutArgs a) {
+  constexpr int D = 4;
+  using IA = NetImageA16<A>;
+  using IC = NetImageX2<D, 1, false>;
+  constexpr int ICMAX = NetImageX3<D, 1, false>::SIZE;   // room for the bf16x3 fallback image of the critic
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* imgA0 = smem;
+  float* imgC0 = imgA0 + IA::SIZE;
+  float* xch = imgC0 + ICMAX;                                              // [2][TILE][4] observations
+  uint2* pcsA = reinterpret_cast<uint2*>(xch + 2 * TILE * 4);              // [s 2][ct 2][piece 3][lane 64][half 2] x 8 B: the actor's h1 pieces in B-fragment order
+  f16x8* pcsC = reinterpret_cast<f16x8*>(pcsA + 2 * 2 * 3 * 64 * 2);       // [mo 2][q 2][piece 2][lane 64]: the critic's h1 pieces
+  float* hdA = reinterpret_cast<float*>(pcsC + 2 * 2 * 2 * 64);            // [wave 4][A][TILE] partial logits
+  float* hdC = hdA + 4 * A * TILE;                                         // [mo 2][TILE] partial values
+  int* flag = reinterpret_cast<int*>(hdC + 2 * TILE);
+  stage_net_a16<A>(imgA0, a.params, threadIdx.x, blockDim.x);
+  bool cx2 = true;   // block-uniform: false = the critic's weights left the fp16 window and wave 4 runs it as bf16x3
+  if (!stage_net_x2<D, 1, false>(imgC0, a.params + NetParams<D, A>::SIZE, threadIdx.x, blockDim.x, flag)) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) a.range_err[0] = 1.0;
+    cx2 = false;
+    stage_net_x3<D, 1, false>(imgC0, a.params + NetParams<D, A>::SIZE, threadIdx.x, blockDim.x);
+  }
+  const DevCfg& c = a.c;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // env role: wave 0, lanes 0-31, one env each
+  const int e = blockIdx.x * TILE + (lane & 31);
+  const bool envlane = wave == 0 && lane < 32;
+  const bool ok = e < c.nt;
+  const bool writer = ok && envlane;
+  const int ee = ok ? e : 0;
+  const uint32_t gid = c.env_id_offset + (uint32_t)ee;
+  float s[4] = {0, 0, 0, 0}, co[4] = {0, 0, 0, 0};
+  int t_env = 0, ep_len = 0;
+  uint8_t nd = 0;
+  float ep_ret = 0.0f;
+  double st_n = 0.0, st_ret = 0.0, st_len = 0.0, st_max = 0.0;
+  if (envlane) {
+    const float4 sv = reinterpret_cast<const float4*>(a.env_state)[ee];
+    const float4 cv = reinterpret_cast<const float4*>(a.cur_obs)[ee];
+    s[0] = sv.x; s[1] = sv.y; s[2] = sv.z; s[3] = sv.w;
+    co[0] = cv.x; co[1] = cv.y; co[2] = cv.z; co[3] = cv.w;
+    t_env = a.env_t[ee]; nd = a.next_done[ee]; ep_ret = a.ep_return[ee]; ep_len = a.ep_length[ee];
+    reinterpret_cast<float4*>(xch)[lane] = cv;
+  }
+  // actor role (waves 0-3): lane (n, g), rows 16·wave + 4g + i
+  const int n = lane & 15, g = lane >> 4;
+  float w1a = 0.0f, b1a[4] = {0, 0, 0, 0}, b2a[4] = {0, 0, 0, 0}, w3a[A][4];
+#pragma unroll
+  for (int o = 0; o < A; ++o)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w3a[o][i] = 0.0f;
+  __syncthreads();
+  if (wave < 4) {
+    w1a = imgA0[IA::WF1 + wave * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 16 * wave + 4 * g + i;
+      b1a[i] = imgA0[IA::B1 + row]; b2a[i] = imgA0[IA::B2 + row];
+#pragma unroll
+      for (int o = 0; o < A; ++o) w3a[o][i] = imgA0[IA::W3 + o * 64 + row];
+    }
+  }
+
+  for (int step = 0; step < c.k; ++step) {
+    const uint64_t gstep = a.iteration * (uint64_t)c.k + (uint64_t)step;
+    const size_t b = (size_t)ee + (size_t)c.nt * step;
+    int lds_off = 0;
+    asm volatile("" : "+v"(lds_off));  // keep the weight reads in LDS (see rollout_cartpole_kernel)
+    const float* xcur = xch + (step & 1) * (TILE * 4) + lds_off;
+    if (wave < 4) {
+      double u = 0.0;
+      if (envlane) { ep_len += 1; u = u53(philox_env(c.seed, gid, gstep, 0)); }                // ppo.jl:125; drawn early
+      // layer 1: this wave's 16 rows, two 16-sample tiles
+      f32x4 h1[2];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        f32x4 acc; acc[0] = b1a[0]; acc[1] = b1a[1]; acc[2] = b1a[2]; acc[3] = b1a[3];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1a, xcur[(16 * ct + n) * 4 + g], acc, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h1[ct][i] = tanh_fast(acc[i]);
+      }
+      {
+        const float xb[8] = {h1[0][0], h1[0][1], h1[0][2], h1[0][3], h1[1][0], h1[1][1], h1[1][2], h1[1][3]};
+        const P3 p = split3(xb);
+        const u32x4v ph = __builtin_bit_cast(u32x4v, p.hi), pm = __builtin_bit_cast(u32x4v, p.mid), pl = __builtin_bit_cast(u32x4v, p.lo);
+        const int s2 = wave >> 1, half = wave & 1;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          uint2* dst = pcsA + ((((s2 * 2 + ct) * 3) * 64 + lane) * 2 + half);
+          dst[0] = make_uint2(ph[2 * ct], ph[2 * ct + 1]);
+          dst[128] = make_uint2(pm[2 * ct], pm[2 * ct + 1]);
+          dst[256] = make_uint2(pl[2 * ct], pl[2 * ct + 1]);
+        }
+      }
+      __syncthreads();                                                                        // (1) all of h1 is published
+      f32x4 acc2[2];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) { acc2[ct][0] = b2a[0]; acc2[ct][1] = b2a[1]; acc2[ct][2] = b2a[2]; acc2[ct][3] = b2a[3]; }
+      const bf16x8* wf = reinterpret_cast<const bf16x8*>(imgA0 + IA::WF2 + lds_off);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        P3 wa;
+        wa.hi = wf[((0 * 4 + wave) * 2 + s2) * 64 + lane]; wa.mid = wf[((1 * 4 + wave) * 2 + s2) * 64 + lane]; wa.lo = wf[((2 * 4 + wave) * 2 + s2) * 64 + lane];
+        P3 bq[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const bf16x8* src = reinterpret_cast<const bf16x8*>(pcsA) + ((s2 * 2 + ct) * 3) * 64 + lane;
+          bq[ct].hi = src[0]; bq[ct].mid = src[64]; bq[ct].lo = src[128];
+        }
+        // the two tiles' chains interleaved, smallest partial products first (mfma_x3's order)
+        acc2[0] = mfma16_bf16(wa.lo, bq[0].hi, acc2[0]);   acc2[1] = mfma16_bf16(wa.lo, bq[1].hi, acc2[1]);
+        acc2[0] = mfma16_bf16(wa.hi, bq[0].lo, acc2[0]);   acc2[1] = mfma16_bf16(wa.hi, bq[1].lo, acc2[1]);
+        acc2[0] = mfma16_bf16(wa.mid, bq[0].mid, acc2[0]); acc2[1] = mfma16_bf16(wa.mid, bq[1].mid, acc2[1]);
+        acc2[0] = mfma16_bf16(wa.mid, bq[0].hi, acc2[0]);  acc2[1] = mfma16_bf16(wa.mid, bq[1].hi, acc2[1]);
+        acc2[0] = mfma16_bf16(wa.hi, bq[0].mid, acc2[0]);  acc2[1] = mfma16_bf16(wa.hi, bq[1].mid, acc2[1]);
+        acc2[0] = mfma16_bf16(wa.hi, bq[0].hi, acc2[0]);   acc2[1] = mfma16_bf16(wa.hi, bq[1].hi, acc2[1]);
+      }
+      // head partials of this wave's 16 rows: per sample, folded over the four row groups
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        float h2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h2[i] = tanh_fast(acc2[ct][i]);
+#pragma unroll
+        for (int o = 0; o < A; ++o) {
+          float pz = w3a[o][0] * h2[0];
+#pragma unroll
+          for (int i = 1; i < 4; ++i) pz = __builtin_fmaf(w3a[o][i], h2[i], pz);
+          pz = rows4_sum_f(pz);
+          if (g == 0) hdA[(wave * A + o) * TILE + 16 * ct + n] = pz;
+        }
+      }
+      __syncthreads();                                                                        // (2) every wave's partial logits (and the critic's partial values) are there
+      if (envlane) {
+        float z[A], p[A], lp[A];
+#pragma unroll
+        for (int o = 0; o < A; ++o)
+          z[o] = ((hdA[(0 * A + o) * TILE + lane] + hdA[(1 * A + o) * TILE + lane]) + (hdA[(2 * A + o) * TILE + lane] + hdA[(3 * A + o) * TILE + lane])) + imgA0[IA::B3 + o];
+        softmax_logsoftmax<A>(z, p, lp);                                                      // ppo.jl:127 get_action
+        const int act = sample_weights<A>(p, u);
+        float lpa = lp[0];
+#pragma unroll
+        for (int i = 1; i < A; ++i) lpa = (act == i) ? lp[i] : lpa;
+        const bool done = cartpole_step(s, t_env, act);                                       // ppo.jl:130
+        const float rew = done ? 0.0f : 1.0f;                                                 // ppo.jl:132
+        if (writer) {                                                                         // ppo.jl:133-140 Buffer.add! (value: wave 4)
+          store_nt4(reinterpret_cast<f32x4*>(a.obs) + b, co[0], co[1], co[2], co[3]);
+          __builtin_nontemporal_store(act, a.action + b); __builtin_nontemporal_store(lpa, a.logprob + b);
+          a.reward[b] = rew; a.terminal[b] = nd;
+        }
+        co[0] = s[0]; co[1] = s[1]; co[2] = s[2]; co[3] = s[3];                              // ppo.jl:143
+        nd = done ? 1 : 0;                                                                    // ppo.jl:144
+        ep_ret += rew;                                                                        // ppo.jl:145
+        if (done) {                                                                           // ppo.jl:147-165
+          if (writer) {
+            st_n += 1.0; st_ret += (double)ep_ret; st_len += (double)ep_len; st_max = fmax(st_max, (double)ep_ret);
+            if (a.ring_cap > 0) {
+              const uint32_t slot = atomicAdd(a.ring_count, 1u);
+              if (slot < (uint32_t)a.ring_cap) a.ring[slot] = crl_episode_record{ep_ret, ep_len, (int32_t)gid, step};
+            }
+          }
+          ep_ret = 0.0f; ep_len = 0;
+          cartpole_reset(s, c.seed, gid, gstep, 1);                                           // ppo.jl:164
+          t_env = 0;
+          if (!c.stale_obs) { co[0] = s[0]; co[1] = s[1]; co[2] = s[2]; co[3] = s[3]; }
+        }
+        reinterpret_cast<float4*>(xch + ((step + 1) & 1) * (TILE * 4))[lane] = make_float4(co[0], co[1], co[2], co[3]);
+      }
+    } else if (!cx2) {
+      // critic as bf16x3 (the fallback flavour) on wave 4 alone; wave 5 keeps the barriers
+      const int j = lane & 31, hf = lane >> 5;
+      if (wave == 4) {
+        const float4 cv = reinterpret_cast<const float4*>(xcur)[j];
+        const float cx[4] = {cv.x, cv.y, cv.z, cv.w};
+        f32x16 h1[2], h2[2];
+        float v[1];
+        mlp_forward_x3<D, 1, false>(imgC0 + lds_off, cx, h1, h2, v, lane);                    // ppo.jl:128
+        __syncthreads();                                                                      // (1)
+        __syncthreads();                                                                      // (2)
+        if (ok && hf == 0) a.value[(size_t)(blockIdx.x * TILE + j) + (size_t)c.nt * step] = v[0];
+      } else { __syncthreads(); __syncthreads(); }
+    } else {
+      // critic (ppo.jl:128) as fp16x2 on two waves: wave 4 + mo owns hidden rows 32·mo … of both layers (the split3 kernel's actor structure)
+      const int mo = wave - 4, j = lane & 31, hf = lane >> 5;
+      const float* img = imgC0 + lds_off;
+      const float4 cv = reinterpret_cast<const float4*>(xcur)[j];
+      const float cx[4] = {cv.x, cv.y, cv.z, cv.w};
+      f32x16 acc = load16(img + IC::B1C + hf * 32 + 16 * mo);
+#pragma unroll
+      for (int ks = 0; ks < D / 2; ++ks) {
+        const float bv = hf ? cx[2 * ks + 1] : cx[2 * ks];
+        acc = mfma32(img[IC::WF1 + (mo * (D / 2) + ks) * 64 + lane], bv, acc);
+      }
+      P2 mine[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float xb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xb[i] = tanh_exp2_arg(acc[8 * q + i], X2_ACT_SCALE);
+        mine[q] = split2(xb);
+        f16x8* dst = pcsC + ((mo * 2 + q) * 2) * 64 + lane;
+        dst[0] = mine[q].hi; dst[64] = mine[q].lo;
+      }
+      __syncthreads();                                                                        // (1)
+      P2 other[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f16x8* src = pcsC + (((1 - mo) * 2 + q) * 2) * 64 + lane;
+        other[q].hi = src[0]; other[q].lo = src[64];
+      }
+      acc = load16(img + IC::B2C + hf * 32 + 16 * mo);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const P2& bq = ((ks >> 1) == mo) ? mine[ks & 1] : other[ks & 1];
+        acc = mfma_x2(load_wfrag2(img + IC::WF2H, mo, ks, lane), bq, acc);
+      }
+      const f32x4* w = reinterpret_cast<const f32x4*>(img + IC::W3 + hf * 32 + 16 * mo);
+      float accv = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 wv = w[q];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accv = __builtin_fmaf(wv[i], tanh_exp2(acc[q * 4 + i], TWO_LOG2E * X2_FWD_UNSCALE, 1.0f), accv);
+      }
+      accv += xor32(accv);
+      if (hf == 0) hdC[mo * TILE + j] = accv;
+      __syncthreads();                                                                        // (2)
+      if (mo == 0 && hf == 0 && ok) a.value[(size_t)(blockIdx.x * TILE + j) + (size_t)c.nt * step] = (hdC[j] + hdC[TILE + j]) + img[IC::B3];
+    }
+    __syncthreads();                                                                          // (3) next observations are published, the exchange buffers are free
+  }
+  if (wave == 0) {
+    if (writer) {
+      reinterpret_cast<float4*>(a.env_state)[e] = make_float4(s[0], s[1], s[2], s[3]);
+      reinterpret_cast<float4*>(a.cur_obs)[e] = make_float4(co[0], co[1], co[2], co[3]);
+      a.env_t[e] = t_env; a.next_done[e] = nd; a.ep_return[e] = ep_ret; a.ep_length[e] = ep_len;
+      // value[] was written by wave 4 of this block; the step loop's closing __syncthreads() made it visible here
+      if (a.fuse_gae) gae_tail_compat(a, e);
+    }
+    st_n = wave_sum(st_n); st_ret = wave_sum(st_ret); st_len = wave_sum(st_len);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) st_max = fmax(st_max, __shfl_xor(st_max, o, 64));
+    if (lane == 0 && st_n > 0.0) {
+      atomicAdd(&a.ep_stats[0], st_n); atomicAdd(&a.ep_stats[1], st_ret); atomicAdd(&a.ep_stats[2], st_len);
+      atomicMax(reinterpret_cast<unsigned long long*>(&a.ep_stats[3]), (unsigned long long)__double_as_longlong(st_max));
+    }
+  }
+}
+
 template <int D, int A>
 static size_t act_smem() { return sizeof(float) * (NetImage<D, A, false>::SIZE + NetImage<D, 1, false>::SIZE); }
 
@@ -713,7 +1016,11 @@ int launch_rollout(crl_ppo* h, bool fuse_gae) {
   const int split = (int)opt(h, OPT_ROLLOUT_SPLIT);
   const bool small = tiles <= (int)opt(h, OPT_ROLLOUT_SPLIT_MAX_TILES);
   a.range_err = h->vfix + 5;
-  if (gemm_x2(h) && split == 1 && small) {
+  if (gemm_x2(h) && split == 3 && small) {
+    // six waves per tile: the actor's hidden rows over four waves (16x16x32 products), the critic's over two
+    const size_t smem = sizeof(float) * (NetImageA16<2>::SIZE + NetImageX3<4, 1, false>::SIZE + 2 * TILE * 4 + 2 * 2 * 3 * 64 * 2 * 2 + 2 * 2 * 2 * 64 * 4 + 4 * 2 * TILE + 2 * TILE + 4);
+    hipLaunchKernelGGL((rollout_split6_kernel<2>), dim3(tiles), dim3(384), smem, h->stream, a);
+  } else if (gemm_x2(h) && split == 1 && small) {
     // three waves per tile: the actor's hidden rows split over two waves, the critic (fp16x2) on the third
     const size_t smem = sizeof(float) * (NetImageX3<4, 2, false>::SIZE + NetImageX3<4, 1, false>::SIZE + 2 * TILE * 4 + 2 * 2 * 3 * 64 * 4 + 2 * 64 + 4);
     hipLaunchKernelGGL((rollout_split3_kernel<2>), dim3(tiles), dim3(192), smem, h->stream, a);

@@ -23,9 +23,12 @@ class Collect(logging.Handler):
 
 
 out = {}
-for name, kw in (("compat (reference semantics: stale obs after reset, GAE slot k = 0), gemm = 2 (fp16x2)", dict(gae_mode=crl._lib.GAE_COMPAT, stale_obs=1, options={"gemm": 2})),
-                 ("compat, gemm = 1 (bf16x3: strict_f32)", dict(gae_mode=crl._lib.GAE_COMPAT, stale_obs=1, options={"gemm": 1})),
-                 ("fixed (bootstrap GAE, fresh obs after reset), gemm = 2", dict(gae_mode=crl._lib.GAE_FIXED, stale_obs=0, options={"gemm": 2}))):
+runs = []
+for seed in (1, 2, 3):     # three seeds per flavour: a trajectory is chaotic in the last bits of every product, so flavours are compared as distributions
+    runs.append((f"compat (reference semantics: stale obs after reset, GAE slot k = 0), gemm = 2 (fp16x2), seed {seed}", seed, dict(gae_mode=crl._lib.GAE_COMPAT, stale_obs=1, options={"gemm": 2})))
+    runs.append((f"compat, gemm = 1 (bf16x3: strict_f32), seed {seed}", seed, dict(gae_mode=crl._lib.GAE_COMPAT, stale_obs=1, options={"gemm": 1})))
+runs.append(("fixed (bootstrap GAE, fresh obs after reset), gemm = 2, seed 1", 1, dict(gae_mode=crl._lib.GAE_FIXED, stale_obs=0, options={"gemm": 2})))
+for name, seed, kw in runs:
     col = Collect()
     lg = logging.getLogger("CleanRL")
     # ppo() installs its logger first (ppo.jl:77: make_logger replaces every handler): the collector is added right behind that call
@@ -36,12 +39,12 @@ for name, kw in (("compat (reference semantics: stale obs after reset, GAE slot 
         r_ = _orig(*a, **kw_); lg.addHandler(col); return r_
     _logger.make_logger = _mk
     # episode_records = 0: one aggregate "Episode Statistics" record per update (the mean over the episodes that ended in its rollout)
-    crl.ppo(crl.PPOConfig(num_envs=nt, num_steps=k, total_timesteps=nt * k * iters), seed=1, episode_records=0,
+    crl.ppo(crl.PPOConfig(num_envs=nt, num_steps=k, total_timesteps=nt * k * iters), seed=seed, init_seed=seed, episode_records=0,
             logger_kw=dict(to_terminal=False, to_tensorboard=False, to_json=False), **kw)
     lg.removeHandler(col); _logger.make_logger = _orig
     r = col.returns
     per = max(1, len(r) // 10)
     curve = [round(sum(r[i:i + per]) / len(r[i:i + per]), 1) for i in range(0, per * 10, per)]
-    out[name] = {"mean_episode_return_per_30_updates": curve, "episode_records": len(r), "training_records": col.losses, "final": curve[-1], "reaches_475": curve[-1] >= 475.0}
+    out[name] = {"mean_episode_return_per_30_updates": curve, "episode_records": len(r), "training_records": col.losses, "final": curve[-1], "best": max(curve), "reaches_475": max(curve) >= 475.0}
 print(json.dumps({"config": f"ppo(PPOConfig(num_envs={nt}, num_steps={k}, total_timesteps={nt*k*iters})) — {iters} updates, {nt*k*iters/1e6:.1f} M env steps, reference defaults otherwise",
                   "entry_point": "cleanrl.jl_amd/ppo.py: ppo() -> train() -> crl_ppo_iterate (one call per update), records collected from the CleanRL logger", "curves": out}, indent=1))

@@ -130,11 +130,12 @@ def _oracle_state(nt, k, params, **kw):
     return cfg, st
 
 
-@pytest.mark.parametrize("split", ["1", "2", "0"])
+@pytest.mark.parametrize("split", ["1", "2", "0", "3"])
 @pytest.mark.parametrize("nt,stale", [(8, 1), (8, 0), (70, 1)])
 def test_rollout_matches_oracle(crl, nt, stale, split):
     """Option rollout_split = 1: three waves per tile (actor rows 0-31 + sampling + env | actor rows 32-63 | critic), the small-shard
-    kernel; 2: two waves per tile (actor + env | critic); 0: one wave per tile."""
+    kernel; 2: two waves per tile (actor + env | critic); 0: one wave per tile; 3: six waves per tile (the actor's rows over four waves on
+    16x16x32 products, the critic's over two: rollout_split6_kernel)."""
     k = 128
     agent = make_agent(crl, nt=nt, k=k, stale_obs=stale, options={"rollout_split": int(split)})
     params = agent.get_params()
@@ -743,7 +744,7 @@ def test_options_are_validated_and_fallback_is_automatic(crl):
     p = params.copy()
     p[off[8] + 5] = 300.0
     agent.set_params(p)
-    for split in (0, 1):
+    for split in (0, 1, 3):
         h.set_option("rollout_split", split)
         st2 = O.State(cfgo); st2.params[:] = p; st2.env_init()
         h.env_reset(); h.rollout_run(); st2.rollout()
@@ -789,7 +790,7 @@ def _episodes_from_buffers(reward, terminal, next_done, env_id_offset=0):
     return out
 
 
-@pytest.mark.parametrize("kind", ["fused-split", "fused-single", "wide"])
+@pytest.mark.parametrize("kind", ["fused-split", "fused-split6", "fused-single", "wide"])
 def test_episode_record_ring(crl, kind, monkeypatch):
     """ppo.jl:147-165 per-episode records (opt-in ring): every episode end of a rollout with its return, length, env and
     step — equal to what the stored rewards / terminals imply; overflow is counted, not stored."""
@@ -797,7 +798,7 @@ def test_episode_record_ring(crl, kind, monkeypatch):
     nt, k = 70, 128
     if kind == "wide":
         monkeypatch.setenv("CRL_FORCE_WIDE", "1")      # read once, by crl_ppo_create
-    agent = make_agent(crl, nt=nt, k=k, env_id_offset=1000, options={"rollout_split": 1 if kind == "fused-split" else 0})
+    agent = make_agent(crl, nt=nt, k=k, env_id_offset=1000, options={"rollout_split": {"fused-split": 1, "fused-split6": 3}.get(kind, 0)})
     h = agent.handle
     with pytest.raises(crl.CrlError, match="not enabled"):
         h._ring_cap = 4; h.episode_records()
