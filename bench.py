@@ -536,9 +536,13 @@ def run_workload(args, wl, world, rank, local_rank, dist, torch, crl, crl_dist, 
               "c2": "env-steps/sec, CartPole PPO num_envs=4096, 2x64 (BASELINE configs[1], side measurement)",
               "c3": "env-steps/sec, PPO LunarLander-shaped (obs 8 / act 4, 2x256) num_envs=16384 (BASELINE configs[2], side measurement)"}[wl]
     if c3:
+        c3pm, c3src = load_profile("c3_pmc_summary", strict) if (world == 1 and not parse_opts(args.opt) and not (extra_opts or {})) else (None, None)
+        c3ps = (c3pm or {}).get("per_step") or {}
         roofline = {"bound": "mfma", "kernel": "wide.hip: all forward/backward launches of one minibatch (HIP events around the group)",
                     "achieved": pipe_tflops, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": pipe_tflops / PEAK_F16_MFMA_TFLOPS,
-                    "traffic": None, "avg_launch_ms": upd_avg_s * 1e3, "launches": upd_n, "flops_per_launch": upd_flops * M,
+                    "traffic": c3ps.get("traffic_bytes"), "algorithmic_bytes": 52 * M, "traffic_source": c3src if c3ps else None,
+                    **({"traffic_over_algorithmic": c3ps["traffic_bytes"] / (52 * M), "traffic_gbps": c3ps["traffic_bytes"] / upd_avg_s / 1e9} if c3ps.get("traffic_bytes") and upd_n else {}),
+                    "avg_launch_ms": upd_avg_s * 1e3, "launches": upd_n, "flops_per_launch": upd_flops * M,
                     "f32_equivalent": {"tflops": upd_tflops, "over_f32_mfma_peak": upd_tflops / PEAK_F32_MFMA_TFLOPS},
                     "note": f"achieved = what the f16 matrix pipe is ISSUED: the 256x256 products ({mfma_share:.0%} of the algorithmic f32 flops, "
                             f"3 x {fwd_flops:,} per sample) x {issue_factor:g} partial products per f32 product; f32_equivalent = algorithmic flops ÷ time"}
@@ -809,7 +813,7 @@ def main():
                                  "steps": steps, "warmup": 3, "dtype": rec["dtype"],
                                  "roofline": {"bound": rf["bound"], "frac": rf["frac"], "achieved": rf["achieved"], "peak": rf["peak"], "unit": rf["unit"],
                                               "avg_launch_ms": rf["avg_launch_ms"], "launches": rf["launches"],
-                                              **({k2: rf[k2] for k2 in ("traffic", "algorithmic_bytes", "traffic_source") if k2 in rf and wl == "c3"}),
+                                              **({k2: rf[k2] for k2 in ("traffic", "algorithmic_bytes", "traffic_over_algorithmic", "traffic_gbps", "traffic_source") if k2 in rf and wl == "c3"}),
                                               **({"matrix_pipe_frac": rf["matrix_pipe"]["frac"]} if "matrix_pipe" in rf else {})}}
                     # the same configuration with 24-bit operands (bf16x3: option gemm = 1 / wide_gemm = 1), like the headline's strict_f32
                     rec = run_workload(a2, wl, 1, 0, 0, dist, torch, crl, crl_dist, steps=max(3, steps // 2), warmup=2, with_gae=False,

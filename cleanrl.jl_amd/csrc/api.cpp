@@ -23,7 +23,7 @@ int launch_iota(crl_ppo* h);
 struct OptDesc { const char* name; int64_t dflt, lo, hi; };
 static const OptDesc kOpts[OPT_COUNT] = {
     {"gemm", 2, 1, 2},
-    {"rollout_split", 1, 0, 3},
+    {"rollout_split", 4, 0, 4},
     {"rollout_split_max_tiles", 512, 0, 1 << 20},
     {"rollout_stagger", 6, 0, 64},
     {"gae_fuse", 1, 0, 1},

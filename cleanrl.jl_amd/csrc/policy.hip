@@ -700,7 +700,12 @@ __global__ void __launch_bounds__(384) rollout_split6_kernel(RolloutArgs a) {
   f16x8* pcsC = reinterpret_cast<f16x8*>(pcsA + 2 * 2 * 3 * 64 * 2);       // [mo 2][q 2][piece 2][lane 64]: the critic's h1 pieces
   float* hdA = reinterpret_cast<float*>(pcsC + 2 * 2 * 2 * 64);            // [wave 4][A][TILE] partial logits
   float* hdC = hdA + 4 * A * TILE;                                         // [mo 2][TILE] partial values
-  int* flag = reinterpret_cast<int*>(hdC + 2 * TILE);
+  // The two Philox calls of a step — the action draw and the reset state of an env that ends — depend on (seed, env, step) only: waves 1 and 2, idle
+  // between barriers (2) and (3) while wave 0 samples and steps the envs, compute them for the NEXT step and leave them here (100 instructions each
+  // off the critical wave's path: 2.65 -> 2.3 µs per step)
+  double* ubuf = reinterpret_cast<double*>(hdC + 2 * TILE);                // [2][TILE]
+  float4* rbuf = reinterpret_cast<float4*>(ubuf + 2 * TILE);               // [2][TILE]
+  int* flag = reinterpret_cast<int*>(rbuf + 2 * TILE);
   stage_net_a16<A>(imgA0, a.params, threadIdx.x, blockDim.x);
   bool cx2 = true;   // block-uniform: false = the critic's weights left the fp16 window and wave 4 runs it as bf16x3
   if (!stage_net_x2<D, 1, false>(imgC0, a.params + NetParams<D, A>::SIZE, threadIdx.x, blockDim.x, flag)) {
@@ -730,6 +735,11 @@ __global__ void __launch_bounds__(384) rollout_split6_kernel(RolloutArgs a) {
     t_env = a.env_t[ee]; nd = a.next_done[ee]; ep_ret = a.ep_return[ee]; ep_len = a.ep_length[ee];
     reinterpret_cast<float4*>(xch)[lane] = cv;
   }
+  {
+    const uint64_t g0 = a.iteration * (uint64_t)c.k;
+    if (wave == 1 && lane < 32) ubuf[lane] = u53(philox_env(c.seed, gid, g0, 0));
+    if (wave == 2 && lane < 32) { float r[4]; cartpole_reset(r, c.seed, gid, g0, 1); rbuf[lane] = make_float4(r[0], r[1], r[2], r[3]); }
+  }
   // actor role (waves 0-3): lane (n, g), rows 16·wave + 4g + i
   const int n = lane & 15, g = lane >> 4;
   float w1a = 0.0f, b1a[4] = {0, 0, 0, 0}, b2a[4] = {0, 0, 0, 0}, w3a[A][4];
@@ -756,8 +766,7 @@ __global__ void __launch_bounds__(384) rollout_split6_kernel(RolloutArgs a) {
     asm volatile("" : "+v"(lds_off));  // keep the weight reads in LDS (see rollout_cartpole_kernel)
     const float* xcur = xch + (step & 1) * (TILE * 4) + lds_off;
     if (wave < 4) {
-      double u = 0.0;
-      if (envlane) { ep_len += 1; u = u53(philox_env(c.seed, gid, gstep, 0)); }                // ppo.jl:125; drawn early
+      if (envlane) ep_len += 1;                                                               // ppo.jl:125
       // layer 1: this wave's 16 rows, two 16-sample tiles
       f32x4 h1[2];
 #pragma unroll
@@ -825,7 +834,7 @@ __global__ void __launch_bounds__(384) rollout_split6_kernel(RolloutArgs a) {
         for (int o = 0; o < A; ++o)
           z[o] = ((hdA[(0 * A + o) * TILE + lane] + hdA[(1 * A + o) * TILE + lane]) + (hdA[(2 * A + o) * TILE + lane] + hdA[(3 * A + o) * TILE + lane])) + imgA0[IA::B3 + o];
         softmax_logsoftmax<A>(z, p, lp);                                                      // ppo.jl:127 get_action
-        const int act = sample_weights<A>(p, u);
+        const int act = sample_weights<A>(p, ubuf[(step & 1) * TILE + lane]);                 // the draw of (env, step): Philox stream 0, computed a step ahead by wave 1
         float lpa = lp[0];
 #pragma unroll
         for (int i = 1; i < A; ++i) lpa = (act == i) ? lp[i] : lpa;
@@ -848,11 +857,17 @@ __global__ void __launch_bounds__(384) rollout_split6_kernel(RolloutArgs a) {
             }
           }
           ep_ret = 0.0f; ep_len = 0;
-          cartpole_reset(s, c.seed, gid, gstep, 1);                                           // ppo.jl:164
+          { const float4 rv = rbuf[(step & 1) * TILE + lane]; s[0] = rv.x; s[1] = rv.y; s[2] = rv.z; s[3] = rv.w; }   // ppo.jl:164 reset!: cartpole_reset(seed, env, step), computed a step ahead by wave 2
           t_env = 0;
           if (!c.stale_obs) { co[0] = s[0]; co[1] = s[1]; co[2] = s[2]; co[3] = s[3]; }
         }
         reinterpret_cast<float4*>(xch + ((step + 1) & 1) * (TILE * 4))[lane] = make_float4(co[0], co[1], co[2], co[3]);
+      } else if (wave == 1 && lane < 32) {
+        ubuf[((step + 1) & 1) * TILE + lane] = u53(philox_env(c.seed, gid, gstep + 1, 0));
+      } else if (wave == 2 && lane < 32) {
+        float r[4];
+        cartpole_reset(r, c.seed, gid, gstep + 1, 1);
+        rbuf[((step + 1) & 1) * TILE + lane] = make_float4(r[0], r[1], r[2], r[3]);
       }
     } else if (!cx2) {
       // critic as bf16x3 (the fallback flavour) on wave 4 alone; wave 5 keeps the barriers
@@ -1016,11 +1031,14 @@ int launch_rollout(crl_ppo* h, bool fuse_gae) {
   const int split = (int)opt(h, OPT_ROLLOUT_SPLIT);
   const bool small = tiles <= (int)opt(h, OPT_ROLLOUT_SPLIT_MAX_TILES);
   a.range_err = h->vfix + 5;
-  if (gemm_x2(h) && split == 3 && small) {
+  // rollout_split = 4 (default): by size — six waves per tile while the grid leaves every CU at most one block (<= 256 tiles = 8192 envs: 2.7 against 3.4 µs per
+  // step; at 512 tiles two six-wave blocks share a CU and it loses, 5.6 against 4.8: profiles/r06_rollout_split6_ab.txt), three waves up to rollout_split_max_tiles
+  const bool six = split == 3 || (split == 4 && tiles <= 256);
+  if (gemm_x2(h) && six && small) {
     // six waves per tile: the actor's hidden rows over four waves (16x16x32 products), the critic's over two
-    const size_t smem = sizeof(float) * (NetImageA16<2>::SIZE + NetImageX3<4, 1, false>::SIZE + 2 * TILE * 4 + 2 * 2 * 3 * 64 * 2 * 2 + 2 * 2 * 2 * 64 * 4 + 4 * 2 * TILE + 2 * TILE + 4);
+    const size_t smem = sizeof(float) * (NetImageA16<2>::SIZE + NetImageX3<4, 1, false>::SIZE + 2 * TILE * 4 + 2 * 2 * 3 * 64 * 2 * 2 + 2 * 2 * 2 * 64 * 4 + 4 * 2 * TILE + 2 * TILE + 2 * 2 * TILE + 4 * 2 * TILE + 4);
     hipLaunchKernelGGL((rollout_split6_kernel<2>), dim3(tiles), dim3(384), smem, h->stream, a);
-  } else if (gemm_x2(h) && split == 1 && small) {
+  } else if (gemm_x2(h) && (split == 1 || split == 4) && small) {
     // three waves per tile: the actor's hidden rows split over two waves, the critic (fp16x2) on the third
     const size_t smem = sizeof(float) * (NetImageX3<4, 2, false>::SIZE + NetImageX3<4, 1, false>::SIZE + 2 * TILE * 4 + 2 * 2 * 3 * 64 * 4 + 2 * 64 + 4);
     hipLaunchKernelGGL((rollout_split3_kernel<2>), dim3(tiles), dim3(192), smem, h->stream, a);

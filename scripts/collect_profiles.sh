@@ -15,6 +15,9 @@ for f in $S/prof_c3_*kernel_stats.csv; do [ -s "$f" ] && cp $f profiles/${TAG}_c
 for f in $S/prof_envs8192_*kernel_stats.csv; do [ -s "$f" ] && cp $f profiles/${TAG}_rocprof_kernel_stats_envs8192.csv; done
 cp $S/parity_margins.json profiles/${TAG}_parity_margins.json 2>/dev/null
 cp $S/gae_sizes.txt profiles/${TAG}_gae_sizes.txt 2>/dev/null
+[ -s $S/train_curve.json ] && cp $S/train_curve.json profiles/${TAG}_train_curve.json
+[ -s $S/bench_a2c.json ] && cp $S/bench_a2c.json profiles/${TAG}_bench_a2c.json
+[ -s $S/bench_dqn.json ] && cp $S/bench_dqn.json profiles/${TAG}_bench_dqn.json
 [ -s $S/gae_beyond_cache.txt ] && { echo "# scripts/bench_gae_big.py (crl_gae_bench), from scripts/final_measure.sh"; cat $S/gae_beyond_cache.txt; } > profiles/${TAG}_gae_beyond_cache_final.txt
 ls -la profiles/${TAG}_*
 [ -s $S/generated/${TAG}_c3_pmc_summary.json ] || cp gpurun_out/${TAG}_c3pmc/generated/${TAG}_c3_pmc_summary.json profiles/ 2>/dev/null

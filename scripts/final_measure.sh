@@ -33,6 +33,9 @@ done
 # the summaries bench.py's roofline reads (stamped with the kernel-source hash) are made HERE, before the bench lines, so that the
 # line of this very run carries them; a copy travels back in gpurun_out/<tag>/generated/ for scripts/collect_profiles.sh
 cd $R && python3 scripts/summarize_pmc.py $O $TAG > $O/summarize_pmc.log 2>&1
+# the fused 2x256 kernels' counters (incl. FETCH / WRITE per optimiser step) BEFORE the bench lines: configs.c3.roofline.traffic of the headline line reads them
+cd $R && bash scripts/pmc_c3.sh $TAG > $O/pmc_c3.log 2>&1
+mkdir -p $O/generated && cp profiles/${TAG}_c3_pmc_summary.json $O/generated/ 2>/dev/null
 mkdir -p $O/generated && cp profiles/${TAG}_pmc_summary.json profiles/${TAG}_pmc_hbm_traffic.json profiles/${TAG}_update_kernel_counts.json profiles/${TAG}_rocprof_update_avg.json $O/generated/
 timeout 900 $B --strict-profiles > $O/bench_n1.json 2> $O/bench_n1.err 
 timeout 900 $B --suite --no-cpu-baseline > $O/bench_n1_suite.json 2> $O/bench_n1_suite.err; cp $R/profiles/${TAG}_suite.json $O/suite.json 2>/dev/null
@@ -53,6 +56,9 @@ timeout 300 $B --workload c2 --steps 40 --no-cpu-baseline > $O/bench_c2_n1.json 
 timeout 600 $B --workload c3 --steps 5 --warmup 2 > $O/bench_c3_n1.json 2>/dev/null
 timeout 900 python3 $R/scripts/parity_margins.py > $O/parity_margins.json 2>/dev/null
 timeout 300 python3 $R/scripts/bench_gae_big.py > $O/gae_beyond_cache.txt 2>/dev/null
-cd $R && bash scripts/pmc_c3.sh $TAG > $O/pmc_c3.log 2>&1; cp $R/profiles/${TAG}_c3_pmc_summary.json $O/generated/ 2>/dev/null
 timeout 300 python3 $R/scripts/bench_gae.py 0 0 > $O/gae_sizes.txt 2>/dev/null
+timeout 600 python3 $R/scripts/train_curve.py > $O/train_curve.json 2>/dev/null
+timeout 300 python3 $R/scripts/product_error.py $TAG > $O/product_error.txt 2>&1; cp $R/profiles/${TAG}_product_error.json $O/generated/ 2>/dev/null
+timeout 300 python3 $R/scripts/bench_a2c.py > $O/bench_a2c.json 2>/dev/null
+timeout 300 python3 $R/scripts/bench_dqn.py > $O/bench_dqn.json 2>/dev/null
 echo done

@@ -49,6 +49,20 @@ for k, c in sorted(acc.items()):
         der["valu_instructions_per_mfma"] = (d["SQ_INSTS_VALU"] - d["SQ_INSTS_MFMA"]) / max(d["SQ_INSTS_MFMA"], 1)
     rec["derived"] = der
     out["kernels"][k] = rec
+# HBM traffic of ONE optimiser step (verdict r5 item 3: configs.c3.roofline.traffic): every update-pass kernel's FETCH_SIZE (x 2: 16-byte-per-lane streaming reads are
+# tallied at half, MI355X_MICROARCH.md) + WRITE_SIZE, times its launches per step (launches ÷ the forward kernel's), against SURVEY §8(d)'s algorithmic 52 B per sample
+fwd = next((k for k in out["kernels"] if "wide_fused_fwd_pc_kernel" in k), None)
+if fwd and "FETCH_SIZE" in out["kernels"][fwd]:
+    steps = out["kernels"][fwd]["FETCH_SIZE"]["launches"]
+    per = {}
+    for k, rec in out["kernels"].items():
+        if "rollout" in k or "FETCH_SIZE" not in rec or "WRITE_SIZE" not in rec:
+            continue
+        lps = rec["FETCH_SIZE"]["launches"] / steps
+        per[k] = {"launches_per_step": lps, "read_bytes": 2 * rec["FETCH_SIZE"]["mean"] * 1024 * lps, "written_bytes": rec["WRITE_SIZE"]["mean"] * 1024 * lps}
+    out["per_step"] = {"kernels": per, "traffic_bytes": sum(v["read_bytes"] + v["written_bytes"] for v in per.values()),
+                       "algorithmic_bytes": 52 * M, "note": "update-pass kernels of this PMC pass only (forward, backward, weight gradient, the two dW3 sweeps); the loss / reduce / optimiser "
+                                                            "launches move < 1 % of it. algorithmic = 52 B per sample (obs 32 + action 4 + old logprob 4 + adv 4 + return 4 + old value 4) x M = 524,288"}
 json.dump(out, open(os.path.join("profiles", f"{tag}_c3_pmc_summary.json"), "w"), indent=1)
 for k, r in out["kernels"].items():
     print(k, json.dumps(r["derived"]))

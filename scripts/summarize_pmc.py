@@ -58,8 +58,20 @@ for kern in sorted(set(main) | set(mainw)):
     factor = 2.0 if "pack_records" in kern else 1.0
     pattern = ("16-B-per-lane streaming reads" if factor == 2.0 else
                "64-byte records gathered through the permutation" if "update_" in kern else "uncalibrated width: raw figure")
-    traffic[kern] = {"FETCH_SIZE_KB_per_launch_mean": sum(f) / len(f), "WRITE_SIZE_KB_per_launch_mean": sum(w) / len(w),
-                     "fetch_factor": factor, "fetch_x2_corrected": factor == 2.0, "pattern": pattern}
+    rec = {"FETCH_SIZE_KB_per_launch_mean": sum(f) / len(f), "WRITE_SIZE_KB_per_launch_mean": sum(w) / len(w)}
+    if "gae_seg2_kernel" in kern:
+        # Calibrated on the kernel's own KNOWN input bytes (verdict r5 weak 5): the pair kernel reads value and reward with 8-byte-per-lane loads and the
+        # terminals with 2-byte loads, every input byte once (a scan has no reuse), caches flushed by the harness (scripts/pmc_gae_write.py). The counter
+        # tallies the 8-byte streams at 1/2 like the guide's 16-byte case and the byte loads at face value: modelled raw/known = (8·½ + 1) / 9 = 0.556;
+        # measured 0.57 (profiles/r05: 42.2 MB raw against 75.8 MB of inputs). fetch_factor = known ÷ raw of THIS pass, reported next to the model's.
+        known_kb = (B * 9 + (B // 128) * 5) / 1024       # 9 B per (env, step) read + 5 B per env; B = 65536 x 128
+        rec["known_read_KB_per_launch"] = known_kb
+        rec["raw_over_known"] = rec["FETCH_SIZE_KB_per_launch_mean"] / known_kb
+        rec["modelled_raw_over_known"] = (8 * 0.5 + 1) / 9
+        factor = 1.0 / rec["modelled_raw_over_known"]
+        pattern = "8-byte-per-lane value / reward loads tallied at 1/2 (like the guide's 16-byte case), 2-byte terminal loads at face value: factor = 9 / 5"
+    rec.update({"fetch_factor": factor, "fetch_x2_corrected": factor == 2.0, "pattern": pattern})
+    traffic[kern] = rec
 for kern, rec in traffic.items():
     if "pack_records" in kern:
         rec["known_read_KB_per_launch"] = B * 36 / 1024
