@@ -21,8 +21,8 @@ IT_LOSS, IT_PARAM = 2e-6, 1e-6
 LOSS_FLOOR = 5e-7
 
 
-def loss_close(key, got, want, rtol):
-    floor = LOSS_FLOOR if key in ("loss", "pg_loss") else 0.0
+def loss_close(key, got, want, rtol, floor=LOSS_FLOOR):
+    floor = floor if key in ("loss", "pg_loss") else 0.0
     return abs(got - want) <= rtol * abs(want) + floor
 
 
@@ -628,8 +628,12 @@ def test_iteration_with_live_unclipped_value_branch(crl, forced_comm):
         assert max(s["n_unclipped_wins"] for s in os_) > 0, "the test must exercise the u > q branch"
         for a, b in zip(gs, os_):
             assert a["n_unclipped_wins"] == b["n_unclipped_wins"]
+            # pg_loss floor of THIS configuration: γ = 0 and a critic bias of 5 make every advantage ≈ −4 with a spread of a few hundredths, so the
+            # normalisation (adv − mean) / std amplifies the float32 rounding of the VALUES (1e-7 relative of 5 = 5e-7 absolute, on both sides) by
+            # 1 / std: measured |Δ pg_loss| over three iterations 0.8 / 4.6 / 5.9 e-7 with the three-wave rollout kernel and 0.5 / 5.9 / 5.0 e-7 with the
+            # six-wave one (scripts/diag_split.py; logprob deviations identical: 1.2e-7 max) — the default floor of 5e-7 sat inside that band
             for key in ("loss", "v_loss", "pg_loss"):
-                assert loss_close(key, a[key], b[key], IT_LOSS), (it, key, a[key], b[key])
+                assert loss_close(key, a[key], b[key], IT_LOSS, floor=1.5e-6), (it, key, a[key], b[key])
         assert np.max(np.abs(h.read(crl._lib.F_PARAMS) - st.params)) < IT_PARAM
     assert h.exact_reruns == 2, "both iterations had to be repeated with the exact value-loss pass (guard window)"
     agent.close(); st.close()
