@@ -697,8 +697,8 @@ __global__ void __launch_bounds__(384) rollout_split6_kernel(RolloutArgs a) {
   float* imgC0 = imgA0 + IA::SIZE;
   float* xch = imgC0 + ICMAX;                                              // [2][TILE][4] observations
   uint2* pcsA = reinterpret_cast<uint2*>(xch + 2 * TILE * 4);              // [s 2][ct 2][piece 3][lane 64][half 2] x 8 B: the actor's h1 pieces in B-fragment order
-  f16x8* pcsC = reinterpret_cast<f16x8*>(pcsA + 2 * 2 * 3 * 64 * 2);       // [mo 2][q 2][piece 2][lane 64]: the critic's h1 pieces
-  float* hdA = reinterpret_cast<float*>(pcsC + 2 * 2 * 2 * 64);            // [wave 4][A][TILE] partial logits
+  f16x8* pcsC = reinterpret_cast<f16x8*>(pcsA + 2 * 2 * 3 * 64 * 2);       // [mo 2][q 2][piece 2][lane 64]: the critic's h1 pieces (three bf16 pieces in the fallback flavour: sized for those)
+  float* hdA = reinterpret_cast<float*>(pcsC + 2 * 2 * 3 * 64);            // [wave 4][A][TILE] partial logits
   float* hdC = hdA + 4 * A * TILE;                                         // [mo 2][TILE] partial values
   // The two Philox calls of a step — the action draw and the reset state of an env that ends — depend on (seed, env, step) only: waves 1 and 2, idle
   // between barriers (2) and (3) while wave 0 samples and steps the envs, compute them for the NEXT step and leave them here (100 instructions each
@@ -870,18 +870,51 @@ __global__ void __launch_bounds__(384) rollout_split6_kernel(RolloutArgs a) {
         rbuf[((step + 1) & 1) * TILE + lane] = make_float4(r[0], r[1], r[2], r[3]);
       }
     } else if (!cx2) {
-      // critic as bf16x3 (the fallback flavour) on wave 4 alone; wave 5 keeps the barriers
-      const int j = lane & 31, hf = lane >> 5;
-      if (wave == 4) {
-        const float4 cv = reinterpret_cast<const float4*>(xcur)[j];
-        const float cx[4] = {cv.x, cv.y, cv.z, cv.w};
-        f32x16 h1[2], h2[2];
-        float v[1];
-        mlp_forward_x3<D, 1, false>(imgC0 + lds_off, cx, h1, h2, v, lane);                    // ppo.jl:128
-        __syncthreads();                                                                      // (1)
-        __syncthreads();                                                                      // (2)
-        if (ok && hf == 0) a.value[(size_t)(blockIdx.x * TILE + j) + (size_t)c.nt * step] = v[0];
-      } else { __syncthreads(); __syncthreads(); }
+      // critic as bf16x3 (the fallback flavour: a hidden-layer weight left the fp16 window), in the same two-wave form — wave 4 + mo owns hidden rows 32·mo …
+      // (mlp_forward_x3 whole on one wave needs 221 VGPRs, which alone made this kernel too fat for the shuffle's blocks to share its CUs: the iteration's
+      // first leg then ended with the shuffle, not the rollout)
+      const int mo = wave - 4, j = lane & 31, hf = lane >> 5;
+      using IC3 = NetImageX3<D, 1, false>;
+      const float* img = imgC0 + lds_off;
+      const float4 cv = reinterpret_cast<const float4*>(xcur)[j];
+      const float cx[4] = {cv.x, cv.y, cv.z, cv.w};
+      f32x16 acc = load16(img + IC3::B1C + hf * 32 + 16 * mo);
+#pragma unroll
+      for (int ks = 0; ks < D / 2; ++ks) {
+        const float bv = hf ? cx[2 * ks + 1] : cx[2 * ks];
+        acc = mfma32(img[IC3::WF1 + (mo * (D / 2) + ks) * 64 + lane], bv, acc);
+      }
+      bf16x8* pcs3 = reinterpret_cast<bf16x8*>(pcsC);                  // [mo 2][q 2][piece 3][lane 64]
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float xb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xb[i] = tanh_fast(acc[8 * q + i]);
+        const P3 mine = split3(xb);
+        bf16x8* dst = pcs3 + ((mo * 2 + q) * 3) * 64 + lane;
+        dst[0] = mine.hi; dst[64] = mine.mid; dst[128] = mine.lo;
+      }
+      __syncthreads();                                                                        // (1)
+      acc = load16(img + IC3::B2C + hf * 32 + 16 * mo);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {     // every k-step's B pieces come back from LDS (this wave's own too): 12 registers live instead of 48
+        const bf16x8* src = pcs3 + (((ks >> 1) * 2 + (ks & 1)) * 3) * 64 + lane;
+        P3 bq; bq.hi = src[0]; bq.mid = src[64]; bq.lo = src[128];
+        acc = mfma_x3(load_wfrag(img + IC3::WF2P, mo, ks, lane), bq, acc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const f32x4* w = reinterpret_cast<const f32x4*>(img + IC3::W3 + hf * 32 + 16 * mo);
+      float accv = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 wv = w[q];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accv = __builtin_fmaf(wv[i], tanh_fast(acc[q * 4 + i]), accv);
+      }
+      accv += xor32(accv);
+      if (hf == 0) hdC[mo * TILE + j] = accv;
+      __syncthreads();                                                                        // (2)
+      if (mo == 0 && hf == 0 && ok) a.value[(size_t)(blockIdx.x * TILE + j) + (size_t)c.nt * step] = (hdC[j] + hdC[TILE + j]) + img[IC3::B3];
     } else {
       // critic (ppo.jl:128) as fp16x2 on two waves: wave 4 + mo owns hidden rows 32·mo … of both layers (the split3 kernel's actor structure)
       const int mo = wave - 4, j = lane & 31, hf = lane >> 5;
@@ -1036,7 +1069,7 @@ int launch_rollout(crl_ppo* h, bool fuse_gae) {
   const bool six = split == 3 || (split == 4 && tiles <= 256);
   if (gemm_x2(h) && six && small) {
     // six waves per tile: the actor's hidden rows over four waves (16x16x32 products), the critic's over two
-    const size_t smem = sizeof(float) * (NetImageA16<2>::SIZE + NetImageX3<4, 1, false>::SIZE + 2 * TILE * 4 + 2 * 2 * 3 * 64 * 2 * 2 + 2 * 2 * 2 * 64 * 4 + 4 * 2 * TILE + 2 * TILE + 2 * 2 * TILE + 4 * 2 * TILE + 4);
+    const size_t smem = sizeof(float) * (NetImageA16<2>::SIZE + NetImageX3<4, 1, false>::SIZE + 2 * TILE * 4 + 2 * 2 * 3 * 64 * 2 * 2 + 2 * 2 * 3 * 64 * 4 + 4 * 2 * TILE + 2 * TILE + 2 * 2 * TILE + 4 * 2 * TILE + 4);
     hipLaunchKernelGGL((rollout_split6_kernel<2>), dim3(tiles), dim3(384), smem, h->stream, a);
   } else if (gemm_x2(h) && (split == 1 || split == 4) && small) {
     // three waves per tile: the actor's hidden rows split over two waves, the critic (fp16x2) on the third
