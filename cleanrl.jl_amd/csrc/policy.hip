@@ -686,8 +686,10 @@ __device__ __forceinline__ void stage_net_a16(float* img, const float* __restric
   for (int idx = tid; idx < A; idx += nthreads) img[I::B3 + idx] = p[P::B3 + idx];
 }
 
+// 128 VGPRs at most: six waves on four SIMDs put two of them on two SIMDs, and 2 x 128 leaves the other half of those register files to the shuffle's leaf blocks
+// (1024 threads = four 56-register waves per SIMD), which otherwise wait for the whole rollout to end and the iteration's first leg gains nothing
 template <int A>
-__global__ void __launch_bounds__(384) rollout_split6_kernel(RolloutArgs a) {
+__global__ void __attribute__((amdgpu_flat_work_group_size(384, 384), amdgpu_waves_per_eu(4, 4))) rollout_split6_kernel(RolloutArgs a) {
   constexpr int D = 4;
   using IA = NetImageA16<A>;
   using IC = NetImageX2<D, 1, false>;
@@ -927,27 +929,21 @@ __global__ void __launch_bounds__(384) rollout_split6_kernel(RolloutArgs a) {
         const float bv = hf ? cx[2 * ks + 1] : cx[2 * ks];
         acc = mfma32(img[IC::WF1 + (mo * (D / 2) + ks) * 64 + lane], bv, acc);
       }
-      P2 mine[2];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         float xb[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) xb[i] = tanh_exp2_arg(acc[8 * q + i], X2_ACT_SCALE);
-        mine[q] = split2(xb);
+        const P2 mine = split2(xb);
         f16x8* dst = pcsC + ((mo * 2 + q) * 2) * 64 + lane;
-        dst[0] = mine[q].hi; dst[64] = mine[q].lo;
+        dst[0] = mine.hi; dst[64] = mine.lo;
       }
       __syncthreads();                                                                        // (1)
-      P2 other[2];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const f16x8* src = pcsC + (((1 - mo) * 2 + q) * 2) * 64 + lane;
-        other[q].hi = src[0]; other[q].lo = src[64];
-      }
       acc = load16(img + IC::B2C + hf * 32 + 16 * mo);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const P2& bq = ((ks >> 1) == mo) ? mine[ks & 1] : other[ks & 1];
+      for (int ks = 0; ks < 4; ++ks) {     // every k-step's B pieces come back from LDS, this wave's own too: the kernel stays inside 128 registers (see the attribute above)
+        const f16x8* src = pcsC + (((ks >> 1) * 2 + (ks & 1)) * 2) * 64 + lane;
+        P2 bq; bq.hi = src[0]; bq.lo = src[64];
         acc = mfma_x2(load_wfrag2(img + IC::WF2H, mo, ks, lane), bq, acc);
       }
       const f32x4* w = reinterpret_cast<const f32x4*>(img + IC::W3 + hf * 32 + 16 * mo);
