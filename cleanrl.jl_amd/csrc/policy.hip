@@ -1060,9 +1060,10 @@ int launch_rollout(crl_ppo* h, bool fuse_gae) {
   const int split = (int)opt(h, OPT_ROLLOUT_SPLIT);
   const bool small = tiles <= (int)opt(h, OPT_ROLLOUT_SPLIT_MAX_TILES);
   a.range_err = h->vfix + 5;
-  // rollout_split = 4 (default): by size — six waves per tile while the grid leaves every CU at most one block (<= 256 tiles = 8192 envs: 2.7 against 3.4 µs per
-  // step; at 512 tiles two six-wave blocks share a CU and it loses, 5.6 against 4.8: profiles/r06_rollout_split6_ab.txt), three waves up to rollout_split_max_tiles
-  const bool six = split == 3 || (split == 4 && tiles <= 256);
+  // rollout_split = 4 (default): by size — six waves per tile wherever the split kernels apply (<= rollout_split_max_tiles = 512 tiles = 16384 envs): 2.6 against
+  // 3.4 µs per step at 4096 / 8192 envs, 4.25 against 4.8 at 16384 (two six-wave blocks per CU: they fit because the kernel stays inside 128 registers);
+  // profiles/r06_rollout_split6_ab.txt. 1 selects the three-wave kernel.
+  const bool six = split == 3 || split == 4;
   if (gemm_x2(h) && six && small) {
     // six waves per tile: the actor's hidden rows over four waves (16x16x32 products), the critic's over two
     const size_t smem = sizeof(float) * (NetImageA16<2>::SIZE + NetImageX3<4, 1, false>::SIZE + 2 * TILE * 4 + 2 * 2 * 3 * 64 * 2 * 2 + 2 * 2 * 3 * 64 * 4 + 4 * 2 * TILE + 2 * TILE + 2 * 2 * TILE + 4 * 2 * TILE + 4);

@@ -47,7 +47,7 @@ static_assert(sizeof(SampleRec) == 64, "SampleRec is one 64-byte record");
 // between calls, is testable in-process and is reported by bench.py. The table (name, default, range) lives in api.cpp.
 enum OptId {
   OPT_GEMM = 0,               // 2 = fp16x2 split products (default), 1 = bf16x3 (the documented fallback flavour)
-  OPT_ROLLOUT_SPLIT,          // small-shard rollout: 4 = by size (default: six waves per tile up to 256 tiles, three up to rollout_split_max_tiles), 3 = six waves, 1 = three, 2 = two, 0 = one wave per tile
+  OPT_ROLLOUT_SPLIT,          // small-shard rollout: 4 = by size (default: six waves per tile up to rollout_split_max_tiles), 3 = six waves, 1 = three, 2 = two, 0 = one wave per tile
   OPT_ROLLOUT_SPLIT_MAX_TILES,// largest shard (in 32-env tiles) the split kernels take
   OPT_ROLLOUT_STAGGER,        // start delay of waves 4-7 of an 8-wave rollout block (units of 1024 clocks)
   OPT_GAE_FUSE,               // 1 = compat-mode GAE rides on the rollout kernel's tail inside crl_ppo_iterate

@@ -222,7 +222,7 @@ int32_t crl_comm_destroy(crl_ppo* h);
  *   gemm                    2 = 64x64 products as fp16x2 split operands (default); 1 = bf16x3 everywhere — the fallback flavour, which
  *                           a launch also takes by itself, per role, when a hidden-layer weight leaves the fp16 window (|w| >= 255)
  *   rollout_split (4)       small-shard rollout kernel, waves per 32-env tile: 4 = by size (default) — six (the actor's hidden rows over four waves on 16x16x32 products,
- *                           the critic's over two: rollout_split6_kernel) for shards of 8192 envs and below, three up to rollout_split_max_tiles; 3 = six, 1 = three, 2 = two, 0 = one
+ *                           the critic's over two: rollout_split6_kernel) for shards up to rollout_split_max_tiles; 3 = six, 1 = three, 2 = two, 0 = one
  *   rollout_split_max_tiles largest shard, in 32-env tiles, the split kernels take (512)
  *   rollout_stagger         start delay of waves 4-7 of an 8-wave rollout block, units of 1024 clocks (6)
  *   gae_fuse                1 = inside crl_ppo_iterate the compat-mode GAE is the tail of the rollout kernel (default), 0 = own launch

@@ -123,7 +123,7 @@ def test_c4_shards_at_full_size_match_the_oracle(crl):
     """BASELINE config 4 — num_envs = 65536 sharded 8192 per GPU over 8 GPUs, one gradient all-reduce per optimiser step
     (ppo.jl:197,250 cadence) — on ONE GPU, shard by shard, at full size: ranks 0, 3 and 7 of the 8-rank job each build
     their handle exactly as `bench.py --gpus 8` does (num_envs = 8192, env_id_offset = 8192·rank, world 8), run one whole iteration
-    (default options ⇒ the six-wave `rollout_split6_kernel` — 8192 envs = 256 tiles — with the fused compat-GAE tail, the blocked shuffle, 16 optimiser
+    (default options ⇒ the six-wave `rollout_split6_kernel` with the fused compat-GAE tail, the blocked shuffle, 16 optimiser
     steps) and are checked against the 65536-env CPU oracle:
       (a) the shard's rollout buffers == envs [8192·r, 8192·(r+1)) of the oracle's 65536-env rollout (global env ids key the RNG):
           actions / observations / rewards / terminals exact under the knot-margin rule, logprob / value / advantages / returns 1e-5;
@@ -146,8 +146,8 @@ def test_c4_shards_at_full_size_match_the_oracle(crl):
         agent = crl.Agent(cfg, env_id_offset=n * r)
         h = agent.handle
         h.comm_init_external(W, r)
-        assert h.get_option("rollout_split") == 4 and n // 32 <= 256 and h.get_option("rollout_split_max_tiles") >= n // 32 and h.get_option("gae_fuse") == 1, \
-            "defaults must select rollout_split6_kernel (rollout_split = 4: by size, six waves up to 256 tiles) with the fused GAE tail for an 8192-env shard"
+        assert h.get_option("rollout_split") == 4 and h.get_option("rollout_split_max_tiles") >= n // 32 and h.get_option("gae_fuse") == 1, \
+            "defaults must select rollout_split6_kernel (rollout_split = 4: by size) with the fused GAE tail for an 8192-env shard"
         params = agent.get_params()
         cfgo, o = oracle_rollout(NT, params)
         sl = slice(n * r, n * (r + 1))
