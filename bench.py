@@ -21,6 +21,10 @@ iteration one more carries the advantage sums of all 16 minibatches.
   --minibatches 1     north_star's "single all-reduce per update epoch" (one optimiser step per epoch, ppo.jl:5)
   --strict-profiles   exit 2 (instead of reporting traffic = null) when the committed PMC summaries were taken with other kernel sources
 
+The default N = 1 run repeats the commanded timed region (exactly K iterations between barrier + synchronize pairs) FIVE times on one handle: `value` / `ms_per_step` are the
+median region, `ms_per_step_runs` lists all five; `clock` carries the shader clock the box sustains under vector load (crl_clock_probe) before and after. Side records on the same line:
+`strict_f32` (24-bit operands), `with_stats_readback`, `configs` = BASELINE configs[1] (c2), [2] (c3), one shard of [3] (shard_8192) — each with its own strict_f32 twin — and [4] (a2c, dqn).
+
 The `roofline` record of the headline prices the dominant kernel (update_x2_kernel, ≈80 % of the iteration) against what PMC shows
 it bound by: vector-instruction ISSUE. achieved = vector-ALU instructions per launch (SQ_INSTS_VALU of the committed PMC pass,
 profiles/<tag>_update_kernel_counts.json, next to the static ISA count of scripts/count_isa.py) ÷ HIP-event launch time; peak = 1 wave64

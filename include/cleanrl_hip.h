@@ -260,6 +260,10 @@ int32_t crl_comm_destroy(crl_ppo* h);
  *   wide_d2_split (1)       wide_fuse = 3 with wide_wgrad_full = 1: the backward kernel hands δ2 to the weight-gradient kernel as the fp16x2 pieces it makes for
  *                           its own product (two f16 planes, one power-of-two scale per sample; the same bytes as the f32 array) and the weight-gradient kernel
  *                           multiplies straight from them (LDS-DMA + transposing LDS reads, no conversion); 0 = δ2 as f32, split again by its reader
+ *   update_tile (0)         update pass of the 4 / 2 / 64 path: 32 = 32-sample tiles (update_x2_kernel), 16 = 16-sample tiles at three waves per SIMD (update16.hpp: one early-exit
+ *                           repair launch redoes a minibatch as bf16x3 when a tile misses the carried weight-gradient scale or a weight leaves the fp16 window; 17 = the same with
+ *                           every tile reporting a miss: test hook), 0 = by launch size — which currently means 32 everywhere: the 16-sample kernel measured slower at every
+ *                           size it was built for (profiles/r06_update_tile16_ab.txt)
  *   fuse_optim (1)          speculative step of the 4 / 2 / 64 path: gradient reduction + ClipNorm + Adam as ONE launch (reduce_optim_kernel; 0 = two launches) — on one
  *                           GPU, and under data parallelism over the peer mailboxes, where the same launch also runs the exchange (reduce -> push -> wait ->
  *                           rank-order sum -> ClipNorm + Adam). Taken only where the launch's whole grid can be resident (checked at crl_ppo_create) and never
