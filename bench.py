@@ -472,13 +472,19 @@ def run_workload(args, wl, world, rank, local_rank, dist, torch, crl, crl_dist, 
     for _ in range(max(1, regions)):
         t0 = time.perf_counter()
         for _ in range(steps):
-            if readback:
-                # the loop as ppo() / train() drive it (cleanrl.jl_amd/ppo.py, julia/CleanRLHip.jl: ppo.jl:147-165,246-248): the 16 "Training
-                # Statistics" records and the episode statistics are read back after EVERY update, which settles the guard window each time
+            if readback == "sync":
+                # the loop as ppo() / train() drove it up to round 5: the 16 "Training Statistics" records and the episode statistics read back
+                # synchronously after EVERY update (ppo.jl:147-165,246-248), which settles the guard window each time
                 h.iterate(1, want_stats=True)
                 h.episode_stats()
+            elif readback:
+                # the loop as ppo() / train() drive it (cleanrl.jl_amd/ppo.py, julia/CleanRLHip.jl): the same records through crl_ppo_iterate_async — update k's
+                # are picked up after update k + 1 has been enqueued; the region ends with crl_ppo_drain
+                h.iterate_async(want_stats=True)
             else:
                 h.iterate(1, want_stats=False)
+        if readback and readback != "sync":
+            h.drain(want_stats=True)
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -800,10 +806,14 @@ def main():
                                  "note": "option gemm = 1: hidden-layer products as bf16x3 split operands (24 significant bits = f32's own), six MFMAs per product"}
         if plain:
             rec = run_workload(args, "cartpole", 1, 0, 0, dist, torch, crl, crl_dist, steps=10, warmup=2, with_gae=False, readback=True)
+            rec_s = run_workload(args, "cartpole", 1, 0, 0, dist, torch, crl, crl_dist, steps=10, warmup=2, with_gae=False, readback="sync")
             out["with_stats_readback"] = {"value": rec["value"], "unit": "env-steps/s", "ms_per_step": rec["ms_per_step"], "steps": 10, "warmup": 2,
-                                          "note": "the loop as ppo() / train() drive it: after every update the 16 loss records and the episode statistics are "
-                                                  "read back (cleanrl.jl_amd/ppo.py, julia/CleanRLHip.jl; ppo.jl:147-165,246-248), which settles the speculation "
-                                                  "guard window every iteration instead of every 8"}
+                                          "synchronous": {"value": rec_s["value"], "ms_per_step": rec_s["ms_per_step"]},
+                                          "note": "the loop as ppo() / train() drive it (cleanrl.jl_amd/ppo.py, julia/CleanRLHip.jl; ppo.jl:147-165,246-248): the 16 loss "
+                                                  "records and the episode statistics of EVERY update reach the host, through crl_ppo_iterate_async — each update's status is "
+                                                  "gathered into a pinned slot on the stream and picked up one update later, so the GPU does not wait for the host; "
+                                                  "`synchronous` = the same records read with crl_ppo_iterate(h, 1, stats) + crl_episode_stats_read after every update "
+                                                  "(what the loop did up to round 5: the guard window settles and the queue drains every iteration)"}
         if plain and not parse_opts(args.opt):
             # the other BASELINE configurations, driver-observed: configs[1] (C2), configs[2] (C3) and the per-GPU share of configs[3]
             # (one 8192-env shard of the 8-GPU job, on this one GPU without the exchange); compact records, full ones: --workload / --total-envs

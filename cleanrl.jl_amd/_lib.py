@@ -45,6 +45,11 @@ class CrlEpisodeStats(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("episodes", "return_sum", "length_sum", "return_max")]
 
 
+class CrlIterationReport(C.Structure):
+    """crl_ppo_iteration_report: whose records crl_ppo_iterate_async / crl_ppo_drain handed back."""
+    _fields_ = [("iteration", C.c_int64), ("episodes", CrlEpisodeStats), ("n_episodes", C.c_int64), ("n_ring", C.c_int32), ("pad", C.c_int32)]
+
+
 # every symbol include/cleanrl_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "crl_version", "crl_last_error", "crl_device_count", "crl_ppo_create", "crl_ppo_destroy", "crl_ppo_param_count",
@@ -58,7 +63,7 @@ EXPORTS = [
     "crl_a2c_read_env", "crl_a2c_read_buffer", "crl_a2c_run_until_update", "crl_a2c_discounted_future_rewards",
     "crl_dqn_create", "crl_dqn_destroy", "crl_dqn_write_params", "crl_dqn_read_params", "crl_dqn_status_read", "crl_dqn_run",
     "crl_dqn_q_values",
-    "crl_make_actor_critic", "crl_ppo_init_params", "crl_a2c_init_params", "crl_dqn_make_nn", "crl_dqn_init_params", "crl_comm_info", "crl_clock_probe", "crl_product_probe",
+    "crl_make_actor_critic", "crl_ppo_init_params", "crl_a2c_init_params", "crl_dqn_make_nn", "crl_dqn_init_params", "crl_comm_info", "crl_clock_probe", "crl_product_probe", "crl_ppo_iterate_async", "crl_ppo_drain",
 ]
 
 DQN_PARAM_COUNT = 10934
@@ -188,6 +193,8 @@ def load():
     L.crl_dqn_init_params.argtypes = [vp, C.c_uint64]
     L.crl_comm_info.argtypes = [C.c_char_p, C.c_size_t, ip]
     L.crl_clock_probe.argtypes = [C.c_int32, C.c_double, dp, dp, dp]
+    L.crl_ppo_iterate_async.argtypes = [vp, C.POINTER(CrlIterationReport), C.POINTER(CrlStats), C.POINTER(CrlEpisodeRecord), C.c_int32]
+    L.crl_ppo_drain.argtypes = [vp, C.POINTER(CrlIterationReport), C.POINTER(CrlStats), C.POINTER(CrlEpisodeRecord), C.c_int32]
     L.crl_product_probe.argtypes = [C.c_int32, C.c_int32, fp, fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, fp, fp]
     for name in EXPORTS:
         if name not in ("crl_version", "crl_last_error"):
@@ -365,6 +372,28 @@ class Handle:
         arr = (CrlStats * n)()
         check(load().crl_ppo_iterate(self._h, n_iters, arr if want_stats else None))
         return [a.as_dict() for a in arr] if want_stats else None
+
+    def _report(self, fn, want_stats):
+        n = self.cfg.update_epochs * self.cfg.num_minibatches
+        cap = getattr(self, "_ring_cap", 0)
+        rep = CrlIterationReport(); arr = (CrlStats * n)(); ring = (CrlEpisodeRecord * max(cap, 1))()
+        check(fn(self._h, C.byref(rep), arr if want_stats else None, ring if cap else None, cap))
+        if rep.iteration < 0:
+            return None
+        recs = sorted((ring[i].step, ring[i].env, ring[i].episode_return, ring[i].episode_length) for i in range(rep.n_ring))
+        return {"iteration": rep.iteration, "stats": [a.as_dict() for a in arr] if want_stats else None,
+                "episodes": {"episodes": rep.episodes.episodes, "return_sum": rep.episodes.return_sum, "length_sum": rep.episodes.length_sum,
+                             "return_max": rep.episodes.return_max},
+                "records": recs, "n_episodes": rep.n_episodes}
+
+    def iterate_async(self, want_stats=True):
+        """crl_ppo_iterate_async: enqueues one iteration and returns the report of the iteration BEFORE it (None on the first call): its loss records,
+        episode statistics and per-episode records (sorted by (step, env) like episode_records()) — read without making the GPU wait for the host."""
+        return self._report(load().crl_ppo_iterate_async, want_stats)
+
+    def drain(self, want_stats=True):
+        """crl_ppo_drain: the report of the last iteration enqueued through iterate_async (None: nothing pending)."""
+        return self._report(load().crl_ppo_drain, want_stats)
 
     @property
     def iteration(self):

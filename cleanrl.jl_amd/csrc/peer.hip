@@ -203,6 +203,10 @@ int peer_next_args(crl_ppo* h, PeerArgs* a, int chunks, size_t floats) {
 }
 
 // Sticky time-out word (read where the other sticky flags are read: crl_sync and the ends of guard windows).
+const uint32_t* peer_err_word(const crl_ppo* h) {
+  const PeerState* s = static_cast<const PeerState*>(h->peer);
+  return (s && s->attached) ? s->err : nullptr;
+}
 int peer_check(crl_ppo* h) {
   PeerState* s = peer_of(h);
   if (!s || !s->attached) return 0;

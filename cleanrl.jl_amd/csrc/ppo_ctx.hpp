@@ -168,6 +168,14 @@ struct crl_ppo {
   // staging for host-pointer calls
   void* stage = nullptr; size_t stage_bytes = 0;
   void* pinned = nullptr; size_t pinned_bytes = 0;
+  // Pipelined read-back (crl_ppo_iterate_async): what a logging host reads after every update — the loss records, the episode statistics, the per-episode ring,
+  // the speculation flag and the error words — is gathered by ONE launch into a device slot at the end of an iteration, copied to pinned host memory on the
+  // stream and fenced by an event; the host picks it up one iteration later, behind the next iteration's launches, so the GPU never waits for the host.
+  char* status_dev[2] = {nullptr, nullptr}; char* status_host[2] = {nullptr, nullptr}; hipEvent_t status_ev[2] = {nullptr, nullptr};
+  size_t status_bytes = 0; int status_ring_cap = -1;
+  int64_t status_iter[2] = {-1, -1};      // iteration whose status a slot holds
+  int64_t staged_last = -1, delivered_last = -1;
+  bool pipelined = false;                  // the replay of a guard window re-stages the status of every iteration it repeats
 
   // RCCL (loaded lazily; world_size 1 = no communicator)
   void* comm = nullptr; int world = 1, rank = 0;
@@ -282,6 +290,7 @@ struct PeerArgs {
 // one flag per chunk): bumps the sequence number like peer_allreduce does; `chunks` flag words are needed
 int peer_next_args(crl_ppo* h, PeerArgs* out, int chunks, size_t floats);
 int peer_check(crl_ppo* h);
+const uint32_t* peer_err_word(const crl_ppo* h);   // device address of the exchange's sticky time-out word (nullptr: no peer exchange)
 int fused_optim_fits(crl_ppo* h, bool* fits);   // update.hip: occupancy of reduce_optim_kernel's grid on this device
 int fused_optim_check(crl_ppo* h);              // update.hip: sticky time-out word of its meeting point
 void peer_destroy(crl_ppo* h);

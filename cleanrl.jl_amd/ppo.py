@@ -145,17 +145,16 @@ def train(agent: Agent, num_updates=None, log_every=1, episode_records=0):
     if h.iteration == 0:
         h.env_reset()
     start_time = time.time()
-    global_step = h.iteration * batch_size
     last_log_step = 0
-    for _ in range(num_updates):
-        stats = h.iterate(1, want_stats=True)
-        global_step += batch_size
-        ep = h.episode_stats()
-        steps_per_sec = int(global_step / max(time.time() - start_time, 1e-9))
+
+    def emit(rep):
+        """The records of one update, in the reference's order: its episodes (ppo.jl:147-165), then its 16 minibatches (ppo.jl:246-248)."""
+        nonlocal last_log_step
+        base = rep["iteration"] * batch_size
+        global_step = base + batch_size
+        ep = rep["episodes"]
         if episode_records:
-            recs, _ = h.episode_records()
-            base = global_step - batch_size
-            for step, env, ret, length in recs:
+            for step, env, ret, length in rep["records"]:
                 gs = base + (step + 1) * cfg.num_envs                              # ppo.jl:124 global_step += num_envs
                 inc = 0 if last_log_step == 0 else gs - last_log_step
                 log.info("Episode Statistics", extra={"crl": dict(
@@ -166,15 +165,25 @@ def train(agent: Agent, num_updates=None, log_every=1, episode_records=0):
             inc = 0 if last_log_step == 0 else global_step - last_log_step
             log.info("Episode Statistics", extra={"crl": dict(
                 episode_return=ep["return_sum"] / ep["episodes"], episode_length=ep["length_sum"] / ep["episodes"],
-                global_step=global_step, steps_per_sec=steps_per_sec, log_step_increment=inc)})
+                global_step=global_step, steps_per_sec=int(global_step / max(time.time() - start_time, 1e-9)), log_step_increment=inc)})
             last_log_step = global_step
         if log_every:
-            for s in stats:
+            for s in rep["stats"]:
                 inc = 0 if last_log_step == 0 else global_step - last_log_step
                 log.info("Training Statistics", extra={"crl": dict(
                     loss=s["loss"], pg_loss=s["pg_loss"], v_loss=s["v_loss"], entropy_loss=s["entropy_loss"],
                     log_step_increment=inc)})
                 last_log_step = global_step
+
+    # Pipelined read-back (crl_ppo_iterate_async): update k's records are picked up after update k + 1 has been enqueued, so the GPU never idles while the host
+    # logs; the record stream is the same, one update late, and crl_ppo_drain hands over the last one.
+    for _ in range(num_updates):
+        rep = h.iterate_async(want_stats=bool(log_every))
+        if rep is not None:
+            emit(rep)
+    rep = h.drain(want_stats=bool(log_every))
+    if rep is not None:
+        emit(rep)
     return agent
 
 

@@ -184,6 +184,24 @@ int32_t crl_ppo_update_minibatch(crl_ppo* h, int32_t mb, double eta, int32_t app
  * update_epochs*num_minibatches records of the LAST iteration. */
 int32_t crl_ppo_iterate(crl_ppo* h, int32_t n_iters, crl_ppo_stats* stats);
 int32_t crl_ppo_iteration(const crl_ppo* h, int64_t* it);
+/* The same loop body for a host that LOGS every update — ppo.jl:147-165 ("Episode Statistics") and :246-248 ("Training Statistics") — without making the GPU wait for
+ * it. crl_ppo_iterate_async enqueues ONE iteration and hands back the records of the iteration BEFORE it (prev->iteration = its 0-based index; -1 on the first
+ * call): at the end of every iteration one launch gathers its update_epochs * num_minibatches loss records, its episode statistics, its per-episode ring
+ * (crl_episode_ring_enable; prev_ring receives up to max_ring records in arrival order), the value-loss speculation flag and the error words into a slot that
+ * travels to pinned host memory on the stream; the host picks it up one call later, behind the launches of the next iteration. A host loop logs one iteration late
+ * — the record stream (names, keys, order, global_step) is the reference's — and ends with crl_ppo_drain, which returns the last iteration's records (iteration =
+ * -1: nothing pending). A failed speculation seen in a slot repeats the guard window exactly before the records are handed out, like every other read-back.
+ * Measured against crl_ppo_iterate(h, 1, stats) + crl_episode_stats_read per update: 10.18 -> 9.9 ms per iteration at 65536 envs, 2.04 -> 1.86 at 8192
+ * (scripts/readback_cost.py). prev_stats may be NULL; the blocked shuffle limits update_epochs to 8 here. */
+typedef struct crl_ppo_iteration_report {
+  int64_t iteration;            /* which iteration the records belong to, -1 = none */
+  crl_episode_stats episodes;   /* ppo.jl:147-162 aggregated over its rollout */
+  int64_t n_episodes;           /* episodes that ended in its rollout */
+  int32_t n_ring;               /* per-episode records copied to prev_ring */
+  int32_t pad;
+} crl_ppo_iteration_report;
+int32_t crl_ppo_iterate_async(crl_ppo* h, crl_ppo_iteration_report* prev, crl_ppo_stats* prev_stats, crl_episode_record* prev_ring, int32_t max_ring);
+int32_t crl_ppo_drain(crl_ppo* h, crl_ppo_iteration_report* last, crl_ppo_stats* last_stats, crl_episode_record* last_ring, int32_t max_ring);
 /* how many iterations had their update phase re-run with the exact value-loss pass under data parallelism: the fused
  * kernels speculate on u = mean(v - R^2) <= 0 (ppo.jl:232-237); with an RCCL communicator a failed speculation restores the
  * parameters / Adam state of the iteration's start and repeats its optimiser steps exactly (two more small all-reduces each) */

@@ -51,6 +51,9 @@ end
 struct CrlEpisodeRecord    # crl_episode_record: one per finished episode (ppo.jl:147-162)
   episode_return::Float32; episode_length::Int32; env::Int32; step::Int32
 end
+struct CrlIterationReport  # crl_ppo_iteration_report: whose records crl_ppo_iterate_async / crl_ppo_drain handed back
+  iteration::Int64; episodes::CrlEpisodeStats; n_episodes::Int64; n_ring::Int32; pad::Int32
+end
 
 check(rc::Int32) = rc == 0 || error(unsafe_string(ccall((:crl_last_error, libcrl), Cstring, ())))
 
@@ -213,32 +216,27 @@ function ppo(config::PPOConfig=PPOConfig(); device::Integer=0, params::Union{Not
   batch_size = config.num_steps * config.num_envs * world          # ppo.jl:89 over the whole job
   num_updates = config.total_timesteps ÷ batch_size                # ppo.jl:91
   nstats = config.update_epochs * config.num_minibatches
-  stats = Vector{CrlStats}(undef, nstats); ep = Ref{CrlEpisodeStats}()
-  recs = Vector{CrlEpisodeRecord}(undef, max(episode_records, 1)); n_stored = Ref{Int32}(0); n_episodes = Ref{Int64}(0)
-  global_step = 0; last_log_step = 0; start_time = time()
-  for update in 1:num_updates
-    GC.@preserve stats check(ccall((:crl_ppo_iterate, libcrl), Int32, (Ptr{Cvoid}, Int32, Ptr{CrlStats}), agent.h, 1, stats))
-    base = global_step
-    global_step += batch_size
+  stats = Vector{CrlStats}(undef, nstats)
+  recs = Vector{CrlEpisodeRecord}(undef, max(episode_records, 1)); rep = Ref{CrlIterationReport}()
+  last_log_step = 0; start_time = time()
+  # the records of one update, in the reference's order: its episodes (ppo.jl:147-165), then its minibatches (ppo.jl:246-248)
+  function emit(r::CrlIterationReport)
+    base = r.iteration * batch_size
+    global_step = base + batch_size
     if episode_records > 0
-      GC.@preserve recs check(ccall((:crl_episode_ring_read, libcrl), Int32, (Ptr{Cvoid}, Ptr{CrlEpisodeRecord}, Int32, Ref{Int32}, Ref{Int64}),
-                                    agent.h, recs, episode_records, n_stored, n_episodes))
-      for r in sort!(recs[1:n_stored[]]; by = r -> (r.step, r.env))      # the reference's order
-        gs = base + (r.step + 1) * config.num_envs * world                # ppo.jl:124 global_step += num_envs per step
+      for e in sort!(recs[1:r.n_ring]; by = x -> (x.step, x.env))          # the reference's order: step by step, done envs ascending
+        gs = base + (e.step + 1) * config.num_envs * world                # ppo.jl:124 global_step += num_envs per step
         steps_per_sec = trunc(gs / (time() - start_time))
         log_step_inc = last_log_step == 0 ? 0 : gs - last_log_step
-        @info "Episode Statistics" episode_return = r.episode_return episode_length = r.episode_length global_step = gs steps_per_sec log_step_increment = log_step_inc
+        @info "Episode Statistics" episode_return = e.episode_return episode_length = e.episode_length global_step = gs steps_per_sec log_step_increment = log_step_inc
         last_log_step = gs
       end
-    else
-      check(ccall((:crl_episode_stats_read, libcrl), Int32, (Ptr{Cvoid}, Ref{CrlEpisodeStats}), agent.h, ep))
-      if ep[].episodes > 0
-        steps_per_sec = trunc(global_step / (time() - start_time))
-        episode_return = ep[].return_sum / ep[].episodes; episode_length = ep[].length_sum / ep[].episodes
-        log_step_inc = last_log_step == 0 ? 0 : global_step - last_log_step
-        @info "Episode Statistics" episode_return episode_length global_step steps_per_sec log_step_increment = log_step_inc
-        last_log_step = global_step
-      end
+    elseif r.episodes.episodes > 0
+      steps_per_sec = trunc(global_step / (time() - start_time))
+      episode_return = r.episodes.return_sum / r.episodes.episodes; episode_length = r.episodes.length_sum / r.episodes.episodes
+      log_step_inc = last_log_step == 0 ? 0 : global_step - last_log_step
+      @info "Episode Statistics" episode_return episode_length global_step steps_per_sec log_step_increment = log_step_inc
+      last_log_step = global_step
     end
     for s in stats
       log_step_inc = last_log_step == 0 ? 0 : global_step - last_log_step
@@ -246,6 +244,16 @@ function ppo(config::PPOConfig=PPOConfig(); device::Integer=0, params::Union{Not
       last_log_step = global_step
     end
   end
+  # Pipelined read-back (crl_ppo_iterate_async): update k's records are handed over after update k + 1 has been enqueued, so the GPU never waits while Julia
+  # logs; the record stream is the reference's, one update late, and crl_ppo_drain hands over the last one.
+  for update in 1:num_updates
+    GC.@preserve stats recs check(ccall((:crl_ppo_iterate_async, libcrl), Int32, (Ptr{Cvoid}, Ref{CrlIterationReport}, Ptr{CrlStats}, Ptr{CrlEpisodeRecord}, Int32),
+                                        agent.h, rep, stats, recs, episode_records))
+    rep[].iteration >= 0 && emit(rep[])
+  end
+  GC.@preserve stats recs check(ccall((:crl_ppo_drain, libcrl), Int32, (Ptr{Cvoid}, Ref{CrlIterationReport}, Ptr{CrlStats}, Ptr{CrlEpisodeRecord}, Int32),
+                                      agent.h, rep, stats, recs, episode_records))
+  rep[].iteration >= 0 && emit(rep[])
   agent
 end
 

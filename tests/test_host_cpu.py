@@ -112,8 +112,8 @@ int main(void) {
   crl_ppo_config cfg; memset(&cfg, 0, sizeof cfg);
   if (crl_ppo_create(&cfg, 0, &h) == 0) return 4;         /* an all-zero config must be rejected, with a message */
   if (strlen(crl_last_error()) == 0) return 5;
-  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(crl_ppo_config), sizeof(crl_ppo_stats), sizeof(crl_episode_stats),
-         sizeof(crl_episode_record), sizeof(crl_a2c_config), sizeof(crl_dqn_config), sizeof(crl_dqn_status));
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(crl_ppo_config), sizeof(crl_ppo_stats), sizeof(crl_episode_stats),
+         sizeof(crl_episode_record), sizeof(crl_a2c_config), sizeof(crl_dqn_config), sizeof(crl_dqn_status), sizeof(crl_ppo_iteration_report));
   return 0;
 }
 '''
@@ -137,8 +137,8 @@ def test_header_is_c99_and_a_c_program_links_the_library(crl, tmp_path):
     sizes = [int(x) for x in out.stdout.split()]
     L = crl._lib
     assert sizes == [C.sizeof(L.CrlConfig), C.sizeof(L.CrlStats), C.sizeof(L.CrlEpisodeStats), C.sizeof(L.CrlEpisodeRecord),
-                     C.sizeof(L.CrlA2CConfig), C.sizeof(L.CrlDQNConfig), C.sizeof(L.CrlDQNStatus)], sizes
-    assert sizes[:1] == [104] and sizes[4] == 40 and sizes[5] == 112
+                     C.sizeof(L.CrlA2CConfig), C.sizeof(L.CrlDQNConfig), C.sizeof(L.CrlDQNStatus), C.sizeof(L.CrlIterationReport)], sizes
+    assert sizes[:1] == [104] and sizes[4] == 40 and sizes[5] == 112 and sizes[7] == 56
 
 
 def test_a2c_and_dqn_config_mirrors_follow_the_header(crl):
@@ -160,7 +160,8 @@ def test_julia_shell_structs_and_symbols_follow_the_header(crl):
     jl = open(os.path.join(ROOT, "julia", "CleanRLHip.jl")).read()
     L = crl._lib
     for jname, mirror in (("CrlConfig", L.CrlConfig), ("CrlStats", L.CrlStats), ("CrlEpisodeStats", L.CrlEpisodeStats),
-                          ("CrlEpisodeRecord", L.CrlEpisodeRecord), ("CrlA2CConfig", L.CrlA2CConfig), ("CrlDQNConfig", L.CrlDQNConfig)):
+                          ("CrlEpisodeRecord", L.CrlEpisodeRecord), ("CrlA2CConfig", L.CrlA2CConfig), ("CrlDQNConfig", L.CrlDQNConfig),
+                          ("CrlIterationReport", L.CrlIterationReport)):
         m = re.search(r"struct %s\b(.*?)\bend" % jname, jl, re.S)
         assert m, jname
         body = re.sub(r"#.*", "", m.group(1))
@@ -168,7 +169,7 @@ def test_julia_shell_structs_and_symbols_follow_the_header(crl):
         assert names == [n for n, _ in mirror._fields_], (jname, names)
     called = set(re.findall(r"ccall\(\(:(crl_[a-z_0-9]+),", jl))
     assert called and called <= set(L.EXPORTS), called - set(L.EXPORTS)
-    for must in ("crl_comm_init", "crl_comm_unique_id", "crl_episode_ring_enable", "crl_episode_ring_read", "crl_dqn_run", "crl_dqn_q_values",
+    for must in ("crl_comm_init", "crl_comm_unique_id", "crl_episode_ring_enable", "crl_ppo_iterate_async", "crl_ppo_drain", "crl_dqn_run", "crl_dqn_q_values",
                  "crl_ppo_set_option", "crl_ppo_get_option", "crl_comm_destroy"):
         assert must in called, must
     assert "shuffle_mode::Integer=2" in jl     # exact blocked Fisher-Yates by default, like the ctypes mirror
@@ -223,6 +224,9 @@ def test_julia_shell_cannot_train_a_dead_network(crl):
     m = re.search(r"if params === nothing\n\s+init_params!\(agent, init_seed\).*?\n\s+else\n(.*?)\n\s+end", ppo, re.S)
     assert m and "set_params!(agent, params)" in m.group(1)
     assert ppo.index("init_params!(agent, init_seed)") < ppo.index(":crl_ppo_iterate")
+    # the loop is the pipelined one: every iterate_async is followed by a drain, and the records of an update are emitted from ITS report (iteration index), not from the loop counter
+    assert ppo.count(":crl_ppo_iterate_async") == 1 and ppo.count(":crl_ppo_drain") == 1 and ppo.index(":crl_ppo_iterate_async") < ppo.index(":crl_ppo_drain")
+    assert "base = r.iteration * batch_size" in ppo and ppo.count("rep[].iteration >= 0 && emit(rep[])") == 2
     assert "crl_ppo_init_params" in _jl_function(jl + "\nend\n", "init_params!(a::Agent")
     # a2c / dqn: same rule (they used to demand `params`; now the reference's default call works and still cannot reach zeros)
     a2c = _jl_function(jl, "function a2c(config;")
