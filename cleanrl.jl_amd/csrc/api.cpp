@@ -951,7 +951,7 @@ static int deliver_status(crl_ppo* h, int64_t k, crl_ppo_iteration_report* rep, 
   CRL_HIP_CHECK(hipEventSynchronize(h->status_ev[s]));
   double sticky = 0.0;
   std::memcpy(&sticky, h->status_host[s] + ST_OFF_STICKY, 8);
-  if (sticky != 0.0) {
+  if (sticky != 0.0 && guard_on(h) && h->window_count > 0) {   // (the layer-wise path computes the exact value loss in line: its flag is informational)
     // a speculation failed inside the open guard window: the window is repeated exactly — every repeated iteration re-stages its slot — and the slot is read again
     if (settle(h)) return 1;
     CRL_HIP_CHECK(hipStreamSynchronize(h->stream));
