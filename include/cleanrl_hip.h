@@ -191,7 +191,7 @@ int32_t crl_ppo_iteration(const crl_ppo* h, int64_t* it);
  * travels to pinned host memory on the stream; the host picks it up one call later, behind the launches of the next iteration. A host loop logs one iteration late
  * — the record stream (names, keys, order, global_step) is the reference's — and ends with crl_ppo_drain, which returns the last iteration's records (iteration =
  * -1: nothing pending). A failed speculation seen in a slot repeats the guard window exactly before the records are handed out, like every other read-back.
- * Measured against crl_ppo_iterate(h, 1, stats) + crl_episode_stats_read per update: 10.18 -> 9.9 ms per iteration at 65536 envs, 2.04 -> 1.86 at 8192
+ * Measured against crl_ppo_iterate(h, 1, stats) + crl_episode_stats_read per update: 10.45 -> 10.21 ms per iteration at 65536 envs, 2.04 -> 1.86 at 8192, 1.65 -> 1.45 at 4096
  * (scripts/readback_cost.py). prev_stats may be NULL; the blocked shuffle limits update_epochs to 8 here. */
 typedef struct crl_ppo_iteration_report {
   int64_t iteration;            /* which iteration the records belong to, -1 = none */
