@@ -25,7 +25,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr float X2_ACT_SCALE = 16384.0f;          // 2^14 on tanh outputs
-constexpr float TWO_LOG2E = 2.8853900817779268f;  // 2·log2(e): tanh(x) = 1 − 2/(2^(TWO_LOG2E·x) + 1)
 constexpr float X2_W_SCALE = 256.0f;              // 2^8 on weights
 constexpr float X2_W_LIMIT = 255.0f;              // |w|·2^8 must stay below the largest half (65504)
 constexpr float X2_FWD_UNSCALE = 1.0f / (16384.0f * 256.0f);
@@ -153,21 +152,6 @@ __device__ __forceinline__ void dense64_x2(const float* wimg, const f32x16 (&xs)
     acc1 = mfma_x2(load_wfrag2(wimg, 1, ks, lane), b, acc1);
   }
 }
-
-// The activation of the fp16x2 update kernel: S·tanh(x·c) = S − 2S / (2^(x·pre) + 1) with pre = 2·log2(e)·c — five
-// instructions (v_mul, v_exp_f32, v_add, v_rcp_f32, v_fma) instead of the thirteen of the rational tanh_fast (networks.jl:6),
-// which were 40 % of the kernel's VALU instructions (the kernel is VALU-issue-bound: §3 of DESIGN.md). Both approximate tanh:
-// the rational form to a few ulp relative, this one to ≈1e-7 ABSOLUTE (v_exp_f32 / v_rcp_f32 are 1 ulp; 1 − 2r cancels for
-// small |x|), which is the rounding unit of an activation in (−1, 1) anyway. Measured against the oracle (which evaluates the
-// reference's rational form): gradients 1.16e-6 vs 1.12e-6 relative L2, parameters after three iterations 3e-8 vs 2e-8
-// (profiles/r02_parity_margins.json) — far inside the 1e-5 bar. Saturation needs no clamp: 2^(+big) = inf → S, 2^(−big) = 0 → −S.
-// The rollout keeps tanh_fast: action indices there are bit-compared with the oracle.
-__device__ __forceinline__ float tanh_exp2_arg(float t, float S) {   // t = 2·log2(e)·x already
-  const float e = __builtin_amdgcn_exp2f(t);
-  const float r = __builtin_amdgcn_rcpf(e + 1.0f);
-  return __builtin_fmaf(-2.0f * S, r, S);
-}
-__device__ __forceinline__ float tanh_exp2(float x, float pre, float S) { return tanh_exp2_arg(x * pre, S); }
 
 // Forward of one network for a 32-sample tile: h1s = 2^14·h1 (what the next product and the backward pass consume), h2 and
 // the head outputs unscaled

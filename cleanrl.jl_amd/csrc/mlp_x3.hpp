@@ -15,6 +15,24 @@ namespace crl {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+constexpr float TWO_LOG2E = 2.8853900817779268f;  // 2·log2(e): tanh(x) = 1 − 2/(2^(TWO_LOG2E·x) + 1)
+// The activation of the update kernels (fp16x2, and since round 6 the bf16x3 flavour too — the operand width of the products is what `gemm = 1` is about, not the
+// tanh approximation; the rollout's actor keeps the reference's rational tanh_fast because its logits decide action indices): S·tanh(x·c) = S − 2S / (2^(x·pre) + 1) with pre = 2·log2(e)·c — five
+// instructions (v_mul, v_exp_f32, v_add, v_rcp_f32, v_fma) instead of the thirteen of the rational tanh_fast (networks.jl:6),
+// which were 40 % of the kernel's VALU instructions (the kernel is VALU-issue-bound: §3 of DESIGN.md). Both approximate tanh:
+// the rational form to a few ulp relative, this one to ≈1e-7 ABSOLUTE (v_exp_f32 / v_rcp_f32 are 1 ulp; 1 − 2r cancels for
+// small |x|), which is the rounding unit of an activation in (−1, 1) anyway. Measured against the oracle (which evaluates the
+// reference's rational form): gradients 1.16e-6 vs 1.12e-6 relative L2, parameters after three iterations 3e-8 vs 2e-8
+// (profiles/r02_parity_margins.json) — far inside the 1e-5 bar. Saturation needs no clamp: 2^(+big) = inf → S, 2^(−big) = 0 → −S.
+// The rollout keeps tanh_fast: action indices there are bit-compared with the oracle.
+__device__ __forceinline__ float tanh_exp2_arg(float t, float S) {   // t = 2·log2(e)·x already
+  const float e = __builtin_amdgcn_exp2f(t);
+  const float r = __builtin_amdgcn_rcpf(e + 1.0f);
+  return __builtin_fmaf(-2.0f * S, r, S);
+}
+__device__ __forceinline__ float tanh_exp2(float x, float pre, float S) { return tanh_exp2_arg(x * pre, S); }
+
+
 struct P3 { bf16x8 hi, mid, lo; };
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -149,7 +167,9 @@ __device__ __forceinline__ void dense64_x3(const float* wimg, const f32x16 (&x)[
 }
 
 // Forward of one network for a 32-sample tile (same contract as mlp_forward in common.hpp)
-// DBG (timing experiments only, CRL_ABLATE builds): bit 2 = cheap activation instead of tanh_fast, bit 6 = no layer-2 MFMAs
+// DBG: bit 7 (128) = the exp2-based activation of tanh_exp2 instead of the rational tanh_fast — what the UPDATE pass uses in every flavour (5 vector
+// instructions per element instead of 13; update_x3_kernel 0.81 -> 0.7x ms per launch); timing experiments only (CRL_ABLATE builds): bit 2 = cheap
+// activation instead of tanh_fast, bit 6 = no layer-2 MFMAs
 template <int D, int NOUT, bool BWD, int DBG = 0>
 __device__ __forceinline__ void mlp_forward_x3(const float* img, const float (&x)[D], f32x16 (&h1)[2], f32x16 (&h2)[2],
                                                float (&out)[NOUT], int lane) {
@@ -167,6 +187,7 @@ __device__ __forceinline__ void mlp_forward_x3(const float* img, const float (&x
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     if constexpr (DBG & 4) { h1[0][r] = a0[r] * 0.5f; h1[1][r] = a1[r] * 0.5f; }
+    else if constexpr (DBG & 128) { h1[0][r] = tanh_exp2(a0[r], TWO_LOG2E, 1.0f); h1[1][r] = tanh_exp2(a1[r], TWO_LOG2E, 1.0f); }
     else { h1[0][r] = tanh_fast(a0[r]); h1[1][r] = tanh_fast(a1[r]); }
   }
   // layer 2 on the bf16 pipe
@@ -179,6 +200,7 @@ __device__ __forceinline__ void mlp_forward_x3(const float* img, const float (&x
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     if constexpr (DBG & 4) { h2[0][r] = a0[r] * 0.5f; h2[1][r] = a1[r] * 0.5f; }
+    else if constexpr (DBG & 128) { h2[0][r] = tanh_exp2(a0[r], TWO_LOG2E, 1.0f); h2[1][r] = tanh_exp2(a1[r], TWO_LOG2E, 1.0f); }
     else { h2[0][r] = tanh_fast(a0[r]); h2[1][r] = tanh_fast(a1[r]); }
   }
   // head on VALU

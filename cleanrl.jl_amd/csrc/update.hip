@@ -313,7 +313,7 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
     float* xs = T + 64 * TSTRIDE;
     float* d3s = xs + TILE * D;
     if constexpr (X2) mlp_forward_x2<D, NOUT>(img, x, h1, h2, out, lane);   // h1 = 2^14·tanh(…) from here on
-    else if constexpr (X3) mlp_forward_x3<D, NOUT, true, ABL>(img, x, h1, h2, out, lane);
+    else if constexpr (X3) mlp_forward_x3<D, NOUT, true, ABL | 128>(img, x, h1, h2, out, lane);   // the update pass's activation is the exp2 form in every flavour (mlp_x3.hpp)
     else mlp_forward<D, NOUT, true>(img, x, h1, h2, out, lane);
     CRL_TS(2);
 
