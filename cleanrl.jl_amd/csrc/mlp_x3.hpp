@@ -16,8 +16,9 @@ namespace crl {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr float TWO_LOG2E = 2.8853900817779268f;  // 2·log2(e): tanh(x) = 1 − 2/(2^(TWO_LOG2E·x) + 1)
-// The activation of the update kernels (fp16x2, and since round 6 the bf16x3 flavour too — the operand width of the products is what `gemm = 1` is about, not the
-// tanh approximation; the rollout's actor keeps the reference's rational tanh_fast because its logits decide action indices): S·tanh(x·c) = S − 2S / (2^(x·pre) + 1) with pre = 2·log2(e)·c — five
+// The activation of the update kernels (fp16x2, and since round 6 update_x3_kernel too — the operand width of the products is what `gemm = 1` is about, not the
+// tanh approximation; the rollout's actor keeps the reference's rational tanh_fast because its logits decide action indices, the bf16x3 fallbacks because they run
+// when weights are extreme): S·tanh(x·c) = S − 2S / (2^(x·pre) + 1) with pre = 2·log2(e)·c — five
 // instructions (v_mul, v_exp_f32, v_add, v_rcp_f32, v_fma) instead of the thirteen of the rational tanh_fast (networks.jl:6),
 // which were 40 % of the kernel's VALU instructions (the kernel is VALU-issue-bound: §3 of DESIGN.md). Both approximate tanh:
 // the rational form to a few ulp relative, this one to ≈1e-7 ABSOLUTE (v_exp_f32 / v_rcp_f32 are 1 ulp; 1 − 2r cancels for
@@ -167,8 +168,8 @@ __device__ __forceinline__ void dense64_x3(const float* wimg, const f32x16 (&x)[
 }
 
 // Forward of one network for a 32-sample tile (same contract as mlp_forward in common.hpp)
-// DBG: bit 7 (128) = the exp2-based activation of tanh_exp2 instead of the rational tanh_fast — what the UPDATE pass uses in every flavour (5 vector
-// instructions per element instead of 13; update_x3_kernel 0.81 -> 0.7x ms per launch); timing experiments only (CRL_ABLATE builds): bit 2 = cheap
+// DBG: bit 7 (128) = the exp2-based activation of tanh_exp2 instead of the rational tanh_fast — what update_x3_kernel (option gemm = 1) uses, like the fp16x2
+// update pass (5 vector instructions per element instead of 13: 0.81 -> 0.73 ms per launch); timing experiments only (CRL_ABLATE builds): bit 2 = cheap
 // activation instead of tanh_fast, bit 6 = no layer-2 MFMAs
 template <int D, int NOUT, bool BWD, int DBG = 0>
 __device__ __forceinline__ void mlp_forward_x3(const float* img, const float (&x)[D], f32x16 (&h1)[2], f32x16 (&h2)[2],

@@ -313,7 +313,7 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
     float* xs = T + 64 * TSTRIDE;
     float* d3s = xs + TILE * D;
     if constexpr (X2) mlp_forward_x2<D, NOUT>(img, x, h1, h2, out, lane);   // h1 = 2^14·tanh(…) from here on
-    else if constexpr (X3) mlp_forward_x3<D, NOUT, true, ABL | 128>(img, x, h1, h2, out, lane);   // the update pass's activation is the exp2 form in every flavour (mlp_x3.hpp)
+    else if constexpr (X3) mlp_forward_x3<D, NOUT, true, ABL>(img, x, h1, h2, out, lane);   // ABL bit 128 (update_x3_kernel): the exp2 activation (mlp_x3.hpp)
     else mlp_forward<D, NOUT, true>(img, x, h1, h2, out, lane);
     CRL_TS(2);
 
@@ -756,8 +756,13 @@ __global__ void __launch_bounds__(512, 2) update_x3_kernel(UpdateArgs a) {
   if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= 4) {
     for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
   }
-  if ((int)blockIdx.x < a.nblk[0]) update_role<D, A, 0, false, true, 8>(a, blockIdx.x, smem, smem + NetImageX3<D, A, true>::SIZE);
-  else update_role<D, A, 1, false, true, 8>(a, blockIdx.x - a.nblk[0], smem, smem + NetImageX3<D, 1, true>::SIZE);
+  // Option gemm = 1 (bench.py `strict_f32`: 24-bit operands by construction) with the update pass's exp2 activation, like the fp16x2 default — the option is about the
+  // operand width of the products, not about which approximation of tanh runs: 0.81 -> 0.73 ms per launch at M = 2,097,152, parity margins unchanged
+  // (profiles/r06_parity_margins.json). The bf16x3 FALLBACKS below (a weight outside the fp16 window, a weight-gradient scale miss) keep NNlib's rational tanh_fast: they
+  // run exactly when weights are extreme and units saturate, where 1 - h² of the two approximations differs in relative terms
+  // (test_options_are_validated_and_fallback_is_automatic: a weight of 300).
+  if ((int)blockIdx.x < a.nblk[0]) update_role<D, A, 0, false, true, 8, 128>(a, blockIdx.x, smem, smem + NetImageX3<D, A, true>::SIZE);
+  else update_role<D, A, 1, false, true, 8, 128>(a, blockIdx.x - a.nblk[0], smem, smem + NetImageX3<D, 1, true>::SIZE);
 }
 // After update_t16_kernel (update16.hpp): nothing unless a tile of that launch did not fit the carried weight-gradient scale (or a weight left the fp16
 // window) — then the whole minibatch is recomputed on bf16x3 (no range limits) into the same partial buffers, before the reduce reads them.
