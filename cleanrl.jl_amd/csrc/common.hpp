@@ -54,6 +54,17 @@ __device__ __forceinline__ double u53(u32x4 o) {
 }
 
 __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
+// v + xor32(v) and max(v, xor32(v)) without the LDS crossbar: v_permlane32_swap_b32 (gfx950) swaps the upper half of its first operand with the lower half of
+// its second, so two copies of v come back as {lower, lower} and {upper, upper} — a vector instruction, where __shfl_xor is a ds_bpermute_b32 with an lgkmcnt
+// round trip. Same bits as the shuffle form (lower + upper in both halves). Inline asm: with __builtin_amdgcn_permlane32_swap this compiler (ROCm 7.2) hands out
+// the FIRST result for both elements of the returned pair (r[0] + r[1] compiles to 2·r[0]).
+__device__ __forceinline__ void swap32(float v, float& lo, float& hi) {
+  unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b));
+  lo = __builtin_bit_cast(float, a); hi = __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float add32(float v) { float lo, hi; swap32(v, lo, hi); return lo + hi; }
+__device__ __forceinline__ float max32(float v) { float lo, hi; swap32(v, lo, hi); return __builtin_fmaxf(lo, hi); }
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

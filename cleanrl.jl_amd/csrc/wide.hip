@@ -1736,8 +1736,11 @@ struct WStepArgs {
   uint64_t iteration; int step;
 };
 
-// one env, one step; the episode statistics of a finished episode are added to the caller's running sums
-__device__ __forceinline__ void wide_step_env(const WStepArgs& a, int e, int step, double& st_n, double& st_ret, double& st_len, double& st_max) {
+// one env, one step; the episode statistics of a finished episode are added to the caller's running sums. zreg: the env's logits when the caller holds them
+// in registers (else they come from a.Z); xout: receives the env's next observation (16 floats, zero beyond obs_dim) besides cur_obs; a.V may be null (the
+// caller fills the value buffer later: wide_rs_rollout_kernel)
+__device__ __forceinline__ void wide_step_env(const WStepArgs& a, int e, int step, double& st_n, double& st_ret, double& st_len, double& st_max,
+                                              const float* zreg = nullptr, float* xout = nullptr) {
   const DevCfg& c = a.c;
   const int D = c.D, A = c.A;
   const uint32_t gid = c.env_id_offset + (uint32_t)e;
@@ -1745,7 +1748,10 @@ __device__ __forceinline__ void wide_step_env(const WStepArgs& a, int e, int ste
   const size_t b = (size_t)e + (size_t)c.nt * step;
   int ep_len = a.ep_length[e] + 1;                                   // ppo.jl:125
   float z[AMAX], p[AMAX], lp[AMAX];
-  load_logits(a.Z, a.A8, A, (size_t)e, z);
+  if (zreg) {
+#pragma unroll
+    for (int i = 0; i < AMAX; ++i) z[i] = (i < A && i < 8) ? zreg[i & 7] : 0.0f;
+  } else load_logits(a.Z, a.A8, A, (size_t)e, z);
   softmax_rt(z, A, p, lp);                                          // ppo.jl:127 get_action
   const double u = u53(philox_env(c.seed, gid, gstep, 0));
   const int act = sample_rt(p, A, u);
@@ -1754,26 +1760,42 @@ __device__ __forceinline__ void wide_step_env(const WStepArgs& a, int e, int ste
   float* es = a.env_state + (size_t)D * e;
   float* ob = a.obs + b * (size_t)D;
   for (int i = 0; i < D; ++i) ob[i] = co[i];                        // ppo.jl:133-140 Buffer.add!
-  a.action[b] = act; a.logprob[b] = lpa; a.terminal[b] = a.next_done[e]; a.value[b] = a.V[e];
+  a.action[b] = act; a.logprob[b] = lpa; a.terminal[b] = a.next_done[e]; if (a.V) a.value[b] = a.V[e];
   bool done; float rew;
   if (c.env_kind == CRL_ENV_CARTPOLE) {
     float s[4] = {es[0], es[1], es[2], es[3]};
     int t_env = a.env_t[e];
     done = cartpole_step(s, t_env, act);                             // ppo.jl:130
     rew = done ? 0.0f : 1.0f;                                        // ppo.jl:132
-    for (int i = 0; i < 4; ++i) co[i] = s[i];                        // ppo.jl:143 (before reset!, Q7)
+    float so[4] = {s[0], s[1], s[2], s[3]};                          // ppo.jl:143: the observation is taken before the reset (Q7)
     if (done) {
       cartpole_reset(s, c.seed, gid, gstep, 1);                      // ppo.jl:164
       t_env = 0;
-      if (!c.stale_obs) for (int i = 0; i < 4; ++i) co[i] = s[i];
+      if (!c.stale_obs) for (int i = 0; i < 4; ++i) so[i] = s[i];
     }
-    for (int i = 0; i < 4; ++i) es[i] = s[i];
+    for (int i = 0; i < 4; ++i) { co[i] = so[i]; es[i] = s[i]; }
     a.env_t[e] = t_env;
+    if (xout) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) xout[i] = i < 4 ? so[i] : 0.0f;
+    }
   } else {
+    if (xout) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) xout[i] = 0.0f;
+    }
     for (int q = 0; 4 * q < D; ++q) {
       float o4[4];
       synth_obs4(c.seed, gid, gstep, q, o4);
       for (int i = 0; i < 4 && 4 * q + i < D; ++i) { es[4 * q + i] = o4[i]; co[4 * q + i] = o4[i]; }
+      if (xout) {                                                    // constant indices: the caller's array stays in registers
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+          if (q == qq) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xout[4 * qq + i] = 4 * qq + i < D ? o4[i] : 0.0f;
+          }
+      }
     }
     synth_reward_done(c.seed, gid, gstep, rew, done);
   }
@@ -2124,6 +2146,10 @@ __global__ void __launch_bounds__(512) wide_rollout_pc_kernel(RollPCArgs r) {
   }
 }
 
+}  // namespace crl
+#include "wide_rs.hpp"
+namespace crl {
+
 // env construction for the synthetic env (oracle: orc_env_init, gstep = ~0)
 __global__ void __launch_bounds__(256) wide_synth_reset_kernel(DevCfg c, float* env_state, int32_t* env_t, float* cur_obs,
                                                               uint8_t* next_done, float* ep_return, int32_t* ep_length, double* ep_stats) {
@@ -2433,6 +2459,7 @@ int wide_env_reset(crl_ppo* h) {
   return 0;
 }
 
+static bool wide_fused_ok(const crl_ppo* h);
 int wide_rollout(crl_ppo* h) {
   WideWs* w = static_cast<WideWs*>(h->wide_ws);
   if (ensure_pack(h)) return 1;
@@ -2445,6 +2472,49 @@ int wide_rollout(crl_ppo* h) {
   a.ring = h->ep_ring; a.ring_count = h->ep_ring_count; a.ring_cap = h->ep_ring_cap;
   if (h->ep_ring_cap > 0) CRL_HIP_CHECK(hipMemsetAsync(h->ep_ring_count, 0, sizeof(uint32_t), h->stream));
   ProfScope ps(h, CRL_K_ROLLOUT);
+  if ((opt(h, OPT_WIDE_RS) & 2) && w->H == 256 && wide_x2(h) && w->D <= 16 && w->A <= 8 && opt(h, OPT_WIDE_ROLLOUT_PERSIST) >= 2 && h->dc.nt % RR_MB == 0 &&
+      w->lds_max >= RR_LDS && wide_fused_ok(h) && h->dc.B % FX_MB == 0) {
+    // register-stationary actor for all steps (wide_rs_rollout_kernel), then the critic over the stored observations as ONE batched forward
+    RsRollArgs r;
+    {
+      const NetOff o = net_off(256, w->D, w->A);
+      const float* pk = w->pack + w->pk_base[0];
+      RollPCNet& n = r.n;
+      n.W1f = pk + w->pk[0].w1f; n.w1sc = w->wsc + 4; n.Wx2 = pk + w->pk[0].x2f; n.b2 = h->params + o.b2; n.wsc = w->wsc;
+      n.W3t = pk + w->pk[0].w3t; n.b3 = h->params + o.b3; n.Z = w->z; n.A = w->A; n.ldz = w->A8; n.rat = 1;
+    }
+    r.s = a; r.s.V = nullptr; r.D = w->D;
+    const int nb = h->dc.nt / RR_MB;
+#define CRL_RSROLL(dp, na) hipLaunchKernelGGL((wide_rs_rollout_kernel<dp, na>), dim3(nb), dim3(512), RR_LDS, h->stream, r)
+    if (w->D8 == 8 && w->A <= 4) CRL_RSROLL(8, 4);
+    else if (w->D8 == 8) CRL_RSROLL(8, 8);
+    else if (w->A <= 4) CRL_RSROLL(16, 4);
+    else CRL_RSROLL(16, 8);
+#undef CRL_RSROLL
+    CRL_HIP_CHECK(hipGetLastError());
+    // values of all num_steps x num_envs stored observations (ppo.jl:128 evaluates the critic on the same observation the buffer keeps)
+    FusedFwdPCArgs q;
+    {
+      const NetOff o = net_off(256, w->D, 1);
+      const float* P = h->params + h->Pa;
+      const float* pk = w->pack + w->pk_base[1];
+      q.obs = h->obs; q.perm = nullptr; q.D = w->D; q.W1f = pk + w->pk[1].w1f; q.w1sc = w->wsc + 4 + 2; q.Wx2 = pk + w->pk[1].x2f; q.b2 = P + o.b2;
+      q.wsc = w->wsc + 2; q.W3t = pk + w->pk[1].w3t; q.b3 = P + o.b3; q.A = 1; q.ldz = 1; q.H1 = nullptr; q.H2 = nullptr; q.Z = h->value; q.M = h->dc.B;
+    }
+    if (!(opt(h, OPT_WIDE_RS) & 4)) {  // (bit 2: the same pass on the register-stationary forward instead — measured slower: 1.21 vs 0.87 ms at C3)
+      int nbc = w->cus; const int ntiles = h->dc.B / FX_MB; if (nbc > ntiles) nbc = ntiles;
+      if (w->D8 == 8) hipLaunchKernelGGL((wide_fused_fwd_pc_kernel<8, false, 2>), dim3(nbc, 1), dim3(512), pc_lds(2), h->stream, q, q);
+      else hipLaunchKernelGGL((wide_fused_fwd_pc_kernel<16, false, 2>), dim3(nbc, 1), dim3(512), pc_lds(2), h->stream, q, q);
+    } else {
+      // register-stationary forward, every block on the critic: the grid's y = 0 half (the actor flavour) gets an empty argument and leaves at once
+      FusedFwdPCArgs q0 = q; q0.M = 0;
+      int nbc = w->cus; const int nt32 = h->dc.B / RS_MB; if (nbc > nt32) nbc = nt32;
+      if (w->D8 == 8) hipLaunchKernelGGL((wide_rs_fwd_kernel<8, 4>), dim3(nbc, 2), dim3(512), RS_LDS, h->stream, q0, q);
+      else hipLaunchKernelGGL((wide_rs_fwd_kernel<16, 4>), dim3(nbc, 2), dim3(512), RS_LDS, h->stream, q0, q);
+    }
+    CRL_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   if (w->H == 256 && wide_x2(h) && w->D <= 16 && w->A <= PC_AMAX && opt(h, OPT_WIDE_ROLLOUT_PERSIST) >= 2 && h->dc.nt % RP_MB == 0 && w->lds_max >= RP_LDS) {
     // one launch for all steps, producer / consumer form (wide_rollout_pc_kernel)
     RollPCArgs r;
@@ -2587,6 +2657,16 @@ static int wide_forward_fused(crl_ppo* h, const int32_t* perm, int M) {
       q[net].obs = a[net].obs; q[net].perm = perm; q[net].D = w->D; q[net].W1f = pk + w->pk[net].w1f; q[net].w1sc = w->wsc + 4 + 2 * net;
       q[net].Wx2 = a[net].Wx2; q[net].b2 = a[net].b2; q[net].wsc = a[net].wsc; q[net].W3t = a[net].W3t; q[net].b3 = a[net].b3; q[net].A = a[net].A;
       q[net].ldz = a[net].ldz; q[net].H1 = a[net].H1; q[net].H2 = a[net].H2; q[net].Z = a[net].Z; q[net].M = M;
+    }
+    if ((opt(h, OPT_WIDE_RS) & 1) && wide_h1_free(h) && M % RS_MB == 0 && w->lds_max >= RS_LDS) {
+      // register-stationary form (wide_rs.hpp): no weight stream at all
+      int nbr = w->cus / 2; const int nt32 = M / RS_MB; if (nbr > nt32) nbr = nt32; if (nbr < 1) nbr = 1;
+      if (w->D8 == 8 && w->A <= 4) hipLaunchKernelGGL((wide_rs_fwd_kernel<8, 4>), dim3(nbr, 2), dim3(512), RS_LDS, h->stream, q[0], q[1]);
+      else if (w->D8 == 8) hipLaunchKernelGGL((wide_rs_fwd_kernel<8, 8>), dim3(nbr, 2), dim3(512), RS_LDS, h->stream, q[0], q[1]);
+      else if (w->A <= 4) hipLaunchKernelGGL((wide_rs_fwd_kernel<16, 4>), dim3(nbr, 2), dim3(512), RS_LDS, h->stream, q[0], q[1]);
+      else hipLaunchKernelGGL((wide_rs_fwd_kernel<16, 8>), dim3(nbr, 2), dim3(512), RS_LDS, h->stream, q[0], q[1]);
+      CRL_HIP_CHECK(hipGetLastError());
+      return 0;
     }
     int nb = w->cus / 2; const int ntiles = M / FX_MB; if (nb > ntiles) nb = ntiles; if (nb < 1) nb = 1;
     // three weight buffers (the slab after next in flight) where the W3ᵀ table leaves room for them, option wide_fwd_wbufs = 2 keeps two

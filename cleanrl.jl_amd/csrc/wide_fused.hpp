@@ -938,6 +938,7 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
         if (a.M < 0)   // (timing ablation: no h2 stores)
 #endif
 #if CRL_FWD_DIRECT_H2
+        if (a.H2) {        // (null: values only — the rollout's batched critic pass)
         // h2 straight from the accumulator layout (lane = sample, 4 consecutive units per register quad): 16-byte stores, 32 B per sample and instruction; the
         // eight instructions of a sample's 256 B of this consumer follow each other, so L2 still writes whole lines
 #pragma unroll
@@ -948,6 +949,7 @@ __device__ __forceinline__ void wide_fused_fwd_pc_body(const FusedFwdPCArgs& a) 
             f32x4 o; o[0] = acc[ai][bi][4 * g]; o[1] = acc[ai][bi][4 * g + 1]; o[2] = acc[ai][bi][4 * g + 2]; o[3] = acc[ai][bi][4 * g + 3];
             *reinterpret_cast<f32x4*>(hrow + 8 * g) = o;
           }
+        }
         }
 #else
 #pragma unroll

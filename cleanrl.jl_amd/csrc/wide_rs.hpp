@@ -1,0 +1,636 @@
+// wide_rs.hpp — register-stationary forward of the 2x256 networks (included by wide.hip behind wide_fused.hpp; BASELINE config C3).
+//
+// wide_fused_fwd_pc_kernel streams all 256 KB of a network's fp16x2 W2 pieces through LDS for EVERY 128-sample tile — 8 slabs, a barrier and
+// 32 LDS-DMA pieces each, 0.4 µs of vector-issue time per slab and SIMD whoever issues them (profiles/r05_c3_fwd_stamps.txt) — and ends at 3.5 x
+// its matrix time. But 256 rows x 256 k x two f16 pieces is exactly 8 waves x 128 VGPRs x 64 lanes x 4 B: the block's eight waves can HOLD the
+// layer. Here wave w keeps the A-fragments of rows 32w … 32w + 31 (all 16 k-steps, both pieces: 128 registers, loaded once per launch) and the
+// only operand that moves is the activation tile:
+//   P  wave w makes units 32w … 32w + 31 of h1 for the tile's 32 samples — layer 1 as one fp16x2 product (its W1 fragment comes from LDS), exp2 activation, split, 8-byte LDS stores into a [piece][sample][256 k + 8] tile (33 KB, two of them);
+//   M  48 MFMAs per wave: its rows x the tile, B-fragments from LDS (two 16-byte reads per three MFMAs), two accumulators (cross terms,
+//      hi·hi), so consecutive MFMAs are independent and the small terms are summed among themselves first;
+//   E  h2 = tanh(acc·unscale + b2) out in 16-byte stores (optional), head partials of the wave's 32 rows into LDS; a fold of the 8 partials later.
+// No weight traffic, no slab loop, ONE barrier per phase. The two waves of a SIMD (w and w + 4) run half a period apart — waves 0-3 multiply
+// tile t while waves 4-7 finish tile t - 1 and prepare their share of t + 1, then the roles swap — so every SIMD always has one wave on the
+// matrix pipe and one on the vector pipe:
+//   phase 2t    : A = M(t)                               B = E(t-1), P(t+1)
+//   phase 2t+1  : A = E(t), P(t+1), fold(t-1)            B = M(t)
+// h1(t+1) is written (B in 2t, A in 2t+1) while h1(t) is read (A in 2t, B in 2t+1): two tile buffers; the head partials alternate by tile parity.
+#pragma once
+
+namespace crl {
+
+#ifndef CRL_RS_ABL
+#define CRL_RS_ABL 0   // timing ablations (results are garbage): 1 no layer-2 products, 2 no epilogue, 4 no h1 production, 8 no h2 stores
+#endif
+#ifdef CRL_EXP_WSTAMPS
+// diagnostic build only (bash scripts/build_variant.sh wstamps -DCRL_EXP_WSTAMPS wide; scripts/rs_stamps.py): [block][wave][slot] wall-clock stamps of two phases
+__device__ unsigned long long crl_dbg_rs_stamps[256 * 8 * 16];
+#define RS_STAMP(slot) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 256u && blockIdx.y == 0) crl_dbg_rs_stamps[((blockIdx.x) * 8 + (threadIdx.x >> 6)) * 16 + (slot)] = wall_clock64(); } while (0)
+#else
+#define RS_STAMP(slot) do { } while (0)
+#endif
+constexpr int RS_MB = 32;                                     // samples per tile
+constexpr int RS_ROW = 264;                                   // halves per sample row of an h1 tile: 256 k + 8 pad (528 B: conflict-free b128 reads, b64 writes)
+constexpr int RS_XBYTES = 2 * RS_MB * RS_ROW * 2;             // 33,792: one h1 tile, [piece][sample][RS_ROW halves]
+constexpr int RS_OFF_B1 = 2 * RS_XBYTES;                      // b1·2·log2(e) [256] f32
+constexpr int RS_OFF_W3 = RS_OFF_B1 + 1024;                   // W3ᵀ [A <= 8][256] f32
+constexpr int RS_OFF_B2 = RS_OFF_W3 + 8 * 1024;               // b2 [256] f32
+constexpr int RS_OFF_HP = RS_OFF_B2 + 1024;                   // head partials [tile parity 2][wave 8][sample 32][8] f32
+constexpr int RS_OFF_W1 = RS_OFF_HP + 2 * 8 * RS_MB * 8 * 4;  // W1 fragments [slab 8][piece 2][lane 64] f16x8 (pack w1f): 16 KB
+constexpr int RS_LDS = RS_OFF_W1 + 16384;                     // 110,592 bytes
+
+// the stationary operand: this wave's 32 rows of W2 (fp16x2 A-fragments of all 16 k-steps) and of W1 (one k-step)
+struct RsWeights { f16x8 wh[16], wl[16]; };
+__device__ __forceinline__ void rs_load_weights(const float* Wx2, int wave, int lane, RsWeights& W) {
+  const f16x8* wp = reinterpret_cast<const f16x8*>(Wx2) + wave * 64 + lane;       // pack x2f: [slab 8][piece 2][k-step 2][row tile 8][lane 64] f16x8
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      W.wh[2 * s + ks] = wp[s * 2048 + ks * 512];
+      W.wl[2 * s + ks] = wp[s * 2048 + 1024 + ks * 512];
+    }
+}
+// rows x tile: two accumulator chains — the cross terms (lo·hi, hi·lo) and hi·hi — so that consecutive MFMAs are independent
+template <int MB = RS_MB>
+__device__ __forceinline__ void rs_multiply(const RsWeights& W, const _Float16* Xl, int j, int hf, f32x16& aa, f32x16& ac) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { aa[r] = 0.0f; ac[r] = 0.0f; }
+  const _Float16* xr = Xl + j * RS_ROW + 8 * hf;
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const f16x8 bh = *reinterpret_cast<const f16x8*>(xr + 16 * ks);
+    const f16x8 bl = *reinterpret_cast<const f16x8*>(xr + MB * RS_ROW + 16 * ks);
+    aa = mfma_f16(W.wl[ks], bh, aa);
+    ac = mfma_f16(W.wh[ks], bh, ac);
+    aa = mfma_f16(W.wh[ks], bl, aa);
+  }
+}
+// this lane's observation half of one sample, scaled per sample into the fp16 window and split (the B-fragment of layer 1)
+template <int DP>
+__device__ __forceinline__ void rs_xfrag(float (&xr)[8], int D, int hf, P2& xb, float& xinv, float w1un) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) if (8 * hf + c >= D || 8 * hf >= DP) xr[c] = 0.0f;
+  float m = 0.0f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) m = __builtin_fmaxf(m, __builtin_fabsf(xr[c]));
+  m = max32(m);
+  float s1, i1;
+  pow2_scale(m, s1, i1);
+  float v[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) v[c] = xr[c] * s1;
+  xb = split2(v);
+  xinv = i1 * w1un;
+}
+// layer 1 of the wave's 32 units for a tile: W1 fragment (LDS) x observation fragment, 2·log2(e)·scale folded into the pack — issued at the END of the wave's
+// own multiply phase: inside the vector phase the three MFMAs would queue behind the SIMD partner's 48 (0.4 µs of waiting per tile, profiles/r04_c3_stamps.txt)
+__device__ __forceinline__ f32x16 rs_layer1(const f16x8* w1l, const P2& xb) {
+  f32x16 c;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+  P2 w1; w1.hi = w1l[0]; w1.lo = w1l[64];                                                 // [piece 2][lane 64] f16x8
+  return mfma_x2(w1, xb, c);
+}
+// units 32·wave … of h1 for the tile's 32 samples into the tile buffer, from the layer-1 product c. RAT: the reference's rational tanh_fast (the rollout's
+// actor), else the exp2 form
+template <bool RAT, int MB = RS_MB>
+__device__ __forceinline__ void rs_produce(const f32x16& c, float xinv, const float* b1tab, _Float16* Xl, int wave, int j, int hf) {
+  const float* b1l = b1tab + 32 * wave + 4 * hf;
+  f32x4 bv[4];
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) bv[q4] = *reinterpret_cast<const f32x4*>(b1l + 8 * q4);   // registers 4q4 … 4q4 + 3 = units 32·wave + 8q4 + 4hf + {0..3}
+  float tt[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) tt[i] = __builtin_fmaf(c[i], xinv, bv[i >> 2][i & 3]);        // 2·log2(e)·(W1·x + b1)
+  if (RAT) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tt[i] = tanh_fast(tt[i] * INV_TWO_LOG2E) * X2_ACT_SCALE;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tt[i] = __builtin_amdgcn_exp2f(tt[i]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tt[i] = __builtin_amdgcn_rcpf(tt[i] + 1.0f);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tt[i] = __builtin_fmaf(-2.0f * X2_ACT_SCALE, tt[i], X2_ACT_SCALE);
+  }
+  uint2 hh[4], ll[4];
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) {
+    f32x4 hv; hv[0] = tt[4 * q4]; hv[1] = tt[4 * q4 + 1]; hv[2] = tt[4 * q4 + 2]; hv[3] = tt[4 * q4 + 3];
+    split2x4(hv, 1.0f, hh[q4], ll[q4]);
+  }
+  _Float16* xo = Xl + j * RS_ROW + 32 * wave + 4 * hf;
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) {
+    *reinterpret_cast<uint2*>(xo + 8 * q4) = hh[q4];
+    *reinterpret_cast<uint2*>(xo + MB * RS_ROW + 8 * q4) = ll[q4];
+  }
+}
+// head partials of an ACTIVATED tile (h2 of the wave's 32 rows in aa) into hp [sample 32][8]
+template <int NA>
+__device__ __forceinline__ void rs_heads(const f32x16& aa, const float* w3tab, float* hp, int wave, int j, int hf) {
+  float pp[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+    if (a && (a & 1) == 0) __builtin_amdgcn_sched_barrier(0);          // two actions' table reads (32 registers) in flight at a time, not all of them
+    const float* w3l = w3tab + 256 * a + 32 * wave + 4 * hf;
+    float q = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(w3l + 8 * g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) q = __builtin_fmaf(w[e], aa[4 * g + e], q);
+    }
+    pp[a] = q;
+  }
+#pragma unroll
+  for (int a = 0; a < NA; ++a) pp[a] = add32(pp[a]);
+  if (hf == 0) {
+    if constexpr (NA == 1) hp[j * 8] = pp[0];
+    else {
+#pragma unroll
+      for (int a4 = 0; a4 < NA / 4; ++a4) {
+        f32x4 o; o[0] = pp[4 * a4]; o[1] = pp[4 * a4 + 1]; o[2] = pp[4 * a4 + 2]; o[3] = pp[4 * a4 + 3];
+        *reinterpret_cast<f32x4*>(hp + j * 8 + 4 * a4) = o;
+      }
+    }
+  }
+}
+// h2 of the wave's 32 rows for the tile (in place of the summed accumulators) and its head partials into hp [sample 32][8]. NA = head rows computed
+// (the W3ᵀ table is zero beyond n_act): a compile-time count keeps the sixteen table reads and the sums in one basic block
+template <bool RAT, int NA>
+__device__ __forceinline__ void rs_epilogue(f32x16& aa, float cs, const float* b2tab, const float* w3tab,
+                                            float* hp, float* H2row, int wave, int j, int hf, bool st_ = false) {
+  const float* b2l = b2tab + 32 * wave + 4 * hf;
+  f32x4 bv[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const f32x4*>(b2l + 8 * g);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) aa[i] = __builtin_fmaf(aa[i], cs, bv[i >> 2][i & 3]);
+  if (RAT) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) aa[i] = tanh_fast(aa[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) aa[i] = __builtin_amdgcn_exp2f(aa[i] * TWO_LOG2E);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) aa[i] = __builtin_amdgcn_rcpf(aa[i] + 1.0f);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) aa[i] = __builtin_fmaf(-2.0f, aa[i], 1.0f);                // tanh_exp2, stage by stage
+  }
+  if (st_) RS_STAMP(6);
+  if (H2row) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 o; o[0] = aa[4 * g]; o[1] = aa[4 * g + 1]; o[2] = aa[4 * g + 2]; o[3] = aa[4 * g + 3];
+      *reinterpret_cast<f32x4*>(H2row + 32 * wave + 4 * hf + 8 * g) = o;
+    }
+  }
+  if (st_) RS_STAMP(7);
+  rs_heads<NA>(aa, w3tab, hp, wave, j, hf);
+}
+
+template <int DP, int NA>
+__device__ __forceinline__ void wide_rs_fwd_body(const FusedFwdPCArgs& a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
+  if (a.M <= 0) return;                                                 // (a one-network launch: the other half of the grid has nothing to do)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int j = lane & 31, hf = lane >> 5;
+  const int grp = wave >> 2;
+  float* b1tab = reinterpret_cast<float*>(smx + RS_OFF_B1);
+  float* w3tab = reinterpret_cast<float*>(smx + RS_OFF_W3);
+  float* b2tab = reinterpret_cast<float*>(smx + RS_OFF_B2);
+  float* hpall = reinterpret_cast<float*>(smx + RS_OFF_HP);
+  if (tid < 256) { b1tab[tid] = a.W1f[4096 + tid]; b2tab[tid] = a.b2[tid]; }
+  for (int i = tid; i < NA * 256; i += 512) w3tab[i] = i < a.A * 256 ? a.W3t[i] : 0.0f;
+  for (int i = tid; i < 1024; i += 512) reinterpret_cast<f32x4*>(smx + RS_OFF_W1)[i] = reinterpret_cast<const f32x4*>(a.W1f)[i];
+  RsWeights W;
+  rs_load_weights(a.Wx2, wave, lane, W);
+  const float w1un = a.w1sc[1];
+  const float cs = a.wsc[1] * (1.0f / X2_ACT_SCALE);
+  const int ntiles = a.M / RS_MB;
+  const int nloc = (int)blockIdx.x < ntiles ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  auto tile_of = [&](int i) { return (int)blockIdx.x + i * (int)gridDim.x; };
+  // observations: the row index goes through the permutation and is loaded a tile ahead of the row (as in wide_fused_fwd_pc_kernel)
+  const int k0x = (8 * hf < a.D && 8 * hf < DP) ? 8 * hf : 0;
+  int srcn = 0;
+  float xr[8];
+  auto perm_of = [&](int i) { int g = tile_of(i) * RS_MB + j; g = g < a.M ? g : a.M - 1; return a.perm ? a.perm[g] : g; };
+  auto load_x = [&](int inext) {                                        // the row srcn; then the index of local tile inext
+    if ((a.D & 3) == 0) {
+      const f32x4* q = reinterpret_cast<const f32x4*>(a.obs + (size_t)srcn * (size_t)a.D + k0x);
+      const f32x4 q0 = q[0], q1 = q[k0x + 4 < a.D ? 1 : 0];
+      xr[0] = q0[0]; xr[1] = q0[1]; xr[2] = q0[2]; xr[3] = q0[3]; xr[4] = q1[0]; xr[5] = q1[1]; xr[6] = q1[2]; xr[7] = q1[3];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { const int cc = k0x + c < a.D ? k0x + c : a.D - 1; xr[c] = a.obs[(size_t)srcn * (size_t)a.D + cc]; }
+    }
+    srcn = perm_of(inext);
+  };
+  // a wave produces its share of h1 for local tiles pi = 0, 1, 2, … in order, each in two steps: the layer-1 product behind its own multiply phase (stage_l1),
+  // the vector part in its next vector phase (finish_p)
+  int pi = 0;
+  f32x16 c1; float xinv = 0.0f;
+  auto stage_l1 = [&]() {
+    if ((CRL_RS_ABL & 4) && pi > 1) return;
+    if (pi < nloc) {
+      P2 xb;
+      rs_xfrag<DP>(xr, a.D, hf, xb, xinv, w1un);
+      if (pi + 1 < nloc) load_x(pi + 2);
+      c1 = rs_layer1(reinterpret_cast<const f16x8*>(smx + RS_OFF_W1) + (wave * 2) * 64 + 32 * hf + j, xb);
+    }
+  };
+  auto finish_p = [&]() {
+    if (pi < nloc && !((CRL_RS_ABL & 4) && pi > 1)) rs_produce<false>(c1, xinv, b1tab, reinterpret_cast<_Float16*>(smx + (pi & 1) * RS_XBYTES), wave, j, hf);
+    ++pi;
+  };
+  bool st_ = false;
+  f32x16 aa, ac;
+  auto multiply = [&](int i) { if (CRL_RS_ABL & 1) return; rs_multiply(W, reinterpret_cast<const _Float16*>(smx + (i & 1) * RS_XBYTES), j, hf, aa, ac); };
+  auto sum = [&]() {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) aa[r] += ac[r];
+  };
+  auto epilogue = [&](int i) {
+    if (CRL_RS_ABL & 2) return;
+    const int m0 = tile_of(i) * RS_MB;
+    rs_epilogue<false, NA>(aa, cs, b2tab, w3tab, hpall + ((i & 1) * 8 + wave) * (RS_MB * 8), (a.H2 && !(CRL_RS_ABL & 8)) ? a.H2 + (size_t)256 * (m0 + j) : nullptr, wave, j, hf, st_);
+  };
+  // the fold's bias: loaded ONCE — a global load behind the epilogue's h2 stores waits for their acknowledgements (vmcnt is in order), 1-2 µs per tile
+  const float b3q = (tid & 7) < a.A ? a.b3[tid & 7] : 0.0f;
+  auto fold = [&](int i) {                                              // waves 0-3: 32 samples x 8 head slots
+    const int tl = 64 * wave + 32 * hf + j, m = tl >> 3, q = tl & 7;
+    if (q < a.A) {
+      const float* hp = hpall + (i & 1) * 8 * (RS_MB * 8) + m * 8 + q;
+      float z = 0.0f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) z += hp[w8 * (RS_MB * 8)];
+      a.Z[(size_t)a.ldz * (tile_of(i) * RS_MB + m) + q] = z + b3q;
+    }
+  };
+  __syncthreads();
+  if (nloc > 0) { srcn = perm_of(0); load_x(1); }
+  stage_l1(); finish_p();
+  if (grp == 1) stage_l1();                                             // waves 4-7 open with a vector phase: P(1)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+  for (int ph = 0; ph <= 2 * nloc + 1; ++ph) {
+    const int t = ph >> 1;
+    // every per-lane address below hangs on (j, hf): opaque once per phase, they are formed where they are used instead of being kept in
+    // registers across the loop (the kernel holds 128 registers of weights; hoisted addresses spilled)
+    asm volatile("" : "+v"(j), "+v"(hf));
+    st_ = ph == 16 || ph == 17;
+    [[maybe_unused]] const bool mphase = (ph & 1) == grp;
+    if (st_) RS_STAMP(mphase ? 0 : 4);
+    if (grp == 0) {
+      if ((ph & 1) == 0) { if (t < nloc) multiply(t); if (st_) RS_STAMP(1); stage_l1(); if (t < nloc) sum(); }
+      else {
+        finish_p();
+        if (st_) RS_STAMP(5);
+        if (t < nloc) epilogue(t);
+        if (st_) RS_STAMP(8);
+        if (t >= 1) fold(t - 1);
+      }
+    } else {
+      if (ph & 1) { if (t < nloc) multiply(t); if (st_) RS_STAMP(1); stage_l1(); if (t < nloc) sum(); }
+      else {
+        finish_p();
+        if (st_) RS_STAMP(5);
+        if (t >= 1 && t - 1 < nloc) epilogue(t - 1);
+        if (st_) RS_STAMP(8);
+      }
+    }
+    if (st_) RS_STAMP(mphase ? 2 : 9);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (st_) RS_STAMP(mphase ? 3 : 10);
+  }
+}
+
+// ======================================================================================================================================
+// The rollout with the ACTOR register-stationary (ppo.jl:123-166; option wide_rs bit 1). wide_rollout_pc_kernel walks 16 weight slabs per step —
+// both networks, 32 KB each through LDS-DMA with a barrier per slab — and a step costs 30 µs at C3, almost all of it the latency of the slab
+// stream. The env loop only needs the ACTOR: the critic's values are stored for the GAE pass and nothing in the loop reads them, so the critic
+// leaves the loop (one batched forward over the stored observations behind the rollout: wide_rollout in wide.hip) and the actor's 256 KB of
+// fp16x2 W2 pieces live in the eight waves' registers for all num_steps steps. A block owns 64 envs; per step
+//   P  every wave: layer 1 of its 32 units for the 64 envs (one fp16x2 product per 32-env half, tanh_fast, split, into the h1 tile in LDS)
+//   M  every wave: its 32 rows x 64 envs, 96 MFMAs, B-fragments from the h1 tile
+//   E  tanh_fast, head partials of its rows into LDS
+//   S  wave 0, lane = env: the eight partials + b3 in fixed order, softmax / sample / env step / Buffer.add! (wide_step_env), the next observation
+//      into LDS for everybody
+// with three barriers. The actor keeps the reference's rational tanh_fast in both layers, as in the other rollout kernels: its logits decide
+// action indices.
+// ======================================================================================================================================
+constexpr int RR_MB = 64;
+constexpr int RR_XBYTES = 2 * RR_MB * RS_ROW * 2;              // 67,584: the h1 tile, [piece][env][RS_ROW halves]
+constexpr int RR_OFF_B1 = RR_XBYTES;
+constexpr int RR_OFF_W3 = RR_OFF_B1 + 1024;
+constexpr int RR_OFF_B2 = RR_OFF_W3 + 8 * 1024;
+constexpr int RR_OFF_HP = RR_OFF_B2 + 1024;                    // head partials [wave 8][env 64][8] f32
+constexpr int RR_OFF_W1 = RR_OFF_HP + 8 * RR_MB * 8 * 4;       // W1 fragments (pack w1f) 16 KB
+constexpr int RR_OFF_OBS = RR_OFF_W1 + 16384;                  // current observations [env 64][16] f32
+constexpr int RR_OFF_ST = RR_OFF_OBS + RR_MB * 16 * 4;         // per-env state [env 64][8] words: next_done, ep_return, ep_length, env_t, env_state[0..3]
+constexpr int RR_OFF_B3 = RR_OFF_ST + RR_MB * 8 * 4;           // b3 [8] f32
+constexpr int RR_LDS = RR_OFF_B3 + 32;                         // 116,768 bytes
+struct RsRollArgs { RollPCNet n; WStepArgs s; int D; };
+
+// softmax_rt / sample_rt / pick_rt of wide.hip on N <= 8 slots (same operation order)
+template <int N>
+__device__ __forceinline__ void softmax_n(const float (&z)[N], int A, float (&p)[N], float (&lp)[N]) {
+  float m = z[0];
+#pragma unroll
+  for (int a = 1; a < N; ++a) if (a < A) m = fmaxf(m, z[a]);
+  float sm = 0.0f;
+#pragma unroll
+  for (int a = 0; a < N; ++a) if (a < A) { p[a] = expf(z[a] - m); sm += p[a]; }
+#pragma unroll
+  for (int a = 0; a < N; ++a) if (a < A) p[a] = p[a] / sm;
+  float ls = 0.0f;
+#pragma unroll
+  for (int a = 0; a < N; ++a) if (a < A) { lp[a] = z[a] - m; ls += expf(lp[a]); }
+  const float l = logf(ls);
+#pragma unroll
+  for (int a = 0; a < N; ++a) if (a < A) lp[a] = lp[a] - l;
+}
+template <int N>
+__device__ __forceinline__ int sample_n(const float (&p)[N], int A, double u) {
+  float sw = 0.0f;
+#pragma unroll
+  for (int a = 0; a < N; ++a) if (a < A) sw += p[a];
+  const double t = u * (double)sw;
+  int i = 0;
+  float cw = p[0];
+#pragma unroll
+  for (int a = 1; a < N; ++a) {
+    const bool go = (a < A) && ((double)cw < t) && (i == a - 1);
+    i = go ? a : i;
+    cw = go ? cw + p[a] : cw;
+  }
+  return i;
+}
+template <int N>
+__device__ __forceinline__ float pick_n(const float (&v)[N], int A, int i) {
+  float r = v[0];
+#pragma unroll
+  for (int a = 1; a < N; ++a) if (a < A) r = (i == a) ? v[a] : r;
+  return r;
+}
+
+// wide_step_env (ppo.jl:125-165) with the env's running state in LDS instead of global memory: a step then LOADS nothing from HBM / L2 — in
+// wide_step_env the dozen dependent loads (episode counters, env state, the observation to copy) were 3-4 of a step's 5.4 µs behind the previous
+// step's stores (vmcnt is in order). obs_l: the env's current observation [16] (in: what the buffer keeps, out: the next one); st_l: its 8 state words.
+template <int NA>
+__device__ __forceinline__ void rs_step_env(const WStepArgs& a, int e, int step, const float (&z)[NA], float* obs_l, float* st_l,
+                                            double& st_n, double& st_ret, double& st_len, double& st_max) {
+  const DevCfg& c = a.c;
+  const int D = c.D, A = c.A;
+  const uint32_t gid = c.env_id_offset + (uint32_t)e;
+  const uint64_t gstep = a.iteration * (uint64_t)c.k + (uint64_t)step;
+  const size_t b = (size_t)e + (size_t)c.nt * step;
+  const f32x4 s0 = *reinterpret_cast<const f32x4*>(st_l), s1 = *reinterpret_cast<const f32x4*>(st_l + 4);
+  f32x4 x[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) x[q] = *reinterpret_cast<const f32x4*>(obs_l + 4 * q);
+  const int nd = __float_as_int(s0[0]);
+  int ep_len = __float_as_int(s0[2]) + 1;                            // ppo.jl:125
+  float p[NA], lp[NA];
+  softmax_n<NA>(z, A, p, lp);                                        // ppo.jl:127 get_action
+  const double u = u53(philox_env(c.seed, gid, gstep, 0));
+  const int act = sample_n<NA>(p, A, u);
+  const float lpa = pick_n<NA>(lp, A, act);
+  float* ob = a.obs + b * (size_t)D;
+  if ((D & 3) == 0) {                                                // ppo.jl:133-140 Buffer.add!
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (4 * q < D) *reinterpret_cast<f32x4*>(ob + 4 * q) = x[q];
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) if (4 * q + i < D) ob[4 * q + i] = x[q][i];
+  }
+  a.action[b] = act; a.logprob[b] = lpa; a.terminal[b] = (uint8_t)nd;
+  bool done; float rew;
+  f32x4 es = s1; int t_env = __float_as_int(s0[3]);
+  if (c.env_kind == CRL_ENV_CARTPOLE) {
+    float s[4] = {s1[0], s1[1], s1[2], s1[3]};
+    done = cartpole_step(s, t_env, act);                             // ppo.jl:130
+    rew = done ? 0.0f : 1.0f;                                        // ppo.jl:132
+    float so[4] = {s[0], s[1], s[2], s[3]};                          // ppo.jl:143: the observation is taken before the reset (Q7)
+    if (done) {
+      cartpole_reset(s, c.seed, gid, gstep, 1);                      // ppo.jl:164
+      t_env = 0;
+      if (!c.stale_obs) for (int i = 0; i < 4; ++i) so[i] = s[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { x[0][i] = so[i]; es[i] = s[i]; }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (4 * q < D) {
+        float o4[4];
+        synth_obs4(c.seed, gid, gstep, q, o4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[q][i] = 4 * q + i < D ? o4[i] : 0.0f;
+      }
+    synth_reward_done(c.seed, gid, gstep, rew, done);
+  }
+  a.reward[b] = rew;
+  float ep_ret = s0[1] + rew;                                        // ppo.jl:145
+  if (done) {                                                        // ppo.jl:147-165
+    st_n += 1.0; st_ret += (double)ep_ret; st_len += (double)ep_len; st_max = fmax(st_max, fmax(0.0, (double)ep_ret));
+    if (a.ring_cap > 0) {
+      const uint32_t slot = atomicAdd(a.ring_count, 1u);
+      if (slot < (uint32_t)a.ring_cap) a.ring[slot] = crl_episode_record{ep_ret, ep_len, (int32_t)gid, step};
+    }
+    ep_ret = 0.0f; ep_len = 0;
+  }
+  f32x4 n0; n0[0] = __int_as_float(done ? 1 : 0); n0[1] = ep_ret; n0[2] = __int_as_float(ep_len); n0[3] = __int_as_float(t_env);   // ppo.jl:144
+  *reinterpret_cast<f32x4*>(st_l) = n0; *reinterpret_cast<f32x4*>(st_l + 4) = es;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(obs_l + 4 * q) = x[q];
+}
+
+template <int DP, int NA>
+__global__ void __launch_bounds__(512) wide_rs_rollout_kernel(RsRollArgs r) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int j = lane & 31, hf = lane >> 5;
+  const int m0 = blockIdx.x * RR_MB;
+  const RollPCNet& nn = r.n;
+  float* b1tab = reinterpret_cast<float*>(smx + RR_OFF_B1);
+  float* w3tab = reinterpret_cast<float*>(smx + RR_OFF_W3);
+  float* b2tab = reinterpret_cast<float*>(smx + RR_OFF_B2);
+  float* hpall = reinterpret_cast<float*>(smx + RR_OFF_HP);
+  float* obsl = reinterpret_cast<float*>(smx + RR_OFF_OBS);
+  float* stl = reinterpret_cast<float*>(smx + RR_OFF_ST);
+  float* b3l = reinterpret_cast<float*>(smx + RR_OFF_B3);
+  _Float16* Xl = reinterpret_cast<_Float16*>(smx);
+  const int D = r.D, Dst = r.s.c.D;
+  if (tid < 256) { b1tab[tid] = nn.W1f[4096 + tid]; b2tab[tid] = nn.b2[tid]; }
+  for (int i = tid; i < NA * 256; i += 512) w3tab[i] = i < nn.A * 256 ? nn.W3t[i] : 0.0f;
+  for (int i = tid; i < 1024; i += 512) reinterpret_cast<f32x4*>(smx + RR_OFF_W1)[i] = reinterpret_cast<const f32x4*>(nn.W1f)[i];
+  for (int i = tid; i < RR_MB * 16; i += 512) { const int e = i >> 4, c = i & 15; obsl[i] = c < D ? r.s.cur_obs[(size_t)(m0 + e) * D + c] : 0.0f; }
+  if (tid < 8) b3l[tid] = tid < nn.A ? nn.b3[tid] : 0.0f;
+  if (tid < RR_MB) {                                                    // the envs' running state: global -> LDS for the launch
+    const int e = m0 + tid;
+    float* q = stl + tid * 8;
+    q[0] = __int_as_float((int)r.s.next_done[e]); q[1] = r.s.ep_return[e]; q[2] = __int_as_float(r.s.ep_length[e]); q[3] = __int_as_float(r.s.env_t[e]);
+    for (int i = 0; i < 4; ++i) q[4 + i] = i < Dst ? r.s.env_state[(size_t)Dst * e + i] : 0.0f;
+  }
+  RsWeights W;
+  rs_load_weights(nn.Wx2, wave, lane, W);
+  const float w1un = nn.w1sc[1];
+  const float cs = nn.wsc[1] * (1.0f / X2_ACT_SCALE);
+  double st_n = 0.0, st_ret = 0.0, st_len = 0.0, st_max = 0.0;
+  const int nsteps = r.s.c.k;
+  __syncthreads();
+  // layer 1 of one 32-env half: observation fragment from LDS, product, activation, split, h1 tile
+  auto p_begin = [&](int ct, P2& xb, float& xinv) {
+    float xr[8];
+    const float* xo = obsl + (32 * ct + j) * 16 + 8 * hf;
+    const f32x4 q0 = *reinterpret_cast<const f32x4*>(xo), q1 = *reinterpret_cast<const f32x4*>(xo + 4);
+    xr[0] = q0[0]; xr[1] = q0[1]; xr[2] = q0[2]; xr[3] = q0[3]; xr[4] = q1[0]; xr[5] = q1[1]; xr[6] = q1[2]; xr[7] = q1[3];
+    rs_xfrag<DP>(xr, D, hf, xb, xinv, w1un);
+  };
+#pragma unroll 1
+  for (int step = 0; step < nsteps; ++step) {
+    asm volatile("" : "+v"(j), "+v"(hf));                               // per-lane addresses are formed per step, not kept across the loop
+    const bool st_ = step == 64;
+    if (st_) RS_STAMP(0);
+    const f16x8* w1l = reinterpret_cast<const f16x8*>(smx + RR_OFF_W1) + (wave * 2) * 64 + 32 * hf + j;
+    // P(0): this wave's 32 units of h1 for envs 0-31
+    P2 xb; float xinv;
+    p_begin(0, xb, xinv);
+    f32x16 c1 = rs_layer1(w1l, xb);
+    rs_produce<true, RR_MB>(c1, xinv, b1tab, Xl, wave, j, hf);
+    p_begin(1, xb, xinv);
+    c1 = rs_layer1(w1l, xb);                                            // the second half's layer-1 product: ahead of the 48 MFMAs it would queue behind
+    if (st_) RS_STAMP(1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                       // B1: h1 of envs 0-31 is complete
+    if (st_) RS_STAMP(2);
+    f32x16 a0, c0;
+    // M(0) beside P(1): the matrix pipe multiplies the first half while the vector pipe makes the second half's h1. Four groups of four k-steps, each
+    // followed by the activation of four elements; the scheduler may reorder inside a group, not across (one bias quad in flight ahead)
+    {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { a0[q] = 0.0f; c0[q] = 0.0f; }
+      const _Float16* x0 = Xl + j * RS_ROW + 8 * hf;
+      const float* b1l = b1tab + 32 * wave + 4 * hf;
+      f32x4 bv = *reinterpret_cast<const f32x4*>(b1l);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bn = *reinterpret_cast<const f32x4*>(b1l + 8 * (g < 3 ? g + 1 : 3));
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int ks = 4 * g + kk;
+          const f16x8 bh = *reinterpret_cast<const f16x8*>(x0 + 16 * ks), bl = *reinterpret_cast<const f16x8*>(x0 + RR_MB * RS_ROW + 16 * ks);
+          a0 = mfma_f16(W.wl[ks], bh, a0);
+          c0 = mfma_f16(W.wh[ks], bh, c0);
+          a0 = mfma_f16(W.wh[ks], bl, a0);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c1[4 * g + e] = tanh_fast(__builtin_fmaf(c1[4 * g + e], xinv, bv[e]) * INV_TWO_LOG2E) * X2_ACT_SCALE;   // P(1), in place
+        uint2 hh, ll;
+        f32x4 hv; hv[0] = c1[4 * g]; hv[1] = c1[4 * g + 1]; hv[2] = c1[4 * g + 2]; hv[3] = c1[4 * g + 3];
+        split2x4(hv, 1.0f, hh, ll);
+        _Float16* xo = Xl + (32 + j) * RS_ROW + 32 * wave + 4 * hf + 8 * g;
+        *reinterpret_cast<uint2*>(xo) = hh;
+        *reinterpret_cast<uint2*>(xo + RR_MB * RS_ROW) = ll;
+        bv = bn;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) a0[q] += c0[q];
+    }
+    if (st_) RS_STAMP(3);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                       // B2: h1 of envs 32-63 is complete
+    if (st_) RS_STAMP(4);
+    // M(1) beside E(0)
+    f32x16 a1, c1b;
+    {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { a1[q] = 0.0f; c1b[q] = 0.0f; }
+      const _Float16* x1 = Xl + (32 + j) * RS_ROW + 8 * hf;
+      const float* b2l = b2tab + 32 * wave + 4 * hf;
+      f32x4 bv = *reinterpret_cast<const f32x4*>(b2l);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bn = *reinterpret_cast<const f32x4*>(b2l + 8 * (g < 3 ? g + 1 : 3));
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int ks = 4 * g + kk;
+          const f16x8 bh = *reinterpret_cast<const f16x8*>(x1 + 16 * ks), bl = *reinterpret_cast<const f16x8*>(x1 + RR_MB * RS_ROW + 16 * ks);
+          a1 = mfma_f16(W.wl[ks], bh, a1);
+          c1b = mfma_f16(W.wh[ks], bh, c1b);
+          a1 = mfma_f16(W.wh[ks], bl, a1);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a0[4 * g + e] = tanh_fast(__builtin_fmaf(a0[4 * g + e], cs, bv[e]));                                  // E(0), in place
+        bv = bn;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    float* hp = hpall + wave * (RR_MB * 8);
+    rs_heads<NA>(a0, w3tab, hp, wave, j, hf);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) a1[q] += c1b[q];
+    rs_epilogue<true, NA>(a1, cs, b2tab, w3tab, hp + 32 * 8, nullptr, wave, j, hf);
+    if (st_) RS_STAMP(5);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                       // B3: all head partials are in LDS
+    if (st_) RS_STAMP(6);
+    if (wave == 0) {
+      float z[NA];
+#pragma unroll
+      for (int q = 0; q < NA; ++q) z[q] = 0.0f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) {                                  // the eight row groups' partials in fixed order, then the bias
+        const float* hq = hpall + w8 * (RR_MB * 8) + lane * 8;
+#pragma unroll
+        for (int q4 = 0; q4 < NA / 4; ++q4) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(hq + 4 * q4);
+          z[4 * q4] += v[0]; z[4 * q4 + 1] += v[1]; z[4 * q4 + 2] += v[2]; z[4 * q4 + 3] += v[3];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NA; ++q) z[q] += b3l[q];
+      if (st_) RS_STAMP(8);
+      rs_step_env<NA>(r.s, m0 + lane, step, z, obsl + lane * 16, stl + lane * 8, st_n, st_ret, st_len, st_max);
+    }
+    if (st_) RS_STAMP(7);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                       // B4: the next observations are in LDS
+    if (st_) RS_STAMP(9);
+  }
+  if (wave == 0) wide_step_stats(r.s.ep_stats, st_n, st_ret, st_len, st_max);
+  if (tid < RR_MB) {                                                    // the envs' state back to global memory for the next launch
+    const int e = m0 + tid;
+    const float* q = stl + tid * 8;
+    r.s.next_done[e] = (uint8_t)__float_as_int(q[0]); r.s.ep_return[e] = q[1]; r.s.ep_length[e] = __float_as_int(q[2]); r.s.env_t[e] = __float_as_int(q[3]);
+    const bool cart = r.s.c.env_kind == CRL_ENV_CARTPOLE;
+    for (int i = 0; i < Dst; ++i) {
+      const float o = obsl[tid * 16 + (i < 16 ? i : 0)];
+      r.s.cur_obs[(size_t)Dst * e + i] = o;
+      r.s.env_state[(size_t)Dst * e + i] = cart ? (i < 4 ? q[4 + i] : 0.0f) : o;   // the synthetic env's state is its observation
+    }
+  }
+}
+
+// NA: head rows the actor's blocks compute (4 or 8); the critic's compute one
+template <int DP, int NA>
+__global__ void __launch_bounds__(512) wide_rs_fwd_kernel(FusedFwdPCArgs a0, FusedFwdPCArgs a1) {
+  if (blockIdx.y == 0) wide_rs_fwd_body<DP, NA>(a0); else wide_rs_fwd_body<DP, 1>(a1);
+}
+
+}  // namespace crl
+
+#ifdef CRL_EXP_WSTAMPS
+extern "C" int32_t crl_debug_read_rs_stamps(unsigned long long* out, int32_t n) {
+  if (n > 256 * 8 * 16) n = 256 * 8 * 16;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(crl::crl_dbg_rs_stamps), (size_t)n * 8) == hipSuccess ? 0 : 1;
+}
+#endif
