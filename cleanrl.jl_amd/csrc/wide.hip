@@ -2501,7 +2501,7 @@ int wide_rollout(crl_ppo* h) {
       q.obs = h->obs; q.perm = nullptr; q.D = w->D; q.W1f = pk + w->pk[1].w1f; q.w1sc = w->wsc + 4 + 2; q.Wx2 = pk + w->pk[1].x2f; q.b2 = P + o.b2;
       q.wsc = w->wsc + 2; q.W3t = pk + w->pk[1].w3t; q.b3 = P + o.b3; q.A = 1; q.ldz = 1; q.H1 = nullptr; q.H2 = nullptr; q.Z = h->value; q.M = h->dc.B;
     }
-    if (!(opt(h, OPT_WIDE_RS) & 4)) {  // (bit 2: the same pass on the register-stationary forward instead — measured slower: 1.21 vs 0.87 ms at C3)
+    if (!(opt(h, OPT_WIDE_RS) & 4) || w->D % 4 != 0 || w->lds_max < R2_LDS) {  // (bit 2: the same pass on the register-stationary forward instead — measured slower: 1.21 vs 0.87 ms at C3)
       int nbc = w->cus; const int ntiles = h->dc.B / FX_MB; if (nbc > ntiles) nbc = ntiles;
       if (w->D8 == 8) hipLaunchKernelGGL((wide_fused_fwd_pc_kernel<8, false, 2>), dim3(nbc, 1), dim3(512), pc_lds(2), h->stream, q, q);
       else hipLaunchKernelGGL((wide_fused_fwd_pc_kernel<16, false, 2>), dim3(nbc, 1), dim3(512), pc_lds(2), h->stream, q, q);
@@ -2509,8 +2509,8 @@ int wide_rollout(crl_ppo* h) {
       // register-stationary forward, every block on the critic: the grid's y = 0 half (the actor flavour) gets an empty argument and leaves at once
       FusedFwdPCArgs q0 = q; q0.M = 0;
       int nbc = w->cus; const int nt32 = h->dc.B / RS_MB; if (nbc > nt32) nbc = nt32;
-      if (w->D8 == 8) hipLaunchKernelGGL((wide_rs_fwd_kernel<8, 4>), dim3(nbc, 2), dim3(512), RS_LDS, h->stream, q0, q);
-      else hipLaunchKernelGGL((wide_rs_fwd_kernel<16, 4>), dim3(nbc, 2), dim3(512), RS_LDS, h->stream, q0, q);
+      if (w->D8 == 8) hipLaunchKernelGGL((wide_rs_fwd_kernel<8, 4, false>), dim3(nbc, 2), dim3(512), R2_LDS, h->stream, q0, q);
+      else hipLaunchKernelGGL((wide_rs_fwd_kernel<16, 4, false>), dim3(nbc, 2), dim3(512), R2_LDS, h->stream, q0, q);
     }
     CRL_HIP_CHECK(hipGetLastError());
     return 0;
@@ -2658,13 +2658,13 @@ static int wide_forward_fused(crl_ppo* h, const int32_t* perm, int M) {
       q[net].Wx2 = a[net].Wx2; q[net].b2 = a[net].b2; q[net].wsc = a[net].wsc; q[net].W3t = a[net].W3t; q[net].b3 = a[net].b3; q[net].A = a[net].A;
       q[net].ldz = a[net].ldz; q[net].H1 = a[net].H1; q[net].H2 = a[net].H2; q[net].Z = a[net].Z; q[net].M = M;
     }
-    if ((opt(h, OPT_WIDE_RS) & 1) && wide_h1_free(h) && M % RS_MB == 0 && w->lds_max >= RS_LDS) {
+    if ((opt(h, OPT_WIDE_RS) & 1) && wide_h1_free(h) && M % RS_MB == 0 && w->D % 4 == 0 && w->lds_max >= R2_LDS) {
       // register-stationary form (wide_rs.hpp): no weight stream at all
       int nbr = w->cus / 2; const int nt32 = M / RS_MB; if (nbr > nt32) nbr = nt32; if (nbr < 1) nbr = 1;
-      if (w->D8 == 8 && w->A <= 4) hipLaunchKernelGGL((wide_rs_fwd_kernel<8, 4>), dim3(nbr, 2), dim3(512), RS_LDS, h->stream, q[0], q[1]);
-      else if (w->D8 == 8) hipLaunchKernelGGL((wide_rs_fwd_kernel<8, 8>), dim3(nbr, 2), dim3(512), RS_LDS, h->stream, q[0], q[1]);
-      else if (w->A <= 4) hipLaunchKernelGGL((wide_rs_fwd_kernel<16, 4>), dim3(nbr, 2), dim3(512), RS_LDS, h->stream, q[0], q[1]);
-      else hipLaunchKernelGGL((wide_rs_fwd_kernel<16, 8>), dim3(nbr, 2), dim3(512), RS_LDS, h->stream, q[0], q[1]);
+      if (w->D8 == 8 && w->A <= 4) hipLaunchKernelGGL((wide_rs_fwd_kernel<8, 4, true>), dim3(nbr, 2), dim3(512), R2_LDS, h->stream, q[0], q[1]);
+      else if (w->D8 == 8) hipLaunchKernelGGL((wide_rs_fwd_kernel<8, 8, true>), dim3(nbr, 2), dim3(512), R2_LDS, h->stream, q[0], q[1]);
+      else if (w->A <= 4) hipLaunchKernelGGL((wide_rs_fwd_kernel<16, 4, true>), dim3(nbr, 2), dim3(512), R2_LDS, h->stream, q[0], q[1]);
+      else hipLaunchKernelGGL((wide_rs_fwd_kernel<16, 8, true>), dim3(nbr, 2), dim3(512), R2_LDS, h->stream, q[0], q[1]);
       CRL_HIP_CHECK(hipGetLastError());
       return 0;
     }

@@ -652,6 +652,7 @@ struct FusedFwdPCArgs {
   const float* Wx2; const float* b2; const float* wsc;
   const float* W3t; const float* b3; int A; int ldz;
   float* H1; float* H2; float* Z; int M;
+  int nblk = 0;                                   // wide_rs_fwd_kernel: blocks this network's tiles are spread over (0 = the grid's x extent)
 };
 
 template <int DP, bool WRITE_H1, int NWB>

@@ -19,9 +19,6 @@
 
 namespace crl {
 
-#ifndef CRL_RS_ABL
-#define CRL_RS_ABL 0   // timing ablations (results are garbage): 1 no layer-2 products, 2 no epilogue, 4 no h1 production, 8 no h2 stores
-#endif
 #ifdef CRL_EXP_WSTAMPS
 // diagnostic build only (bash scripts/build_variant.sh wstamps -DCRL_EXP_WSTAMPS wide; scripts/rs_stamps.py): [block][wave][slot] wall-clock stamps of two phases
 __device__ unsigned long long crl_dbg_rs_stamps[256 * 8 * 16];
@@ -50,21 +47,6 @@ __device__ __forceinline__ void rs_load_weights(const float* Wx2, int wave, int 
       W.wh[2 * s + ks] = wp[s * 2048 + ks * 512];
       W.wl[2 * s + ks] = wp[s * 2048 + 1024 + ks * 512];
     }
-}
-// rows x tile: two accumulator chains — the cross terms (lo·hi, hi·lo) and hi·hi — so that consecutive MFMAs are independent
-template <int MB = RS_MB>
-__device__ __forceinline__ void rs_multiply(const RsWeights& W, const _Float16* Xl, int j, int hf, f32x16& aa, f32x16& ac) {
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { aa[r] = 0.0f; ac[r] = 0.0f; }
-  const _Float16* xr = Xl + j * RS_ROW + 8 * hf;
-#pragma unroll
-  for (int ks = 0; ks < 16; ++ks) {
-    const f16x8 bh = *reinterpret_cast<const f16x8*>(xr + 16 * ks);
-    const f16x8 bl = *reinterpret_cast<const f16x8*>(xr + MB * RS_ROW + 16 * ks);
-    aa = mfma_f16(W.wl[ks], bh, aa);
-    ac = mfma_f16(W.wh[ks], bh, ac);
-    aa = mfma_f16(W.wh[ks], bl, aa);
-  }
 }
 // this lane's observation half of one sample, scaled per sample into the fp16 window and split (the B-fragment of layer 1)
 template <int DP>
@@ -191,122 +173,229 @@ __device__ __forceinline__ void rs_epilogue(f32x16& aa, float cs, const float* b
   rs_heads<NA>(aa, w3tab, hp, wave, j, hf);
 }
 
-template <int DP, int NA>
+// The forward pass of one network, persistent over 32-sample tiles, all eight waves in lock step. Stage s (one barrier each):
+//   the matrix pipe   M(s): this wave's 32 rows x tile s, 48 MFMAs (+ 3 for layer 1 of tile s + 1 at the top)
+//   the vector pipe   P(s + 1): the wave's h1 share of the next tile; E(s - 1): activation, h2 out, head partials of the previous tile; fold(s - 2)
+// interleaved in ONE instruction stream — four groups of (four k-steps, four elements of P, four elements of E) — so that each wave's vector work runs in
+// the shadow of its own and its SIMD partner's MFMAs. (The first form of this kernel gave the two waves of a SIMD opposite phases — one multiplies, one
+// does all the vector work — with a barrier per phase: 0.82 ms per launch against the producer / consumer kernel's 0.58, the vector phase 3 µs per tile
+// where 1.1 were issued: exposed LDS latency beside the partner's b128 stream, the layer-1 MFMAs queued behind the partner's 48, and every global load
+// consumed behind the h2 stores' acknowledgements — vmcnt is in order. profiles/r06_c3_rs_forward.txt.)
+// Observations never touch registers on their way in: 16-tile chunks are gathered by LDS-DMA (global_load_lds_dwordx4, lane = row piece) two chunks ahead,
+// the row indices a chunk before that; the one s_waitcnt vmcnt(0) this needs sits at a chunk boundary — once per 16 tiles — not in every tile.
+constexpr int R2_OFF_B1 = 2 * RS_XBYTES;                       // b1·2·log2(e) [256] f32
+constexpr int R2_OFF_B2 = R2_OFF_B1 + 1024;                    // b2·2·log2(e) [256] f32
+constexpr int R2_OFF_W3 = R2_OFF_B2 + 1024;                    // W3ᵀ [8][256] f32 (zero beyond n_act)
+constexpr int R2_OFF_HP = R2_OFF_W3 + 8 * 1024;                // head partials [tile parity 2][wave 8][sample 32][8] f32
+constexpr int R2_OFF_W1 = R2_OFF_HP + 2 * 8 * RS_MB * 8 * 4;   // W1 fragments (pack w1f) 16 KB
+constexpr int R2_OFF_OBS = R2_OFF_W1 + 16384;                  // three observation chunks, [tile][piece][row 32][16 B]
+constexpr int R2_OBS_BYTES = 16 * 32 * 8 * 4;                  // one chunk: 16 tiles of 8 floats per row, or 8 tiles of 16
+constexpr int R2_LDS = R2_OFF_OBS + 3 * R2_OBS_BYTES;          // 159,744 bytes
+
+template <int DP, int NA, bool STORE>
 __device__ __forceinline__ void wide_rs_fwd_body(const FusedFwdPCArgs& a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
   if (a.M <= 0) return;                                                 // (a one-network launch: the other half of the grid has nothing to do)
+  constexpr int CH = DP == 8 ? 16 : 8;                                  // tiles per observation chunk
+  constexpr int TB = 32 * DP * 4;                                       // bytes of one tile's observations
+  constexpr int NP = DP / 4;                                            // 16-byte pieces per row
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int j = lane & 31, hf = lane >> 5;
-  const int grp = wave >> 2;
-  float* b1tab = reinterpret_cast<float*>(smx + RS_OFF_B1);
-  float* w3tab = reinterpret_cast<float*>(smx + RS_OFF_W3);
-  float* b2tab = reinterpret_cast<float*>(smx + RS_OFF_B2);
-  float* hpall = reinterpret_cast<float*>(smx + RS_OFF_HP);
-  if (tid < 256) { b1tab[tid] = a.W1f[4096 + tid]; b2tab[tid] = a.b2[tid]; }
+  float* b1tab = reinterpret_cast<float*>(smx + R2_OFF_B1);
+  float* b2tab = reinterpret_cast<float*>(smx + R2_OFF_B2);
+  float* w3tab = reinterpret_cast<float*>(smx + R2_OFF_W3);
+  float* hpall = reinterpret_cast<float*>(smx + R2_OFF_HP);
+  if (tid < 256) { b1tab[tid] = a.W1f[4096 + tid]; b2tab[tid] = a.b2[tid] * TWO_LOG2E; }
   for (int i = tid; i < NA * 256; i += 512) w3tab[i] = i < a.A * 256 ? a.W3t[i] : 0.0f;
-  for (int i = tid; i < 1024; i += 512) reinterpret_cast<f32x4*>(smx + RS_OFF_W1)[i] = reinterpret_cast<const f32x4*>(a.W1f)[i];
+  for (int i = tid; i < 1024; i += 512) reinterpret_cast<f32x4*>(smx + R2_OFF_W1)[i] = reinterpret_cast<const f32x4*>(a.W1f)[i];
   RsWeights W;
   rs_load_weights(a.Wx2, wave, lane, W);
   const float w1un = a.w1sc[1];
-  const float cs = a.wsc[1] * (1.0f / X2_ACT_SCALE);
+  const float cs2 = a.wsc[1] * (1.0f / X2_ACT_SCALE) * TWO_LOG2E;       // accumulator -> 2·log2(e)·(W2·h1)
   const int ntiles = a.M / RS_MB;
-  const int nloc = (int)blockIdx.x < ntiles ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-  auto tile_of = [&](int i) { return (int)blockIdx.x + i * (int)gridDim.x; };
-  // observations: the row index goes through the permutation and is loaded a tile ahead of the row (as in wide_fused_fwd_pc_kernel)
-  const int k0x = (8 * hf < a.D && 8 * hf < DP) ? 8 * hf : 0;
-  int srcn = 0;
-  float xr[8];
-  auto perm_of = [&](int i) { int g = tile_of(i) * RS_MB + j; g = g < a.M ? g : a.M - 1; return a.perm ? a.perm[g] : g; };
-  auto load_x = [&](int inext) {                                        // the row srcn; then the index of local tile inext
-    if ((a.D & 3) == 0) {
-      const f32x4* q = reinterpret_cast<const f32x4*>(a.obs + (size_t)srcn * (size_t)a.D + k0x);
-      const f32x4 q0 = q[0], q1 = q[k0x + 4 < a.D ? 1 : 0];
-      xr[0] = q0[0]; xr[1] = q0[1]; xr[2] = q0[2]; xr[3] = q0[3]; xr[4] = q1[0]; xr[5] = q1[1]; xr[6] = q1[2]; xr[7] = q1[3];
-    } else {
+  const int nblk = a.nblk > 0 ? a.nblk : (int)gridDim.x;
+  const int nloc = ((int)blockIdx.x < ntiles && (int)blockIdx.x < nblk) ? (ntiles - (int)blockIdx.x + nblk - 1) / nblk : 0;
+  if (nloc == 0) return;
+  auto tile_of = [&](int i) { return (int)blockIdx.x + i * nblk; };
+  // ---- observation chunks: wave w gathers tiles CH·c + w (+ 8): lane = 32·piece + row
+  const int nper = CH / 8;                                              // tiles per wave and chunk
+  auto row_index = [&](int i) { int g = tile_of(i) * RS_MB + j; g = g < a.M ? g : a.M - 1; return a.perm ? a.perm[g] : g; };
+  int srcn[CH / 8];
+  auto load_idx = [&](int c) {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) { const int cc = k0x + c < a.D ? k0x + c : a.D - 1; xr[c] = a.obs[(size_t)srcn * (size_t)a.D + cc]; }
-    }
-    srcn = perm_of(inext);
+    for (int q = 0; q < CH / 8; ++q) srcn[q] = row_index(CH * c + 8 * q + wave);
   };
-  // a wave produces its share of h1 for local tiles pi = 0, 1, 2, … in order, each in two steps: the layer-1 product behind its own multiply phase (stage_l1),
-  // the vector part in its next vector phase (finish_p)
-  int pi = 0;
-  f32x16 c1; float xinv = 0.0f;
-  auto stage_l1 = [&]() {
-    if ((CRL_RS_ABL & 4) && pi > 1) return;
-    if (pi < nloc) {
-      P2 xb;
-      rs_xfrag<DP>(xr, a.D, hf, xb, xinv, w1un);
-      if (pi + 1 < nloc) load_x(pi + 2);
-      c1 = rs_layer1(reinterpret_cast<const f16x8*>(smx + RS_OFF_W1) + (wave * 2) * 64 + 32 * hf + j, xb);
+  auto dma_chunk = [&](int c) {
+    const unsigned base = lds_addr_of(smx + R2_OFF_OBS + (c % 3) * R2_OBS_BYTES);
+#pragma unroll
+    for (int q = 0; q < CH / 8; ++q) {
+      const char* row = reinterpret_cast<const char*>(a.obs + (size_t)srcn[q] * (size_t)a.D);
+#pragma unroll
+      for (int pp = 0; pp < NP; pp += 2) {
+        const int piece = pp + hf;
+        if (4 * piece < a.D) lds_dma16_v(row + 16 * piece, base + (8 * q + wave) * TB + pp * 512);
+      }
     }
   };
-  auto finish_p = [&]() {
-    if (pi < nloc && !((CRL_RS_ABL & 4) && pi > 1)) rs_produce<false>(c1, xinv, b1tab, reinterpret_cast<_Float16*>(smx + (pi & 1) * RS_XBYTES), wave, j, hf);
-    ++pi;
-  };
-  bool st_ = false;
-  f32x16 aa, ac;
-  auto multiply = [&](int i) { if (CRL_RS_ABL & 1) return; rs_multiply(W, reinterpret_cast<const _Float16*>(smx + (i & 1) * RS_XBYTES), j, hf, aa, ac); };
-  auto sum = [&]() {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) aa[r] += ac[r];
-  };
-  auto epilogue = [&](int i) {
-    if (CRL_RS_ABL & 2) return;
-    const int m0 = tile_of(i) * RS_MB;
-    rs_epilogue<false, NA>(aa, cs, b2tab, w3tab, hpall + ((i & 1) * 8 + wave) * (RS_MB * 8), (a.H2 && !(CRL_RS_ABL & 8)) ? a.H2 + (size_t)256 * (m0 + j) : nullptr, wave, j, hf, st_);
-  };
-  // the fold's bias: loaded ONCE — a global load behind the epilogue's h2 stores waits for their acknowledgements (vmcnt is in order), 1-2 µs per tile
-  const float b3q = (tid & 7) < a.A ? a.b3[tid & 7] : 0.0f;
-  auto fold = [&](int i) {                                              // waves 0-3: 32 samples x 8 head slots
-    const int tl = 64 * wave + 32 * hf + j, m = tl >> 3, q = tl & 7;
-    if (q < a.A) {
-      const float* hp = hpall + (i & 1) * 8 * (RS_MB * 8) + m * 8 + q;
-      float z = 0.0f;
-#pragma unroll
-      for (int w8 = 0; w8 < 8; ++w8) z += hp[w8 * (RS_MB * 8)];
-      a.Z[(size_t)a.ldz * (tile_of(i) * RS_MB + m) + q] = z + b3q;
-    }
-  };
+  (void)nper;
+  load_idx(0);
+  dma_chunk(0);
+  load_idx(1);
+  dma_chunk(1);
+  load_idx(2);
+  const float b3q = (lane & 7) < a.A ? a.b3[lane & 7] : 0.0f;           // the fold's bias, once (a load behind the h2 stores waits for their acknowledgements)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (nloc > 0) { srcn = perm_of(0); load_x(1); }
-  stage_l1(); finish_p();
-  if (grp == 1) stage_l1();                                             // waves 4-7 open with a vector phase: P(1)
+  // ---- helpers
+  auto xfrag_of = [&](int i, P2& xb, float& xinv) {                     // observation fragment of local tile i from its chunk
+    const unsigned char* tb = smx + R2_OFF_OBS + ((i / CH) % 3) * R2_OBS_BYTES + (i % CH) * TB;
+    const int p0 = (8 * hf < DP) ? 2 * hf : 0;
+    const f32x4 q0 = *reinterpret_cast<const f32x4*>(tb + p0 * 512 + 16 * j), q1 = *reinterpret_cast<const f32x4*>(tb + (p0 + 1) * 512 + 16 * j);
+    float xr[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+    rs_xfrag<DP>(xr, a.D, hf, xb, xinv, w1un);
+  };
+  auto fold = [&](int i) {                                              // wave w: samples 4w … 4w + 3 of local tile i, lanes 0-31 = (sample, head slot)
+    if (lane < 32) {
+      const int m = 4 * wave + (lane >> 3), q = lane & 7;
+      if (q < a.A) {
+        const float* hp = hpall + (i & 1) * 8 * (RS_MB * 8) + m * 8 + q;
+        float z = 0.0f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) z += hp[w8 * (RS_MB * 8)];
+        a.Z[(size_t)a.ldz * (tile_of(i) * RS_MB + m) + q] = z + b3q;
+      }
+    }
+  };
+  // ---- prologue: h1 of tile 0, the observation fragment of tile 1
+  f32x16 c1; float xinv;
+  P2 xbn; float xinvn = 0.0f;
+  {
+    xfrag_of(0, xbn, xinv);
+    c1 = rs_layer1(reinterpret_cast<const f16x8*>(smx + R2_OFF_W1) + (wave * 2) * 64 + 32 * hf + j, xbn);
+    rs_produce<false>(c1, xinv, b1tab, reinterpret_cast<_Float16*>(smx), wave, j, hf);
+    xfrag_of(1, xbn, xinvn);
+  }
+  f32x16 acc0, acc1;                                                    // M(s) accumulates into one while E(s - 1) reads the other: the roles swap every stage
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc1[q] = 0.0f;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-#pragma unroll 1
-  for (int ph = 0; ph <= 2 * nloc + 1; ++ph) {
-    const int t = ph >> 1;
-    // every per-lane address below hangs on (j, hf): opaque once per phase, they are formed where they are used instead of being kept in
-    // registers across the loop (the kernel holds 128 registers of weights; hoisted addresses spilled)
-    asm volatile("" : "+v"(j), "+v"(hf));
-    st_ = ph == 16 || ph == 17;
-    [[maybe_unused]] const bool mphase = (ph & 1) == grp;
-    if (st_) RS_STAMP(mphase ? 0 : 4);
-    if (grp == 0) {
-      if ((ph & 1) == 0) { if (t < nloc) multiply(t); if (st_) RS_STAMP(1); stage_l1(); if (t < nloc) sum(); }
-      else {
-        finish_p();
-        if (st_) RS_STAMP(5);
-        if (t < nloc) epilogue(t);
-        if (st_) RS_STAMP(8);
-        if (t >= 1) fold(t - 1);
+  auto stage = [&](int s, f32x16& acc, f32x16& ep) __attribute__((always_inline)) {
+    asm volatile("" : "+v"(j), "+v"(hf));                               // per-lane addresses are formed per stage, not kept across the loop
+    const bool st_ = s == 20;
+    if (st_) RS_STAMP(0);
+    if (s % CH == 0) {                                                  // chunk boundary: chunk s / CH + 1 has landed, the indices of + 2 are here
+      const int c = s / CH;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      dma_chunk(c + 2);
+      load_idx(c + 3);
+    }
+    if (s >= 2) fold(s - 2);                                            // (at the stage's tail instead: 526 vs 489 µs)
+    // layer 1 of tile s + 1 (a tile beyond the block's last one is made from clamped rows and never read)
+    xinv = xinvn;                                                       // (the fragment made here, at the stage's top, instead of a stage ahead: 489 vs 473 µs)
+    c1 = rs_layer1(reinterpret_cast<const f16x8*>(smx + R2_OFF_W1) + (wave * 2) * 64 + 32 * hf + j, xbn);
+    if (st_) RS_STAMP(1);
+    const _Float16* Xs = reinterpret_cast<const _Float16*>(smx + (s & 1) * RS_XBYTES) + j * RS_ROW + 8 * hf;
+    _Float16* Xn = reinterpret_cast<_Float16*>(smx + ((s + 1) & 1) * RS_XBYTES) + j * RS_ROW + 32 * wave + 4 * hf;
+    const float* b1l = b1tab + 32 * wave + 4 * hf;
+    const float* b2l = b2tab + 32 * wave + 4 * hf;
+    const float* w3l = w3tab + 32 * wave + 4 * hf;
+    // E(s - 1) goes to the previous tile's rows; in stage 0 there is none: the stores land on tile 0's own rows and stage 1 overwrites them
+    const int te = s >= 1 ? s - 1 : 0;
+    float* H2row = STORE ? a.H2 + (size_t)256 * (tile_of(te) * RS_MB + j) + 32 * wave + 4 * hf : nullptr;
+    float pp[NA];
+#pragma unroll
+    for (int q = 0; q < NA; ++q) pp[q] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+    // One group = four k-steps of M(s) (twelve MFMAs, ONE dependent chain: a single accumulator) + four elements each of P(s + 1) and E(s - 1) (~150 vector
+    // instructions). Issued in the compiler's order — the chain first — the chain stalls the wave 32+ cycles per MFMA while the vector pipe idles, then the
+    // vector block runs with the matrix pipe idle, and with both waves of a SIMD in lock step neither hides the other's: 3.8 µs per stage against 2.0 of vector
+    // and 1.5 of matrix work. So the SIMD partners run the two halves in OPPOSITE order: waves 0-3 chain then vector block, waves 4-7 vector block then chain.
+    auto mpart = [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int ks = 4 * g + kk;
+        const f16x8 bh = *reinterpret_cast<const f16x8*>(Xs + 16 * ks), bl = *reinterpret_cast<const f16x8*>(Xs + RS_MB * RS_ROW + 16 * ks);
+        acc = mfma_f16(W.wl[ks], bh, acc);                                // (a second accumulator for the hi·hi terms — independent neighbours — measured equal: 483 vs 482 µs)
+        acc = mfma_f16(W.wh[ks], bl, acc);
+        acc = mfma_f16(W.wh[ks], bh, acc);
       }
-    } else {
-      if (ph & 1) { if (t < nloc) multiply(t); if (st_) RS_STAMP(1); stage_l1(); if (t < nloc) sum(); }
+    };
+    auto vpart = [&](int g) __attribute__((always_inline)) {
+      const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1l + 8 * g), bv2 = *reinterpret_cast<const f32x4*>(b2l + 8 * g);
+      // P(s + 1), elements 4g … 4g + 3
+      {
+        f32x4 hv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(c1[4 * g + e], xinv, bv1[e]));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[e] = __builtin_amdgcn_rcpf(hv[e] + 1.0f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[e] = __builtin_fmaf(-2.0f * X2_ACT_SCALE, hv[e], X2_ACT_SCALE);
+        uint2 hh, ll;
+        split2x4(hv, 1.0f, hh, ll);
+        *reinterpret_cast<uint2*>(Xn + 8 * g) = hh;
+        *reinterpret_cast<uint2*>(Xn + RS_MB * RS_ROW + 8 * g) = ll;
+      }
+      // E(s - 1), elements 4g … 4g + 3
+      {
+        f32x4 hv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(ep[4 * g + e], cs2, bv2[e]));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[e] = __builtin_amdgcn_rcpf(hv[e] + 1.0f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[e] = __builtin_fmaf(-2.0f, hv[e], 1.0f);
+        if (STORE) *reinterpret_cast<f32x4*>(H2row + 8 * g) = hv;
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(w3l + 256 * q + 8 * g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pp[q] = __builtin_fmaf(w[e], hv[e], pp[q]);
+        }
+      }
+    };
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      mpart(g);
+      vpart(g);
+      if (g == 2) xfrag_of(s + 2, xbn, xinvn);                          // the tile after next: its fragment is ready when the next stage opens
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (st_) RS_STAMP(2);
+#pragma unroll
+    for (int q = 0; q < NA; ++q) pp[q] = add32(pp[q]);
+    if (hf == 0) {
+      float* hp = hpall + ((te & 1) * 8 + wave) * (RS_MB * 8) + j * 8;
+      if constexpr (NA == 1) hp[0] = pp[0];
       else {
-        finish_p();
-        if (st_) RS_STAMP(5);
-        if (t >= 1 && t - 1 < nloc) epilogue(t - 1);
-        if (st_) RS_STAMP(8);
+#pragma unroll
+        for (int a4 = 0; a4 < NA / 4; ++a4) {
+          f32x4 o; o[0] = pp[4 * a4]; o[1] = pp[4 * a4 + 1]; o[2] = pp[4 * a4 + 2]; o[3] = pp[4 * a4 + 3];
+          *reinterpret_cast<f32x4*>(hp + 4 * a4) = o;
+        }
       }
     }
-    if (st_) RS_STAMP(mphase ? 2 : 9);
+    if (st_) RS_STAMP(3);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (st_) RS_STAMP(mphase ? 3 : 10);
+    if (st_) RS_STAMP(4);
+  };
+#pragma unroll 1
+  for (int s = 0; s <= nloc; ++s) {
+    stage(s, acc0, acc1);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc1[q] = acc0[q];                     // (two copies of the stage with the accumulators' roles swapped instead: the same 492 µs)
   }
+  if (nloc >= 1) fold(nloc - 1);
+  // (stage 0's head partials of "tile -1" went to parity 0 of tile 0's slot … and were rewritten by stage 1 before any fold read them)
+}
+
+// NA: head rows the actor's blocks compute (4 or 8); the critic's compute one
+template <int DP, int NA, bool STORE>
+__global__ void __launch_bounds__(512) wide_rs_fwd_kernel(FusedFwdPCArgs a0, FusedFwdPCArgs a1) {
+  if (blockIdx.y == 0) wide_rs_fwd_body<DP, NA, STORE>(a0); else wide_rs_fwd_body<DP, 1, STORE>(a1);
 }
 
 // ======================================================================================================================================
@@ -618,12 +707,6 @@ __global__ void __launch_bounds__(512) wide_rs_rollout_kernel(RsRollArgs r) {
       r.s.env_state[(size_t)Dst * e + i] = cart ? (i < 4 ? q[4 + i] : 0.0f) : o;   // the synthetic env's state is its observation
     }
   }
-}
-
-// NA: head rows the actor's blocks compute (4 or 8); the critic's compute one
-template <int DP, int NA>
-__global__ void __launch_bounds__(512) wide_rs_fwd_kernel(FusedFwdPCArgs a0, FusedFwdPCArgs a1) {
-  if (blockIdx.y == 0) wide_rs_fwd_body<DP, NA>(a0); else wide_rs_fwd_body<DP, 1>(a1);
 }
 
 }  // namespace crl

@@ -1,7 +1,5 @@
-"""In-kernel timeline of the register-stationary forward (diagnostic build: bash scripts/build_variant.sh wstamps -DCRL_EXP_WSTAMPS wide).
-CRL_LIB_PATH=cleanrl.jl_amd/variants/wstamps/libcleanrl_hip.so python scripts/rs_stamps.py
-Phases 16 / 17 of every actor block; M-phase slots: 0 top, 1 products issued, 2 layer-1 staged + sum, 3 past the barrier; vector-phase slots: 4 top, 5 h1 share written,
-6 activation done, 7 h2 stores issued, 8 head partials written, 9 fold done, 10 past the barrier."""
+"""In-kernel timeline of one stage (stage 20 of every actor block) of the register-stationary forward, wide_rs_fwd_kernel (diagnostic build:
+bash scripts/build_variant.sh wstamps -DCRL_EXP_WSTAMPS wide).   CRL_LIB_PATH=cleanrl.jl_amd/variants/wstamps/libcleanrl_hip.so python scripts/rs_stamps.py"""
 import ctypes as C
 import os
 import sys
@@ -21,12 +19,8 @@ lib = L.load()
 buf = np.zeros(256 * 8 * 16, np.uint64)
 lib.crl_debug_read_rs_stamps.argtypes = [C.c_void_p, C.c_int32]
 assert lib.crl_debug_read_rs_stamps(buf.ctypes.data_as(C.c_void_p), buf.size) == 0
-st = buf.reshape(256, 8, 16)[:128].astype(np.int64)          # the actor's blocks
-for g, nm in ((slice(0, 4), "waves 0-3 (M in phase 16, V in 17)"), (slice(4, 8), "waves 4-7 (V in phase 16, M in 17)")):
-    s = st[:, g, :]
-    m = (s[..., 1] - s[..., 0]) / 100.0, (s[..., 2] - s[..., 1]) / 100.0, (s[..., 3] - s[..., 2]) / 100.0
-    v = [(s[..., b] - s[..., a]) / 100.0 for a, b in ((4, 5), (5, 6), (6, 7), (7, 8), (8, 9), (9, 10))]
-    print(nm)
-    print("   M phase: products %.2f | layer-1 stage + sum %.2f | wait + barrier %.2f us" % tuple(np.median(x) for x in m))
-    print("   V phase: h1 share %.2f | bias + activation %.2f | h2 stores %.2f | heads %.2f | fold %.2f | wait + barrier %.2f us" % tuple(np.median(x) for x in v))
+s = buf.reshape(256, 8, 16)[:128].astype(np.int64)
+d = lambda a, b: np.median((s[..., b] - s[..., a]) / 100.0)
+print("stage 20, median over the actor's blocks and waves (us): fold + layer 1 of the next tile %.2f | group 0 %.2f | group 1 %.2f | group 2 %.2f | group 3 %.2f | "
+      "head sums + accumulator hand-over %.2f | wait + barrier %.2f | stage %.2f" % (d(0, 1), d(1, 5), d(5, 6), d(6, 7), d(7, 8), d(2, 3), d(3, 4), d(0, 4)))
 agent.close()

@@ -139,12 +139,15 @@ def test_wide_update_gradient_matches_oracle(crl, D, A, Hd, nt, k, ret_scale, cl
 @pytest.mark.parametrize("opts", [
     {"wide_fuse": 0}, {"wide_fuse": 1}, {"wide_fuse": 2}, {"wide_fuse": 3},
     {"wide_fuse": 3, "wide_fuse_pc": 0}, {"wide_fuse": 2, "wide_fuse_pc": 0}, {"wide_fuse": 3, "wide_wgrad_full": 0},
-    {"wide_fuse": 3, "shuffle_overlap": 0}, {"wide_fuse": 3, "wide_fwd_wbufs": 3}, {"wide_fuse": 3, "wide_fwd_wbufs": 0}, {"wide_fuse": 3, "wide_d2_split": 0}], ids=lambda o: ",".join(f"{a}={b}" for a, b in o.items()))
+    {"wide_fuse": 3, "shuffle_overlap": 0}, {"wide_fuse": 3, "wide_fwd_wbufs": 3, "wide_rs": 0}, {"wide_fuse": 3, "wide_fwd_wbufs": 0, "wide_rs": 0},
+    {"wide_fuse": 3, "wide_d2_split": 0}, {"wide_fuse": 3, "wide_rs": 0}, {"wide_fuse": 3, "wide_rs": 1}], ids=lambda o: ",".join(f"{a}={b}" for a, b in o.items()))
 @pytest.mark.parametrize("D,A,nt", [(8, 4, 24), (16, 8, 16), (3, 2, 12)])
 def test_every_2x256_kernel_flavour_matches_the_oracle(crl, opts, D, A, nt):
     """The 2x256 shape has four selectable pipelines (option wide_fuse: 0 layer-wise GEMMs, 1 tile-resident forward, 2 + tile-
     resident backward, 3 + h1 never stored) and the flavours under them (producer/consumer forward, the two weight-gradient
-    kernels, dW3 on the side stream, δ2 handed to the weight gradient as f32 instead of as the backward's fp16x2 planes).  Every one of them must give the oracle's loss scalars and gradient on the same
+    kernels, dW3 on the side stream, δ2 handed to the weight gradient as f32 instead of as the backward's fp16x2 planes; since round 6 the
+    forward of wide_fuse = 3 is the register-stationary wide_rs_fwd_kernel — option wide_rs bit 0, obs_dim a multiple of 4 — and wide_rs = 0
+    keeps the producer / consumer kernel and its weight-buffer flavours alive).  Every one of them must give the oracle's loss scalars and gradient on the same
     buffers — the default is only the fastest of equals.  Shapes: C3's, the largest the fused kernels take (obs 16, 8
     actions) and an odd small one (obs 3, 2 actions)."""
     k, Hd = 128, 256
@@ -294,6 +297,43 @@ def test_wide_full_iteration_matches_oracle(crl, D, A, Hd, nt, k):
     agent.close(); st.close()
 
 
+@pytest.mark.parametrize("rs", [0, 2, 6])
+@pytest.mark.parametrize("env,D,A,nt,k", [("synthetic", 8, 4, 128, 40), ("synthetic", 16, 8, 64, 24), ("synthetic", 5, 3, 64, 16), ("cartpole", 4, 2, 128, 160)])
+def test_2x256_rollout_flavours_match_the_oracle(crl, rs, env, D, A, nt, k):
+    """Option wide_rs bit 1 (default): the rollout of a 2x256 shape keeps the ACTOR's weights in the eight waves' registers for all num_steps steps
+    (wide_rs_rollout_kernel, env state and observations in LDS) and evaluates the critic over the stored observations as one batched forward behind it
+    (bit 2: on the register-stationary forward instead of the producer / consumer kernel); wide_rs = 0 is round 5's wide_rollout_pc_kernel. All three
+    against the oracle: actions, observations, rewards, terminals, episode statistics exact, log-probabilities / values / advantages at 1e-5 —
+    on the synthetic env (obs 8 / 16 / an odd 5) and on CartPole itself (160 steps: episodes end and reset inside the launch; the state that
+    lives in LDS during the launch must come back to global memory for the next one, so TWO rollouts are compared)."""
+    Hd = 256
+    cart = env == "cartpole"
+    cfg = O.make_config(num_envs=nt, num_steps=k, obs_dim=D, n_act=A, hidden=Hd, env_kind=0 if cart else 1)
+    params = spread_params(cfg, 5)
+    if cart:
+        off = O.param_offsets(cfg); params[off[4]:off[5]] /= 10     # logits ±0.5: both actions occur and episodes last
+    pc = crl.PPOConfig(num_envs=nt, num_steps=k, total_timesteps=nt * k * 10)
+    agent = crl.Agent(pc, params=params, obs_dim=D, n_act=A, hidden=Hd, env_kind=crl._lib.ENV_CARTPOLE if cart else crl._lib.ENV_SYNTHETIC,
+                      options={"wide_rs": rs})
+    st = O.State(cfg); st.params[:] = params; st.env_init()
+    h = agent.handle; F = crl._lib
+    h.env_reset()
+    for it in range(2):
+        h.rollout_run(); st.rollout()
+        assert np.array_equal(h.read(F.F_ACTION), st.action), f"rollout {it}: {np.sum(h.read(F.F_ACTION) != st.action)} actions differ"
+        assert np.array_equal(h.read(F.F_OBS), st.obs) and np.array_equal(h.read(F.F_REWARD), st.reward)
+        assert np.array_equal(h.read(F.F_TERMINAL), st.terminal) and np.array_equal(h.read(F.F_NEXT_DONE), st.next_done)
+        assert np.array_equal(h.read(F.F_CUR_OBS), st.cur_obs)
+        assert rel_err_s(h.read(F.F_LOGPROB), st.logprob) < RTOL and rel_err(h.read(F.F_VALUE), st.value) < RTOL
+        es = h.episode_stats(); n_ep, ret_sum, len_sum = st.episode_stats
+        assert es["episodes"] == n_ep and es["length_sum"] == len_sum and abs(es["return_sum"] - ret_sum) < 1e-4 * max(1, abs(ret_sum))
+        if cart:
+            assert n_ep > 0, "the test must see episodes end inside the launch"
+        h.compute_gae(); st.compute_gae()
+        assert rel_err(h.read(F.F_ADVANTAGE), st.adv) < RTOL and rel_err(h.read(F.F_RETURN), st.ret) < RTOL
+    agent.close(); st.close()
+
+
 @pytest.mark.parametrize("persist", [2, 1, 0])
 def test_c3_shaped_iteration_at_1024_envs_matches_oracle(crl, persist):
     """(wide_rollout_persist = 2: the rollout as one launch in producer / consumer form, wide_rollout_pc_kernel — the default when num_envs
@@ -360,8 +400,8 @@ def test_c3_full_size_properties(crl):
 
 
 def test_c3_full_size_rollout_slices_match_the_oracle(crl):
-    """BASELINE configs[2] at full size: the whole 16384-env x 128-step rollout of the full-grid `wide_rollout_pc_kernel` (256 blocks of 64
-    envs, one per CU — the default for this shape) against the oracle on three 64-env slices — the first block, one in the middle of the
+    """BASELINE configs[2] at full size: the whole 16384-env x 128-step rollout of the full-grid `wide_rs_rollout_kernel` (256 blocks of 64
+    envs, one per CU, and the batched critic pass behind it — the default for this shape since round 6) against the oracle on three 64-env slices — the first block, one in the middle of the
     grid and the last — for ALL 128 steps: the oracle rolls envs [o, o + 64) out under `env_id_offset = o` (global env ids key every
     random stream, so a slice is independent of the other envs). Actions exact under the knot-margin rule (a draw within 1e-6 of a CDF
     knot may flip; the synthetic env's observations do not depend on the action, so nothing else moves), observations / rewards /
@@ -371,7 +411,7 @@ def test_c3_full_size_rollout_slices_match_the_oracle(crl):
     params = spread_params(cfg_full, 17)
     agent = make_wide(crl, nt, k, D, A, Hd, params=params)
     h = agent.handle; F = crl._lib
-    assert h.get_option("wide_rollout_persist") == 2 and h.get_option("wide_fuse") == 3, "defaults must select wide_rollout_pc_kernel"
+    assert h.get_option("wide_rollout_persist") == 2 and h.get_option("wide_fuse") == 3 and h.get_option("wide_rs") == 3, "defaults must select wide_rs_rollout_kernel"
     h.env_reset(); h.rollout_run(); h.compute_gae()
     act, obs, rew, term = h.read(F.F_ACTION), h.read(F.F_OBS), h.read(F.F_REWARD), h.read(F.F_TERMINAL)
     lp, val, adv, ret = h.read(F.F_LOGPROB), h.read(F.F_VALUE), h.read(F.F_ADVANTAGE), h.read(F.F_RETURN)
