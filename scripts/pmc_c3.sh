@@ -9,7 +9,7 @@ O=$R/gpurun_out/${TAG}_c3pmc
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 P="python3 $R/bench.py --workload c3 --steps 1 --warmup 1 --no-cpu-baseline --no-extras --opt shuffle_overlap=0"
-KR="wide_fused_fwd_pc_kernel|wide_fused_bwd_kernel|wide_wgrad_gen_kernel|wide_wgrad_split_kernel|wide_rollout_pc_kernel|wide_skinny_kernel"
+KR="wide_rs_fwd_kernel|wide_rs_rollout_kernel|wide_fused_fwd_pc_kernel|wide_fused_bwd_kernel|wide_wgrad_gen_kernel|wide_wgrad_split_kernel|wide_rollout_pc_kernel|wide_skinny_kernel"
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC" "FETCH_SIZE" "WRITE_SIZE"; do
   n=$(echo $set | cut -d' ' -f1)
   timeout 300 rocprofv3 --pmc $set --kernel-include-regex "$KR" --output-format csv -d $O/p_$n -- $P > /dev/null 2>&1
@@ -51,12 +51,13 @@ for k, c in sorted(acc.items()):
     out["kernels"][k] = rec
 # HBM traffic of ONE optimiser step (verdict r5 item 3: configs.c3.roofline.traffic): every update-pass kernel's FETCH_SIZE (x 2: 16-byte-per-lane streaming reads are
 # tallied at half, MI355X_MICROARCH.md) + WRITE_SIZE, times its launches per step (launches ÷ the forward kernel's), against SURVEY §8(d)'s algorithmic 52 B per sample
-fwd = next((k for k in out["kernels"] if "wide_fused_fwd_pc_kernel" in k), None)
+# the update pass's forward: wide_rs_fwd_kernel<…, true> since round 6 (wide_fused_fwd_pc_kernel then only runs as the rollout's batched critic pass and is left out below)
+fwd = next((k for k in out["kernels"] if "wide_rs_fwd_kernel" in k and "true" in k), None) or next((k for k in out["kernels"] if "wide_fused_fwd_pc_kernel" in k), None)
 if fwd and "FETCH_SIZE" in out["kernels"][fwd]:
     steps = out["kernels"][fwd]["FETCH_SIZE"]["launches"]
     per = {}
     for k, rec in out["kernels"].items():
-        if "rollout" in k or "FETCH_SIZE" not in rec or "WRITE_SIZE" not in rec:
+        if "rollout" in k or "FETCH_SIZE" not in rec or "WRITE_SIZE" not in rec or (k != fwd and "fwd" in k):
             continue
         lps = rec["FETCH_SIZE"]["launches"] / steps
         per[k] = {"launches_per_step": lps, "read_bytes": 2 * rec["FETCH_SIZE"]["mean"] * 1024 * lps, "written_bytes": rec["WRITE_SIZE"]["mean"] * 1024 * lps}
