@@ -2711,6 +2711,16 @@ static int wide_backward_fused(crl_ppo* h, const int32_t* perm, int M) {
     a[net].D2h = split ? reinterpret_cast<_Float16*>(net ? w->dB : w->dA) : nullptr; a[net].d2s = split ? w->d2s + (size_t)net * w->Mw : nullptr;
   }
   const size_t lds = (size_t)FB_OFF_W3 + (size_t)w->A * 1024;
+  const bool rsb = split && (opt(h, OPT_WIDE_RS) & 8) && M % RS_MB == 0 && w->A <= 8 && w->D % 4 == 0 && w->lds_max >= RB_LDS;
+  if (rsb) {     // register-stationary form (wide_rs.hpp)
+    for (int net = 0; net < 2; ++net) { const float* pk = w->pack + w->pk_base[net]; a[net].W1f = pk + w->pk[net].w1f; a[net].w1sc = w->wsc + 4 + 2 * net; }
+    int nbr = w->cus / 2; const int nt32 = M / RS_MB; if (nbr > nt32) nbr = nt32; if (nbr > w->Ss) nbr = w->Ss; if (nbr < 1) nbr = 1;
+    nb = nbr;
+    if (w->D8 == 8 && w->A <= 4) hipLaunchKernelGGL((wide_rs_bwd_kernel<8, 4>), dim3(nb, 2), dim3(512), RB_LDS, h->stream, a[0], a[1]);
+    else if (w->D8 == 8) hipLaunchKernelGGL((wide_rs_bwd_kernel<8, 8>), dim3(nb, 2), dim3(512), RB_LDS, h->stream, a[0], a[1]);
+    else if (w->A <= 4) hipLaunchKernelGGL((wide_rs_bwd_kernel<16, 4>), dim3(nb, 2), dim3(512), RB_LDS, h->stream, a[0], a[1]);
+    else hipLaunchKernelGGL((wide_rs_bwd_kernel<16, 8>), dim3(nb, 2), dim3(512), RB_LDS, h->stream, a[0], a[1]);
+  } else {
 #define CRL_BWD(dp, na)                                                                                                                  \
   do {                                                                                                                                   \
     if (split) hipLaunchKernelGGL((wide_fused_bwd_kernel<dp, na, true>), dim3(nb, 2), dim3(512), lds, h->stream, a[0], a[1]);            \
@@ -2721,6 +2731,7 @@ static int wide_backward_fused(crl_ppo* h, const int32_t* perm, int M) {
   else if (w->A <= 4) CRL_BWD(16, 4);
   else CRL_BWD(16, 8);
 #undef CRL_BWD
+  }
   CRL_HIP_CHECK(hipGetLastError());
   w->fb_blocks = nb;
   // The dW3 sweeps over h2 depend on the loss kernel only, like the fused backward: they run on the second stream beside it and join at

@@ -16,6 +16,7 @@
 //   phase 2t+1  : A = E(t), P(t+1), fold(t-1)            B = M(t)
 // h1(t+1) is written (B in 2t, A in 2t+1) while h1(t) is read (A in 2t, B in 2t+1): two tile buffers; the head partials alternate by tile parity.
 #pragma once
+#include <type_traits>
 
 namespace crl {
 
@@ -396,6 +397,285 @@ __device__ __forceinline__ void wide_rs_fwd_body(const FusedFwdPCArgs& a) {
 template <int DP, int NA, bool STORE>
 __global__ void __launch_bounds__(512) wide_rs_fwd_kernel(FusedFwdPCArgs a0, FusedFwdPCArgs a1) {
   if (blockIdx.y == 0) wide_rs_fwd_body<DP, NA, STORE>(a0); else wide_rs_fwd_body<DP, 1, STORE>(a1);
+}
+
+// ======================================================================================================================================
+// The backward pass of one network with W2ᵀ register-stationary (option wide_rs bit 3; replaces wide_fused_bwd_kernel in its split-plane flavour).
+// The same lock-step stage as the forward: wave w holds the fp16x2 fragments of W2ᵀ for hidden units v = 32w … 32w + 31 (pack x2b, 128 registers) and uses
+// them as the B operand — mfma(δ2 fragment, W2ᵀ fragment) — so that the product comes out TRANSPOSED: rows (registers) = samples, columns (lanes) = units,
+// and the sums over samples that dW1 / db1 need are per-lane sums (8 + 1 accumulators per lane, no cross-lane work until the launch ends). Per 32-sample stage s:
+//   M(s)      δ1ᵀ-pre = δ2(s)ᵀ·W2ᵀ: 48 MFMAs, A-fragments from the δ2 tile in LDS;
+//   P(s + 1)  the wave's 32 units of the next tile's δ2 = (W3ᵀ·δ3) ⊙ (1 − h2²) — h2 arrives by LDS-DMA two tiles ahead, δ3 (A floats per sample) in registers — scaled
+//             per sample into the fp16 window (bound Σ|δ3|·max|W3|, as before), split, into the δ2 tile AND out to the f16 planes the weight-gradient kernel reads;
+//   E(s - 1)  h1 of the previous tile recomputed on the matrix pipe (one fp16x2 product per wave, operands swapped like the main product), 1 − h1² = 4r(1 − r),
+//             δ1 = acc·(4/(s1·scale))·r(1 − r), db1 += δ1, dW1[c] += δ1·x[c] with the sample's observation broadcast from LDS.
+// h2 tiles: [sample][256] f32 rows of 1 KB at a pitch of 1040 B (conflict-free 16-byte reads), two buffers; one `s_waitcnt vmcnt(4)` per stage waits for the
+// tile's four LDS-DMA pieces per wave and leaves the stage's last four plane stores in flight.
+// ======================================================================================================================================
+constexpr int RB_HROW = 1040;
+constexpr int RB_HBYTES = RS_MB * RB_HROW;                     // 33,280: one h2 tile
+constexpr int RB_OFF_H = 2 * RS_XBYTES;                        // two δ2 tiles first
+constexpr int RB_OFF_W3 = RB_OFF_H + 2 * RB_HBYTES;            // W3ᵀ [8][256] f32 (zero beyond n_act)
+constexpr int RB_OFF_XS = RB_OFF_W3 + 8192;                    // observations [tile parity 2][piece 4][sample 32][4] f32
+constexpr int RB_OFF_DZ = RB_OFF_XS + 2 * 4 * RS_MB * 16;      // head cotangents [tile & 3][piece 2][sample 32][4] f32
+constexpr int RB_OFF_TAB = RB_OFF_DZ + 4 * 2 * RS_MB * 16;     // per wave: xinv [32], then inv4 [tile & 3][32] f32
+constexpr int RB_LDS = RB_OFF_TAB + 8 * 5 * RS_MB * 4;         // 155,648 bytes
+static_assert(RB_LDS <= 160 * 1024, "register-stationary backward: LDS budget");
+
+template <int DP, int NA>
+__device__ __forceinline__ void wide_rs_bwd_body(const FusedBwdArgs& a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
+  if (a.M <= 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int j = lane & 31, hf = lane >> 5;
+  float* w3tab = reinterpret_cast<float*>(smx + RB_OFF_W3);
+  float* xsall = reinterpret_cast<float*>(smx + RB_OFF_XS);
+  float* dzall = reinterpret_cast<float*>(smx + RB_OFF_DZ);
+  float* tabw = reinterpret_cast<float*>(smx + RB_OFF_TAB) + wave * (5 * RS_MB);    // this wave's private tables
+  for (int i = tid; i < (RB_LDS - RB_OFF_XS) / 4; i += 512) xsall[i] = 0.0f;           // observations, cotangents and tables: stage 0 "finishes" a tile that does not exist
+  for (int i = tid; i < NA * 256; i += 512) w3tab[i] = i < a.A * 256 ? a.W3t[i] : 0.0f;
+  RsWeights W;
+  rs_load_weights(a.Wx2b, wave, lane, W);
+  P2 w1f;
+  { const f16x8* w1p = reinterpret_cast<const f16x8*>(a.W1f) + (wave * 2) * 64 + lane; w1f.hi = w1p[0]; w1f.lo = w1p[64]; }
+  const float b1v = a.W1s[256 * DP + 32 * wave + j];                   // 2·log2(e)·b1 of this lane's unit
+  const float w1un = a.w1sc[1];
+  const float wun4 = 4.0f * a.wsc[1];
+  float wmaxr[NA];
+#pragma unroll
+  for (int q = 0; q < NA; ++q) wmaxr[q] = q < a.A ? a.wmax[q] : 0.0f;
+  const int ntiles = a.M / RS_MB;
+  const int nblk = (int)gridDim.x;
+  const int nloc = (int)blockIdx.x < ntiles ? (ntiles - (int)blockIdx.x + nblk - 1) / nblk : 0;
+  if (nloc == 0) return;
+  auto tile_of = [&](int i) { return (int)blockIdx.x + (i < nloc ? i : nloc - 1) * nblk; };   // tiles beyond the block's last are made from its last one and never used
+  float gW1[DP], gB1 = 0.0f;
+#pragma unroll
+  for (int c = 0; c < DP; ++c) gW1[c] = 0.0f;
+  // ---- input pipelines
+  auto dma_h2 = [&](int i) {                                            // tile i's h2 rows 4·wave … 4·wave + 3 into buffer i & 1
+    const float* src = a.H2 + (size_t)256 * (tile_of(i) * RS_MB + 4 * wave);
+    const unsigned base = lds_addr_of(smx + RB_OFF_H + (i & 1) * RB_HBYTES) + 4 * wave * RB_HROW;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lds_dma16(src + 256 * r, lane * 16, base + r * RB_HROW);
+  };
+  // δ3 and the observations come by per-lane LDS-DMA as well (lane = 32·piece + sample): no registers hold inputs across a stage
+  auto dma_dz = [&](int i) {                                            // wave 1: the tile's head cotangents, pieces of 4 floats
+    if (4 * hf < NA) {
+      const float* src = a.dZ + (size_t)a.ldd * (tile_of(i) * RS_MB + j) + 4 * hf;
+      lds_dma16_v(src, lds_addr_of(dzall + (i & 3) * (2 * RS_MB * 4)));
+    }
+  };
+  int srcn = 0;
+  auto row_index = [&](int i) { int g = tile_of(i) * RS_MB + j; return a.perm ? a.perm[g] : g; };
+  auto dma_obs = [&](int i) {                                           // wave 0: the tile's observation rows through the permutation (index in srcn), 4-float pieces
+    const char* row = reinterpret_cast<const char*>(a.obs + (size_t)srcn * (size_t)a.D);
+#pragma unroll
+    for (int pp = 0; pp < DP / 4; pp += 2) {
+      const int piece = pp + hf;
+      if (4 * piece < a.D) lds_dma16_v(row + 16 * piece, lds_addr_of(xsall + (i & 1) * (4 * RS_MB * 4)) + pp * 512);
+    }
+  };
+  auto load_dz = [&](int i, float (&o)[NA]) {                           // this lane's sample's cotangents from the LDS copy
+    const float* p = dzall + (i & 3) * (2 * RS_MB * 4) + j * 4;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(p);
+    if constexpr (NA == 1) o[0] = v0[0];
+    else {
+      o[0] = v0[0]; o[1] = v0[1]; o[2] = v0[2]; o[3] = v0[3];
+      if constexpr (NA == 8) { const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + RS_MB * 4); o[4] = v1[0]; o[5] = v1[1]; o[6] = v1[2]; o[7] = v1[3]; }
+#pragma unroll
+      for (int q = 0; q < NA; ++q) o[q] = q < a.A ? o[q] : 0.0f;
+    }
+  };
+  // ---- P: this wave's 32 units (lane: sample j, units 32·wave + 16·hf + 0 … 15) of tile i's δ2
+  auto stage_d2 = [&](int i, bool store) {
+    float dzv[NA];
+    load_dz(i, dzv);
+    float bound = 0.0f;
+#pragma unroll
+    for (int q = 0; q < NA; ++q) bound = __builtin_fmaf(__builtin_fabsf(dzv[q]), wmaxr[q], bound);
+    float s1, i1;
+    pow2_scale(bound, s1, i1);
+    if (hf == 0) tabw[RS_MB + (i & 3) * RS_MB + j] = i1 * wun4;
+    const int gm = tile_of(i) * RS_MB + j;
+    if (store && wave == 0 && hf == 0) a.d2s[gm] = i1;
+    const unsigned char* hb = smx + RB_OFF_H + (i & 1) * RB_HBYTES + j * RB_HROW + (32 * wave + 16 * hf) * 4;
+    _Float16* xo = reinterpret_cast<_Float16*>(smx + (i & 1) * RS_XBYTES) + j * RS_ROW + 32 * wave + 16 * hf;
+    _Float16* dh = a.D2h + (size_t)256 * gm + 32 * wave + 16 * hf;
+    uint2 hp, lp;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 hq = *reinterpret_cast<const f32x4*>(hb + 16 * g);
+      f32x4 d = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int q = 0; q < NA; ++q) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(w3tab + 256 * q + 32 * wave + 16 * hf + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = __builtin_fmaf(w[e], dzv[q], d[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = d[e] * __builtin_fmaf(-hq[e], hq[e], 1.0f);
+      uint2 hh, ll;
+      split2x4(d, s1, hh, ll);
+      *reinterpret_cast<uint2*>(xo + 4 * g) = hh;
+      *reinterpret_cast<uint2*>(xo + RS_MB * RS_ROW + 4 * g) = ll;
+      if (g & 1) {
+        if (store) {
+          uint4 oh, ol; oh.x = hp.x; oh.y = hp.y; oh.z = hh.x; oh.w = hh.y; ol.x = lp.x; ol.y = lp.y; ol.z = ll.x; ol.w = ll.y;
+          *reinterpret_cast<uint4*>(dh + 4 * (g - 1)) = oh;
+          *reinterpret_cast<uint4*>(dh + (size_t)256 * a.M + 4 * (g - 1)) = ol;
+        }
+      } else { hp = hh; lp = ll; }
+    }
+  };
+  // ---- prologue: h2 and δ3 of tiles 0 and 1, the row indices of tile 0
+  dma_h2(0); dma_h2(1);
+  if (wave == 1) { dma_dz(0); dma_dz(1); }
+  if (wave == 0) srcn = row_index(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  stage_d2(0, true);
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc1[q] = 0.0f;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  // pst: tile s + 1 exists (its δ2 planes and scale are stored). A compile-time flag: a branch around the stores inside the groups ends the basic block,
+  // and the compiler then gathers ALL of E behind the last MFMA (nothing overlaps, 120 registers spill)
+  auto stage = [&](int s, f32x16& acc, const f32x16& ep, auto pst_) __attribute__((always_inline)) {
+    constexpr bool pst = decltype(pst_)::value;
+    asm volatile("" : "+v"(j), "+v"(hf));
+    // inputs, all by LDS-DMA: h2 of tile s + 2 (buffer s & 1: its last reader was P(s) a stage ago), δ3 of tile s + 2, the observations of tile s
+    // (read from the next stage on: E(s) and its layer 1), the row indices of tile s + 1
+    dma_h2(s + 2);
+    if (wave == 1) dma_dz(s + 2);
+    if (wave == 0) { dma_obs(s); srcn = row_index(s + 1); }
+    float dz[NA];
+    load_dz(s + 1, dz);
+    // layer 1 of tile s - 1 on the matrix pipe, operands swapped: rows = samples
+    f32x16 c1;
+    {
+      const float* xr = xsall + ((s + 1) & 1) * (4 * RS_MB * 4) + ((8 * hf < DP) ? 2 * hf : 0) * (RS_MB * 4) + j * 4;
+      const f32x4 q0 = *reinterpret_cast<const f32x4*>(xr), q1 = *reinterpret_cast<const f32x4*>(xr + RS_MB * 4);
+      float xv[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+      P2 xb; float xinv;
+      rs_xfrag<DP>(xv, a.D, hf, xb, xinv, w1un);
+      if (hf == 0) tabw[j] = xinv;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c1[r] = 0.0f;
+      c1 = mfma_x2(xb, w1f, c1);
+    }
+    const _Float16* Xs = reinterpret_cast<const _Float16*>(smx + (s & 1) * RS_XBYTES) + j * RS_ROW + 8 * hf;
+    const float* xe = xsall + ((s + 1) & 1) * (4 * RS_MB * 4);         // observations of tile s - 1, [piece][sample][4]
+    const float* inv4t = tabw + RS_MB + ((s + 3) & 3) * RS_MB;         // (s - 1) & 3
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+    // P(s + 1) runs in four parts beside the groups below: its state
+    float bound = 0.0f;
+#pragma unroll
+    for (int q = 0; q < NA; ++q) bound = __builtin_fmaf(__builtin_fabsf(dz[q]), wmaxr[q], bound);
+    float s1, i1;
+    pow2_scale(bound, s1, i1);
+    if (hf == 0) tabw[RS_MB + ((s + 1) & 3) * RS_MB + j] = i1 * wun4;
+    const int gmn = tile_of(s + 1) * RS_MB + j;
+    if (pst && wave == 0 && hf == 0) a.d2s[gmn] = i1;
+    const unsigned char* hb = smx + RB_OFF_H + ((s + 1) & 1) * RB_HBYTES + j * RB_HROW + (32 * wave + 16 * hf) * 4;
+    _Float16* xo = reinterpret_cast<_Float16*>(smx + ((s + 1) & 1) * RS_XBYTES) + j * RS_ROW + 32 * wave + 16 * hf;
+    _Float16* dh = a.D2h + (size_t)256 * gmn + 32 * wave + 16 * hf;
+    uint2 hp, lp;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int ks = 4 * g + kk;
+        P2 xa;
+        xa.hi = *reinterpret_cast<const f16x8*>(Xs + 16 * ks); xa.lo = *reinterpret_cast<const f16x8*>(Xs + RS_MB * RS_ROW + 16 * ks);
+        acc = mfma_f16(xa.lo, W.wh[ks], acc);
+        acc = mfma_f16(xa.hi, W.wl[ks], acc);
+        acc = mfma_f16(xa.hi, W.wh[ks], acc);
+      }
+      __builtin_amdgcn_sched_barrier(0);                                // (three scheduling regions per group: with one, the register allocator spilled ~120 registers)
+      // P(s + 1), units 4g … 4g + 3 of this lane's sixteen
+      {
+        const f32x4 hq = *reinterpret_cast<const f32x4*>(hb + 16 * g);
+        f32x4 d = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(w3tab + 256 * q + 32 * wave + 16 * hf + 4 * g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) d[e] = __builtin_fmaf(w[e], dz[q], d[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = d[e] * __builtin_fmaf(-hq[e], hq[e], 1.0f);
+        uint2 hh, ll;
+        split2x4(d, s1, hh, ll);
+        *reinterpret_cast<uint2*>(xo + 4 * g) = hh;
+        *reinterpret_cast<uint2*>(xo + RS_MB * RS_ROW + 4 * g) = ll;
+        if (g & 1) {
+          if (pst) {
+            uint4 oh, ol; oh.x = hp.x; oh.y = hp.y; oh.z = hh.x; oh.w = hh.y; ol.x = lp.x; ol.y = lp.y; ol.z = ll.x; ol.w = ll.y;
+            *reinterpret_cast<uint4*>(dh + 4 * (g - 1)) = oh;
+            *reinterpret_cast<uint4*>(dh + (size_t)256 * a.M + 4 * (g - 1)) = ol;
+          }
+        } else { hp = hh; lp = ll; }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // E(s - 1), samples 8g + 4hf + 0 … 3 of this lane's unit
+      {
+        const f32x4 xiq = *reinterpret_cast<const f32x4*>(tabw + 8 * g + 4 * hf), ivq = *reinterpret_cast<const f32x4*>(inv4t + 8 * g + 4 * hf);
+        f32x4 d1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d1[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(c1[4 * g + e], xiq[e], b1v));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d1[e] = __builtin_amdgcn_rcpf(d1[e] + 1.0f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d1[e] = (ep[4 * g + e] * ivq[e]) * __builtin_fmaf(-d1[e], d1[e], d1[e]);   // acc·(4/(s1·scale))·r(1 − r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          gB1 += d1[e];
+          const float* xs = xe + (8 * g + 4 * hf + e) * 4;
+#pragma unroll
+          for (int c4 = 0; c4 < DP / 4; ++c4) {
+            const f32x4 xq = *reinterpret_cast<const f32x4*>(xs + c4 * (RS_MB * 4));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gW1[4 * c4 + c] = __builtin_fmaf(d1[e], xq[c], gW1[4 * c4 + c]);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // the h2 pieces of tile s + 2 have landed (only this stage's last four plane stores may still be in flight), LDS writes are done
+    if (pst) asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");      // (no plane stores behind the pieces in the block's last stages)
+    __builtin_amdgcn_s_barrier();
+  };
+#pragma unroll 1
+  for (int s = 0; s + 1 < nloc; ++s) {
+    stage(s, acc0, acc1, std::true_type{});
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc1[q] = acc0[q];
+  }
+  for (int s = nloc - 1; s <= nloc; ++s) {                              // the block's last tile is multiplied, then finished
+    stage(s, acc0, acc1, std::false_type{});
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc1[q] = acc0[q];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // no LDS-DMA piece may land after the block has given its LDS back
+  // ---- the block's dW1 / db1 partial: the two lane halves hold different samples of the same unit
+  gB1 = add32(gB1);
+#pragma unroll
+  for (int c = 0; c < DP; ++c) gW1[c] = add32(gW1[c]);
+  if (hf == 0) {
+    const int v = 32 * wave + j;
+    a.pB1[(size_t)blockIdx.x * 256 + v] = gB1;
+#pragma unroll
+    for (int c = 0; c < DP; ++c) if (c < a.D) a.pW1[(size_t)blockIdx.x * 256 * a.D + v + 256 * c] = gW1[c];
+  }
+}
+
+template <int DP, int NA0>
+__global__ void __launch_bounds__(512) wide_rs_bwd_kernel(FusedBwdArgs a0, FusedBwdArgs a1) {
+  if (blockIdx.y == 0) wide_rs_bwd_body<DP, NA0>(a0); else wide_rs_bwd_body<DP, 1>(a1);
 }
 
 // ======================================================================================================================================

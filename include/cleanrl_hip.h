@@ -278,12 +278,13 @@ int32_t crl_comm_destroy(crl_ppo* h);
  *   wide_d2_split (1)       wide_fuse = 3 with wide_wgrad_full = 1: the backward kernel hands δ2 to the weight-gradient kernel as the fp16x2 pieces it makes for
  *                           its own product (two f16 planes, one power-of-two scale per sample; the same bytes as the f32 array) and the weight-gradient kernel
  *                           multiplies straight from them (LDS-DMA + transposing LDS reads, no conversion); 0 = δ2 as f32, split again by its reader
- *   wide_rs (3)             2x256 fp16x2, register-stationary kernels (csrc/wide_rs.hpp: a network's 256 KB of W2 pieces live in the eight waves' registers
+ *   wide_rs (11)            2x256 fp16x2, register-stationary kernels (csrc/wide_rs.hpp: a network's 256 KB of W2 pieces live in the eight waves' registers
  *                           for the whole launch, nothing but the 32-sample activation tile moves): bit 0 = the update pass's forward (wide_rs_fwd_kernel,
  *                           obs_dim a multiple of 4; else the producer / consumer kernel), bit 1 = the rollout (wide_rs_rollout_kernel: the actor in the
  *                           step loop, env state in LDS; the critic as ONE batched forward over the stored observations behind it — ppo.jl:128 evaluates it
  *                           on the observation the buffer keeps), bit 2 = that critic pass on the register-stationary forward instead of the producer /
- *                           consumer kernel (measured slower); 0 = round 5's kernels
+ *                           consumer kernel (measured slower), bit 3 = the update pass's backward (wide_rs_bwd_kernel: W2ᵀ stationary as the B operand, h2 /
+ *                           δ3 / observations by LDS-DMA, layer 1 recomputed on the matrix pipe; with wide_d2_split = 1, obs_dim a multiple of 4); 0 = round 5's kernels
  *   update_tile (0)         update pass of the 4 / 2 / 64 path: 32 = 32-sample tiles (update_x2_kernel), 16 = 16-sample tiles at three waves per SIMD (update16.hpp: one early-exit
  *                           repair launch redoes a minibatch as bf16x3 when a tile misses the carried weight-gradient scale or a weight leaves the fp16 window; 17 = the same with
  *                           every tile reporting a miss: test hook), 0 = by launch size — which currently means 32 everywhere: the 16-sample kernel measured slower at every

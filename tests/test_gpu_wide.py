@@ -140,14 +140,14 @@ def test_wide_update_gradient_matches_oracle(crl, D, A, Hd, nt, k, ret_scale, cl
     {"wide_fuse": 0}, {"wide_fuse": 1}, {"wide_fuse": 2}, {"wide_fuse": 3},
     {"wide_fuse": 3, "wide_fuse_pc": 0}, {"wide_fuse": 2, "wide_fuse_pc": 0}, {"wide_fuse": 3, "wide_wgrad_full": 0},
     {"wide_fuse": 3, "shuffle_overlap": 0}, {"wide_fuse": 3, "wide_fwd_wbufs": 3, "wide_rs": 0}, {"wide_fuse": 3, "wide_fwd_wbufs": 0, "wide_rs": 0},
-    {"wide_fuse": 3, "wide_d2_split": 0}, {"wide_fuse": 3, "wide_rs": 0}, {"wide_fuse": 3, "wide_rs": 1}], ids=lambda o: ",".join(f"{a}={b}" for a, b in o.items()))
+    {"wide_fuse": 3, "wide_d2_split": 0}, {"wide_fuse": 3, "wide_rs": 0}, {"wide_fuse": 3, "wide_rs": 1}, {"wide_fuse": 3, "wide_rs": 8}, {"wide_fuse": 3, "wide_rs": 9}], ids=lambda o: ",".join(f"{a}={b}" for a, b in o.items()))
 @pytest.mark.parametrize("D,A,nt", [(8, 4, 24), (16, 8, 16), (3, 2, 12)])
 def test_every_2x256_kernel_flavour_matches_the_oracle(crl, opts, D, A, nt):
     """The 2x256 shape has four selectable pipelines (option wide_fuse: 0 layer-wise GEMMs, 1 tile-resident forward, 2 + tile-
     resident backward, 3 + h1 never stored) and the flavours under them (producer/consumer forward, the two weight-gradient
     kernels, dW3 on the side stream, δ2 handed to the weight gradient as f32 instead of as the backward's fp16x2 planes; since round 6 the
-    forward of wide_fuse = 3 is the register-stationary wide_rs_fwd_kernel — option wide_rs bit 0, obs_dim a multiple of 4 — and wide_rs = 0
-    keeps the producer / consumer kernel and its weight-buffer flavours alive).  Every one of them must give the oracle's loss scalars and gradient on the same
+    forward and backward of wide_fuse = 3 are the register-stationary wide_rs_fwd_kernel / wide_rs_bwd_kernel — option wide_rs bits 0 and 3,
+    obs_dim a multiple of 4 — and wide_rs = 0 keeps round 5's kernels and their flavours alive).  Every one of them must give the oracle's loss scalars and gradient on the same
     buffers — the default is only the fastest of equals.  Shapes: C3's, the largest the fused kernels take (obs 16, 8
     actions) and an odd small one (obs 3, 2 actions)."""
     k, Hd = 128, 256
@@ -411,7 +411,7 @@ def test_c3_full_size_rollout_slices_match_the_oracle(crl):
     params = spread_params(cfg_full, 17)
     agent = make_wide(crl, nt, k, D, A, Hd, params=params)
     h = agent.handle; F = crl._lib
-    assert h.get_option("wide_rollout_persist") == 2 and h.get_option("wide_fuse") == 3 and h.get_option("wide_rs") == 3, "defaults must select wide_rs_rollout_kernel"
+    assert h.get_option("wide_rollout_persist") == 2 and h.get_option("wide_fuse") == 3 and h.get_option("wide_rs") == 11, "defaults must select wide_rs_rollout_kernel"
     h.env_reset(); h.rollout_run(); h.compute_gae()
     act, obs, rew, term = h.read(F.F_ACTION), h.read(F.F_OBS), h.read(F.F_REWARD), h.read(F.F_TERMINAL)
     lp, val, adv, ret = h.read(F.F_LOGPROB), h.read(F.F_VALUE), h.read(F.F_ADVANTAGE), h.read(F.F_RETURN)
