@@ -74,6 +74,7 @@ enum OptId {
   OPT_WIDE_D2_SPLIT,          // fused backward -> 256x256 weight gradient: 1 = δ2 travels as the backward's own fp16x2 pieces (two f16 planes + a scale per sample), 0 = as f32
   OPT_UPDATE_TILE,            // update pass of the 4 / 2 / 64 path: 32 = 32-sample tiles (update_x2_kernel), 16 = 16-sample tiles at three waves per SIMD (update16.hpp), 0 = by launch size (see update.hip)
   OPT_WIDE_RS,                // 2x256 fp16x2: register-stationary kernels of wide_rs.hpp — bit 0 = the update pass's forward, bit 1 = the rollout (actor in the loop, critic as one batched pass behind it)
+  OPT_WIDE_RS_ACTOR_PCT,      // register-stationary backward: share of the CUs given to the actor's blocks (its tile costs n_act head rows against one)
   OPT_COUNT
 };
 

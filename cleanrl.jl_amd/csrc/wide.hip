@@ -74,6 +74,8 @@ struct WideWs {
   double* vpart = nullptr;       // [1024]
   double* u_dev = nullptr;       // [0] u (reserved), [1] = double(count) under DP
   int cus = 256;                 // compute units of the device (grid of the persistent fused backward)
+  int w3_blocks = 0;             // 1: the last backward (wide_rs_bwd_kernel) left the dW3 partials itself (one per block, like dW1): no sweeps over h2
+  int fb_blocks_net[2] = {0, 0}; // … per network (the register-stationary backward may split the CUs unevenly)
   int fb_blocks = 0;             // > 0: the last backward ran fused (wide_fused.hpp) and left this many dW1 / db1 partials per network
   int lds_max = 160 * 1024;      // LDS a block may ask for on this device: the fused kernels need 133-160 KB and are not chosen below that
 };
@@ -2713,13 +2715,26 @@ static int wide_backward_fused(crl_ppo* h, const int32_t* perm, int M) {
   const size_t lds = (size_t)FB_OFF_W3 + (size_t)w->A * 1024;
   const bool rsb = split && (opt(h, OPT_WIDE_RS) & 8) && M % RS_MB == 0 && w->A <= 8 && w->D % 4 == 0 && w->lds_max >= RB_LDS;
   if (rsb) {     // register-stationary form (wide_rs.hpp)
-    for (int net = 0; net < 2; ++net) { const float* pk = w->pack + w->pk_base[net]; a[net].W1f = pk + w->pk[net].w1f; a[net].w1sc = w->wsc + 4 + 2 * net; }
+    for (int net = 0; net < 2; ++net) { const float* pk = w->pack + w->pk_base[net]; a[net].W1f = pk + w->pk[net].w1f; a[net].w1sc = w->wsc + 4 + 2 * net; a[net].pW3 = w->pW3[net]; }
     int nbr = w->cus / 2; const int nt32 = M / RS_MB; if (nbr > nt32) nbr = nt32; if (nbr > w->Ss) nbr = w->Ss; if (nbr < 1) nbr = 1;
     nb = nbr;
-    if (w->D8 == 8 && w->A <= 4) hipLaunchKernelGGL((wide_rs_bwd_kernel<8, 4>), dim3(nb, 2), dim3(512), RB_LDS, h->stream, a[0], a[1]);
-    else if (w->D8 == 8) hipLaunchKernelGGL((wide_rs_bwd_kernel<8, 8>), dim3(nb, 2), dim3(512), RB_LDS, h->stream, a[0], a[1]);
-    else if (w->A <= 4) hipLaunchKernelGGL((wide_rs_bwd_kernel<16, 4>), dim3(nb, 2), dim3(512), RB_LDS, h->stream, a[0], a[1]);
-    else hipLaunchKernelGGL((wide_rs_bwd_kernel<16, 8>), dim3(nb, 2), dim3(512), RB_LDS, h->stream, a[0], a[1]);
+    w->fb_blocks_net[0] = w->fb_blocks_net[1] = nbr;
+    const int pct = (int)opt(h, OPT_WIDE_RS_ACTOR_PCT);
+    if (pct != 50 && 2 * nbr == w->cus && w->cus <= 2 * w->Ss) {        // uneven split of the CUs: the grid's x extent is the larger share
+      int na = w->cus * pct / 100; if (na < 1) na = 1; if (na > w->cus - 1) na = w->cus - 1;
+      if (na <= w->Ss && w->cus - na <= w->Ss) { a[0].nblk = na; a[1].nblk = w->cus - na; w->fb_blocks_net[0] = na; w->fb_blocks_net[1] = w->cus - na; nb = na > w->cus - na ? na : w->cus - na; }
+    }
+    const bool dw3 = (opt(h, OPT_WIDE_RS) & 16) != 0;                 // dW3 inside the backward kernel instead of the two sweeps over h2
+#define CRL_RSB(dp, na)                                                                                                              \
+    do {                                                                                                                             \
+      if (dw3) hipLaunchKernelGGL((wide_rs_bwd_kernel<dp, na, true>), dim3(nb, 2), dim3(512), RB_LDS, h->stream, a[0], a[1]);        \
+      else hipLaunchKernelGGL((wide_rs_bwd_kernel<dp, na, false>), dim3(nb, 2), dim3(512), RB_LDS, h->stream, a[0], a[1]);           \
+    } while (0)
+    if (w->D8 == 8 && w->A <= 4) CRL_RSB(8, 4);
+    else if (w->D8 == 8) CRL_RSB(8, 8);
+    else if (w->A <= 4) CRL_RSB(16, 4);
+    else CRL_RSB(16, 8);
+#undef CRL_RSB
   } else {
 #define CRL_BWD(dp, na)                                                                                                                  \
   do {                                                                                                                                   \
@@ -2734,6 +2749,9 @@ static int wide_backward_fused(crl_ppo* h, const int32_t* perm, int M) {
   }
   CRL_HIP_CHECK(hipGetLastError());
   w->fb_blocks = nb;
+  if (!rsb) w->fb_blocks_net[0] = w->fb_blocks_net[1] = nb;
+  const bool rsb_dw3 = rsb && (opt(h, OPT_WIDE_RS) & 16) != 0;
+  w->w3_blocks = rsb_dw3 ? 1 : 0;
   // The dW3 sweeps over h2 depend on the loss kernel only, like the fused backward: they run on the second stream beside it and join at
   // the end of this function.
   const bool side = opt(h, OPT_SHUFFLE_OVERLAP) != 0;
@@ -2746,7 +2764,7 @@ static int wide_backward_fused(crl_ppo* h, const int32_t* perm, int M) {
     SkinnyArgs s;   // dW3[a, k] = Σ δ3[a]·h2[k]
     s.Big = w->h2[net]; s.H = 256; s.Small = dOut; s.lds = ldd; s.idx = nullptr; s.M = M; s.chunk = w->chunks;
     s.pW = w->pW3[net]; s.os_row = NO; s.os_s = 1; s.St = NO; s.wsize = 256 * NO; s.pB = nullptr; s.D2out = nullptr; s.W3t = pk + w->pk[net].w3t;
-    if (skinny_launch(sk, w->Ss, s)) return 1;
+    if (!rsb_dw3 && skinny_launch(sk, w->Ss, s)) return 1;
     if (!wide_h1_free(h)) {
       WgradArgs g;    // dW2 = δ2·h1ᵀ, db2 = Σ δ2 from the stored h1
       g.dY = net ? w->dB : w->dA; g.X = w->h1[net]; g.H = 256; g.M = M; g.chunk = w->chunk2; g.pW = w->pW2[net]; g.pB = w->pB2[net];
@@ -2839,7 +2857,7 @@ static int wide_grad_passes(crl_ppo* h, int mb, const int32_t* perm, double Mglo
     hipLaunchKernelGGL(wide_loss_kernel, dim3(w->nlb), dim3(256), 0, h->stream, a);
     CRL_HIP_CHECK(hipGetLastError());
   }
-  w->fb_blocks = 0;
+  w->fb_blocks = 0; w->w3_blocks = 0;
   if (wide_fused_ok(h) && M % FX_MB == 0 && w->A <= FB_AMAX && opt(h, OPT_WIDE_FUSE) >= 2) {
     if (opt(h, OPT_SHUFFLE_OVERLAP)) CRL_HIP_CHECK(hipEventRecord(h->ev_fork, h->stream));   // behind the loss kernel: the side stream starts here
     return wide_backward_fused(h, perm, M);
@@ -2874,11 +2892,11 @@ int wide_update(crl_ppo* h, int mb, crl_ppo_stats* stats_slot) {
     for (int i = 0; i < 12; ++i) r.off[i + 1] = r.off[i] + sizes[i];
     for (int n = 0; n < 2; ++n) {
       const int b = 6 * n;
-      r.part[b + 0] = w->pW1[n]; r.nparts[b + 0] = w->fb_blocks ? w->fb_blocks : w->Ss;
-      r.part[b + 1] = w->pB1[n]; r.nparts[b + 1] = w->fb_blocks ? w->fb_blocks : w->Ss;
+      r.part[b + 0] = w->pW1[n]; r.nparts[b + 0] = w->fb_blocks ? w->fb_blocks_net[n] : w->Ss;
+      r.part[b + 1] = w->pB1[n]; r.nparts[b + 1] = w->fb_blocks ? w->fb_blocks_net[n] : w->Ss;
       r.part[b + 2] = w->pW2[n]; r.nparts[b + 2] = w->S2;
       r.part[b + 3] = w->pB2[n]; r.nparts[b + 3] = w->S2;
-      r.part[b + 4] = w->pW3[n]; r.nparts[b + 4] = w->Ss;
+      r.part[b + 4] = w->pW3[n]; r.nparts[b + 4] = w->w3_blocks ? w->fb_blocks_net[n] : w->Ss;
       r.part[b + 5] = nullptr; r.nparts[b + 5] = 0;
     }
     r.lpart = w->lpart; r.nlb = w->nlb; r.out = h->comm_buf; r.P = P; r.A = A;

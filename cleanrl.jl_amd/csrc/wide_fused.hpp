@@ -310,6 +310,8 @@ struct FusedBwdArgs {
   // of two s1 — in two [M][256] f16 planes (hi at D2h, lo at D2h + 256·M: the bytes of the f32 array), and 1/s1 per sample in d2s; D2 is not written
   _Float16* D2h; float* d2s;
   const float* W1f = nullptr; const float* w1sc = nullptr;   // wide_rs_bwd_kernel: W1 as fp16x2 fragments (pack w1f) and its scale pair, for layer 1 on the matrix pipe
+  int nblk = 0;                                              // wide_rs_bwd_kernel: blocks this network's tiles are spread over (0 = the grid's x extent)
+  float* pW3 = nullptr;                                      // wide_rs_bwd_kernel: dW3 partials [block][unit·A + a] (the kernel has h2 and δ3 on chip: no sweep over h2)
 };
 
 // one h2 slab (units 32s …, samples m0 …) into LDS as [sample][32 units]: 16 pieces of 1 KB (8 samples x 128 B), two per wave

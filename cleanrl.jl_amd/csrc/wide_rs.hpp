@@ -422,7 +422,7 @@ constexpr int RB_OFF_TAB = RB_OFF_DZ + 4 * 2 * RS_MB * 16;     // per wave: xinv
 constexpr int RB_LDS = RB_OFF_TAB + 8 * 5 * RS_MB * 4;         // 155,648 bytes
 static_assert(RB_LDS <= 160 * 1024, "register-stationary backward: LDS budget");
 
-template <int DP, int NA>
+template <int DP, int NA, bool DW3>
 __device__ __forceinline__ void wide_rs_bwd_body(const FusedBwdArgs& a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
   if (a.M <= 0) return;
@@ -445,13 +445,39 @@ __device__ __forceinline__ void wide_rs_bwd_body(const FusedBwdArgs& a) {
 #pragma unroll
   for (int q = 0; q < NA; ++q) wmaxr[q] = q < a.A ? a.wmax[q] : 0.0f;
   const int ntiles = a.M / RS_MB;
-  const int nblk = (int)gridDim.x;
-  const int nloc = (int)blockIdx.x < ntiles ? (ntiles - (int)blockIdx.x + nblk - 1) / nblk : 0;
+  const int nblk = a.nblk > 0 ? a.nblk : (int)gridDim.x;
+  const int nloc = ((int)blockIdx.x < ntiles && (int)blockIdx.x < nblk) ? (ntiles - (int)blockIdx.x + nblk - 1) / nblk : 0;
   if (nloc == 0) return;
   auto tile_of = [&](int i) { return (int)blockIdx.x + (i < nloc ? i : nloc - 1) * nblk; };   // tiles beyond the block's last are made from its last one and never used
-  float gW1[DP], gB1 = 0.0f;
+  float gW1[DP], gB1 = 0.0f, gW3[NA];
 #pragma unroll
   for (int c = 0; c < DP; ++c) gW1[c] = 0.0f;
+#pragma unroll
+  for (int q = 0; q < NA; ++q) gW3[q] = 0.0f;
+  // dW3[a][v] += δ3[a][sample]·h2[v][sample] for four samples (rows 8g + 4hf + e) of tile i: lane = unit v like the epilogue — the tile's h2 and δ3 are
+  // both in LDS while its δ2 is staged, so the two dW3 sweeps over h2 (1.07 GB per optimiser step, 2 x 0.11 ms alone) need not be launched. Template flag DW3
+  // (option wide_rs bit 4), off by default: measured 865 vs 665 µs for this kernel against 117 µs that the co-running sweeps cost the weight-gradient kernel
+  auto dw3_part = [&](int i, int g) __attribute__((always_inline)) {
+    const float* hcol = reinterpret_cast<const float*>(smx + RB_OFF_H + (i & 1) * RB_HBYTES) + 32 * wave + j;
+    const float* dzt = dzall + (i & 3) * (2 * RS_MB * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (e == 2) __builtin_amdgcn_sched_barrier(0);                     // two samples' reads in flight at a time (four spilled)
+      const int sidx = 8 * g + 4 * hf + e;
+      const float hv = hcol[sidx * (RB_HROW / 4)];
+      const f32x4 z0 = *reinterpret_cast<const f32x4*>(dzt + sidx * 4);
+      if constexpr (NA == 1) gW3[0] = __builtin_fmaf(z0[0], hv, gW3[0]);
+      else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gW3[q] = __builtin_fmaf(z0[q], hv, gW3[q]);
+        if constexpr (NA == 8) {
+          const f32x4 z1 = *reinterpret_cast<const f32x4*>(dzt + RS_MB * 4 + sidx * 4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) gW3[4 + q] = __builtin_fmaf(z1[q], hv, gW3[4 + q]);
+        }
+      }
+    }
+  };
   // ---- input pipelines
   auto dma_h2 = [&](int i) {                                            // tile i's h2 rows 4·wave … 4·wave + 3 into buffer i & 1
     const float* src = a.H2 + (size_t)256 * (tile_of(i) * RS_MB + 4 * wave);
@@ -535,6 +561,8 @@ __device__ __forceinline__ void wide_rs_bwd_body(const FusedBwdArgs& a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   stage_d2(0, true);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) if constexpr (DW3) dw3_part(0, g);
   f32x16 acc0, acc1;
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc1[q] = 0.0f;
@@ -642,6 +670,7 @@ __device__ __forceinline__ void wide_rs_bwd_body(const FusedBwdArgs& a) {
           }
         }
       }
+      if constexpr (pst && DW3) dw3_part(s + 1, g);
       __builtin_amdgcn_sched_barrier(0);
     }
     // the h2 pieces of tile s + 2 have landed (only this stage's last four plane stores may still be in flight), LDS writes are done
@@ -665,17 +694,21 @@ __device__ __forceinline__ void wide_rs_bwd_body(const FusedBwdArgs& a) {
   gB1 = add32(gB1);
 #pragma unroll
   for (int c = 0; c < DP; ++c) gW1[c] = add32(gW1[c]);
+#pragma unroll
+  for (int q = 0; q < NA; ++q) gW3[q] = add32(gW3[q]);
   if (hf == 0) {
     const int v = 32 * wave + j;
+#pragma unroll
+    for (int q = 0; q < NA; ++q) if (DW3 && q < a.A) a.pW3[(size_t)blockIdx.x * 256 * a.A + (size_t)v * a.A + q] = gW3[q];
     a.pB1[(size_t)blockIdx.x * 256 + v] = gB1;
 #pragma unroll
     for (int c = 0; c < DP; ++c) if (c < a.D) a.pW1[(size_t)blockIdx.x * 256 * a.D + v + 256 * c] = gW1[c];
   }
 }
 
-template <int DP, int NA0>
+template <int DP, int NA0, bool DW3>
 __global__ void __launch_bounds__(512) wide_rs_bwd_kernel(FusedBwdArgs a0, FusedBwdArgs a1) {
-  if (blockIdx.y == 0) wide_rs_bwd_body<DP, NA0>(a0); else wide_rs_bwd_body<DP, 1>(a1);
+  if (blockIdx.y == 0) wide_rs_bwd_body<DP, NA0, DW3>(a0); else wide_rs_bwd_body<DP, 1, DW3>(a1);
 }
 
 // ======================================================================================================================================

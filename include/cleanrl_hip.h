@@ -284,7 +284,10 @@ int32_t crl_comm_destroy(crl_ppo* h);
  *                           step loop, env state in LDS; the critic as ONE batched forward over the stored observations behind it — ppo.jl:128 evaluates it
  *                           on the observation the buffer keeps), bit 2 = that critic pass on the register-stationary forward instead of the producer /
  *                           consumer kernel (measured slower), bit 3 = the update pass's backward (wide_rs_bwd_kernel: W2ᵀ stationary as the B operand, h2 /
- *                           δ3 / observations by LDS-DMA, layer 1 recomputed on the matrix pipe; with wide_d2_split = 1, obs_dim a multiple of 4); 0 = round 5's kernels
+ *                           δ3 / observations by LDS-DMA, layer 1 recomputed on the matrix pipe; with wide_d2_split = 1, obs_dim a multiple of 4), bit 4 = that kernel
+ *                           also forms dW3 (h2 and δ3 are on chip: the two sweeps over h2 are not launched; measured slower, off); 0 = round 5's kernels
+ *   wide_rs_actor_pct (52)  register-stationary backward: share of the CUs whose blocks take the actor's tiles (its δ2 staging costs n_act head rows against the
+ *                           critic's one): 676 / 666 / 679 / 717 µs per launch at 50 / 52 / 54 / 56 % (C3)
  *   update_tile (0)         update pass of the 4 / 2 / 64 path: 32 = 32-sample tiles (update_x2_kernel), 16 = 16-sample tiles at three waves per SIMD (update16.hpp: one early-exit
  *                           repair launch redoes a minibatch as bf16x3 when a tile misses the carried weight-gradient scale or a weight leaves the fp16 window; 17 = the same with
  *                           every tile reporting a miss: test hook), 0 = by launch size — which currently means 32 everywhere: the 16-sample kernel measured slower at every

@@ -140,7 +140,7 @@ def test_wide_update_gradient_matches_oracle(crl, D, A, Hd, nt, k, ret_scale, cl
     {"wide_fuse": 0}, {"wide_fuse": 1}, {"wide_fuse": 2}, {"wide_fuse": 3},
     {"wide_fuse": 3, "wide_fuse_pc": 0}, {"wide_fuse": 2, "wide_fuse_pc": 0}, {"wide_fuse": 3, "wide_wgrad_full": 0},
     {"wide_fuse": 3, "shuffle_overlap": 0}, {"wide_fuse": 3, "wide_fwd_wbufs": 3, "wide_rs": 0}, {"wide_fuse": 3, "wide_fwd_wbufs": 0, "wide_rs": 0},
-    {"wide_fuse": 3, "wide_d2_split": 0}, {"wide_fuse": 3, "wide_rs": 0}, {"wide_fuse": 3, "wide_rs": 1}, {"wide_fuse": 3, "wide_rs": 8}, {"wide_fuse": 3, "wide_rs": 9}], ids=lambda o: ",".join(f"{a}={b}" for a, b in o.items()))
+    {"wide_fuse": 3, "wide_d2_split": 0}, {"wide_fuse": 3, "wide_rs": 0}, {"wide_fuse": 3, "wide_rs": 1}, {"wide_fuse": 3, "wide_rs": 8}, {"wide_fuse": 3, "wide_rs": 9}, {"wide_fuse": 3, "wide_rs": 27}], ids=lambda o: ",".join(f"{a}={b}" for a, b in o.items()))
 @pytest.mark.parametrize("D,A,nt", [(8, 4, 24), (16, 8, 16), (3, 2, 12)])
 def test_every_2x256_kernel_flavour_matches_the_oracle(crl, opts, D, A, nt):
     """The 2x256 shape has four selectable pipelines (option wide_fuse: 0 layer-wise GEMMs, 1 tile-resident forward, 2 + tile-
