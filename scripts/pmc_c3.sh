@@ -9,7 +9,7 @@ O=$R/gpurun_out/${TAG}_c3pmc
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 P="python3 $R/bench.py --workload c3 --steps 1 --warmup 1 --no-cpu-baseline --no-extras --opt shuffle_overlap=0"
-KR="wide_rs_fwd_kernel|wide_rs_rollout_kernel|wide_fused_fwd_pc_kernel|wide_fused_bwd_kernel|wide_wgrad_gen_kernel|wide_wgrad_split_kernel|wide_rollout_pc_kernel|wide_skinny_kernel"
+KR="wide_rs_fwd_kernel|wide_rs_bwd_kernel|wide_rs_rollout_kernel|wide_fused_fwd_pc_kernel|wide_fused_bwd_kernel|wide_wgrad_gen_kernel|wide_wgrad_split_kernel|wide_rollout_pc_kernel|wide_skinny_kernel"
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC" "FETCH_SIZE" "WRITE_SIZE"; do
   n=$(echo $set | cut -d' ' -f1)
   timeout 300 rocprofv3 --pmc $set --kernel-include-regex "$KR" --output-format csv -d $O/p_$n -- $P > /dev/null 2>&1
