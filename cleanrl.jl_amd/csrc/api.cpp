@@ -49,7 +49,7 @@ static const OptDesc kOpts[OPT_COUNT] = {
     {"wide_fwd_wbufs", 2, 0, 3},
     {"wide_d2_split", 1, 0, 1},
     {"update_tile", 0, 0, 32},
-    {"wide_rs", 11, 0, 31},
+    {"wide_rs", 27, 0, 31},
     {"wide_rs_actor_pct", 52, 10, 90},
 };
 static bool gae_seg_ok(int64_t v) { return v == 0 || v == 4 || v == 8 || v == 16; }

@@ -456,13 +456,14 @@ __device__ __forceinline__ void wide_rs_bwd_body(const FusedBwdArgs& a) {
   for (int q = 0; q < NA; ++q) gW3[q] = 0.0f;
   // dW3[a][v] += δ3[a][sample]·h2[v][sample] for four samples (rows 8g + 4hf + e) of tile i: lane = unit v like the epilogue — the tile's h2 and δ3 are
   // both in LDS while its δ2 is staged, so the two dW3 sweeps over h2 (1.07 GB per optimiser step, 2 x 0.11 ms alone) need not be launched. Template flag DW3
-  // (option wide_rs bit 4), off by default: measured 865 vs 665 µs for this kernel against 117 µs that the co-running sweeps cost the weight-gradient kernel
+  // (option wide_rs bit 4, on by default). Placement matters: inside the groups its reads and sums spilled ~20 registers (865 vs 665 µs for this kernel — more
+  // than the 117 µs the co-running sweeps cost the weight-gradient kernel); as four scheduling regions BEHIND the groups: 740 vs 691 µs, weight gradient
+  // 580 -> 465 µs, iteration 34.6 -> 32.5 ms on one box
   auto dw3_part = [&](int i, int g) __attribute__((always_inline)) {
     const float* hcol = reinterpret_cast<const float*>(smx + RB_OFF_H + (i & 1) * RB_HBYTES) + 32 * wave + j;
     const float* dzt = dzall + (i & 3) * (2 * RS_MB * 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      if (e == 2) __builtin_amdgcn_sched_barrier(0);                     // two samples' reads in flight at a time (four spilled)
       const int sidx = 8 * g + 4 * hf + e;
       const float hv = hcol[sidx * (RB_HROW / 4)];
       const f32x4 z0 = *reinterpret_cast<const f32x4*>(dzt + sidx * 4);
@@ -670,8 +671,12 @@ __device__ __forceinline__ void wide_rs_bwd_body(const FusedBwdArgs& a) {
           }
         }
       }
-      if constexpr (pst && DW3) dw3_part(s + 1, g);
       __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (pst && DW3) {                                         // behind the groups, in regions of its own (a ROLLED loop here: 580 B of scratch)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { dw3_part(s + 1, g); __builtin_amdgcn_sched_barrier(0); }
     }
     // the h2 pieces of tile s + 2 have landed (only this stage's last four plane stores may still be in flight), LDS writes are done
     if (pst) asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");

@@ -278,14 +278,14 @@ int32_t crl_comm_destroy(crl_ppo* h);
  *   wide_d2_split (1)       wide_fuse = 3 with wide_wgrad_full = 1: the backward kernel hands δ2 to the weight-gradient kernel as the fp16x2 pieces it makes for
  *                           its own product (two f16 planes, one power-of-two scale per sample; the same bytes as the f32 array) and the weight-gradient kernel
  *                           multiplies straight from them (LDS-DMA + transposing LDS reads, no conversion); 0 = δ2 as f32, split again by its reader
- *   wide_rs (11)            2x256 fp16x2, register-stationary kernels (csrc/wide_rs.hpp: a network's 256 KB of W2 pieces live in the eight waves' registers
+ *   wide_rs (27)            2x256 fp16x2, register-stationary kernels (csrc/wide_rs.hpp: a network's 256 KB of W2 pieces live in the eight waves' registers
  *                           for the whole launch, nothing but the 32-sample activation tile moves): bit 0 = the update pass's forward (wide_rs_fwd_kernel,
  *                           obs_dim a multiple of 4; else the producer / consumer kernel), bit 1 = the rollout (wide_rs_rollout_kernel: the actor in the
  *                           step loop, env state in LDS; the critic as ONE batched forward over the stored observations behind it — ppo.jl:128 evaluates it
  *                           on the observation the buffer keeps), bit 2 = that critic pass on the register-stationary forward instead of the producer /
  *                           consumer kernel (measured slower), bit 3 = the update pass's backward (wide_rs_bwd_kernel: W2ᵀ stationary as the B operand, h2 /
  *                           δ3 / observations by LDS-DMA, layer 1 recomputed on the matrix pipe; with wide_d2_split = 1, obs_dim a multiple of 4), bit 4 = that kernel
- *                           also forms dW3 (h2 and δ3 are on chip: the two sweeps over h2 are not launched; measured slower, off); 0 = round 5's kernels
+ *                           also forms dW3 (h2 and δ3 are on chip: the two sweeps over h2 — 1.07 GB per optimiser step — are not launched); 0 = round 5's kernels
  *   wide_rs_actor_pct (52)  register-stationary backward: share of the CUs whose blocks take the actor's tiles (its δ2 staging costs n_act head rows against the
  *                           critic's one): 676 / 666 / 679 / 717 µs per launch at 50 / 52 / 54 / 56 % (C3)
  *   update_tile (0)         update pass of the 4 / 2 / 64 path: 32 = 32-sample tiles (update_x2_kernel), 16 = 16-sample tiles at three waves per SIMD (update16.hpp: one early-exit

@@ -140,7 +140,7 @@ def test_wide_update_gradient_matches_oracle(crl, D, A, Hd, nt, k, ret_scale, cl
     {"wide_fuse": 0}, {"wide_fuse": 1}, {"wide_fuse": 2}, {"wide_fuse": 3},
     {"wide_fuse": 3, "wide_fuse_pc": 0}, {"wide_fuse": 2, "wide_fuse_pc": 0}, {"wide_fuse": 3, "wide_wgrad_full": 0},
     {"wide_fuse": 3, "shuffle_overlap": 0}, {"wide_fuse": 3, "wide_fwd_wbufs": 3, "wide_rs": 0}, {"wide_fuse": 3, "wide_fwd_wbufs": 0, "wide_rs": 0},
-    {"wide_fuse": 3, "wide_d2_split": 0}, {"wide_fuse": 3, "wide_rs": 0}, {"wide_fuse": 3, "wide_rs": 1}, {"wide_fuse": 3, "wide_rs": 8}, {"wide_fuse": 3, "wide_rs": 9}, {"wide_fuse": 3, "wide_rs": 27}], ids=lambda o: ",".join(f"{a}={b}" for a, b in o.items()))
+    {"wide_fuse": 3, "wide_d2_split": 0}, {"wide_fuse": 3, "wide_rs": 0}, {"wide_fuse": 3, "wide_rs": 1}, {"wide_fuse": 3, "wide_rs": 8}, {"wide_fuse": 3, "wide_rs": 9}, {"wide_fuse": 3, "wide_rs": 11}, {"wide_fuse": 3, "wide_rs": 27}], ids=lambda o: ",".join(f"{a}={b}" for a, b in o.items()))
 @pytest.mark.parametrize("D,A,nt", [(8, 4, 24), (16, 8, 16), (3, 2, 12)])
 def test_every_2x256_kernel_flavour_matches_the_oracle(crl, opts, D, A, nt):
     """The 2x256 shape has four selectable pipelines (option wide_fuse: 0 layer-wise GEMMs, 1 tile-resident forward, 2 + tile-
@@ -411,7 +411,7 @@ def test_c3_full_size_rollout_slices_match_the_oracle(crl):
     params = spread_params(cfg_full, 17)
     agent = make_wide(crl, nt, k, D, A, Hd, params=params)
     h = agent.handle; F = crl._lib
-    assert h.get_option("wide_rollout_persist") == 2 and h.get_option("wide_fuse") == 3 and h.get_option("wide_rs") == 11, "defaults must select wide_rs_rollout_kernel"
+    assert h.get_option("wide_rollout_persist") == 2 and h.get_option("wide_fuse") == 3 and h.get_option("wide_rs") == 27, "defaults must select wide_rs_rollout_kernel"
     h.env_reset(); h.rollout_run(); h.compute_gae()
     act, obs, rew, term = h.read(F.F_ACTION), h.read(F.F_OBS), h.read(F.F_REWARD), h.read(F.F_TERMINAL)
     lp, val, adv, ret = h.read(F.F_LOGPROB), h.read(F.F_VALUE), h.read(F.F_ADVANTAGE), h.read(F.F_RETURN)
