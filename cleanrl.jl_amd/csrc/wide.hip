@@ -2696,6 +2696,12 @@ static int wide_forward_fused(crl_ppo* h, const int32_t* perm, int M) {
 
 // Backward of BOTH networks: one launch of the tile-resident kernel (δ2 → dA / dB, dW1 / db1 partials), then per network the dW3 sweep over
 // h2 and the 256x256 weight-gradient kernel on the stored δ2 and h1.
+// the register-stationary backward with dW3 inside (wide_rs bits 3 + 4) will run for this minibatch: nothing is launched on the side stream
+static bool wide_rs_bwd_forms_dw3(const crl_ppo* h, int M) {
+  const WideWs* w = static_cast<const WideWs*>(h->wide_ws);
+  const bool split = wide_h1_free(h) && opt(h, OPT_WIDE_WGRAD_FULL) && opt(h, OPT_WIDE_D2_SPLIT) && w->chunk2 % 32 == 0 && w->lds_max >= WS_LDS;
+  return split && (opt(h, OPT_WIDE_RS) & 8) && (opt(h, OPT_WIDE_RS) & 16) && M % RS_MB == 0 && w->A <= 8 && w->D % 4 == 0 && w->lds_max >= RB_LDS;
+}
 static int wide_backward_fused(crl_ppo* h, const int32_t* perm, int M) {
   WideWs* w = static_cast<WideWs*>(h->wide_ws);
   const int ntiles = M / FX_MB;
@@ -2754,7 +2760,7 @@ static int wide_backward_fused(crl_ppo* h, const int32_t* perm, int M) {
   w->w3_blocks = rsb_dw3 ? 1 : 0;
   // The dW3 sweeps over h2 depend on the loss kernel only, like the fused backward: they run on the second stream beside it and join at
   // the end of this function.
-  const bool side = opt(h, OPT_SHUFFLE_OVERLAP) != 0;
+  const bool side = opt(h, OPT_SHUFFLE_OVERLAP) != 0 && !rsb_dw3;      // (nothing goes to the side stream when the backward kernel formed dW3 itself: no fork / join — 13 µs per step)
   hipStream_t sk = side ? h->stream2 : h->stream;
   if (side) CRL_HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));   // ev_fork was recorded behind the loss kernel (wide_grad_passes)
   for (int net = 0; net < 2; ++net) {
@@ -2859,7 +2865,7 @@ static int wide_grad_passes(crl_ppo* h, int mb, const int32_t* perm, double Mglo
   }
   w->fb_blocks = 0; w->w3_blocks = 0;
   if (wide_fused_ok(h) && M % FX_MB == 0 && w->A <= FB_AMAX && opt(h, OPT_WIDE_FUSE) >= 2) {
-    if (opt(h, OPT_SHUFFLE_OVERLAP)) CRL_HIP_CHECK(hipEventRecord(h->ev_fork, h->stream));   // behind the loss kernel: the side stream starts here
+    if (opt(h, OPT_SHUFFLE_OVERLAP) && !wide_rs_bwd_forms_dw3(h, M)) CRL_HIP_CHECK(hipEventRecord(h->ev_fork, h->stream));   // behind the loss kernel: the side stream starts here
     return wide_backward_fused(h, perm, M);
   }
   if (wide_backward(h, 0, w->z, w->A8, perm)) return 1;
