@@ -821,10 +821,11 @@ def main():
             for key, wl, envs, steps in (("c2", "c2", 0, 40), ("c3", "c3", 0, 5), ("shard_8192", "cartpole", 8192, 40)):
                 try:
                     a2 = argparse.Namespace(**vars(args)); a2.total_envs = envs; a2.kernel_breakdown = False
-                    rec = run_workload(a2, wl, 1, 0, 0, dist, torch, crl, crl_dist, steps=steps, warmup=3, with_gae=False)
+                    # three timed regions, the median reported: a side record of 5 iterations is otherwise at the mercy of one host hiccup (the boxes are shared)
+                    rec = run_workload(a2, wl, 1, 0, 0, dist, torch, crl, crl_dist, steps=steps, warmup=3, with_gae=False, regions=3)
                     rf = rec["roofline"]
                     cfgs[key] = {"workload": rec["config"]["workload"], "value": rec["value"], "unit": "env-steps/s", "ms_per_step": rec["ms_per_step"],
-                                 "steps": steps, "warmup": 3, "dtype": rec["dtype"],
+                                 "ms_per_step_runs": rec.get("ms_per_step_runs"), "steps": steps, "warmup": 3, "dtype": rec["dtype"],
                                  "roofline": {"bound": rf["bound"], "frac": rf["frac"], "achieved": rf["achieved"], "peak": rf["peak"], "unit": rf["unit"],
                                               "avg_launch_ms": rf["avg_launch_ms"], "launches": rf["launches"],
                                               **({k2: rf[k2] for k2 in ("traffic", "algorithmic_bytes", "traffic_over_algorithmic", "traffic_gbps", "traffic_source") if k2 in rf and wl == "c3"}),
