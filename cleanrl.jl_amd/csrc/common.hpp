@@ -208,7 +208,7 @@ __device__ __forceinline__ void mlp_forward(const float* img, const float (&x)[D
         acc = __builtin_fmaf(wv[e], h2[idx >> 4][idx & 15], acc);
       }
     }
-    out[a] = acc + xor32(acc) + img[I::B3 + a];
+    out[a] = add32(acc) + img[I::B3 + a];
   }
 }
 

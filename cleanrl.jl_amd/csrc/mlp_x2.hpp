@@ -190,7 +190,7 @@ __device__ __forceinline__ void mlp_forward_x2(const float* img, const float (&x
         acc = __builtin_fmaf(wv[e], h2[idx >> 4][idx & 15], acc);
       }
     }
-    out[a] = acc + xor32(acc) + img[I::B3 + a];
+    out[a] = add32(acc) + img[I::B3 + a];
   }
 }
 
@@ -202,7 +202,7 @@ __device__ __forceinline__ void sample_scale(const f32x16 (&d)[2], float& s, flo
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
     for (int r = 0; r < 16; r += 2) m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(d[mt][r]), __builtin_fabsf(d[mt][r + 1])));
-  m = __builtin_fmaxf(m, xor32(m));
+  m = max32(m);
   int e = (int)((__float_as_uint(m) >> 23) & 0xFFu);   // biased exponent: m in [2^(e-127), 2^(e-126))
   e = e < 16 ? 16 : e;                                   // zero / tiny columns: any scale will do
   s = __uint_as_float((unsigned)(268 - e) << 23);        // 2^(141 − e): m·s in [2^14, 2^15)

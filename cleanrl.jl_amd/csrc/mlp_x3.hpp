@@ -218,7 +218,7 @@ __device__ __forceinline__ void mlp_forward_x3(const float* img, const float (&x
         acc = __builtin_fmaf(wv[e], h2[idx >> 4][idx & 15], acc);
       }
     }
-    out[a] = acc + xor32(acc) + img[I::B3 + a];
+    out[a] = add32(acc) + img[I::B3 + a];
   }
 }
 

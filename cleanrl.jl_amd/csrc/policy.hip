@@ -536,7 +536,7 @@ __global__ void __launch_bounds__(192) rollout_split3_kernel(RolloutArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) accv = __builtin_fmaf(wv[i], h[(q - 4) * 4 + i], accv);
           }
-          z[o] = accv + xor32(accv) + img[IA::B3 + o];
+          z[o] = add32(accv) + img[IA::B3 + o];
         }
         softmax_logsoftmax<A>(z, p, lp);                                                     // ppo.jl:127 get_action
         const int act = sample_weights<A>(p, u);
@@ -608,7 +608,7 @@ __global__ void __launch_bounds__(192) rollout_split3_kernel(RolloutArgs a) {
           accv = __builtin_fmaf(wv[i], hv, accv);
         }
       }
-      const float v = accv + xor32(accv) + img[IC::B3];
+      const float v = add32(accv) + img[IC::B3];
       __syncthreads();                                                                       // (2)
       if (writer) a.value[b] = v;
     }
@@ -913,7 +913,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(384, 384), amdgpu_wav
 #pragma unroll
         for (int i = 0; i < 4; ++i) accv = __builtin_fmaf(wv[i], tanh_fast(acc[q * 4 + i]), accv);
       }
-      accv += xor32(accv);
+      accv = add32(accv);
       if (hf == 0) hdC[mo * TILE + j] = accv;
       __syncthreads();                                                                        // (2)
       if (mo == 0 && hf == 0 && ok) a.value[(size_t)(blockIdx.x * TILE + j) + (size_t)c.nt * step] = (hdC[j] + hdC[TILE + j]) + img[IC3::B3];
@@ -954,7 +954,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(384, 384), amdgpu_wav
 #pragma unroll
         for (int i = 0; i < 4; ++i) accv = __builtin_fmaf(wv[i], tanh_exp2(acc[q * 4 + i], TWO_LOG2E * X2_FWD_UNSCALE, 1.0f), accv);
       }
-      accv += xor32(accv);
+      accv = add32(accv);
       if (hf == 0) hdC[mo * TILE + j] = accv;
       __syncthreads();                                                                        // (2)
       if (mo == 0 && hf == 0 && ok) a.value[(size_t)(blockIdx.x * TILE + j) + (size_t)c.nt * step] = (hdC[j] + hdC[TILE + j]) + img[IC::B3];
