@@ -334,10 +334,12 @@ def test_2x256_rollout_flavours_match_the_oracle(crl, rs, env, D, A, nt, k):
     agent.close(); st.close()
 
 
-@pytest.mark.parametrize("persist", [2, 1, 0])
+@pytest.mark.parametrize("persist", [2, 1, 0, {"wide_rs_actor_pct": 60}, {"wide_rs": 11}, {"wide_rs": 0}], ids=str)
 def test_c3_shaped_iteration_at_1024_envs_matches_oracle(crl, persist):
-    """(wide_rollout_persist = 2: the rollout as one launch in producer / consumer form, wide_rollout_pc_kernel — the default when num_envs
-    is a multiple of 64; 1: one launch, wide_rollout_persist_kernel; 0: three launches per step.)
+    """(wide_rollout_persist = 2: the rollout as one launch — since round 6 the register-stationary wide_rs_rollout_kernel, with wide_rs = 0 round 5's
+    producer / consumer wide_rollout_pc_kernel; 1: one launch, wide_rollout_persist_kernel; 0: three launches per step. The dict cases: the
+    register-stationary backward with the CUs split 60 : 40 between the actor's and the critic's blocks — 128 tiles per network here, the smallest
+    launch that takes the uneven split —, with the dW3 sweeps still launched, and round 5's kernels throughout.)
     BASELINE configs[2]'s shape (obs 8 / act 4 / 2x256, synthetic env) at num_envs = 1024 — 32 tiles per launch, so the multi-tile
     paths of the layer-wise kernels run (chunked weight gradients, several blocks per GEMM) — for one whole iteration against the
     oracle at the north_star bar: actions and permutation bit-equal, advantages / losses within 1e-5 relative, parameters within 1e-5
@@ -347,7 +349,7 @@ def test_c3_shaped_iteration_at_1024_envs_matches_oracle(crl, persist):
     params = spread_params(cfg, 9)
     off = O.param_offsets(cfg)
     params[off[4]:off[5]] /= 10
-    agent = make_wide(crl, nt, k, D, A, Hd, params=params, shuffle_mode=0, options={"wide_rollout_persist": persist})
+    agent = make_wide(crl, nt, k, D, A, Hd, params=params, shuffle_mode=0, options=persist if isinstance(persist, dict) else {"wide_rollout_persist": persist})
     st = O.State(cfg); st.params[:] = params; st.env_init()
     h = agent.handle; F = crl._lib
     h.env_reset()
