@@ -1,5 +1,5 @@
 #!/bin/bash
-# Timing ablations of the register-stationary forward (wide_rs.hpp: CRL_RS_ABL builds made by scripts/build_variant.sh rsabl<N> "-DCRL_RS_ABL=<N>" wide).
+# Average durations of selected kernels of the C3 workload under rocprofv3, per library build (default or variants made by scripts/build_variant.sh): same-box A/Bs of wide_rs.hpp.
 #   bash scripts/rs_abl.sh "<opt string>" <kernel regex> <variant> [<variant> …]   → one line per variant: average duration of the matching kernels
 R=${GRAFT_REPO_ROOT:-$PWD}
 OPTS=$1; KRE=$2; shift 2
