@@ -118,6 +118,9 @@ constexpr int SCR_FLOATS_X3 = SCR_FLOATS + ACC_SLOTS * 64;
 // source address, lane-linear destination) drops the tile's 32 observation quarters (lanes 0-31) and 32 role quarters (lanes 32-63)
 // into a 1 KB wave-private LDS slot; the permutation entries it needs were fetched a tile earlier the same way
 // (global_load_lds_dword into a 256-byte slot). The tile top then is `s_waitcnt vmcnt(0)` on loads issued ≈8 µs ago plus three LDS reads.
+#ifndef CRL_PF_X3
+#define CRL_PF_X3 0   // the record prefetch in update_x3_kernel (option gemm = 1) as well: measured SLOWER there (0.727 vs 0.715 ms per launch, three rounds on one box)
+#endif
 #ifndef CRL_PF_ENABLED
 #define CRL_PF_ENABLED 1
 #endif
@@ -210,7 +213,7 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
     tstride = 8 * (a.nblk[ROLE] >> 3) * RW;
   }
   Gathered<D> cur;
-  constexpr bool PF = X2 && !EXACT && ABL == 0 && CRL_PF_ENABLED != 0;
+  constexpr bool PF = ((X2 && ABL == 0) || (X3 && ABL == 128 && CRL_PF_X3 != 0)) && !EXACT && CRL_PF_ENABLED != 0;   // (X3 with ABL 128 = update_x3_kernel: the gemm = 1 option kernel)
   const f32x4* pf4 = nullptr;
   const int* pfi = nullptr;
   unsigned pf_lds = 0;
@@ -750,6 +753,10 @@ __device__ __forceinline__ bool update_role(const UpdateArgs& a, const int rb, f
 // Speculative pass (assumes u <= 0, see header). Waves w and w+4 of a block share a SIMD.
 // bf16x3 flavour (mlp_x3.hpp): the split weight images are 51 KB per network, so a 512-thread block carries ONE role
 // (blocks [0, nblk[0]) = actor, the rest = critic) and its 8 waves share that image.
+// LDS of the main-pass kernels (both flavours are launched with it): the bf16x3 layout — the larger one, which the fp16x2 kernel falls back to — then 8 record-prefetch slots
+constexpr int X2_KERNEL_LDS_FLOATS = NetImageX3<4, 2, true>::SIZE + 8 * SCR_FLOATS_X3 + 12;   // + the staging flag / the 8 progress counters   // the bf16x3 fallback's layout is the larger one
+static_assert(X2_KERNEL_LDS_FLOATS % 4 == 0, "prefetch slots are 16-byte aligned");
+static_assert(PF_SLOT_FLOATS % 4 == 0 && (X2_KERNEL_LDS_FLOATS + 8 * PF_SLOT_FLOATS) * 4 <= 160 * 1024, "update_x2_kernel's LDS exceeds a CU's 160 KB");
 template <int D, int A>
 __global__ void __launch_bounds__(512, 2) update_x3_kernel(UpdateArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -761,8 +768,9 @@ __global__ void __launch_bounds__(512, 2) update_x3_kernel(UpdateArgs a) {
   // (profiles/r06_parity_margins.json). The bf16x3 FALLBACKS below (a weight outside the fp16 window, a weight-gradient scale miss) keep NNlib's rational tanh_fast: they
   // run exactly when weights are extreme and units saturate, where 1 - h² of the two approximations differs in relative terms
   // (test_options_are_validated_and_fallback_is_automatic: a weight of 300).
-  if ((int)blockIdx.x < a.nblk[0]) update_role<D, A, 0, false, true, 8, 128>(a, blockIdx.x, smem, smem + NetImageX3<D, A, true>::SIZE);
-  else update_role<D, A, 1, false, true, 8, 128>(a, blockIdx.x - a.nblk[0], smem, smem + NetImageX3<D, 1, true>::SIZE);
+  float* pfslots = smem + X2_KERNEL_LDS_FLOATS;   // the record prefetch of the fp16x2 kernel (-1 % there): wired here as well, off (CRL_PF_X3)
+  if ((int)blockIdx.x < a.nblk[0]) update_role<D, A, 0, false, true, 8, 128>(a, blockIdx.x, smem, smem + NetImageX3<D, A, true>::SIZE, pfslots);
+  else update_role<D, A, 1, false, true, 8, 128>(a, blockIdx.x - a.nblk[0], smem, smem + NetImageX3<D, 1, true>::SIZE, pfslots);
 }
 // After update_t16_kernel (update16.hpp): nothing unless a tile of that launch did not fit the carried weight-gradient scale (or a weight left the fp16
 // window) — then the whole minibatch is recomputed on bf16x3 (no range limits) into the same partial buffers, before the reduce reads them.
@@ -777,9 +785,6 @@ __global__ void __launch_bounds__(512, 2) update_repair_kernel(UpdateArgs a) {
 #include "update16.hpp"   // the 16-sample-tile flavour (needs sgpr / CRL_PHASE above)
 namespace crl {
 // fp16x2 flavour (the default): forward / backward-data products on the f16 matrix pipe, three MFMAs per product
-constexpr int X2_KERNEL_LDS_FLOATS = NetImageX3<4, 2, true>::SIZE + 8 * SCR_FLOATS_X3 + 12;   // + the staging flag / the 8 progress counters   // the bf16x3 fallback's layout is the larger one
-static_assert(X2_KERNEL_LDS_FLOATS % 4 == 0, "prefetch slots are 16-byte aligned");
-static_assert(PF_SLOT_FLOATS % 4 == 0 && (X2_KERNEL_LDS_FLOATS + 8 * PF_SLOT_FLOATS) * 4 <= 160 * 1024, "update_x2_kernel's LDS exceeds a CU's 160 KB");
 template <int D, int A>
 __global__ void __launch_bounds__(512, 2) update_x2_kernel(UpdateArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
