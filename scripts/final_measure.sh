@@ -53,7 +53,7 @@ for nt in 8192 16384 32768; do
   timeout 300 $B --total-envs $nt --no-cpu-baseline --kernel-breakdown > $O/bench_n1_envs${nt}_breakdown.json 2>/dev/null
 done
 timeout 300 $B --workload c2 --steps 40 --no-cpu-baseline > $O/bench_c2_n1.json 2>/dev/null
-timeout 600 $B --workload c3 --steps 5 --warmup 2 > $O/bench_c3_n1.json 2>/dev/null
+timeout 600 $B --workload c3 --steps 5 --warmup 2 --regions 3 > $O/bench_c3_n1.json 2>/dev/null
 timeout 900 python3 $R/scripts/parity_margins.py > $O/parity_margins.json 2>/dev/null
 timeout 300 python3 $R/scripts/bench_gae_big.py > $O/gae_beyond_cache.txt 2>/dev/null
 timeout 300 python3 $R/scripts/bench_gae.py 0 0 > $O/gae_sizes.txt 2>/dev/null
