@@ -412,6 +412,14 @@ __global__ void __launch_bounds__(512) wide_rs_fwd_kernel(FusedFwdPCArgs a0, Fus
 // h2 tiles: [sample][256] f32 rows of 1 KB at a pitch of 1040 B (conflict-free 16-byte reads), two buffers; one `s_waitcnt vmcnt(4)` per stage waits for the
 // tile's four LDS-DMA pieces per wave and leaves the stage's last four plane stores in flight.
 // ======================================================================================================================================
+#ifndef CRL_RSB_GW_MFMA
+#define CRL_RSB_GW_MFMA 0   // dW1 / db1 of the backward stage: 1 = on the matrix pipe (v_mfma_f32_32x32x2_f32, the observation as the B operand) — correct, and SLOWER: 794 vs 718 µs
+                           // per launch (16 Float32 MFMAs of 64 cycles per stage cost the matrix pipe more than 144 FMAs cost the vector pipe); 0 = 8 + 1 FMAs per element
+#endif
+#ifndef CRL_RSB_SPLIT
+#define CRL_RSB_SPLIT 1   // scheduling barriers inside a group of the backward stage: bit 0 between the MFMA chain and P, bit 1 between P and E (none: ~50 B of scratch, 823 µs;
+                          // both 716-720; bit 0 alone 711-713; bit 1 alone 728-740)
+#endif
 constexpr int RB_HROW = 1040;
 constexpr int RB_HBYTES = RS_MB * RB_HROW;                     // 33,280: one h2 tile
 constexpr int RB_OFF_H = 2 * RS_XBYTES;                        // two δ2 tiles first
@@ -452,6 +460,12 @@ __device__ __forceinline__ void wide_rs_bwd_body(const FusedBwdArgs& a) {
   float gW1[DP], gB1 = 0.0f, gW3[NA];
 #pragma unroll
   for (int c = 0; c < DP; ++c) gW1[c] = 0.0f;
+  // dW1 / db1 on the matrix pipe (CRL_RSB_GW_MFMA): C[unit][column] += δ1[unit][sample]·B[sample][column] with B = (observation | 1 | 0 …), K = the two samples a register
+  // holds across the lane halves — v_mfma_f32_32x32x2_f32 takes δ1 as it sits in the registers (Float32, no split). Lane = column here: columns 0 … obs_dim - 1 are dW1, column
+  // DP is db1, the others stay zero; 16 registers replace the 8 + 1 per-lane sums, 16 MFMAs and 16 four-byte LDS reads per stage replace 144 FMAs and 32 broadcast reads
+  f32x16 gWm;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) gWm[q] = 0.0f;
 #pragma unroll
   for (int q = 0; q < NA; ++q) gW3[q] = 0.0f;
   // dW3[a][v] += δ3[a][sample]·h2[v][sample] for four samples (rows 8g + 4hf + e) of tile i: lane = unit v like the epilogue — the tile's h2 and δ3 are
@@ -623,7 +637,7 @@ __device__ __forceinline__ void wide_rs_bwd_body(const FusedBwdArgs& a) {
         acc = mfma_f16(xa.hi, W.wl[ks], acc);
         acc = mfma_f16(xa.hi, W.wh[ks], acc);
       }
-      __builtin_amdgcn_sched_barrier(0);                                // (three scheduling regions per group: with one, the register allocator spilled ~120 registers)
+      if (CRL_RSB_SPLIT & 1) __builtin_amdgcn_sched_barrier(0);
       // P(s + 1), units 4g … 4g + 3 of this lane's sixteen
       {
         const f32x4 hq = *reinterpret_cast<const f32x4*>(hb + 16 * g);
@@ -648,7 +662,7 @@ __device__ __forceinline__ void wide_rs_bwd_body(const FusedBwdArgs& a) {
           }
         } else { hp = hh; lp = ll; }
       }
-      __builtin_amdgcn_sched_barrier(0);
+      if (CRL_RSB_SPLIT & 2) __builtin_amdgcn_sched_barrier(0);
       // E(s - 1), samples 8g + 4hf + 0 … 3 of this lane's unit
       {
         const f32x4 xiq = *reinterpret_cast<const f32x4*>(tabw + 8 * g + 4 * hf), ivq = *reinterpret_cast<const f32x4*>(inv4t + 8 * g + 4 * hf);
@@ -659,6 +673,15 @@ __device__ __forceinline__ void wide_rs_bwd_body(const FusedBwdArgs& a) {
         for (int e = 0; e < 4; ++e) d1[e] = __builtin_amdgcn_rcpf(d1[e] + 1.0f);
 #pragma unroll
         for (int e = 0; e < 4; ++e) d1[e] = (ep[4 * g + e] * ivq[e]) * __builtin_fmaf(-d1[e], d1[e], d1[e]);   // acc·(4/(s1·scale))·r(1 − r)
+        if constexpr (CRL_RSB_GW_MFMA != 0) {
+          const int cc = j;                                              // this lane's column of the dW1 | db1 tile
+          const float* xcol = xe + (cc >> 2) * (RS_MB * 4) + (cc & 3) + (8 * g + 4 * hf) * 4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float bx = cc < DP ? xcol[4 * e] : (cc == DP ? 1.0f : 0.0f);
+            gWm = __builtin_amdgcn_mfma_f32_32x32x2f32(d1[e], bx, gWm, 0, 0, 0);
+          }
+        } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           gB1 += d1[e];
@@ -669,6 +692,7 @@ __device__ __forceinline__ void wide_rs_bwd_body(const FusedBwdArgs& a) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) gW1[4 * c4 + c] = __builtin_fmaf(d1[e], xq[c], gW1[4 * c4 + c]);
           }
+        }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -696,6 +720,14 @@ __device__ __forceinline__ void wide_rs_bwd_body(const FusedBwdArgs& a) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // no LDS-DMA piece may land after the block has given its LDS back
   // ---- the block's dW1 / db1 partial: the two lane halves hold different samples of the same unit
+  if constexpr (CRL_RSB_GW_MFMA != 0) {                                  // lane = column, registers = this half's 16 units: 8·(r >> 2) + 4·hf + (r & 3)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int v = 32 * wave + 8 * (r >> 2) + 4 * hf + (r & 3);
+      if (j < a.D) a.pW1[(size_t)blockIdx.x * 256 * a.D + v + 256 * j] = gWm[r];
+      else if (j == DP) a.pB1[(size_t)blockIdx.x * 256 + v] = gWm[r];
+    }
+  }
   gB1 = add32(gB1);
 #pragma unroll
   for (int c = 0; c < DP; ++c) gW1[c] = add32(gW1[c]);
@@ -705,9 +737,11 @@ __device__ __forceinline__ void wide_rs_bwd_body(const FusedBwdArgs& a) {
     const int v = 32 * wave + j;
 #pragma unroll
     for (int q = 0; q < NA; ++q) if (DW3 && q < a.A) a.pW3[(size_t)blockIdx.x * 256 * a.A + (size_t)v * a.A + q] = gW3[q];
-    a.pB1[(size_t)blockIdx.x * 256 + v] = gB1;
+    if constexpr (CRL_RSB_GW_MFMA == 0) {
+      a.pB1[(size_t)blockIdx.x * 256 + v] = gB1;
 #pragma unroll
-    for (int c = 0; c < DP; ++c) if (c < a.D) a.pW1[(size_t)blockIdx.x * 256 * a.D + v + 256 * c] = gW1[c];
+      for (int c = 0; c < DP; ++c) if (c < a.D) a.pW1[(size_t)blockIdx.x * 256 * a.D + v + 256 * c] = gW1[c];
+    }
   }
 }
 
