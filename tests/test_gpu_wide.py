@@ -459,6 +459,31 @@ def test_c3_size_minibatch_gradient_matches_oracle(crl):
     agent.close()
 
 
+@pytest.mark.parametrize("D,A,nt,k,rs", [(16, 8, 4096, 128, 27), (16, 8, 4096, 128, 11), (12, 6, 2048, 128, 27), (8, 4, 6400, 128, 27)])
+def test_2x256_many_tiles_per_block_other_shapes(crl, D, A, nt, k, rs):
+    """The register-stationary kernels away from C3's own shape, with enough tiles per block for their buffers to rotate: obs 16 / 8 actions at
+    M = 131,072 (32 tiles per block: the forward's 8-tile observation chunks go round their three LDS buffers, the 16-float rows take the second
+    DMA piece pair), obs 12 / 6 actions (16 tiles per block, a row width between the two piece pairs), and C3's shape at 6400 envs —
+    M = 204,800: 50 tiles per block, not a multiple of the 16-tile chunk, the CUs split 133 : 123 between the networks — against orc_loss_grad
+    on the rollout's own buffers. wide_rs = 11 keeps the dW3 sweeps (the backward without its dW3 part)."""
+    Hd = 256
+    cfg = ocfg(nt, k, D, A, Hd)
+    params = spread_params(cfg, 21)
+    agent = make_wide(crl, nt, k, D, A, Hd, params=params, shuffle_mode=1, options={"wide_rs": rs})
+    h = agent.handle; F = crl._lib
+    h.env_reset(); h.rollout_run(); h.compute_gae(); h.shuffle(1); h.adv_stats()
+    gs = h.update_minibatch(1, 0.0, apply_update=False)
+    g = h.read(F.F_GRADS)
+    M = nt * k // 4
+    perm = h.read(F.F_PERM)
+    g_o, so = O.loss_grad(cfg, params, h.read(F.F_OBS).reshape(D, -1, order="F"), h.read(F.F_ACTION), h.read(F.F_LOGPROB),
+                          h.read(F.F_VALUE), h.read(F.F_ADVANTAGE), h.read(F.F_RETURN), perm[1 * M:2 * M])
+    for key in ("loss", "pg_loss", "v_loss", "entropy_loss"):
+        assert loss_close(key, gs[key], so[key], RTOL), (key, gs[key], so[key])
+    _grad_close(g, g_o, O.param_offsets(cfg), tol=RTOL)
+    agent.close()
+
+
 def test_wide_rccl_path_world1(crl):
     """C3 shape with a forced 1-rank RCCL communicator: the gradient message, the advantage statistics AND the two extra
     value-loss scalars (Σ(v − R²), #{u > q}) travel through ncclAllReduce; a sum over one rank is the identity."""
